@@ -1,0 +1,324 @@
+"""Stand-in modules that let the *reference's own Python* import in this container.
+
+Used ONLY by ``tests/golden/make_golden.py`` (the committed script that generated the
+``tests/golden/*.npz`` fixtures by running the reference on CPU).  Nothing in the
+product, the oracle, or the test-suite imports this file at run time: the reference does
+not exist on the GPU box.
+
+The reference (``/root/reference/src/torchbox3d``) depends on third-party packages that
+are absent here.  Each stub below restates only the *interface* the
+hot path touches; behaviour that matters numerically is restated faithfully:
+
+* ``torchvision.ops.Conv2dNormActivation`` -- Sequential[Conv2d(bias = norm is None),
+  norm, activation(inplace)], default padding ``(k-1)//2*dilation``, accepts
+  ``padding="same"``; sub-module names "0","1","2" are part of the state-dict keys.
+* ``kornia.geometry.conversions`` -- yaw-only quaternion helpers.
+* ``omegaconf.DictConfig/ListConfig`` -- hashable attr-dict / list.
+* ``hydra.utils.instantiate`` -- non-recursive ``_target_`` instantiation.
+* ``polars`` -- dtype names + a tiny frame with ``select(cols).to_numpy()``.
+* ``numba.njit`` -- identity decorator (the z-buffer loop runs as plain Python).
+"""
+
+from __future__ import annotations
+
+import enum
+import importlib
+import math
+import sys
+import types
+from typing import Any, Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+from torch import nn
+
+
+def _module(name: str) -> types.ModuleType:
+    mod = types.ModuleType(name)
+    mod.__path__ = []  # behave like a package
+    sys.modules[name] = mod
+    parent, _, child = name.rpartition(".")
+    if parent:
+        setattr(sys.modules[parent], child, mod)
+    return mod
+
+
+# --------------------------------------------------------------------------------------
+# torchvision.ops
+# --------------------------------------------------------------------------------------
+class Conv2dNormActivation(nn.Sequential):
+    def __init__(
+        self,
+        in_channels: int,
+        out_channels: int,
+        kernel_size=3,
+        stride=1,
+        padding=None,
+        groups: int = 1,
+        norm_layer=nn.BatchNorm2d,
+        activation_layer=nn.ReLU,
+        dilation=1,
+        inplace: Optional[bool] = True,
+        bias: Optional[bool] = None,
+    ) -> None:
+        if padding is None:
+            if isinstance(kernel_size, int) and isinstance(dilation, int):
+                padding = (kernel_size - 1) // 2 * dilation
+            else:
+                ks = tuple(kernel_size) if not isinstance(kernel_size, int) else (kernel_size,) * 2
+                dl = tuple(dilation) if not isinstance(dilation, int) else (dilation,) * 2
+                padding = tuple((k - 1) // 2 * d for k, d in zip(ks, dl))
+        if bias is None:
+            bias = norm_layer is None
+        if not isinstance(kernel_size, int):
+            kernel_size = tuple(kernel_size)
+        layers: List[nn.Module] = [
+            nn.Conv2d(
+                in_channels,
+                out_channels,
+                kernel_size,
+                stride,
+                padding,
+                dilation=dilation,
+                groups=groups,
+                bias=bias,
+            )
+        ]
+        if norm_layer is not None:
+            layers.append(norm_layer(out_channels))
+        if activation_layer is not None:
+            params = {} if inplace is None else {"inplace": inplace}
+            layers.append(activation_layer(**params))
+        super().__init__(*layers)
+        self.out_channels = out_channels
+
+
+def _sigmoid_focal_loss(*args: Any, **kwargs: Any):  # never called on the configured path
+    raise NotImplementedError
+
+
+# --------------------------------------------------------------------------------------
+# omegaconf / hydra
+# --------------------------------------------------------------------------------------
+class DictConfig(dict):
+    """Attribute dict; hashable by identity (nn.Module machinery hashes dataclass fields)."""
+
+    def __getattr__(self, key: str) -> Any:
+        try:
+            return self[key]
+        except KeyError as exc:
+            raise AttributeError(key) from exc
+
+    def __setattr__(self, key: str, value: Any) -> None:
+        self[key] = value
+
+    def __hash__(self) -> int:  # type: ignore[override]
+        return id(self)
+
+    def __eq__(self, other: Any) -> bool:
+        return self is other
+
+
+class ListConfig(list):
+    def __hash__(self) -> int:  # type: ignore[override]
+        return id(self)
+
+    def __eq__(self, other: Any) -> bool:
+        return self is other
+
+
+def _instantiate(cfg: Dict[str, Any], *args: Any, **kwargs: Any) -> Any:
+    cfg = dict(cfg)
+    target = cfg.pop("_target_")
+    cfg.pop("_recursive_", None)
+    module_name, _, attr = target.rpartition(".")
+    cls = getattr(importlib.import_module(module_name), attr)
+    cfg.update(kwargs)
+    return cls(*args, **cfg)
+
+
+# --------------------------------------------------------------------------------------
+# kornia.geometry.conversions (yaw-only use on the hot path)
+# --------------------------------------------------------------------------------------
+def quaternion_from_euler(roll, pitch, yaw):
+    cy, sy = torch.cos(yaw * 0.5), torch.sin(yaw * 0.5)
+    cp, sp = torch.cos(pitch * 0.5), torch.sin(pitch * 0.5)
+    cr, sr = torch.cos(roll * 0.5), torch.sin(roll * 0.5)
+    qw = cr * cp * cy + sr * sp * sy
+    qx = sr * cp * cy - cr * sp * sy
+    qy = cr * sp * cy + sr * cp * sy
+    qz = cr * cp * sy - sr * sp * cy
+    return qw, qx, qy, qz
+
+
+def euler_from_quaternion(w, x, y, z):
+    sinr_cosp = 2.0 * (w * x + y * z)
+    cosr_cosp = 1.0 - 2.0 * (x * x + y * y)
+    roll = torch.atan2(sinr_cosp, cosr_cosp)
+    sinp = (2.0 * (w * y - z * x)).clamp(-1.0, 1.0)
+    pitch = torch.asin(sinp)
+    siny_cosp = 2.0 * (w * z + x * y)
+    cosy_cosp = 1.0 - 2.0 * (y * y + z * z)
+    yaw = torch.atan2(siny_cosp, cosy_cosp)
+    return roll, pitch, yaw
+
+
+def quaternion_to_rotation_matrix(q, order=None):
+    q = q / q.norm(dim=-1, keepdim=True)
+    w, x, y, z = q.unbind(-1)
+    m = torch.stack(
+        [
+            1 - 2 * (y * y + z * z),
+            2 * (x * y - w * z),
+            2 * (x * z + w * y),
+            2 * (x * y + w * z),
+            1 - 2 * (x * x + z * z),
+            2 * (y * z - w * x),
+            2 * (x * z - w * y),
+            2 * (y * z + w * x),
+            1 - 2 * (x * x + y * y),
+        ],
+        dim=-1,
+    )
+    return m.reshape(q.shape[:-1] + (3, 3))
+
+
+class QuaternionCoeffOrder(enum.Enum):
+    XYZW = "xyzw"
+    WXYZ = "wxyz"
+
+
+# --------------------------------------------------------------------------------------
+# polars (just enough for utils/polars.py and the dtype names in math/ops/coding.py)
+# --------------------------------------------------------------------------------------
+class _PlFrame:
+    def __init__(self, data: Dict[str, Sequence[Any]], **_: Any) -> None:
+        self._data = {k: np.asarray(v) for k, v in data.items()}
+
+    def select(self, columns: Sequence[str]) -> "_PlFrame":
+        return _PlFrame({c: self._data[c] for c in columns})
+
+    def to_numpy(self) -> np.ndarray:
+        cols = list(self._data.values())
+        if not cols:
+            return np.zeros((0, 0))
+        return np.stack([np.asarray(c, dtype=np.float64) for c in cols], axis=1)
+
+    @property
+    def shape(self):
+        n = len(next(iter(self._data.values()))) if self._data else 0
+        return (n, len(self._data))
+
+
+def install() -> None:
+    """Register every stub in ``sys.modules`` and put the reference on ``sys.path``."""
+    import os
+
+    os.environ.setdefault("PYTORCH_JIT", "0")
+    ref_src = "/root/reference/src"
+    if ref_src not in sys.path:
+        sys.path.insert(0, ref_src)
+
+    tv = _module("torchvision")
+    ops = _module("torchvision.ops")
+    ops.Conv2dNormActivation = Conv2dNormActivation
+    ops.sigmoid_focal_loss = _sigmoid_focal_loss
+    tv.ops = ops
+
+    oc = _module("omegaconf")
+    oc.DictConfig = DictConfig
+    oc.ListConfig = ListConfig
+    oc.MISSING = "???"
+
+    class _OmegaConf:
+        @staticmethod
+        def register_new_resolver(*_: Any, **__: Any) -> None:
+            return None
+
+    oc.OmegaConf = _OmegaConf
+
+    _module("hydra")
+    hu = _module("hydra.utils")
+    hu.instantiate = _instantiate
+
+    plm = _module("pytorch_lightning")
+    plm.LightningModule = nn.Module
+    plm.LightningDataModule = object
+    _module("pytorch_lightning.core")
+    core_mod = _module("pytorch_lightning.core.module")
+    core_mod.LightningModule = nn.Module
+
+    pl = _module("polars")
+    for name in ("Float32", "Float64", "UInt8", "UInt16", "UInt32", "Int32", "Int64", "Utf8", "Boolean"):
+        setattr(pl, name, name)
+    pl.DataFrame = _PlFrame
+    pl.col = lambda *a, **k: None
+
+    class _PlConfig:
+        @staticmethod
+        def set_tbl_rows(*_: Any) -> None:
+            return None
+
+    pl.Config = _PlConfig
+    pl.__dict__["__getattr__"] = lambda name: type(name, (), {})  # type names used in annotations only
+
+    _module("kornia")
+    _module("kornia.geometry")
+    kc = _module("kornia.geometry.conversions")
+    kc.quaternion_from_euler = quaternion_from_euler
+    kc.euler_from_quaternion = euler_from_quaternion
+    kc.quaternion_to_rotation_matrix = quaternion_to_rotation_matrix
+    kc.QuaternionCoeffOrder = QuaternionCoeffOrder
+
+    nbm = _module("numba")
+
+    def njit(*args: Any, **kwargs: Any):
+        if len(args) == 1 and callable(args[0]) and not kwargs:
+            return args[0]
+        return lambda fn: fn
+
+    nbm.njit = njit
+
+    _module("detectron2")
+    _module("detectron2.layers")
+    d2 = _module("detectron2.layers.nms")
+    d2.nms_rotated = None
+    wn = _module("weighted_nms_ext")
+    wn.wnms_gpu = None  # binary absent: weighted-NMS arithmetic cannot be run here
+    _module("mmcv")
+    mo = _module("mmcv.ops")
+    mo.box_iou_rotated = None
+    mo.boxes_iou3d = None
+    mob = _module("mmcv.ops.box_iou_rotated")
+    mob.box_iou_rotated = None
+
+    # av2 (only for converters/av2/utils.py -> datasets/argoverse/constants.py)
+    _module("av2")
+    _module("av2.geometry")
+    se3 = _module("av2.geometry.se3")
+    se3.SE3 = object
+    _module("av2.datasets")
+    _module("av2.datasets.sensor")
+    av2c = _module("av2.datasets.sensor.constants")
+
+    class AnnotationCategories(str, enum.Enum):
+        REGULAR_VEHICLE = "REGULAR_VEHICLE"
+
+    av2c.AnnotationCategories = AnnotationCategories
+    ev = _module("av2.evaluation")
+    ev.SensorCompetitionCategories = AnnotationCategories
+    _module("av2.evaluation.detection")
+    eve = _module("av2.evaluation.detection.eval")
+    eve.DetectionCfg = object
+
+
+def load_converter_utils():
+    """Import ``/root/reference/converters/av2/utils.py`` as a module (it is not a package)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location(
+        "ref_converters_av2_utils", "/root/reference/converters/av2/utils.py"
+    )
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod

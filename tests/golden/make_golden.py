@@ -1,0 +1,361 @@
+"""Generate the golden fixtures in ``tests/golden/*.npz`` by running the REFERENCE itself.
+
+Run in the build container only (needs ``/root/reference``):
+
+    PYTORCH_JIT=0 python tests/golden/make_golden.py
+
+The reference's own Python modules (``/root/reference/src/torchbox3d`` and
+``/root/reference/converters/av2/utils.py``) are imported with stand-ins for the absent
+third-party packages (``_ref_stubs.py``), executed on CPU in fp32 with fixed seeds, and
+their inputs / weights / outputs / gradients are stored as small ``.npz`` files.  The
+reference Python never travels to the GPU box; only these arrays do.  The oracle is
+checked against them in ``tests/test_oracle_golden.py``.
+
+Fixtures contain *data only* (arrays produced by or fed to the reference).
+"""
+
+from __future__ import annotations
+
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _ref_stubs  # noqa: E402
+
+_ref_stubs.install()
+
+from omegaconf import DictConfig, ListConfig  # noqa: E402  (stub)
+from torchbox3d.math.numpy import conversions as ref_np  # noqa: E402
+from torchbox3d.math.ops.coding import decode_range_view  # noqa: E402
+from torchbox3d.nn.backbones.dla import RangeNet  # noqa: E402
+from torchbox3d.nn.blocks import AggregationBlock, BasicBlock, ResidualBlock  # noqa: E402
+from torchbox3d.nn.decoders.range_decoder import RangeDecoder, sample_by_range  # noqa: E402
+from torchbox3d.nn.heads.dense_head import DenseHead  # noqa: E402
+from torchbox3d.nn.heads.detection_head import COLS, DetectionHead, compute_targets  # noqa: E402
+from torchbox3d.nn.modules.conv import Conv2dSame  # noqa: E402
+from torchbox3d.nn.stems import MetaKernel  # noqa: E402
+from torchbox3d.math.conversions import (  # noqa: E402
+    cartesian_to_spherical_coordinates,
+    spherical_to_cartesian_coordinates,
+)
+from torchbox3d.math.linalg.lie.SO3 import yaw_to_quat  # noqa: E402
+from torchbox3d.nn.functional import varifocal_loss  # noqa: E402
+
+ref_conv = _ref_stubs.load_converter_utils()
+
+
+def npy(t):
+    return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+
+def save(name: str, **arrays) -> None:
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: npy(v) for k, v in arrays.items()})
+    print(f"{name}.npz: {os.path.getsize(path) / 1024:.1f} KiB, {len(arrays)} arrays")
+
+
+def randomize_bn(module: torch.nn.Module, g: torch.Generator) -> None:
+    """Non-trivial affine + running statistics so that eval-mode parity means something."""
+    for m in module.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data = 0.5 + torch.rand(m.weight.shape, generator=g)
+            m.bias.data = 0.2 * torch.randn(m.bias.shape, generator=g)
+            m.running_mean.data = 0.1 * torch.randn(m.running_mean.shape, generator=g)
+            m.running_var.data = 0.5 + torch.rand(m.running_var.shape, generator=g)
+
+
+def module_case(prefix: str, module: torch.nn.Module, inputs, g: torch.Generator, out: dict) -> None:
+    """Train-mode forward + backward of ``sum(out * probe)``, then an eval-mode forward."""
+    randomize_bn(module, g)
+    sd0 = {k: v.clone() for k, v in module.state_dict().items()}
+    module.train()
+    xs = [x.clone().requires_grad_(True) for x in inputs]
+    y = module(*xs)
+    probe = torch.randn(y.shape, generator=g)
+    (y * probe).sum().backward()
+    for k, v in sd0.items():
+        out[f"{prefix}/sd/{k}"] = v
+    for i, x in enumerate(xs):
+        out[f"{prefix}/in{i}"] = x
+        out[f"{prefix}/gin{i}"] = x.grad
+    out[f"{prefix}/out"] = y
+    out[f"{prefix}/probe"] = probe
+    for k, p in module.named_parameters():
+        out[f"{prefix}/grad/{k}"] = p.grad
+    for k, v in module.state_dict().items():
+        if "running_" in k:
+            out[f"{prefix}/sd_after/{k}"] = v.clone()
+    module.load_state_dict(sd0)
+    module.eval()
+    with torch.no_grad():
+        out[f"{prefix}/out_eval"] = module(*[x.detach() for x in xs])
+
+
+# --------------------------------------------------------------------------------------
+def gen_conv_blocks() -> None:
+    g = torch.Generator().manual_seed(1)
+    out: dict = {}
+    x = torch.randn(2, 8, 6, 32, generator=g)
+    for name, k, s in (("conv3_s11", 3, (1, 1)), ("conv3_s12", 3, (1, 2)), ("conv1_s12", 1, (1, 2)), ("conv1_s11", 1, 1)):
+        m = Conv2dSame(8, 16, kernel_size=k, stride=s, bias=False)
+        module_case(name, m, [x], g, out)
+    module_case("basic_plain", BasicBlock(8, 8), [x], g, out)
+    module_case("basic_proj_s12", BasicBlock(8, 16, stride=(1, 2), project=True), [x], g, out)
+    module_case("basic_k1_proj", BasicBlock(5, 16, kernel_size=1, project=True), [torch.randn(2, 5, 6, 32, generator=g)], g, out)
+    module_case("residual_s12_n3", ResidualBlock(8, 16, num_blocks=3, stride=(1, 2)), [x], g, out)
+    x1 = torch.randn(2, 8, 6, 32, generator=g)
+    x2a = torch.randn(2, 16, 6, 8, generator=g)
+    x2b = torch.randn(2, 16, 6, 16, generator=g)
+    module_case("agg_k8_s4", AggregationBlock(8, 16, 8, kernel_size=(3, 8), stride=(1, 4), padding=(1, 2), num_blocks=2), [x1, x2a], g, out)
+    module_case("agg_k4_s2", AggregationBlock(8, 16, 8, kernel_size=(3, 4), stride=(1, 2), padding=(1, 1), num_blocks=1), [x1, x2b], g, out)
+    save("conv_blocks", **out)
+
+
+def synthetic_sweep(g: torch.Generator, B: int, H: int, W: int, n_feat: int = 5, drop: float = 0.1, smooth: bool = False):
+    """Synthetic range image as SURVEY.md §8d defines it (row inclinations, column azimuths).
+
+    ``smooth``: spatially coherent short ranges, so that boxes contain many pixels.
+    """
+    r = 1.5 + 78.5 * torch.rand(B, 1, H, W, generator=g)
+    if smooth:
+        az_ = torch.linspace(math.pi, -math.pi, W).view(1, 1, 1, W)
+        inc_ = torch.linspace(0.2, -0.4, H).view(1, 1, H, 1)
+        r = 6.0 + 1.5 * torch.sin(3 * az_) + 1.0 * torch.cos(9 * inc_) + 0.2 * torch.rand(B, 1, H, W, generator=g)
+    mask = torch.rand(B, 1, H, W, generator=g) >= drop
+    inc = torch.linspace(0.2, -0.4, H).view(1, 1, H, 1)
+    az = torch.linspace(math.pi, -math.pi, W).view(1, 1, 1, W)
+    cart = torch.cat([r * inc.cos() * az.cos(), r * inc.cos() * az.sin(), r * inc.sin().expand(B, 1, H, W)], dim=1) * mask
+    intensity = torch.rand(B, 1, H, W, generator=g)
+    feats = [intensity, r, cart[:, 0:1], cart[:, 1:2], cart[:, 2:3]]
+    if n_feat == 6:
+        feats = [torch.rand(B, 1, H, W, generator=g)] + feats
+    features = torch.cat(feats, dim=1) * mask
+    return features.float(), cart.float(), mask
+
+
+def gen_meta_kernel() -> None:
+    g = torch.Generator().manual_seed(2)
+    out: dict = {}
+    features, cart, _ = synthetic_sweep(g, 2, 6, 32)
+    m = MetaKernel(in_channels=5, out_channels=16, num_neighbors=3, num_layers=2)
+    module_case("meta", m, [features, cart], g, out)
+    save("meta_kernel", **out)
+
+
+def make_annotations(g: torch.Generator, cart: torch.Tensor, mask: torch.Tensor, n_per: int, n_cls: int) -> np.ndarray:
+    """(M,13) fp64 [xyz,lwh,qwxyz,task,offset,batch]; boxes centred on valid pixels, some nested."""
+    rows = []
+    B, _, H, W = cart.shape
+    for b in range(B):
+        valid = mask[b, 0].nonzero()
+        pick = valid[torch.randperm(valid.shape[0], generator=g)[:n_per]]
+        sweep_rows = []
+        for i, (h, w) in enumerate(pick.tolist()):
+            ctr = cart[b, :, h, w].double()
+            lwh = torch.tensor([1.0, 1.0, 1.0]) + torch.rand(3, generator=g) * torch.tensor([5.0, 2.0, 2.0])
+            if i % 3 == 1:  # a big box around the previous one => contested pixels
+                ctr = torch.tensor(sweep_rows[-1][:3])
+                lwh = torch.tensor(sweep_rows[-1][3:6]) * 2.5
+            yaw = (torch.rand(1, generator=g).item() * 2 - 1) * math.pi
+            q = [math.cos(yaw / 2), 0.0, 0.0, math.sin(yaw / 2)]
+            cat = int(torch.randint(0, n_cls, (1,), generator=g).item())
+            sweep_rows.append(ctr.tolist() + lwh.double().tolist() + q + [0.0, float(cat), float(b)])
+        sweep_rows.sort(key=lambda r: (r[10], r[11]))  # loader.py:700-704 sorts by (task_id, offset)
+        rows += sweep_rows
+    return np.asarray(rows, dtype=np.float64)
+
+
+class Frame(_ref_stubs._PlFrame):
+    pass
+
+
+def gen_tiny_model() -> None:
+    """RangeNet(META, layers=[16]*5) + DetectionHead, full fwd / targets / loss / bwd."""
+    g = torch.Generator().manual_seed(3)
+    torch.manual_seed(3)
+    B, H, W, C, NCLS = 2, 8, 64, 16, 5
+    L = ListConfig([C] * 5)
+    backbone = RangeNet(
+        in_channels=5, layers=L, out_channels=C, projection_kernel_size=1, dataset_name="av2", num_neighbors=3,
+        num_layers=2, stem_type="META",
+        _net=DictConfig(_target_="torchbox3d.nn.backbones.dla.RangeBackbone", in_channels=5, layers=L, out_channels=C),
+    )
+    tasks = DictConfig({0: ListConfig([f"C{i}" for i in range(NCLS)])})
+    tcfg = DictConfig(
+        dataset_name="av2", tasks=tasks, enable_azimuth_invariant_targets=True,
+        range_partitions=DictConfig({1: [0.0, math.inf]}), fpn_assignment_method=None, k=math.inf,
+        affinity_fn="GAUSSIAN", normalize_affinities=False, sigma=0.75,
+    )
+    head = DetectionHead(
+        fpn=DictConfig({1: 2 * C}), fpn_kernel_sizes=DictConfig({1: ListConfig([3, 3])}), targets_config=tcfg,
+        num_classification_blocks=4, num_regression_blocks=4, final_kernel_size=1, tasks_cfg=tasks,
+        task_in_channels=C, classification_weight=1.0, regression_weight=1.0,
+        coding_weights=ListConfig([1.0] * 8), classification_head_channels=2 * C, regression_head_channels=2 * C,
+        classification_normalization_method="FOREGROUND",
+        _cls_loss=DictConfig(_target_="torchbox3d.nn.losses.classification.VarifocalLoss", alpha=0.75, gamma=2.0, reduction="none"),
+        _regression_loss=DictConfig(_target_="torch.nn.L1Loss", reduction="none"),
+    )
+    randomize_bn(backbone, g)
+    randomize_bn(head, g)
+    # larger head weights than the N(0, 0.01) init so that logits / regressands are not ~constant
+    for name, p in head.named_parameters():
+        if name.endswith("0.weight"):
+            p.data = 0.08 * torch.randn(p.shape, generator=g)
+    head.classification_head["1"]["0"].blocks[-1][0].bias.data.fill_(-1.0)  # so that some scores pass 0.1
+    features, cart, mask = synthetic_sweep(g, B, H, W, smooth=True)
+    ann = make_annotations(g, cart, mask, n_per=6, n_cls=NCLS)
+    frame = Frame({c: ann[:, i] for i, c in enumerate(COLS)})
+
+    out: dict = {"features": features, "cart": cart, "mask": mask, "annotations": ann}
+    for k, v in backbone.state_dict().items():
+        out[f"sd/backbone.{k}"] = v.clone()
+    for k, v in head.state_dict().items():
+        out[f"sd/head.{k}"] = v.clone()
+
+    backbone.train()
+    head.train()
+    data = {"features": features, "cart": cart, "mask": mask, "annotations": frame}
+    feats = backbone(data)
+    outputs, losses = head(feats, data, return_loss=True)
+    losses["loss"].backward()
+    for s, t in feats.items():
+        out[f"feat/{s}"] = t
+    out["logits"] = outputs[1][0]["logits"]
+    out["regressands"] = outputs[1][0]["regressands"]
+    for k in ("classification_labels", "panoptics", "regression_targets", "points_per_obj"):
+        out[f"targets/{k}"] = data[1][0][k]
+    out["targets/soft"] = data[1][0]["targets"]
+    for k, v in losses.items():
+        if isinstance(v, torch.Tensor) and "/" not in k:
+            out[f"loss/{k}"] = v
+    aux = losses["aux"][1][0]
+    out["aux/foreground"] = aux["foreground"]
+    out["aux/background"] = aux["background"]
+    for k, p in backbone.named_parameters():
+        out[f"grad/backbone.{k}"] = p.grad
+    for k, p in head.named_parameters():
+        out[f"grad/head.{k}"] = p.grad
+    for k, v in list(backbone.state_dict().items()) + []:
+        if "running_" in k:
+            out[f"sd_after/backbone.{k}"] = v.clone()
+    for k, v in head.state_dict().items():
+        if "running_" in k:
+            out[f"sd_after/head.{k}"] = v.clone()
+
+    # eval-mode forward + decoder (no NMS: the NMS extension is absent)
+    backbone.load_state_dict({k[len("sd/backbone."):]: torch.as_tensor(npy(v)) for k, v in out.items() if k.startswith("sd/backbone.")})
+    head.load_state_dict({k[len("sd/head."):]: torch.as_tensor(npy(v)) for k, v in out.items() if k.startswith("sd/head.")})
+    backbone.eval()
+    head.eval()
+    with torch.no_grad():
+        data = {"features": features, "cart": cart, "mask": mask}
+        feats = backbone(data)
+        outputs, _ = head(feats, data, return_loss=False)
+        out["eval/feat1"] = feats[1]
+        out["eval/logits"] = outputs[1][0]["logits"]
+        out["eval/regressands"] = outputs[1][0]["regressands"]
+        dec = RangeDecoder(True, True, ListConfig([0, 15, 30]), ListConfig([15, 30, math.inf]), ListConfig([8, 2, 1]))
+        params, scores, cats, bidx = dec.decode(
+            outputs, DictConfig(num_pre_nms=50000, num_post_nms=1000, nms_threshold=0.3, min_confidence=0.1, nms_mode="WEIGHTED"),
+            tasks, use_nms=False,
+        )
+        out["eval/dec_params"], out["eval/dec_scores"], out["eval/dec_categories"], out["eval/dec_batch_index"] = params, scores, cats, bidx
+    save("tiny_model", **out)
+
+
+def gen_decode() -> None:
+    g = torch.Generator().manual_seed(4)
+    B, H, W, NCLS = 2, 8, 64, 7
+    _, cart, mask = synthetic_sweep(g, B, H, W, drop=0.2)
+    reg = 0.5 * torch.randn(B, 8, H, W, generator=g)
+    logits = 2.0 * torch.randn(B, NCLS, H, W, generator=g)
+    logits[:, 2, :, ::5] = logits[:, 4, :, ::5]  # exact class ties -> lowest index must win
+    out = {"cart": cart, "mask": mask, "regressands": reg, "logits": logits}
+    out["decoded_inv"] = decode_range_view(reg.clone(), cart.clone(), True)
+    out["decoded_plain"] = decode_range_view(reg.clone(), cart.clone(), False)
+    scores, cats = (logits.sigmoid() * mask).max(dim=1, keepdim=True)
+    s, c, b = sample_by_range(scores, cats, out["decoded_inv"], cart, (0, 15, 30), (15, 30, math.inf), (8, 2, 1))
+    out["sampled_scores"], out["sampled_categories"], out["sampled_cuboids"] = s, c, b
+    dec = RangeDecoder(True, True, ListConfig([0, 15, 30]), ListConfig([15, 30, math.inf]), ListConfig([8, 2, 1]))
+    mo = {1: {"cart": cart, "mask": mask, 0: {"logits": logits, "regressands": reg}}}
+    tasks = DictConfig({0: ListConfig(["c"] * NCLS)})
+    post = DictConfig(num_pre_nms=50000, num_post_nms=1000, nms_threshold=0.3, min_confidence=0.1, nms_mode="WEIGHTED")
+    p, sc, ca, bi = dec.decode(mo, post, tasks, use_nms=False)
+    out["dec_params"], out["dec_scores"], out["dec_categories"], out["dec_batch_index"] = p, sc, ca, bi
+    dec2 = RangeDecoder(True, False, ListConfig([0, 15, 30]), ListConfig([15, 30, math.inf]), ListConfig([8, 2, 1]))
+    p, sc, ca, bi = dec2.decode(mo, post, tasks, use_nms=False)
+    out["dense_params"], out["dense_scores"], out["dense_categories"], out["dense_batch_index"] = p, sc, ca, bi
+    yaw = (torch.rand(33, 1, generator=g) * 2 - 1) * 4.0
+    out["yaw"], out["quat"] = yaw, yaw_to_quat(yaw)
+    x = 3.0 * torch.randn(4, 6, 5, 9, generator=g)
+    t = torch.rand(4, 6, 5, 9, generator=g) * (torch.rand(4, 6, 5, 9, generator=g) > 0.7)
+    out["vfl_x"], out["vfl_t"] = x, t
+    out["vfl"] = varifocal_loss(x, t, 0.75, 2.0, "none")
+    pts = 10 * torch.randn(257, 3, generator=g)
+    out["s1_cart"] = pts
+    out["s1_sph"] = cartesian_to_spherical_coordinates(pts)
+    out["s1_back"] = spherical_to_cartesian_coordinates(out["s1_sph"])
+    save("decode", **out)
+
+
+def gen_projection() -> None:
+    rng = np.random.default_rng(5)
+    N, H, W = 6000, 64, 512
+    out: dict = {}
+    r = rng.uniform(0.3, 90.0, N)  # includes points closer than the 1 m cut
+    az = rng.uniform(-math.pi, math.pi, N)
+    inc = rng.uniform(-0.45, 0.25, N)
+    cart = np.stack([r * np.cos(inc) * np.cos(az), r * np.cos(inc) * np.sin(az), r * np.sin(inc)], axis=1)
+    # forced exact duplicates (ties -> earliest wins) and exact half-bin azimuths (round-half-even)
+    cart[1000:1100] = cart[0:100]
+    k = np.arange(200)
+    az_half = (k + 0.5) * (math.tau / W) - math.pi
+    cart[2000:2200] = np.stack([20 * np.cos(az_half), 20 * np.sin(az_half), np.zeros(200)], axis=1)
+    laser = rng.integers(0, 64, N)
+    intensity = rng.integers(0, 255, N).astype(np.float64)
+    row_map = np.asarray(ref_conv.ROW_MAPPING_64)
+    out["cart"], out["laser_numbers"], out["intensity"], out["row_mapping_64"] = cart, laser, intensity, row_map
+    out["laser_mapping_32"] = np.asarray(ref_conv.LASER_MAPPING)
+    sph = ref_conv.cart_to_sph(cart.copy())
+    out["sph"] = sph.copy()
+    hyb_c = ref_conv.build_range_view_coordinates(cart.copy(), sph.copy(), laser.copy(), row_map, H, W)
+    hyb_l = ref_np.build_range_view_coordinates(cart.copy(), sph.copy(), laser.copy(), row_map, H, W)
+    out["hybrid_converter"], out["hybrid_library"] = hyb_c, hyb_l
+    feats = np.concatenate([sph, cart, intensity[:, None]], axis=1).transpose(1, 0)
+    for tag, hyb in (("converter", hyb_c), ("library", hyb_l)):
+        idx = np.ascontiguousarray(hyb[:, :2].transpose(1, 0).astype(int))
+        out[f"indices_{tag}"] = idx
+        out[f"image_{tag}"] = ref_conv.z_buffer(idx, hyb[:, 2], feats, height=H, width=W)
+    out["features"] = feats
+    # library sph<->cart twins
+    out["np_sph_to_cart"] = ref_np.sph_to_cart(sph.copy())
+    # loader W-pad rule (prototype/loader.py:792-815)
+    try:
+        from torchbox3d.prototype.loader import subsample_range_view
+
+        g = torch.Generator().manual_seed(6)
+        for ds, w in (("av2", 1800), ("waymo", 2650)):
+            rv = torch.randn(2, 2, w, generator=g)
+            m = torch.rand(1, 2, w, generator=g) > 0.2
+            c = torch.randn(3, 2, w, generator=g)
+            for mode in ("constant", "circular"):
+                a, b_, c_ = subsample_range_view(rv.clone(), m.clone().float(), c.clone(), ds, 1, mode)
+                out[f"pad/{ds}/{mode}/rv_in"], out[f"pad/{ds}/{mode}/mask_in"] = rv, m.float()
+                out[f"pad/{ds}/{mode}/rv"], out[f"pad/{ds}/{mode}/mask"] = a, b_
+    except Exception as exc:  # loader imports many absent packages
+        print("loader.subsample_range_view not importable:", repr(exc))
+    save("projection", **out)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    gen_conv_blocks()
+    gen_meta_kernel()
+    gen_decode()
+    gen_projection()
+    gen_tiny_model()
