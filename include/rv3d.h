@@ -1,0 +1,310 @@
+/*
+ * rv3d.h -- C ABI of librv3d_hip.so: the MI355X (gfx950) implementation of the range-view
+ * detector's data-parallel hot path.
+ *
+ * Drop-in boundary.  The reference (benjaminrwilson/range-view-3d-detection, `torchbox3d`)
+ * is pure Python; the native code it reaches on this path is (a) ATen/cuDNN kernels behind
+ * torch.nn modules and (b) ONE explicit op-level FFI, `weighted_nms_ext.wnms_gpu`
+ * (src/torchbox3d/math/ops/nms.py:161-170).  Every entry point below names the reference
+ * interface it replaces (paths relative to the reference root, `src/torchbox3d/` elided
+ * where unambiguous).  The Python host (`range_view_3d_detection_amd`) binds these symbols
+ * with ctypes; INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - Plain C: pointers + sizes.  All pointers are DEVICE pointers unless named `host_*`.
+ *   - The caller (PyTorch's caching allocator in practice) owns every buffer; the library
+ *     never allocates, frees or retains a pointer beyond the call (workspaces are passed in).
+ *   - Every launch is enqueued on `stream` (a hipStream_t passed as void*); calls are
+ *     asynchronous unless documented otherwise (only rv_wnms returns a host count).
+ *   - Return value: 0 on success, non-zero on error; rv_last_error() returns a thread-local
+ *     description.  Shapes are validated on the host before any launch.
+ *   - Activations are NHWC ("pixel-major"): pixel (n,h,w) of a tensor with channel stride
+ *     `ld` starts at element ((n*H + h)*W + w)*ld.  Activations / activation gradients are
+ *     bf16 (uint16 storage); statistics, parameters, parameter gradients and the final
+ *     head outputs are fp32.  Stored channel counts are multiples of 32, zero padded.
+ *   - No global mutable state except a read-only device-property cache; safe to use from
+ *     one process per GPU (the reference's Lightning-DDP process model).
+ */
+#ifndef RV3D_H_
+#define RV3D_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* rvStream; /* hipStream_t */
+
+int rv_version(void);
+const char* rv_last_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Tap geometry of one convolution-like layer.
+ *
+ * A layer owns a torch-layout weight T[cu][cv][kh][kw] and relates a "coarse" tensor U
+ * (N,H,Wu,cu) to a "fine" tensor V (N,H,Wv,cv) through
+ *       (hu, wu, ky, kx)  <->  (hv, wv) = (hu + ky - pad_h, wu*stride_w + kx - pad_w).
+ *   nn.Conv2d (via Conv2dSame, nn/modules/conv.py:25-80; torchvision Conv2dNormActivation in
+ *   nn/heads/dense_head.py:32-57, nn/stems/__init__.py:41-62):
+ *       forward  y = GATHER(x)   (U = y, V = x, T = weight[co][ci][kh][kw])
+ *       d/dx     dx = SCATTER(dy)
+ *   nn.ConvTranspose2d (nn/blocks/__init__.py:149-156):
+ *       forward  y = SCATTER(x)  (U = x, V = y, T = weight[ci][co][kh][kw])
+ *       d/dx     dx = GATHER(dy)
+ *   weight gradient (both): dT[cu][cv][ky][kx] = sum_{n,hu,wu} U[n,hu,wu,cu] * V[n,hv,wv,cv].
+ * Vertical stride is 1 everywhere in this model (nn/backbones/dla.py:37-108).
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t kh, kw;       /* kernel extent */
+    int32_t stride_w;     /* 1, 2 or 4 */
+    int32_t pad_h, pad_w; /* zero padding (top/left); Conv2dSame: (k-1)/2 */
+    int32_t cu, cv;       /* logical channel counts of U and V */
+} rvTapGeom;
+
+/* padded channel count used for every stored tensor / packed weight: round up to 32 */
+int32_t rv_pad_channels(int32_t c);
+
+/* Bytes of the packed bf16 weight images (gather / scatter form) for a geometry. */
+int64_t rv_packed_weight_bytes(const rvTapGeom* g);
+
+/* T (fp32, torch layout [cu][cv][kh][kw]) -> bf16 tap-major images with zero channel padding:
+ *   gather_w  [tap = ky*kw+kx][cu_pad][cv_pad]               (K dim = cv contiguous)
+ *   scatter_w [phase][tap-in-phase][cv_pad][cu_pad]          (K dim = cu contiguous)
+ * Either output may be NULL.  Replaces nothing in the reference (cuDNN re-lays weights
+ * internally); it is what keeps `state_dict()` in the reference's OIHW layout. */
+int rv_pack_weight(const rvTapGeom* g, const float* T, void* gather_w, void* scatter_w, rvStream stream);
+
+/* fp32 packed weight gradient [kh*kw][cu_pad][cv_pad] -> accumulate/store into torch layout
+ * dT[cu][cv][kh][kw] (fp32).  accumulate != 0: dT += value. */
+int rv_unpack_weight_grad(const rvTapGeom* g, const float* packed, float* dT, int32_t accumulate, rvStream stream);
+
+/* flags for rv_tap_gather / rv_tap_scatter */
+#define RV_IN_AFFINE 1   /* operand = in_scale[c]*x + in_shift[c] (folded BatchNorm) */
+#define RV_IN_RELU 2     /* ... followed by ReLU; padding positions stay exactly 0 */
+#define RV_OUT_F32 4     /* dst is fp32 (final head convs); default bf16 */
+#define RV_OUT_BIAS 8    /* dst += bias[c] */
+#define RV_OUT_STATS 16  /* write per-block partial sum / sum-of-squares of the fp32 result */
+#define RV_OUT_ACCUM 32  /* dst += result (gradient fan-in); bf16 dst only */
+
+typedef struct {
+    int32_t N, H, Wu, Wv; /* U is (N,H,Wu), V is (N,H,Wv) */
+    int32_t ld_src, ld_dst; /* channel strides (elements) of the source / destination tensors */
+    int32_t flags;
+} rvTapShape;
+
+/* Rows of the partial-statistics buffer ([rows][2][c_pad] fp32) a launch with RV_OUT_STATS
+ * writes; `scatter` selects the SCATTER form. */
+int32_t rv_tap_stats_rows(const rvTapGeom* g, const rvTapShape* s, int32_t scatter);
+/* Every partial-statistics buffer handed to rv_bn_finalize / rv_bn_bwd_finalize must have room
+ * for this many extra rows after its `rows` partial rows (second-stage reduction scratch). */
+#define RV_STATS_SCRATCH_ROWS 128
+
+/* U = GATHER(V):  U[n,h,wu,cu] = sum_{ky,kx,cv} T[cu][cv][ky][kx] * f(V[n, h+ky-pad_h, wu*s+kx-pad_w, cv]).
+ * Replaces nn.Conv2d forward (cuDNN/ATen conv2d; nn/modules/conv.py:80) including the
+ * F.pad copy of Conv2dSame (:79), the preceding BatchNorm2d+ReLU when RV_IN_AFFINE|RV_IN_RELU
+ * (nn/blocks/__init__.py:41-42), and ATen's conv_transpose2d backward-data. */
+int rv_tap_gather(const rvTapGeom* g, const rvTapShape* s, const void* V, const float* in_scale,
+                  const float* in_shift, const void* gather_w, const float* bias, void* U,
+                  float* stats_partial, rvStream stream);
+
+/* V = SCATTER(U): V[n,h,wv,cv] = sum over (ky,kx,wu) with wu*s+kx-pad_w == wv of
+ *                 T[cu][cv][ky][kx] * f(U[n, h-ky+pad_h, wu, cu]).
+ * Replaces nn.ConvTranspose2d forward (ATen conv_transpose2d; nn/blocks/__init__.py:176)
+ * and cuDNN's conv2d backward-data. */
+int rv_tap_scatter(const rvTapGeom* g, const rvTapShape* s, const void* U, const float* in_scale,
+                   const float* in_shift, const void* scatter_w, const float* bias, void* V,
+                   float* stats_partial, rvStream stream);
+
+/* Weight gradient.  dT_packed[tap][cu_pad][cv_pad] (fp32) = sum_{n,h,wu} U * f(V) (shifted).
+ * `workspace` holds split-K partial slabs; rv_tap_wgrad_workspace_bytes() sizes it.
+ * V may carry the same folded BN+ReLU as in the forward (RV_IN_AFFINE|RV_IN_RELU in
+ * s->flags applies to V when v_affine != 0, else to U).
+ * Replaces cuDNN conv2d backward-weight / ATen conv_transpose2d backward-weight. */
+int64_t rv_tap_wgrad_workspace_bytes(const rvTapGeom* g, const rvTapShape* s);
+int rv_tap_wgrad(const rvTapGeom* g, const rvTapShape* s, const void* U, int32_t ld_u, const void* V, int32_t ld_v,
+                 const float* in_scale, const float* in_shift, int32_t v_affine, float* dT_packed,
+                 void* workspace, rvStream stream);
+
+/* ---------------------------------------------------------------------------------------
+ * BatchNorm2d (nn.BatchNorm2d train/eval; nn/blocks/__init__.py:41,51,63,158; torchvision
+ * Conv2dNormActivation norm layer).  eps / momentum are torch defaults passed by the host.
+ * ------------------------------------------------------------------------------------- */
+/* partial[rows][2][c] (sum, sum of squares) -> batch mean / biased var -> folded affine
+ * scale = gamma*invstd, shift = beta - mean*scale; saves mean/invstd for backward and
+ * updates running_mean / running_var (unbiased) in place when they are non-NULL. */
+int rv_bn_finalize(const float* partial, int32_t rows, int32_t c, int64_t count, const float* gamma,
+                   const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                   float* scale, float* shift, float* mean, float* invstd, rvStream stream);
+/* eval mode: scale/shift from the running statistics */
+int rv_bn_fold_eval(int32_t c, const float* gamma, const float* beta, const float* running_mean,
+                    const float* running_var, float eps, float* scale, float* shift, rvStream stream);
+
+/* out = relu?( fa(a) + fb(b) ), f*(x) = relu?(scale*x + shift) per channel when the scale
+ * pointer is non-NULL, identity otherwise; b may be NULL.  bf16 in / bf16 out.
+ * Replaces `F.relu_(self.net(x) + residual)` (nn/blocks/__init__.py:81), `x_1 + x_2` after
+ * BN+ReLU (:177-180) and standalone BatchNorm2d+ReLU applications. */
+#define RV_EW_RELU_A 1
+#define RV_EW_RELU_B 2
+#define RV_EW_RELU_OUT 4
+int rv_ew_combine(int64_t pixels, int32_t c, const void* a, int32_t ld_a, const float* a_scale,
+                  const float* a_shift, const void* b, int32_t ld_b, const float* b_scale,
+                  const float* b_shift, void* out, int32_t ld_out, int32_t flags, rvStream stream);
+
+/* BatchNorm backward, fused with the ReLU masks around it.
+ *   g  = dOut * [OUT > 0 if out != NULL] * [scale*y+shift > 0 if RV_BNB_RELU_Z]
+ *   pass 1 (reduce): partial[rows][2][c] = (sum g, sum g*xhat), xhat = (y-mean)*invstd
+ *   finalize       : dgamma = sum g*xhat, dbeta = sum g (accumulated into the fp32 grads),
+ *                    coef[0][c] = gamma*invstd, coef[1][c] = mean(g), coef[2][c] = mean(g*xhat)
+ *   pass 2 (apply) : dY = coef0 * (g - coef1 - xhat*coef2)  (bf16), and optionally
+ *                    dRes (+)= g  (identity residual branch).
+ * Replaces cuDNN BatchNorm backward + ReLU backward + the add's gradient fan-out. */
+#define RV_BNB_RELU_Z 1
+#define RV_BNB_RES_ACCUM 2
+int32_t rv_bn_bwd_rows(int64_t pixels);
+int rv_bn_bwd_reduce(int64_t pixels, int32_t c, const void* dout, int32_t ld_dout, const void* out, int32_t ld_out,
+                     const void* y, int32_t ld_y, const float* scale, const float* shift, const float* mean,
+                     const float* invstd, int32_t flags, float* partial, rvStream stream);
+int rv_bn_bwd_finalize(const float* partial, int32_t rows, int32_t c, int64_t count, const float* gamma,
+                       const float* invstd, float* dgamma, float* dbeta, int32_t accumulate, float* coef,
+                       rvStream stream);
+int rv_bn_bwd_apply(int64_t pixels, int32_t c, const void* dout, int32_t ld_dout, const void* out, int32_t ld_out,
+                    const void* y, int32_t ld_y, const float* scale, const float* shift, const float* mean,
+                    const float* invstd, const float* coef, int32_t flags, void* dy, int32_t ld_dy, void* dres,
+                    int32_t ld_dres, rvStream stream);
+/* gradient of rv_ew_combine's plain (non-BN) inputs: d (+)= dOut * [OUT > 0 if out != NULL] */
+int rv_ew_mask_grad(int64_t pixels, int32_t c, const void* dout, int32_t ld_dout, const void* out, int32_t ld_out,
+                    void* d, int32_t ld_d, int32_t accumulate, rvStream stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Layout conversion at the module boundary (the reference's tensors are NCHW fp32).
+ * ------------------------------------------------------------------------------------- */
+int rv_nchw_f32_to_nhwc_bf16(const float* src, int32_t N, int32_t C, int32_t H, int32_t W, void* dst, int32_t ld_dst,
+                             int32_t c_offset, rvStream stream);
+int rv_nhwc_bf16_to_nchw_f32(const void* src, int32_t ld_src, int32_t c_offset, int32_t N, int32_t C, int32_t H,
+                             int32_t W, float* dst, rvStream stream);
+int rv_nhwc_f32_to_nchw_f32(const float* src, int32_t ld_src, int32_t N, int32_t C, int32_t H, int32_t W, float* dst,
+                            rvStream stream);
+int rv_nchw_f32_to_nhwc_f32(const float* src, int32_t N, int32_t C, int32_t H, int32_t W, float* dst, int32_t ld_dst,
+                            rvStream stream);
+
+/* ---------------------------------------------------------------------------------------
+ * MetaKernel stem (nn/stems/__init__.py:64-85): F.unfold of features and of `cart`,
+ * relative coordinates, positional MLP, element-wise product.  The 9x unfolded tensors of
+ * the reference are never written to memory.
+ * ------------------------------------------------------------------------------------- */
+/* rel[n,h,w,tap,0:3] = cart[n,h+dy,w+dx,:] (0 outside) - cart[n,h,w,:], written as a bf16
+ * NHWC tensor (N, H, W*9, 32) whose channels 3..31 are zero (operand of the 3->C 1x1 conv).
+ * `cart` is NCHW fp32 (B,3,H,W) exactly as the reference's batch dict holds it. */
+int rv_meta_relative(const float* cart_nchw, int32_t N, int32_t H, int32_t W, void* rel, rvStream stream);
+/* geo[n,h,w, tap*C + c] = relu(scale[c]*pos[n,h,w,tap,c] + shift[c]) * feat[n,h+dy,w+dx,c]
+ * (zero outside the image).  The reference's channel order c*9+tap (F.unfold) is absorbed
+ * into the packed weight of the 9C->C fusion conv. */
+int rv_meta_modulate(const void* pos_raw, const float* scale, const float* shift, const void* feat, int32_t ld_feat,
+                     int32_t N, int32_t H, int32_t W, int32_t C, void* geo, rvStream stream);
+/* backward of rv_meta_modulate: dpos_act = dgeo * feat_nbr (then ReLU/BN backward via
+ * rv_bn_bwd_*), dfeat[n,h',w',c] += sum_tap dgeo * pos_act. */
+int rv_meta_modulate_bwd(const void* dgeo, const void* pos_raw, const float* scale, const float* shift,
+                         const void* feat, int32_t ld_feat, int32_t N, int32_t H, int32_t W, int32_t C,
+                         void* dpos_act, void* dfeat, int32_t ld_dfeat, rvStream stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Decoder (nn/decoders/range_decoder.py:29-156, math/ops/coding.py:79-144,
+ * math/linalg/lie/SO3.py:122-134).
+ * ------------------------------------------------------------------------------------- */
+/* Per pixel: score = max_c sigmoid(logit_c)*mask (ties -> lowest class), category = argmax,
+ * box = decode_range_view(regressands, cart) evaluated in fp64 and rounded to fp32.
+ * Inputs are NCHW fp32 (the module boundary layout).  With `n_bands` > 0 the outputs are
+ * written in sample_by_range order: K = H * sum_i ceil(W / rate_i) candidates per sweep,
+ * band-major; scores are zeroed outside the band (lower, upper], boxes/categories are not.
+ * With n_bands == 0 the outputs are the dense H*W grid.
+ *   scores (B,K) f32, categories (B,K) i64, boxes (B,K,7) f32. */
+int rv_decode_candidates(const float* logits, const float* regressands, const float* cart, const uint8_t* mask,
+                         int32_t B, int32_t n_cls, int32_t H, int32_t W, int32_t azimuth_invariant, int32_t n_bands,
+                         const float* host_lower, const float* host_upper, const int32_t* host_rates,
+                         int64_t category_offset,
+                         float* scores, int64_t* categories, float* boxes, rvStream stream);
+int64_t rv_decode_num_candidates(int32_t H, int32_t W, int32_t n_bands, const int32_t* host_rates);
+/* decode_range_view alone on NCHW fp32 (B,8,H,W)+(B,3,H,W) -> (B,7,H,W) (math/ops/coding.py:110-144) */
+int rv_decode_range_view(const float* regressands, const float* cart, int32_t B, int32_t H, int32_t W,
+                         int32_t azimuth_invariant, float* out, rvStream stream);
+/* yaw (n,) -> wxyz quaternions (n,4)  (SO3.py:122-134) */
+int rv_yaw_to_quat(const float* yaw, int64_t n, int64_t yaw_stride, float* quat, rvStream stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Weighted NMS -- replaces `weighted_nms_ext.wnms_gpu(boxes, data2merge_score, output, keep,
+ * count, nms_thresh, merge_thresh, device_index) -> int` (math/ops/nms.py:161-170).
+ * Same contract: inputs sorted by score descending; boxes (n,5) = [x1,y1,x2,y2,ry] f32;
+ * data (n,d) f32 with the score in the last column; caller-allocated zero-initialised
+ * `output` (n,d), `keep` (n,) i64, `count` (n,) i64 -- all DEVICE buffers here (the
+ * reference keeps `keep` on the host); returns the number of kept boxes through
+ * `host_num_out` after synchronising `stream` (the reference call is synchronous too).
+ * `workspace`: rv_wnms_workspace_bytes(n) bytes.  Semantics: see oracle/nms.py (the
+ * third-party kernel's arithmetic is not in the reference tree -- parity unpinned).
+ * ------------------------------------------------------------------------------------- */
+int64_t rv_wnms_workspace_bytes(int64_t n);
+int rv_wnms(const float* boxes, const float* data, int64_t n, int32_t d, float nms_thresh, float merge_thresh,
+            float* output, int64_t* keep, int64_t* count, void* workspace, int64_t* host_num_out, rvStream stream);
+/* pairwise rotated BEV IoU (n x m), exposed for tests */
+int rv_rotated_iou(const float* a, int64_t n, const float* b, int64_t m, float* out, rvStream stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Range-image projection (converters/av2/utils.py:108-208 == math/numpy/conversions.py:9-128).
+ * ------------------------------------------------------------------------------------- */
+/* cart (n,3) f64 -> rows/cols (i32) + range (f64); variant 0 = converter binning
+ * (col = W - round((az+pi)*W/tau)), 1 = library binning (col = round(W - (az+pi)*W/tau - 1));
+ * round-half-to-even, clip to [0, W-1] before the integer cast; row = H - laser_mapping[laser] - 1. */
+int rv_project_indices(const double* cart, const int32_t* laser, const int32_t* laser_mapping, int64_t n,
+                       int32_t H, int32_t W, int32_t variant, int32_t* rows, int32_t* cols, double* range,
+                       rvStream stream);
+/* z-buffer with the reference's sequential semantics: skip range < min_range; pixel owner =
+ * the point with the smallest float(range) ... see DESIGN.md §z-buffer for the exact rule
+ * (fp64-vs-fp32 comparison, earliest index on ties).  features (c,n) f64 -> image (c,H,W) f32
+ * (zeros where empty); winner (H,W) i64 (-1 where empty); `keys` is an (H*W) u64 scratch. */
+int rv_z_buffer(const int32_t* rows, const int32_t* cols, const double* range, const double* features, int64_t n,
+                int32_t c, int32_t H, int32_t W, double min_range, uint64_t* keys, float* image, int64_t* winner,
+                rvStream stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Targets + losses on device (nn/heads/detection_head.py:496-665, math/ops/assignment.py:76-161,
+ * nn/functional/__init__.py:8-27, detection_head.py:202-449) -- see rv3d.h section in DESIGN.md.
+ * ------------------------------------------------------------------------------------- */
+/* cuboids (m,10) f64 [x,y,z,l,w,h,yaw,task,category,batch] grouped by sweep; `box_offsets` (B+1) i32 is the
+ * CSR of the grouping (device); cart NCHW f32.  Outputs: labels (B,H,W) i64 (background = n_cls),
+ * panoptics (B,H,W) i64 (0 = background, else 1-based rank of the owning box by interior-point
+ * count ascending, ties in input order == the reference's stable sort), regression targets
+ * (B,8,H,W) f32, points_per_obj (B,H,W) i64, num_objects (1) i32 = boxes owning >= 1 pixel.
+ * counts / order / owned: (m) i32 scratch.  No host synchronisation (the reference's loop calls
+ * .unique()/.tolist() per sweep, task and instance). */
+int rv_assign_targets(const double* cuboids, int32_t m, const int32_t* box_offsets, const float* cart, int32_t B,
+                      int32_t H, int32_t W, int32_t n_cls, int32_t azimuth_invariant, int32_t* counts, int32_t* order,
+                      int32_t* owned, int64_t* labels, int64_t* panoptics, float* reg_targets,
+                      int64_t* points_per_obj, int32_t* num_objects, rvStream stream);
+
+/* Fused detection loss.  logits / regressands are NHWC fp32 with channel strides ld_* (the layout
+ * the head kernels write); cart / reg_targets NCHW fp32; mask (B,H,W) u8.
+ * forward : sums[16] (f64, device) -- [0] sum w*VFL*mask, [1] foreground part, [2] background part,
+ *           [3] #foreground, [4..11] un-normalised regression sums per regressand, [12] max(objects,1),
+ *           [13] #foreground + smoothing; optional soft targets (B,n_cls,H,W) and foreground map.
+ *           loss = sums[0]/sums[13] + (sums[4]+...+sums[11])/sums[12].
+ * backward: d loss / d logits, d loss / d regressands (same NHWC strides), scaled by grad_scale;
+ *           reads sums[12], sums[13] on device (no host round trip). */
+int rv_detection_loss_forward(const float* logits, int32_t ld_logits, const float* regressands, int32_t ld_reg,
+                              const float* cart, const uint8_t* mask, const int64_t* labels, const int64_t* panoptics,
+                              const float* reg_targets, const int64_t* points_per_obj, const int32_t* num_objects,
+                              int32_t B, int32_t n_cls, int32_t H, int32_t W, const float* host_coding_weights,
+                              float cls_weight, float reg_weight, float smoothing, float sigma, float alpha, float gamma,
+                              int32_t azimuth_invariant, double* sums, float* soft_targets, float* foreground,
+                              rvStream stream);
+int rv_detection_loss_backward(const float* logits, int32_t ld_logits, const float* regressands, int32_t ld_reg,
+                               const float* cart, const uint8_t* mask, const int64_t* labels, const int64_t* panoptics,
+                               const float* reg_targets, const int64_t* points_per_obj, const int32_t* num_objects,
+                               int32_t B, int32_t n_cls, int32_t H, int32_t W, const float* host_coding_weights,
+                               float cls_weight, float reg_weight, float smoothing, float sigma, float alpha, float gamma,
+                               int32_t azimuth_invariant, const double* sums, float grad_scale, float* d_logits,
+                               float* d_regressands, rvStream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RV3D_H_ */

@@ -1,0 +1,102 @@
+"""ctypes binding of ``librv3d_hip.so`` (the C ABI declared in ``include/rv3d.h``).
+
+There is deliberately no CPU fallback: if the library is missing or a call fails the host
+code raises.  ``load()`` only dlopens the library (works without a GPU, which is what the
+CPU test-suite checks); every compute entry point needs a device.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from typing import Dict, List, Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librv3d_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "rv3d.h")
+
+# flags (mirror include/rv3d.h)
+IN_AFFINE, IN_RELU, OUT_F32, OUT_BIAS, OUT_STATS, OUT_ACCUM = 1, 2, 4, 8, 16, 32
+EW_RELU_A, EW_RELU_B, EW_RELU_OUT = 1, 2, 4
+BNB_RELU_Z, BNB_RES_ACCUM = 1, 2
+STATS_SCRATCH_ROWS = 128
+
+
+class TapGeom(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("kh", "kw", "stride_w", "pad_h", "pad_w", "cu", "cv")]
+
+
+class TapShape(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("N", "H", "Wu", "Wv", "ld_src", "ld_dst", "flags")]
+
+
+class RvError(RuntimeError):
+    pass
+
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def declared_symbols() -> List[str]:
+    """Every function name declared in include/rv3d.h (used by the export test)."""
+    text = open(HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rv_[a-z0-9_]+)\s*\(", text)))
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RvError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.rv_last_error.restype = ctypes.c_char_p
+    for name in ("rv_packed_weight_bytes", "rv_decode_num_candidates", "rv_wnms_workspace_bytes", "rv_tap_wgrad_workspace_bytes"):
+        if hasattr(lib, name):
+            getattr(lib, name).restype = ctypes.c_int64
+    _lib = lib
+    return lib
+
+
+def _as_arg(v):
+    if v is None:
+        return ctypes.c_void_p(0)
+    if isinstance(v, (ctypes.Structure,)):
+        return ctypes.byref(v)
+    if isinstance(v, float):
+        return ctypes.c_float(v)
+    if isinstance(v, int):
+        return ctypes.c_int64(v) if abs(v) > 0x7FFFFFFF else ctypes.c_int32(v)
+    return v
+
+
+def call(name: str, *args) -> None:
+    """Invoke an int-returning entry point; raise with rv_last_error() on failure."""
+    fn = getattr(load(), name)
+    rc = fn(*args)
+    if rc != 0:
+        raise RvError(f"{name} failed: {load().rv_last_error().decode()}")
+
+
+def ptr(t) -> ctypes.c_void_p:
+    """Device (or host) pointer of a torch tensor / None."""
+    if t is None:
+        return ctypes.c_void_p(0)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr() -> ctypes.c_void_p:
+    import torch
+
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+i32 = ctypes.c_int32
+i64 = ctypes.c_int64
+f32 = ctypes.c_float
+f64 = ctypes.c_double

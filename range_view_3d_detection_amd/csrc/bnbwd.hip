@@ -1,0 +1,264 @@
+// bnbwd.hip -- BatchNorm backward fused with the ReLU masks around it, and the element-wise
+// gradient fan-out of the residual add.  HBM-bound: every tensor is read once per pass in
+// 16-byte channel octets (coalesced pixel rows); per-channel reductions stay in registers, are
+// combined through LDS and leave the block as one partial row (no atomics, fixed order).
+//
+// Replaces cuDNN batch-norm backward + ReLU backward + add backward of
+// nn/blocks/__init__.py:41-51,63,78-81,158-180 (and the Conv2dNormActivation triples).
+#include "common.h"
+
+int rv_col_reduce(const float* partial, int rows, int cols, double* scratch, int* groups, hipStream_t st);
+
+namespace {
+
+constexpr int kPixPerBlock = 512;
+
+struct BnbArgs {
+    const bf16_t* dout;
+    const bf16_t* out;  // optional ReLU mask source (the materialised block output)
+    const bf16_t* y;    // raw conv output
+    const float *scale, *shift, *mean, *invstd, *coef;
+    int64_t pixels;
+    int c, c8;
+    int ld_dout, ld_out, ld_y, ld_dy, ld_dres;
+    int flags;
+    float* partial;
+    bf16_t* dy;
+    bf16_t* dres;
+};
+
+__device__ __forceinline__ void unpack8(const u32x4 v, float* f) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f[2 * j] = bf_lo(v[j]);
+        f[2 * j + 1] = bf_hi(v[j]);
+    }
+}
+__device__ __forceinline__ u32x4 pack8(const float* f) {
+    u32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = pack_bf2(f[2 * j], f[2 * j + 1]);
+    return v;
+}
+
+// g = dout * [out > 0] * [scale*y+shift > 0]; xhat = (y - mean) * invstd
+__device__ __forceinline__ void masked_grad(const BnbArgs& a, int64_t px, int c0, const float* sc, const float* sh,
+                                            const float* mu, const float* is, float* g, float* xhat) {
+    float d[8], yv[8];
+    unpack8(*(const u32x4*)(a.dout + px * a.ld_dout + c0), d);
+    unpack8(*(const u32x4*)(a.y + px * a.ld_y + c0), yv);
+    if (a.out) {
+        float o[8];
+        unpack8(*(const u32x4*)(a.out + px * a.ld_out + c0), o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d[j] = o[j] > 0.f ? d[j] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if ((a.flags & RV_BNB_RELU_Z) && !(yv[j] * sc[j] + sh[j] > 0.f)) d[j] = 0.f;
+        g[j] = d[j];
+        xhat[j] = (yv[j] - mu[j]) * is[j];
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnbArgs a) {
+    __shared__ float red[256][17];
+    const int tid = threadIdx.x;
+    const int lanes_px = 256 / a.c8;           // pixels handled per pass
+    const int oct = tid % a.c8, pl = tid / a.c8;
+    const bool active = pl < lanes_px;
+    const int c0 = oct * 8;
+    float sc[8], sh[8], mu[8], is[8], s0[8], s1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        sc[j] = a.scale[c0 + j];
+        sh[j] = a.shift[c0 + j];
+        mu[j] = a.mean[c0 + j];
+        is[j] = a.invstd[c0 + j];
+        s0[j] = 0.f;
+        s1[j] = 0.f;
+    }
+    const int64_t p0 = (int64_t)blockIdx.x * kPixPerBlock;
+    const int64_t p1 = p0 + kPixPerBlock < a.pixels ? p0 + kPixPerBlock : a.pixels;
+    if (active)
+        for (int64_t px = p0 + pl; px < p1; px += lanes_px) {
+            float g[8], xh[8];
+            masked_grad(a, px, c0, sc, sh, mu, is, g, xh);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                s0[j] += g[j];
+                s1[j] += g[j] * xh[j];
+            }
+        }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        red[tid][j] = s0[j];
+        red[tid][8 + j] = s1[j];
+    }
+    __syncthreads();
+    // thread (oct, j in 0..15) sums over the pixel lanes
+    for (int i = tid; i < a.c8 * 16; i += 256) {
+        const int o = i / 16, j = i - o * 16;
+        float s = 0.f;
+        for (int l = 0; l < lanes_px; ++l) s += red[l * a.c8 + o][j];
+        const int ch = o * 8 + (j & 7);
+        a.partial[((int64_t)blockIdx.x * 2 + (j >> 3)) * a.c + ch] = s;
+    }
+}
+
+__global__ void bn_bwd_finalize_kernel(const double* red, int groups, int c, double inv_count, const float* gamma,
+                                       const float* invstd, float* dgamma, float* dbeta, int accumulate, float* coef) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    double s0 = 0.0, s1 = 0.0;
+    for (int g = 0; g < groups; ++g) {
+        s0 += red[(int64_t)g * 2 * c + ch];
+        s1 += red[(int64_t)g * 2 * c + c + ch];
+    }
+    if (dgamma) dgamma[ch] = (float)((accumulate ? (double)dgamma[ch] : 0.0) + s1);
+    if (dbeta) dbeta[ch] = (float)((accumulate ? (double)dbeta[ch] : 0.0) + s0);
+    coef[ch] = gamma[ch] * invstd[ch];
+    coef[c + ch] = (float)(s0 * inv_count);
+    coef[2 * c + ch] = (float)(s1 * inv_count);
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnbArgs a) {
+    const int64_t total = a.pixels * a.c8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t px = i / a.c8;
+        const int c0 = (int)(i - px * a.c8) * 8;
+        float sc[8], sh[8], mu[8], is[8], g[8], xh[8], o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            sc[j] = a.scale[c0 + j];
+            sh[j] = a.shift[c0 + j];
+            mu[j] = a.mean[c0 + j];
+            is[j] = a.invstd[c0 + j];
+        }
+        masked_grad(a, px, c0, sc, sh, mu, is, g, xh);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            o[j] = a.coef[c0 + j] * (g[j] - a.coef[a.c + c0 + j] - xh[j] * a.coef[2 * a.c + c0 + j]);
+        *(u32x4*)(a.dy + px * a.ld_dy + c0) = pack8(o);
+        if (a.dres) {
+            bf16_t* p = a.dres + px * a.ld_dres + c0;
+            if (a.flags & RV_BNB_RES_ACCUM) {
+                float old[8];
+                unpack8(*(const u32x4*)p, old);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) g[j] += old[j];
+            }
+            *(u32x4*)p = pack8(g);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ew_mask_grad_kernel(int64_t pixels, int c8, const bf16_t* dout, int ld_dout,
+                                                           const bf16_t* out, int ld_out, bf16_t* d, int ld_d,
+                                                           int accumulate) {
+    const int64_t total = pixels * c8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t px = i / c8;
+        const int c0 = (int)(i - px * c8) * 8;
+        float g[8];
+        unpack8(*(const u32x4*)(dout + px * ld_dout + c0), g);
+        if (out) {
+            float o[8];
+            unpack8(*(const u32x4*)(out + px * ld_out + c0), o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[j] = o[j] > 0.f ? g[j] : 0.f;
+        }
+        bf16_t* p = d + px * ld_d + c0;
+        if (accumulate) {
+            float old[8];
+            unpack8(*(const u32x4*)p, old);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[j] += old[j];
+        }
+        *(u32x4*)p = pack8(g);
+    }
+}
+
+int grid_for(int64_t work) {
+    int64_t b = (work + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+int fill(BnbArgs* a, int64_t pixels, int32_t c, const void* dout, int32_t ld_dout, const void* out, int32_t ld_out,
+         const void* y, int32_t ld_y, const float* scale, const float* shift, const float* mean, const float* invstd,
+         int32_t flags) {
+    RV_REQUIRE(dout && y && scale && shift && mean && invstd, "bn backward: null argument");
+    RV_REQUIRE(c % 8 == 0 && c / 8 <= 256 && ld_dout % 8 == 0 && ld_y % 8 == 0 && (!out || ld_out % 8 == 0), "bn backward: channels / strides must be multiples of 8 (c <= 2048)");
+    memset(a, 0, sizeof(*a));
+    a->dout = (const bf16_t*)dout;
+    a->out = (const bf16_t*)out;
+    a->y = (const bf16_t*)y;
+    a->scale = scale;
+    a->shift = shift;
+    a->mean = mean;
+    a->invstd = invstd;
+    a->pixels = pixels;
+    a->c = c;
+    a->c8 = c / 8;
+    a->ld_dout = ld_dout;
+    a->ld_out = ld_out;
+    a->ld_y = ld_y;
+    a->flags = flags;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int32_t rv_bn_bwd_rows(int64_t pixels) { return (int32_t)((pixels + kPixPerBlock - 1) / kPixPerBlock); }
+
+extern "C" int rv_bn_bwd_reduce(int64_t pixels, int32_t c, const void* dout, int32_t ld_dout, const void* out,
+                                int32_t ld_out, const void* y, int32_t ld_y, const float* scale, const float* shift,
+                                const float* mean, const float* invstd, int32_t flags, float* partial, rvStream stream) {
+    BnbArgs a;
+    if (fill(&a, pixels, c, dout, ld_dout, out, ld_out, y, ld_y, scale, shift, mean, invstd, flags)) return 1;
+    RV_REQUIRE(partial, "rv_bn_bwd_reduce: null partial buffer");
+    a.partial = partial;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rv_bn_bwd_rows(pixels)), dim3(256), 0, (hipStream_t)stream, a);
+    RV_CHECK_LAUNCH("bn_bwd_reduce_kernel");
+    return 0;
+}
+
+extern "C" int rv_bn_bwd_finalize(const float* partial, int32_t rows, int32_t c, int64_t count, const float* gamma,
+                                  const float* invstd, float* dgamma, float* dbeta, int32_t accumulate, float* coef,
+                                  rvStream stream) {
+    RV_REQUIRE(partial && gamma && invstd && coef, "rv_bn_bwd_finalize: null argument");
+    double* scratch = (double*)(partial + (int64_t)rows * 2 * c);
+    int groups;
+    if (rv_col_reduce(partial, rows, 2 * c, scratch, &groups, (hipStream_t)stream)) return 1;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(rv_ceil_div(c, 64)), dim3(64), 0, (hipStream_t)stream, scratch, groups, c,
+                       1.0 / (double)count, gamma, invstd, dgamma, dbeta, accumulate, coef);
+    RV_CHECK_LAUNCH("bn_bwd_finalize_kernel");
+    return 0;
+}
+
+extern "C" int rv_bn_bwd_apply(int64_t pixels, int32_t c, const void* dout, int32_t ld_dout, const void* out,
+                               int32_t ld_out, const void* y, int32_t ld_y, const float* scale, const float* shift,
+                               const float* mean, const float* invstd, const float* coef, int32_t flags, void* dy,
+                               int32_t ld_dy, void* dres, int32_t ld_dres, rvStream stream) {
+    BnbArgs a;
+    if (fill(&a, pixels, c, dout, ld_dout, out, ld_out, y, ld_y, scale, shift, mean, invstd, flags)) return 1;
+    RV_REQUIRE(coef && dy && ld_dy % 8 == 0 && (!dres || ld_dres % 8 == 0), "rv_bn_bwd_apply: bad outputs");
+    a.coef = coef;
+    a.dy = (bf16_t*)dy;
+    a.ld_dy = ld_dy;
+    a.dres = (bf16_t*)dres;
+    a.ld_dres = ld_dres;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(pixels * (c / 8))), dim3(256), 0, (hipStream_t)stream, a);
+    RV_CHECK_LAUNCH("bn_bwd_apply_kernel");
+    return 0;
+}
+
+extern "C" int rv_ew_mask_grad(int64_t pixels, int32_t c, const void* dout, int32_t ld_dout, const void* out,
+                               int32_t ld_out, void* d, int32_t ld_d, int32_t accumulate, rvStream stream) {
+    RV_REQUIRE(dout && d, "rv_ew_mask_grad: null argument");
+    RV_REQUIRE(c % 8 == 0 && ld_dout % 8 == 0 && ld_d % 8 == 0 && (!out || ld_out % 8 == 0), "rv_ew_mask_grad: channels / strides must be multiples of 8");
+    hipLaunchKernelGGL(ew_mask_grad_kernel, dim3(grid_for(pixels * (c / 8))), dim3(256), 0, (hipStream_t)stream, pixels,
+                       c / 8, (const bf16_t*)dout, ld_dout, (const bf16_t*)out, ld_out, (bf16_t*)d, ld_d, accumulate);
+    RV_CHECK_LAUNCH("ew_mask_grad_kernel");
+    return 0;
+}

@@ -1,0 +1,179 @@
+// meta.hip -- MetaKernel stem glue (nn/stems/__init__.py:64-85): the reference's two F.unfold
+// calls and the (B, C, 9, H*W) element-wise product, as gather kernels over NHWC bf16 tensors.
+// Pure HBM-bound byte movers: one 16-byte channel octet per thread, consecutive threads on
+// consecutive octets (coalesced 512-byte pixel rows for C = 256).
+//
+// Tap order follows F.unfold: k = ky*3 + kx, neighbour = (h + ky - 1, w + kx - 1), zero padded.
+#include "common.h"
+
+namespace {
+
+__global__ void meta_relative_kernel(const float* cart, int N, int H, int W, bf16_t* rel) {
+    const int64_t hw = (int64_t)H * W;
+    const int64_t total = (int64_t)N * hw * 9;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % 9);
+        const int64_t p = i / 9;  // pixel index n*H*W + h*W + w
+        const int64_t n = p / hw;
+        const int64_t r = p - n * hw;
+        const int h = (int)(r / W), w = (int)(r - (int64_t)h * W);
+        const int hn = h + k / 3 - 1, wn = w + k % 3 - 1;
+        const float* c0 = cart + n * 3 * hw;
+        float v[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float centre = c0[j * hw + r];
+            const float nb = (hn >= 0 && hn < H && wn >= 0 && wn < W) ? c0[j * hw + (int64_t)hn * W + wn] : 0.f;
+            v[j] = nb - centre;
+        }
+        u32x4* dst = (u32x4*)(rel + i * 32);
+        dst[0] = u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], 0.f), 0u, 0u};
+        dst[1] = u32x4{0u, 0u, 0u, 0u};
+        dst[2] = u32x4{0u, 0u, 0u, 0u};
+        dst[3] = u32x4{0u, 0u, 0u, 0u};
+    }
+}
+
+__device__ __forceinline__ void unpack8(const u32x4 v, float* f) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f[2 * j] = bf_lo(v[j]);
+        f[2 * j + 1] = bf_hi(v[j]);
+    }
+}
+__device__ __forceinline__ u32x4 pack8(const float* f) {
+    u32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = pack_bf2(f[2 * j], f[2 * j + 1]);
+    return v;
+}
+
+// geo[p][k*C + c] = relu(scale*pos[p*9+k][c] + shift) * feat[nbr_k(p)][c]
+__global__ __launch_bounds__(256) void meta_modulate_kernel(const bf16_t* pos, const float* scale, const float* shift,
+                                                            const bf16_t* feat, int ld_feat, int N, int H, int W, int C,
+                                                            bf16_t* geo) {
+    const int c8 = C / 8;
+    const int64_t hw = (int64_t)H * W;
+    const int64_t total = (int64_t)N * hw * 9 * c8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int oc = (int)(i % c8);
+        const int64_t pk = i / c8;  // p*9 + k
+        const int k = (int)(pk % 9);
+        const int64_t p = pk / 9;
+        const int64_t n = p / hw;
+        const int64_t r = p - n * hw;
+        const int h = (int)(r / W), w = (int)(r - (int64_t)h * W);
+        const int hn = h + k / 3 - 1, wn = w + k % 3 - 1;
+        float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (hn >= 0 && hn < H && wn >= 0 && wn < W) {
+            float a[8], f[8];
+            unpack8(*(const u32x4*)(pos + pk * C + oc * 8), a);
+            unpack8(*(const u32x4*)(feat + (n * hw + (int64_t)hn * W + wn) * ld_feat + oc * 8), f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = fmaxf(a[j] * scale[oc * 8 + j] + shift[oc * 8 + j], 0.f) * f[j];
+        }
+        *(u32x4*)(geo + pk * C + oc * 8) = pack8(o);
+    }
+}
+
+// dpos_act[p*9+k][c] = dgeo[p][k*C+c] * feat[nbr_k(p)][c]
+__global__ __launch_bounds__(256) void meta_modulate_bwd_pos_kernel(const bf16_t* dgeo, const bf16_t* feat, int ld_feat,
+                                                                    int N, int H, int W, int C, bf16_t* dpos) {
+    const int c8 = C / 8;
+    const int64_t hw = (int64_t)H * W;
+    const int64_t total = (int64_t)N * hw * 9 * c8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int oc = (int)(i % c8);
+        const int64_t pk = i / c8;
+        const int k = (int)(pk % 9);
+        const int64_t p = pk / 9;
+        const int64_t n = p / hw;
+        const int64_t r = p - n * hw;
+        const int h = (int)(r / W), w = (int)(r - (int64_t)h * W);
+        const int hn = h + k / 3 - 1, wn = w + k % 3 - 1;
+        float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (hn >= 0 && hn < H && wn >= 0 && wn < W) {
+            float g[8], f[8];
+            unpack8(*(const u32x4*)(dgeo + pk * C + oc * 8), g);
+            unpack8(*(const u32x4*)(feat + (n * hw + (int64_t)hn * W + wn) * ld_feat + oc * 8), f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = g[j] * f[j];
+        }
+        *(u32x4*)(dpos + pk * C + oc * 8) = pack8(o);
+    }
+}
+
+// dfeat[q][c] = sum_k dgeo[p_k][k*C+c] * relu(scale*pos[p_k*9+k][c]+shift),  p_k = q - offset_k (the pixel whose
+// k-th neighbour is q)
+__global__ __launch_bounds__(256) void meta_modulate_bwd_feat_kernel(const bf16_t* dgeo, const bf16_t* pos,
+                                                                     const float* scale, const float* shift, int N, int H,
+                                                                     int W, int C, bf16_t* dfeat, int ld_dfeat) {
+    const int c8 = C / 8;
+    const int64_t hw = (int64_t)H * W;
+    const int64_t total = (int64_t)N * hw * c8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int oc = (int)(i % c8);
+        const int64_t q = i / c8;
+        const int64_t n = q / hw;
+        const int64_t r = q - n * hw;
+        const int h = (int)(r / W), w = (int)(r - (int64_t)h * W);
+        float sc[8], sh[8], acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            sc[j] = scale[oc * 8 + j];
+            sh[j] = shift[oc * 8 + j];
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int hp = h - (k / 3 - 1), wp = w - (k % 3 - 1);
+            if (hp < 0 || hp >= H || wp < 0 || wp >= W) continue;
+            const int64_t pk = (n * hw + (int64_t)hp * W + wp) * 9 + k;
+            float g[8], a[8];
+            unpack8(*(const u32x4*)(dgeo + pk * C + oc * 8), g);
+            unpack8(*(const u32x4*)(pos + pk * C + oc * 8), a);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += g[j] * fmaxf(a[j] * sc[j] + sh[j], 0.f);
+        }
+        *(u32x4*)(dfeat + q * ld_dfeat + oc * 8) = pack8(acc);
+    }
+}
+
+int grid_for(int64_t work) {
+    int64_t b = (work + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 256 * 16 ? 256 * 16 : b));
+}
+
+}  // namespace
+
+extern "C" int rv_meta_relative(const float* cart_nchw, int32_t N, int32_t H, int32_t W, void* rel, rvStream stream) {
+    RV_REQUIRE(cart_nchw && rel, "rv_meta_relative: null argument");
+    hipLaunchKernelGGL(meta_relative_kernel, dim3(grid_for((int64_t)N * H * W * 9)), dim3(256), 0, (hipStream_t)stream,
+                       cart_nchw, N, H, W, (bf16_t*)rel);
+    RV_CHECK_LAUNCH("meta_relative_kernel");
+    return 0;
+}
+
+extern "C" int rv_meta_modulate(const void* pos_raw, const float* scale, const float* shift, const void* feat,
+                                int32_t ld_feat, int32_t N, int32_t H, int32_t W, int32_t C, void* geo, rvStream stream) {
+    RV_REQUIRE(pos_raw && scale && shift && feat && geo, "rv_meta_modulate: null argument");
+    RV_REQUIRE(C % 8 == 0 && ld_feat % 8 == 0, "rv_meta_modulate: channels must be a multiple of 8");
+    hipLaunchKernelGGL(meta_modulate_kernel, dim3(grid_for((int64_t)N * H * W * 9 * (C / 8))), dim3(256), 0,
+                       (hipStream_t)stream, (const bf16_t*)pos_raw, scale, shift, (const bf16_t*)feat, ld_feat, N, H, W, C,
+                       (bf16_t*)geo);
+    RV_CHECK_LAUNCH("meta_modulate_kernel");
+    return 0;
+}
+
+extern "C" int rv_meta_modulate_bwd(const void* dgeo, const void* pos_raw, const float* scale, const float* shift,
+                                    const void* feat, int32_t ld_feat, int32_t N, int32_t H, int32_t W, int32_t C,
+                                    void* dpos_act, void* dfeat, int32_t ld_dfeat, rvStream stream) {
+    RV_REQUIRE(dgeo && pos_raw && scale && shift && feat && dpos_act && dfeat, "rv_meta_modulate_bwd: null argument");
+    RV_REQUIRE(C % 8 == 0 && ld_feat % 8 == 0 && ld_dfeat % 8 == 0, "rv_meta_modulate_bwd: channels must be a multiple of 8");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(meta_modulate_bwd_pos_kernel, dim3(grid_for((int64_t)N * H * W * 9 * (C / 8))), dim3(256), 0, st,
+                       (const bf16_t*)dgeo, (const bf16_t*)feat, ld_feat, N, H, W, C, (bf16_t*)dpos_act);
+    hipLaunchKernelGGL(meta_modulate_bwd_feat_kernel, dim3(grid_for((int64_t)N * H * W * (C / 8))), dim3(256), 0, st,
+                       (const bf16_t*)dgeo, (const bf16_t*)pos_raw, scale, shift, N, H, W, C, (bf16_t*)dfeat, ld_dfeat);
+    RV_CHECK_LAUNCH("meta_modulate_bwd kernels");
+    return 0;
+}

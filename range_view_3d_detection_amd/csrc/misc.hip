@@ -1,0 +1,392 @@
+// misc.hip -- error state, weight packing, BatchNorm finalisation, element-wise combine and
+// layout conversion kernels (all HBM-bound byte movers: coalesced 16-byte accesses, no MFMA).
+#include <stdarg.h>
+
+#include "common.h"
+#include "tapconv.h"
+
+// ---------------------------------------------------------------------------------------------
+// error state
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void rv_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* rv_last_error(void) { return g_err; }
+extern "C" int rv_version(void) { return 100; }
+extern "C" int32_t rv_pad_channels(int32_t c) { return rv_pad32(c); }
+
+// ---------------------------------------------------------------------------------------------
+// weight packing
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct PackArgs {
+    const float* T;
+    bf16_t* out;
+    int cu, cv, cu_pad, cv_pad, kh, kw;
+    int scatter;
+    TapTable tt;
+    int phases;
+};
+
+__global__ void pack_weight_kernel(const PackArgs a) {
+    const int taps = a.kh * a.kw;
+    const int64_t per_img = (int64_t)a.cu_pad * a.cv_pad;
+    const int64_t total = per_img * taps;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int img = (int)(i / per_img);
+        const int64_t rem = i - img * per_img;
+        int ky, kx, u, v;
+        if (!a.scatter) {  // [tap][cu_pad][cv_pad]
+            ky = img / a.kw;
+            kx = img - ky * a.kw;
+            u = (int)(rem / a.cv_pad);
+            v = (int)(rem - (int64_t)u * a.cv_pad);
+        } else {  // [phase-major tap][cv_pad][cu_pad]
+            int r = 0, idx = img;
+            while (r < a.phases - 1 && idx >= a.tt.ntaps[r]) idx -= a.tt.ntaps[r++];
+            ky = a.tt.ky[r][idx];
+            kx = a.tt.kx[r][idx];
+            v = (int)(rem / a.cu_pad);
+            u = (int)(rem - (int64_t)v * a.cu_pad);
+        }
+        float w = 0.f;
+        if (u < a.cu && v < a.cv) w = a.T[(((int64_t)u * a.cv + v) * a.kh + ky) * a.kw + kx];
+        a.out[i] = f2bf(w);
+    }
+}
+
+__global__ void unpack_wgrad_kernel(const float* packed, float* dT, int cu, int cv, int cu_pad, int cv_pad, int kh,
+                                    int kw, int accumulate) {
+    const int64_t total = (int64_t)cu * cv * kh * kw;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = i;
+        const int kx = (int)(r % kw);
+        r /= kw;
+        const int ky = (int)(r % kh);
+        r /= kh;
+        const int v = (int)(r % cv);
+        const int u = (int)(r / cv);
+        const float g = packed[((int64_t)(ky * kw + kx) * cu_pad + u) * cv_pad + v];
+        dT[i] = accumulate ? dT[i] + g : g;
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t rv_packed_weight_bytes(const rvTapGeom* g) {
+    return (int64_t)g->kh * g->kw * rv_pad32(g->cu) * rv_pad32(g->cv) * (int64_t)sizeof(bf16_t);
+}
+
+extern "C" int rv_pack_weight(const rvTapGeom* g, const float* T, void* gather_w, void* scatter_w, rvStream stream) {
+    RV_REQUIRE(g && T, "rv_pack_weight: null argument");
+    for (int form = 0; form < 2; ++form) {
+        void* out = form ? scatter_w : gather_w;
+        if (!out) continue;
+        PackArgs a;
+        memset(&a, 0, sizeof(a));
+        int step;
+        if (rv_build_tap_table(g, form == 1, &a.tt, &a.phases, &step)) return 1;
+        a.T = T;
+        a.out = (bf16_t*)out;
+        a.cu = g->cu;
+        a.cv = g->cv;
+        a.cu_pad = rv_pad32(g->cu);
+        a.cv_pad = rv_pad32(g->cv);
+        a.kh = g->kh;
+        a.kw = g->kw;
+        a.scatter = form;
+        const int64_t total = (int64_t)a.kh * a.kw * a.cu_pad * a.cv_pad;
+        const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+        RV_CHECK_LAUNCH("pack_weight_kernel");
+    }
+    return 0;
+}
+
+extern "C" int rv_unpack_weight_grad(const rvTapGeom* g, const float* packed, float* dT, int32_t accumulate,
+                                     rvStream stream) {
+    RV_REQUIRE(g && packed && dT, "rv_unpack_weight_grad: null argument");
+    const int64_t total = (int64_t)g->cu * g->cv * g->kh * g->kw;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, packed, dT, g->cu, g->cv,
+                       rv_pad32(g->cu), rv_pad32(g->cv), g->kh, g->kw, accumulate);
+    RV_CHECK_LAUNCH("unpack_wgrad_kernel");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// column reduction of partial rows: in[rows][cols] (fp32) -> out[groups][cols] (fp64)
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int kRedGroups = 64;
+
+__global__ __launch_bounds__(256) void col_reduce_kernel(const float* in, int rows, int cols, double* out) {
+    // block: 32 columns x 8 row lanes; blockIdx.y = row group
+    __shared__ double red[8][33];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int col = blockIdx.x * 32 + cx;
+    const int per = (rows + gridDim.y - 1) / gridDim.y;
+    const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+    double acc = 0.0;
+    if (col < cols)
+        for (int r = r0 + ry; r < r1; r += 8) acc += (double)in[(int64_t)r * cols + col];
+    red[ry][cx] = acc;
+    __syncthreads();
+    if (ry == 0 && col < cols) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += red[k][cx];
+        out[(int64_t)blockIdx.y * cols + col] = s;
+    }
+}
+
+__global__ void bn_finalize_kernel(const double* red, int groups, int c, double inv_count, double unbias,
+                                   const float* gamma, const float* beta, float eps, float momentum,
+                                   float* running_mean, float* running_var, float* scale, float* shift, float* mean_out,
+                                   float* invstd_out) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    double s = 0.0, q = 0.0;
+    for (int g = 0; g < groups; ++g) {
+        s += red[(int64_t)g * 2 * c + ch];
+        q += red[(int64_t)g * 2 * c + c + ch];
+    }
+    const double mean = s * inv_count;
+    double var = q * inv_count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    const double sc = (double)gamma[ch] * invstd;
+    scale[ch] = (float)sc;
+    shift[ch] = (float)((double)beta[ch] - mean * sc);
+    if (mean_out) mean_out[ch] = (float)mean;
+    if (invstd_out) invstd_out[ch] = (float)invstd;
+    if (running_mean) running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * mean);
+    if (running_var) running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * var * unbias);
+}
+
+__global__ void bn_fold_eval_kernel(int c, const float* gamma, const float* beta, const float* rm, const float* rv,
+                                    float eps, float* scale, float* shift) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    const double sc = (double)gamma[ch] / sqrt((double)rv[ch] + (double)eps);
+    scale[ch] = (float)sc;
+    shift[ch] = (float)((double)beta[ch] - (double)rm[ch] * sc);
+}
+
+}  // namespace
+
+// scratch: the caller's partial buffer must have room for kRedGroups extra rows of 2*c doubles
+// == 2 * kRedGroups rows of 2*c floats after the `rows` partial rows (documented in rv3d.h).
+int rv_col_reduce(const float* partial, int rows, int cols, double* scratch, int* groups, hipStream_t st) {
+    int g = rows < kRedGroups ? rows : kRedGroups;
+    if (g < 1) g = 1;
+    *groups = g;
+    hipLaunchKernelGGL(col_reduce_kernel, dim3(rv_ceil_div(cols, 32), g), dim3(256), 0, st, partial, rows, cols, scratch);
+    RV_CHECK_LAUNCH("col_reduce_kernel");
+    return 0;
+}
+
+extern "C" int rv_bn_finalize(const float* partial, int32_t rows, int32_t c, int64_t count, const float* gamma,
+                              const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                              float* scale, float* shift, float* mean, float* invstd, rvStream stream) {
+    RV_REQUIRE(partial && gamma && beta && scale && shift, "rv_bn_finalize: null argument");
+    RV_REQUIRE(rows > 0 && c > 0 && count > 0, "rv_bn_finalize: empty reduction");
+    double* scratch = (double*)(partial + (int64_t)rows * 2 * c);
+    int groups;
+    if (rv_col_reduce(partial, rows, 2 * c, scratch, &groups, (hipStream_t)stream)) return 1;
+    const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(rv_ceil_div(c, 64)), dim3(64), 0, (hipStream_t)stream, scratch, groups, c,
+                       1.0 / (double)count, unbias, gamma, beta, eps, momentum, running_mean, running_var, scale, shift,
+                       mean, invstd);
+    RV_CHECK_LAUNCH("bn_finalize_kernel");
+    return 0;
+}
+
+extern "C" int rv_bn_fold_eval(int32_t c, const float* gamma, const float* beta, const float* running_mean,
+                               const float* running_var, float eps, float* scale, float* shift, rvStream stream) {
+    RV_REQUIRE(gamma && beta && running_mean && running_var && scale && shift, "rv_bn_fold_eval: null argument");
+    hipLaunchKernelGGL(bn_fold_eval_kernel, dim3(rv_ceil_div(c, 64)), dim3(64), 0, (hipStream_t)stream, c, gamma, beta,
+                       running_mean, running_var, eps, scale, shift);
+    RV_CHECK_LAUNCH("bn_fold_eval_kernel");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// element-wise combine: out = relu?( fa(a) + fb(b) )
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct EwArgs {
+    const bf16_t* a;
+    const bf16_t* b;
+    bf16_t* out;
+    const float *a_scale, *a_shift, *b_scale, *b_shift;
+    int64_t pixels;
+    int c8;  // channel octets
+    int ld_a, ld_b, ld_out;
+    int flags;
+};
+
+__device__ __forceinline__ void load8(const bf16_t* p, float* f) {
+    const u32x4 v = *(const u32x4*)p;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f[2 * j] = bf_lo(v[j]);
+        f[2 * j + 1] = bf_hi(v[j]);
+    }
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float* f) {
+    u32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = pack_bf2(f[2 * j], f[2 * j + 1]);
+    *(u32x4*)p = v;
+}
+
+__global__ __launch_bounds__(256) void ew_combine_kernel(const EwArgs e) {
+    const int64_t total = e.pixels * e.c8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t px = i / e.c8;
+        const int c = (int)(i - px * e.c8) * 8;
+        float va[8], vb[8];
+        load8(e.a + px * e.ld_a + c, va);
+        if (e.a_scale) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) va[j] = va[j] * e.a_scale[c + j] + e.a_shift[c + j];
+        }
+        if (e.flags & RV_EW_RELU_A) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) va[j] = fmaxf(va[j], 0.f);
+        }
+        if (e.b) {
+            load8(e.b + px * e.ld_b + c, vb);
+            if (e.b_scale) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) vb[j] = vb[j] * e.b_scale[c + j] + e.b_shift[c + j];
+            }
+            if (e.flags & RV_EW_RELU_B) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) vb[j] = fmaxf(vb[j], 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) va[j] += vb[j];
+        }
+        if (e.flags & RV_EW_RELU_OUT) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) va[j] = fmaxf(va[j], 0.f);
+        }
+        store8(e.out + px * e.ld_out + c, va);
+    }
+}
+
+}  // namespace
+
+static int ew_grid(int64_t work) {
+    int64_t b = (work + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 256 * 8 ? 256 * 8 : b));
+}
+
+extern "C" int rv_ew_combine(int64_t pixels, int32_t c, const void* a, int32_t ld_a, const float* a_scale,
+                             const float* a_shift, const void* b, int32_t ld_b, const float* b_scale,
+                             const float* b_shift, void* out, int32_t ld_out, int32_t flags, rvStream stream) {
+    RV_REQUIRE(a && out, "rv_ew_combine: null argument");
+    RV_REQUIRE(c % 8 == 0 && ld_a % 8 == 0 && ld_out % 8 == 0 && (!b || ld_b % 8 == 0), "rv_ew_combine: channels / strides must be multiples of 8");
+    RV_REQUIRE((a_scale == nullptr) == (a_shift == nullptr) && (b_scale == nullptr) == (b_shift == nullptr), "rv_ew_combine: scale and shift go together");
+    EwArgs e{(const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, a_scale, a_shift, b_scale, b_shift, pixels, c / 8, ld_a, ld_b, ld_out, flags};
+    hipLaunchKernelGGL(ew_combine_kernel, dim3(ew_grid(pixels * (c / 8))), dim3(256), 0, (hipStream_t)stream, e);
+    RV_CHECK_LAUNCH("ew_combine_kernel");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// layout conversion at the module boundary
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+// one thread per pixel; reads are coalesced along W, the few channels are written as one run
+template <typename DstT>
+__global__ void nchw_to_nhwc_kernel(const float* src, int N, int C, int H, int W, DstT* dst, int ld, int c_off) {
+    const int64_t hw = (int64_t)H * W, total = (int64_t)N * hw;
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = p / hw, r = p - n * hw;
+        for (int c = 0; c < C; ++c) {
+            const float v = src[(n * C + c) * hw + r];
+            if constexpr (sizeof(DstT) == 2)
+                dst[p * ld + c_off + c] = f2bf(v);
+            else
+                dst[p * ld + c_off + c] = v;
+        }
+    }
+}
+
+template <typename SrcT>
+__global__ void nhwc_to_nchw_kernel(const SrcT* src, int ld, int c_off, int N, int C, int H, int W, float* dst) {
+    // tile: 64 pixels x 32 channels through LDS so that both sides are coalesced
+    __shared__ float tile[32][65];
+    const int64_t hw = (int64_t)H * W;
+    const int64_t p0 = (int64_t)blockIdx.x * 64;  // pixel tile (within N*H*W)
+    const int c0 = blockIdx.y * 32;
+    const int64_t total = (int64_t)N * hw;
+    for (int i = threadIdx.x; i < 64 * 32; i += blockDim.x) {
+        const int px = i >> 5, c = i & 31;
+        float v = 0.f;
+        if (p0 + px < total && c0 + c < C) {
+            if constexpr (sizeof(SrcT) == 2)
+                v = bf2f(src[(p0 + px) * ld + c_off + c0 + c]);
+            else
+                v = src[(p0 + px) * ld + c_off + c0 + c];
+        }
+        tile[c][px] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 32; i += blockDim.x) {
+        const int c = i >> 6, px = i & 63;
+        const int64_t p = p0 + px;
+        if (p < total && c0 + c < C) {
+            const int64_t n = p / hw, r = p - n * hw;
+            dst[(n * C + c0 + c) * hw + r] = tile[c][px];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int rv_nchw_f32_to_nhwc_bf16(const float* src, int32_t N, int32_t C, int32_t H, int32_t W, void* dst,
+                                        int32_t ld_dst, int32_t c_offset, rvStream stream) {
+    RV_REQUIRE(src && dst && c_offset + C <= ld_dst, "rv_nchw_f32_to_nhwc_bf16: bad arguments");
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(ew_grid((int64_t)N * H * W)), dim3(256), 0, (hipStream_t)stream,
+                       src, N, C, H, W, (bf16_t*)dst, ld_dst, c_offset);
+    RV_CHECK_LAUNCH("nchw_to_nhwc_kernel");
+    return 0;
+}
+extern "C" int rv_nchw_f32_to_nhwc_f32(const float* src, int32_t N, int32_t C, int32_t H, int32_t W, float* dst,
+                                       int32_t ld_dst, rvStream stream) {
+    RV_REQUIRE(src && dst && C <= ld_dst, "rv_nchw_f32_to_nhwc_f32: bad arguments");
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(ew_grid((int64_t)N * H * W)), dim3(256), 0, (hipStream_t)stream,
+                       src, N, C, H, W, dst, ld_dst, 0);
+    RV_CHECK_LAUNCH("nchw_to_nhwc_kernel");
+    return 0;
+}
+extern "C" int rv_nhwc_bf16_to_nchw_f32(const void* src, int32_t ld_src, int32_t c_offset, int32_t N, int32_t C,
+                                        int32_t H, int32_t W, float* dst, rvStream stream) {
+    RV_REQUIRE(src && dst && c_offset + C <= ld_src, "rv_nhwc_bf16_to_nchw_f32: bad arguments");
+    const int64_t total = (int64_t)N * H * W;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3((unsigned)((total + 63) / 64), rv_ceil_div(C, 32)), dim3(256), 0,
+                       (hipStream_t)stream, (const bf16_t*)src, ld_src, c_offset, N, C, H, W, dst);
+    RV_CHECK_LAUNCH("nhwc_to_nchw_kernel");
+    return 0;
+}
+extern "C" int rv_nhwc_f32_to_nchw_f32(const float* src, int32_t ld_src, int32_t N, int32_t C, int32_t H, int32_t W,
+                                       float* dst, rvStream stream) {
+    RV_REQUIRE(src && dst && C <= ld_src, "rv_nhwc_f32_to_nchw_f32: bad arguments");
+    const int64_t total = (int64_t)N * H * W;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3((unsigned)((total + 63) / 64), rv_ceil_div(C, 32)), dim3(256), 0,
+                       (hipStream_t)stream, src, ld_src, 0, N, C, H, W, dst);
+    RV_CHECK_LAUNCH("nhwc_to_nchw_kernel");
+    return 0;
+}

@@ -1,0 +1,236 @@
+// nms.hip -- weighted NMS on device; replaces `weighted_nms_ext.wnms_gpu` (math/ops/nms.py:161-170).
+//
+// The third-party kernel's arithmetic is not in the reference tree (parity unpinned); this
+// file implements the semantics declared in oracle/nms.py and matches oracle/c/oracle.c bit for
+// bit (compiled with -ffp-contract=off; IEEE division; sin/cos of the yaw are fp32 roundings of
+// the fp64 values).  Three stages, all wavefront-level integer/bit work:
+//   1. pairwise rotated-BEV-IoU bit masks (upper triangle): one 64-lane wave = 64 boxes x one
+//      64-box column block staged in LDS; two u64 words per lane (IoU > nms, IoU > merge);
+//   2. the inherently sequential scan over boxes in score order: one workgroup keeps the
+//      suppressed-set bit vector in LDS; per kept box it ORs one mask row into it and masks the
+//      merge row with the boxes still alive (=> cluster membership);
+//   3. cluster merge: one wave per kept box, lanes = data columns, members visited in ascending
+//      index order (fixed summation order => reproducible).
+#include "common.h"
+
+namespace {
+
+struct Pt {
+    float x, y;
+};
+
+__device__ __forceinline__ float cross2(Pt a, Pt b, Pt p) { return (b.x - a.x) * (p.y - a.y) - (b.y - a.y) * (p.x - a.x); }
+
+__device__ void corners(const float* b, float s, float c, Pt* out) {
+    const float cx = (b[0] + b[2]) * 0.5f, cy = (b[1] + b[3]) * 0.5f;
+    const float hx = (b[2] - b[0]) * 0.5f, hy = (b[3] - b[1]) * 0.5f;
+    const float dx[4] = {hx, -hx, -hx, hx};
+    const float dy[4] = {hy, hy, -hy, -hy};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        out[k].x = cx + (dx[k] * c - dy[k] * s);
+        out[k].y = cy + (dx[k] * s + dy[k] * c);
+    }
+}
+
+// rectangle A clipped by the four half-planes of rectangle B (Sutherland-Hodgman), shoelace area
+__device__ float rotated_iou(const float* a, float sa, float ca, const float* b, float sb, float cb) {
+    const float area_a = (a[2] - a[0]) * (a[3] - a[1]);
+    const float area_b = (b[2] - b[0]) * (b[3] - b[1]);
+    if (!(area_a > 0.0f) || !(area_b > 0.0f)) return 0.0f;
+    Pt pa[4], pb[4], poly[16], tmp[16];
+    corners(a, sa, ca, pa);
+    corners(b, sb, cb, pb);
+    int n = 4;
+    for (int k = 0; k < 4; ++k) poly[k] = pa[k];
+    for (int e = 0; e < 4 && n > 0; ++e) {
+        const Pt e0 = pb[e], e1 = pb[(e + 1) & 3];
+        int m = 0;
+        for (int k = 0; k < n; ++k) {
+            const Pt p = poly[k], q = poly[(k + 1 == n) ? 0 : k + 1];
+            const float dp = cross2(e0, e1, p), dq = cross2(e0, e1, q);
+            const bool in_p = dp >= 0.0f, in_q = dq >= 0.0f;
+            if (in_p) tmp[m++] = p;
+            if (in_p != in_q) {
+                const float t = dp / (dp - dq);
+                Pt r;
+                r.x = p.x + t * (q.x - p.x);
+                r.y = p.y + t * (q.y - p.y);
+                tmp[m++] = r;
+            }
+        }
+        n = m;
+        for (int k = 0; k < n; ++k) poly[k] = tmp[k];
+    }
+    if (n < 3) return 0.0f;
+    float twice = 0.0f;
+    for (int k = 0; k < n; ++k) {
+        const Pt p = poly[k], q = poly[(k + 1 == n) ? 0 : k + 1];
+        twice += (p.x - poly[0].x) * (q.y - poly[0].y) - (p.y - poly[0].y) * (q.x - poly[0].x);
+    }
+    const float inter = 0.5f * fabsf(twice);
+    const float uni = area_a + area_b - inter;
+    if (!(uni > 0.0f)) return 0.0f;
+    return inter / uni;
+}
+
+__global__ void sincos_kernel(const float* boxes, int64_t n, float* sc) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double ry = (double)boxes[i * 5 + 4];
+        sc[2 * i] = (float)sin(ry);
+        sc[2 * i + 1] = (float)cos(ry);
+    }
+}
+
+// grid (col_block, row_block); only col_block >= row_block does work
+__global__ __launch_bounds__(64) void iou_mask_kernel(const float* boxes, const float* sc, int64_t n, int cb, float nms_t,
+                                                      float merge_t, unsigned long long* nms_mask,
+                                                      unsigned long long* merge_mask) {
+    const int col = blockIdx.x, row = blockIdx.y;
+    if (col < row) return;
+    __shared__ float cbox[64][7];
+    const int t = threadIdx.x;
+    const int64_t j0 = (int64_t)col * 64;
+    if (j0 + t < n) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) cbox[t][k] = boxes[(j0 + t) * 5 + k];
+        cbox[t][5] = sc[2 * (j0 + t)];
+        cbox[t][6] = sc[2 * (j0 + t) + 1];
+    }
+    __syncthreads();
+    const int64_t i = (int64_t)row * 64 + t;
+    if (i >= n) return;
+    float a[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) a[k] = boxes[i * 5 + k];
+    const float sa = sc[2 * i], ca = sc[2 * i + 1];
+    unsigned long long bits_n = 0ull, bits_m = 0ull;
+    const int jn = (int)((n - j0) < 64 ? (n - j0) : 64);
+    for (int j = 0; j < jn; ++j) {
+        if (j0 + j <= i) continue;
+        const float iou = rotated_iou(a, sa, ca, cbox[j], cbox[j][5], cbox[j][6]);
+        if (iou > nms_t) bits_n |= 1ull << j;
+        if (iou > merge_t) bits_m |= 1ull << j;
+    }
+    nms_mask[i * cb + col] = bits_n;
+    merge_mask[i * cb + col] = bits_m;
+}
+
+// one workgroup; remv (suppressed set) lives in LDS
+__global__ __launch_bounds__(1024) void scan_kernel(int64_t n, int cb, const unsigned long long* nms_mask,
+                                                    unsigned long long* merge_mask, long long* keep, long long* num_out) {
+    extern __shared__ unsigned long long remv[];
+    for (int w = threadIdx.x; w < cb; w += blockDim.x) remv[w] = 0ull;
+    __syncthreads();
+    long long kept = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const int wi = (int)(i >> 6);
+        if (remv[wi] & (1ull << (i & 63))) continue;  // uniform: every thread reads the same word
+        if (threadIdx.x == 0) keep[kept] = i;
+        ++kept;
+        __syncthreads();  // all threads have evaluated the branch on the old remv
+        for (int w = wi + threadIdx.x; w < cb; w += blockDim.x) {
+            const unsigned long long alive = ~remv[w];
+            merge_mask[i * cb + w] &= alive;  // cluster = merge candidates not suppressed before i was visited
+            remv[w] |= nms_mask[i * cb + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *num_out = kept;
+}
+
+// one wave per kept box; lane = data column
+__global__ __launch_bounds__(64) void merge_kernel(const float* data, int d, int cb, const unsigned long long* merge_mask,
+                                                   const long long* keep, const long long* num_out, float* output,
+                                                   long long* count) {
+    const long long o = blockIdx.x;
+    if (o >= *num_out) return;
+    const long long i = keep[o];
+    const int c = threadIdx.x;
+    const bool active = c < d;
+    const float wi = data[i * d + d - 1];
+    float acc = active ? wi * data[i * d + c] : 0.f;
+    float wsum = wi;
+    long long members = 1;
+    for (int w = (int)(i >> 6); w < cb; ++w) {
+        unsigned long long bits = merge_mask[i * cb + w];
+        while (bits) {
+            const int b = __ffsll((long long)bits) - 1;
+            bits &= bits - 1;
+            const long long j = (long long)w * 64 + b;
+            const float wj = data[j * d + d - 1];
+            if (active) acc += wj * data[j * d + c];
+            wsum += wj;
+            ++members;
+        }
+    }
+    if (active) output[o * d + c] = acc / wsum;
+    if (c == 0) count[o] = members;
+}
+
+__global__ void pairwise_iou_kernel(const float* a, int64_t n, const float* b, int64_t m, float* out) {
+    const int64_t total = n * m;
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < total; k += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = k / m, j = k - i * m;
+        const float sa = (float)sin((double)a[i * 5 + 4]), ca = (float)cos((double)a[i * 5 + 4]);
+        const float sb = (float)sin((double)b[j * 5 + 4]), cb = (float)cos((double)b[j * 5 + 4]);
+        out[k] = rotated_iou(a + i * 5, sa, ca, b + j * 5, sb, cb);
+    }
+}
+
+}  // namespace
+
+static int64_t align256(int64_t v) { return (v + 255) & ~255ll; }
+
+extern "C" int64_t rv_wnms_workspace_bytes(int64_t n) {
+    const int64_t cb = (n + 63) / 64;
+    return 2 * align256(n * cb * 8) + align256(n * 2 * 4) + 256;
+}
+
+extern "C" int rv_wnms(const float* boxes, const float* data, int64_t n, int32_t d, float nms_thresh, float merge_thresh,
+                       float* output, int64_t* keep, int64_t* count, void* workspace, int64_t* host_num_out,
+                       rvStream stream) {
+    RV_REQUIRE(host_num_out, "rv_wnms: null host_num_out");
+    *host_num_out = 0;
+    if (n == 0) return 0;
+    RV_REQUIRE(boxes && data && output && keep && count && workspace, "rv_wnms: null argument");
+    RV_REQUIRE(d >= 1 && d <= 64, "rv_wnms: data width %d unsupported (1..64)", d);
+    const int64_t cb64 = (n + 63) / 64;
+    RV_REQUIRE(cb64 * 8 <= 160 * 1024, "rv_wnms: too many boxes (%lld)", (long long)n);
+    const int cb = (int)cb64;
+    hipStream_t st = (hipStream_t)stream;
+    uint8_t* ws = (uint8_t*)workspace;
+    unsigned long long* nms_mask = (unsigned long long*)ws;
+    unsigned long long* merge_mask = (unsigned long long*)(ws + align256(n * cb64 * 8));
+    float* sc = (float*)(ws + 2 * align256(n * cb64 * 8));
+    long long* num_out = (long long*)(ws + 2 * align256(n * cb64 * 8) + align256(n * 2 * 4));
+    hipLaunchKernelGGL(sincos_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, boxes, n, sc);
+    hipLaunchKernelGGL(iou_mask_kernel, dim3(cb, cb), dim3(64), 0, st, boxes, sc, n, cb, nms_thresh, merge_thresh, nms_mask,
+                       merge_mask);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(cb < 1024 ? ((cb + 63) / 64) * 64 : 1024), (size_t)cb * 8, st, n, cb,
+                       nms_mask, merge_mask, (long long*)keep, num_out);
+    hipLaunchKernelGGL(merge_kernel, dim3((unsigned)n), dim3(64), 0, st, data, d, cb, merge_mask, (const long long*)keep,
+                       num_out, output, (long long*)count);
+    RV_CHECK_LAUNCH("wnms kernels");
+    long long host = 0;
+    hipError_t e = hipMemcpyAsync(&host, num_out, sizeof(host), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) RV_FAIL("rv_wnms: %s", hipGetErrorString(e));
+    *host_num_out = host;
+    return 0;
+}
+
+extern "C" int rv_rotated_iou(const float* a, int64_t n, const float* b, int64_t m, float* out, rvStream stream) {
+    if (n * m == 0) return 0;
+    RV_REQUIRE(a && b && out, "rv_rotated_iou: null argument");
+    const int64_t blocks = (n * m + 255) / 256;
+    hipLaunchKernelGGL(pairwise_iou_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream,
+                       a, n, b, m, out);
+    RV_CHECK_LAUNCH("pairwise_iou_kernel");
+    return 0;
+}

@@ -1,0 +1,124 @@
+// project.hip -- range-image projection: spherical binning + z-buffer (integer/atomic work, HBM-bound).
+//
+// Reference: cart_to_sph + build_range_view_coordinates + z_buffer,
+//   converters/av2/utils.py:108-208  (converter binning)  ==  math/numpy/conversions.py:9-128 (library binning).
+//
+// The reference z-buffer is a sequential scan: point i takes pixel p iff range_i (fp64) <
+// buffer[p] (fp32 rounding of the current owner's range).  That scan has a closed form, which
+// is what the three passes below evaluate with 64-bit atomics (result identical to the scan,
+// including the fp64-vs-fp32 quirk):
+//   Bmin(p)  = min_i fp32(range_i)                      (the buffer only ever decreases to this)
+//   i0(p)    = smallest index with fp32(range_i) == Bmin (the point that first writes Bmin)
+//   L(p)     = { i : fp32(range_i) == Bmin and range_i < (fp64)Bmin }   (they all come at or after i0
+//              and each of them overwrites the pixel again)
+//   owner(p) = max(L) if L is non-empty else i0.
+// Pass 1: atomicMin on (float_bits(fp32 range) << 32 | index)  -> Bmin, i0.
+// Pass 2: atomicMax(winner[p], i) over L.       Pass 3: gather the owner's features.
+#include "common.h"
+
+namespace {
+
+__global__ void project_indices_kernel(const double* cart, const int32_t* laser, const int32_t* laser_mapping, int64_t n,
+                                       int H, int W, int variant, int32_t* rows, int32_t* cols, double* range) {
+    const double kPi = 3.141592653589793, kTau = 6.283185307179586;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double x = cart[3 * i], y = cart[3 * i + 1], z = cart[3 * i + 2];
+        const double hyp = hypot(x, y);
+        const double r = hypot(hyp, z);
+        double az = atan2(y, x);
+        az += kPi;
+        az *= (double)W / kTau;
+        double col = variant == 0 ? (double)W - rint(az) : rint((double)W - az - 1.0);  // rint: round-half-even
+        col = fmin(fmax(col, 0.0), (double)(W - 1));
+        rows[i] = H - laser_mapping[laser[i]] - 1;
+        cols[i] = (int32_t)col;
+        range[i] = r;
+    }
+}
+
+__global__ void zbuf_init_kernel(uint64_t* keys, int64_t* winner, int64_t n_pix) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_pix; i += (int64_t)gridDim.x * blockDim.x) {
+        keys[i] = ~0ull;
+        winner[i] = -1;
+    }
+}
+
+__device__ __forceinline__ bool zbuf_pixel(const int32_t* rows, const int32_t* cols, const double* range, int64_t i, int H,
+                                           int W, double min_range, int64_t* pix) {
+    const int r = rows[i], c = cols[i];
+    if (r < 0 || r >= H || c < 0 || c >= W) return false;
+    if (range[i] < min_range) return false;
+    *pix = (int64_t)r * W + c;
+    return true;
+}
+
+__global__ void zbuf_min_kernel(const int32_t* rows, const int32_t* cols, const double* range, int64_t n, int H, int W,
+                                double min_range, unsigned long long* keys) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t p;
+        if (!zbuf_pixel(rows, cols, range, i, H, W, min_range, &p)) continue;
+        const float rf = (float)range[i];  // round-to-nearest-even, as the fp32 buffer store does
+        const unsigned long long key = ((unsigned long long)__float_as_uint(rf) << 32) | (unsigned long long)(uint32_t)i;
+        atomicMin(&keys[p], key);
+    }
+}
+
+__global__ void zbuf_last_kernel(const int32_t* rows, const int32_t* cols, const double* range, int64_t n, int H, int W,
+                                 double min_range, const unsigned long long* keys, long long* winner) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t p;
+        if (!zbuf_pixel(rows, cols, range, i, H, W, min_range, &p)) continue;
+        const float bmin = __uint_as_float((uint32_t)(keys[p] >> 32));
+        if ((float)range[i] == bmin && range[i] < (double)bmin) atomicMax(&winner[p], (long long)i);
+    }
+}
+
+__global__ void zbuf_gather_kernel(const unsigned long long* keys, long long* winner, const double* features, int64_t n,
+                                   int c, int64_t n_pix, float* image) {
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n_pix; p += (int64_t)gridDim.x * blockDim.x) {
+        long long w = winner[p];
+        if (w < 0 && keys[p] != ~0ull) w = (long long)(uint32_t)(keys[p] & 0xffffffffull);
+        winner[p] = w;
+        for (int ch = 0; ch < c; ++ch) image[(int64_t)ch * n_pix + p] = w >= 0 ? (float)features[(int64_t)ch * n + w] : 0.f;
+    }
+}
+
+int grid_for(int64_t work) {
+    int64_t b = (work + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+}  // namespace
+
+extern "C" int rv_project_indices(const double* cart, const int32_t* laser, const int32_t* laser_mapping, int64_t n,
+                                  int32_t H, int32_t W, int32_t variant, int32_t* rows, int32_t* cols, double* range,
+                                  rvStream stream) {
+    if (n == 0) return 0;
+    RV_REQUIRE(cart && laser && laser_mapping && rows && cols && range, "rv_project_indices: null argument");
+    RV_REQUIRE(variant == 0 || variant == 1, "rv_project_indices: variant must be 0 (converter) or 1 (library)");
+    hipLaunchKernelGGL(project_indices_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, cart, laser,
+                       laser_mapping, n, H, W, variant, rows, cols, range);
+    RV_CHECK_LAUNCH("project_indices_kernel");
+    return 0;
+}
+
+extern "C" int rv_z_buffer(const int32_t* rows, const int32_t* cols, const double* range, const double* features,
+                           int64_t n, int32_t c, int32_t H, int32_t W, double min_range, uint64_t* keys, float* image,
+                           int64_t* winner, rvStream stream) {
+    RV_REQUIRE(keys && image && winner, "rv_z_buffer: null output");
+    RV_REQUIRE(n == 0 || (rows && cols && range && features), "rv_z_buffer: null input");
+    RV_REQUIRE(n < (1ll << 32), "rv_z_buffer: more than 2^32 points");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n_pix = (int64_t)H * W;
+    hipLaunchKernelGGL(zbuf_init_kernel, dim3(grid_for(n_pix)), dim3(256), 0, st, keys, winner, n_pix);
+    if (n > 0) {
+        hipLaunchKernelGGL(zbuf_min_kernel, dim3(grid_for(n)), dim3(256), 0, st, rows, cols, range, n, H, W, min_range,
+                           (unsigned long long*)keys);
+        hipLaunchKernelGGL(zbuf_last_kernel, dim3(grid_for(n)), dim3(256), 0, st, rows, cols, range, n, H, W, min_range,
+                           (const unsigned long long*)keys, (long long*)winner);
+    }
+    hipLaunchKernelGGL(zbuf_gather_kernel, dim3(grid_for(n_pix)), dim3(256), 0, st, (const unsigned long long*)keys,
+                       (long long*)winner, features, n, c, n_pix, image);
+    RV_CHECK_LAUNCH("z_buffer kernels");
+    return 0;
+}

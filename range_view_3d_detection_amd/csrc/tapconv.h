@@ -1,0 +1,39 @@
+// Tap tables shared by the tap-conv kernels, the weight packers and the weight-gradient kernel.
+#pragma once
+#include "common.h"
+
+constexpr int kMaxTaps = 24;   // 3x8 (ConvTranspose2d k=(3,8)) is the largest kernel on the path
+constexpr int kMaxPhases = 4;  // stride_w <= 4
+
+struct TapTable {
+    int32_t ntaps[kMaxPhases];    // taps of each output phase
+    int32_t w_first[kMaxPhases];  // index of the phase's first tap image in the packed weight
+    int32_t dw_min[kMaxPhases], dw_max[kMaxPhases];
+    int32_t w_tile[kMaxPhases];   // halo width (pixels) of the LDS input tile, set per launch
+    int32_t dh_min, rows;         // halo rows: dh_min .. dh_min + rows - 1
+    int8_t dh[kMaxPhases][kMaxTaps];
+    int8_t dw[kMaxPhases][kMaxTaps];
+    int8_t ky[kMaxPhases][kMaxTaps];  // kernel coordinates of the tap (weight packing)
+    int8_t kx[kMaxPhases][kMaxTaps];
+};
+
+struct TapConvArgs {
+    const bf16_t* src;
+    void* dst;
+    const bf16_t* w;
+    const float* in_scale;
+    const float* in_shift;
+    const float* bias;
+    float* stats;
+    int32_t N, H, W_src, W_dst;
+    int32_t C_src, C_dst;  // padded channel counts (K and N of the implicit GEMM)
+    int32_t ld_src, ld_dst;
+    int32_t phases, step;
+    int32_t m_tiles;
+    int32_t lds_a_elems;
+    int32_t flags;
+    TapTable tt;
+};
+
+// fills tt (except w_tile), *phases and *step; scatter == false: GATHER form, true: SCATTER form
+int rv_build_tap_table(const rvTapGeom* g, bool scatter, TapTable* tt, int* phases, int* step);

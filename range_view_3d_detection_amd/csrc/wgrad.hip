@@ -1,0 +1,290 @@
+// wgrad.hip -- weight gradient of a tap layer as split-K "TN" GEMMs on the matrix cores.
+//
+//   dT[tap][cu][cv] = sum_{n,h,wu} U[n,h,wu,cu] * f(V[n, h+dh(tap), wu*s+dw(tap), cv])
+//
+// Both operands are NHWC, i.e. the reduction index (the pixel) is the ROW index of both tiles,
+// while the MFMA wants it contiguous per lane.  gfx950's transposed LDS read
+// (ds_read_b64_tr_b16: a 16-lane group reads a 4-row x 16-column block and each lane receives
+// one column) does that transpose for free, so the tiles are staged exactly as they sit in HBM
+// ([32 pixels][128 channels] bf16, whole 256-byte pixel rows => coalesced) and both MFMA
+// operands are read with it.  Rows are 256 B apart (all 64 banks), so the 32-byte column
+// granule a 4-lane quad reads is XOR-swizzled with sigma(k) = (k&3) | ((k>>3)&1)<<2: the eight
+// rows a half-wave touches in one instruction ({0-3, 8-11} + 16g) land on eight distinct
+// 8-bank groups => conflict-free.
+//
+// Block = 4 waves (2x2), tile 128(cu) x 128(cv) of ONE tap, one K slice; fp32 partial slabs are
+// summed by a second kernel in a fixed order (bitwise reproducible, no atomics).
+#include "common.h"
+#include "tapconv.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+
+struct WgradArgs {
+    const bf16_t* U;
+    const bf16_t* V;
+    const float* scale;
+    const float* shift;
+    float* slabs;  // [ksplit][taps][cu_pad][cv_pad]
+    int32_t N, H, Wu, Wv;
+    int32_t cu_pad, cv_pad, ld_u, ld_v;
+    int32_t stride_w;
+    int32_t taps;
+    int32_t ksplit, k_per_split;  // pixels per slice (multiple of 32)
+    int32_t tiles_u, tiles_v;
+    int32_t flags, v_affine;
+    int8_t dh[kMaxTaps], dw[kMaxTaps];
+};
+
+__device__ __forceinline__ int sigma(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+
+__device__ __forceinline__ u32x4 transform8(u32x4 v, const float* sc, const float* sh, bool affine, bool relu) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float lo = bf_lo(v[j]), hi = bf_hi(v[j]);
+        if (affine) {
+            lo = lo * sc[2 * j] + sh[2 * j];
+            hi = hi * sc[2 * j + 1] + sh[2 * j + 1];
+        }
+        if (relu) {
+            lo = fmaxf(lo, 0.f);
+            hi = fmaxf(hi, 0.f);
+        }
+        v[j] = pack_bf2(lo, hi);
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
+    __shared__ __attribute__((aligned(16))) bf16_t lds[2][2][32 * 128];  // [buffer][U/V][k][128]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // block decode: tiles fastest, then tap, then K slice (blocks of one slice run together => L2 reuse)
+    int bx = blockIdx.x;
+    const int tv = bx % a.tiles_v;
+    bx /= a.tiles_v;
+    const int tu = bx % a.tiles_u;
+    bx /= a.tiles_u;
+    const int tap = bx % a.taps;
+    const int ks = bx / a.taps;
+    const int u0 = tu * 128, v0 = tv * 128;
+    const int dh = a.dh[tap], dw = a.dw[tap];
+
+    const int64_t K = (int64_t)a.N * a.H * a.Wu;
+    const int64_t k_begin = (int64_t)ks * a.k_per_split;
+    const int64_t k_end = (k_begin + a.k_per_split < K) ? k_begin + a.k_per_split : K;
+
+    // staging role: 2 pixels x one 16-byte chunk per operand per K step
+    const int chunk = tid & 15;      // 8 channels
+    const int prow = tid >> 4;       // pixel rows prow and prow + 16
+    const bool u_ok = (u0 + chunk * 8) < a.cu_pad, v_ok = (v0 + chunk * 8) < a.cv_pad;
+    const bool affine = a.flags & RV_IN_AFFINE, relu = a.flags & RV_IN_RELU;
+    float sc[8], sh[8];
+    if (affine) {
+        const int c0 = (a.v_affine ? v0 : u0) + chunk * 8;
+        const bool ok = a.v_affine ? v_ok : u_ok;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            sc[j] = ok ? a.scale[c0 + j] : 0.f;
+            sh[j] = ok ? a.shift[c0 + j] : 0.f;
+        }
+    }
+    // pixel coordinates of this thread's two rows, advanced incrementally
+    int pn[2], phh[2], pw[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int64_t k = k_begin + prow + 16 * j;
+        const int64_t hw = (int64_t)a.H * a.Wu;
+        pn[j] = (int)(k / hw);
+        const int64_t r = k - (int64_t)pn[j] * hw;
+        phh[j] = (int)(r / a.Wu);
+        pw[j] = (int)(r - (int64_t)phh[j] * a.Wu);
+    }
+    u32x4 ru[2], rv[2];
+    auto load = [&](int64_t kbase) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t k = kbase + prow + 16 * j;
+            ru[j] = u32x4{0u, 0u, 0u, 0u};
+            rv[j] = u32x4{0u, 0u, 0u, 0u};
+            if (k < k_end) {
+                if (u_ok) {
+                    ru[j] = *(const u32x4*)(a.U + ((int64_t)(pn[j] * a.H + phh[j]) * a.Wu + pw[j]) * a.ld_u + u0 + chunk * 8);
+                    if ((affine || relu) && !a.v_affine) ru[j] = transform8(ru[j], sc, sh, affine, relu);
+                }
+                const int hv = phh[j] + dh, wv = pw[j] * a.stride_w + dw;
+                if (v_ok && hv >= 0 && hv < a.H && wv >= 0 && wv < a.Wv) {
+                    rv[j] = *(const u32x4*)(a.V + ((int64_t)(pn[j] * a.H + hv) * a.Wv + wv) * a.ld_v + v0 + chunk * 8);
+                    if ((affine || relu) && a.v_affine) rv[j] = transform8(rv[j], sc, sh, affine, relu);
+                }
+            }
+            // advance this row by 32 pixels
+            pw[j] += 32;
+            while (pw[j] >= a.Wu) {
+                pw[j] -= a.Wu;
+                if (++phh[j] == a.H) {
+                    phh[j] = 0;
+                    ++pn[j];
+                }
+            }
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = prow + 16 * j;
+            const int off = k * 128 + (((chunk >> 1) ^ sigma(k)) << 4) + (chunk & 1) * 8;
+            *(u32x4*)(&lds[buf][0][off]) = ru[j];
+            *(u32x4*)(&lds[buf][1][off]) = rv[j];
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // transposed-read addressing: lane = 16*g + 4*q + p supplies row (8g + q [+4]), columns 4p..4p+3 of its tile
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int row_lo = 8 * g + q, row_hi = row_lo + 4;
+    auto frag = [&](const bf16_t* tile, int col0) -> bf16x8 {
+        // col0: first channel of the 16-wide fragment inside the 128-wide tile
+        const int gran = col0 >> 4;
+        const bf16_t* p_lo = tile + row_lo * 128 + ((gran ^ sigma(row_lo)) << 4) + 4 * p;
+        const bf16_t* p_hi = tile + row_hi * 128 + ((gran ^ sigma(row_hi)) << 4) + 4 * p;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p_lo);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p_hi);
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, both);
+    };
+
+    if (k_begin < k_end) {
+        load(k_begin);
+        store(0);
+        __syncthreads();
+        int buf = 0;
+        for (int64_t kb = k_begin; kb < k_end; kb += 32) {
+            const bool has_next = kb + 32 < k_end;
+            if (has_next) load(kb + 32);
+            bf16x8 fb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = frag(&lds[buf][1][0], wn * 64 + j * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bf16x8 fa = frag(&lds[buf][0][0], wm * 64 + i * 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[j], acc[i][j], 0, 0, 0);
+            }
+            if (has_next) store(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+    // slab store: D[row = cu][col = cv]: col = lane&15, row = (lane>>4)*4 + r
+    float* slab = a.slabs + ((int64_t)ks * a.taps + tap) * a.cu_pad * a.cv_pad;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int cu = u0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+            if (cu >= a.cu_pad) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int cv = v0 + wn * 64 + j * 16 + (lane & 15);
+                if (cv < a.cv_pad) slab[(int64_t)cu * a.cv_pad + cv] = acc[i][j][r];
+            }
+        }
+}
+
+__global__ void wgrad_reduce_kernel(const float* slabs, int ksplit, int64_t elems, float* out) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < elems; i += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < ksplit; ++k) s += slabs[(int64_t)k * elems + i];
+        out[i] = s;
+    }
+}
+
+struct WgradPlan {
+    int taps, tiles_u, tiles_v, ksplit, k_per_split;
+    int64_t elems;
+};
+
+int plan(const rvTapGeom* g, const rvTapShape* s, WgradPlan* p) {
+    p->taps = g->kh * g->kw;
+    const int cu = rv_pad32(g->cu), cv = rv_pad32(g->cv);
+    p->tiles_u = rv_ceil_div(cu, 128);
+    p->tiles_v = rv_ceil_div(cv, 128);
+    const int64_t K = (int64_t)s->N * s->H * s->Wu;
+    const int64_t chunks = (K + 31) / 32;
+    const int base = p->taps * p->tiles_u * p->tiles_v;
+    int64_t ks = (1024 + base - 1) / base;  // ~4 blocks per CU
+    if (ks > chunks) ks = chunks;
+    if (ks < 1) ks = 1;
+    const int64_t per = (chunks + ks - 1) / ks;
+    p->k_per_split = (int)(per * 32);
+    p->ksplit = (int)((chunks + per - 1) / per);
+    p->elems = (int64_t)p->taps * cu * cv;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int64_t rv_tap_wgrad_workspace_bytes(const rvTapGeom* g, const rvTapShape* s) {
+    WgradPlan p;
+    plan(g, s, &p);
+    return p.elems * p.ksplit * (int64_t)sizeof(float);
+}
+
+extern "C" int rv_tap_wgrad(const rvTapGeom* g, const rvTapShape* s, const void* U, int32_t ld_u, const void* V,
+                            int32_t ld_v, const float* in_scale, const float* in_shift, int32_t v_affine,
+                            float* dT_packed, void* workspace, rvStream stream) {
+    RV_REQUIRE(g && s && U && V && dT_packed && workspace, "rv_tap_wgrad: null argument");
+    RV_REQUIRE(s->Wv == s->Wu * g->stride_w, "rv_tap_wgrad: Wv (%d) must equal Wu (%d) * stride_w (%d)", s->Wv, s->Wu, g->stride_w);
+    RV_REQUIRE(!(s->flags & RV_IN_AFFINE) || (in_scale && in_shift), "rv_tap_wgrad: RV_IN_AFFINE without scale/shift");
+    RV_REQUIRE(g->kh * g->kw <= kMaxTaps, "rv_tap_wgrad: kernel %dx%d unsupported", g->kh, g->kw);
+    WgradPlan p;
+    plan(g, s, &p);
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.U = (const bf16_t*)U;
+    a.V = (const bf16_t*)V;
+    a.scale = in_scale;
+    a.shift = in_shift;
+    a.slabs = (float*)workspace;
+    a.N = s->N;
+    a.H = s->H;
+    a.Wu = s->Wu;
+    a.Wv = s->Wv;
+    a.cu_pad = rv_pad32(g->cu);
+    a.cv_pad = rv_pad32(g->cv);
+    a.ld_u = ld_u;
+    a.ld_v = ld_v;
+    RV_REQUIRE(ld_u >= a.cu_pad && ld_v >= a.cv_pad && ld_u % 8 == 0 && ld_v % 8 == 0, "rv_tap_wgrad: bad channel strides");
+    a.stride_w = g->stride_w;
+    a.taps = p.taps;
+    a.ksplit = p.ksplit;
+    a.k_per_split = p.k_per_split;
+    a.tiles_u = p.tiles_u;
+    a.tiles_v = p.tiles_v;
+    a.flags = s->flags;
+    a.v_affine = v_affine;
+    for (int ky = 0; ky < g->kh; ++ky)
+        for (int kx = 0; kx < g->kw; ++kx) {
+            a.dh[ky * g->kw + kx] = (int8_t)(ky - g->pad_h);
+            a.dw[ky * g->kw + kx] = (int8_t)(kx - g->pad_w);
+        }
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = p.tiles_v * p.tiles_u * p.taps * p.ksplit;
+    hipLaunchKernelGGL(wgrad_kernel, dim3(grid), dim3(256), 0, st, a);
+    RV_CHECK_LAUNCH("wgrad_kernel");
+    const int rb = (int)((p.elems + 255) / 256 < 2048 ? (p.elems + 255) / 256 : 2048);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, st, (const float*)workspace, p.ksplit, p.elems, dT_packed);
+    RV_CHECK_LAUNCH("wgrad_reduce_kernel");
+    return 0;
+}

@@ -1,0 +1,495 @@
+"""Host-side execution engine: NHWC bf16 device tensors + a tape of fused HIP ops.
+
+The reference runs the detector as ~600 separate ATen/cuDNN calls stitched together by
+autograd.  Here a forward pass records a short *tape* of fused operations (tap-conv with
+folded BatchNorm prologue and statistics epilogue, BatchNorm finalisation, element-wise
+combine, MetaKernel gather/modulate); the backward pass replays the tape in reverse with
+hand-derived gradients.  PyTorch only sees two autograd nodes (backbone, head), owns the
+memory (caching allocator) and the stream.  Every op calls the C ABI in ``include/rv3d.h``
+through ``_lib`` -- there is no PyTorch/CPU fallback for any of them.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import torch
+from torch import Tensor, nn
+
+from . import _lib as L
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def pad32(c: int) -> int:
+    return (c + 31) // 32 * 32
+
+
+def _require_cuda(t: Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise L.RvError(
+            f"{what} is on {t.device}: the range_view_3d_detection_amd modules only run on an MI355X "
+            "(HIP kernels, no CPU fallback)."
+        )
+
+
+# ---------------------------------------------------------------------------------------------
+# device tensors
+# ---------------------------------------------------------------------------------------------
+class Act:
+    """NHWC bf16 activation (or activation gradient): ``data`` is (N,H,W,C) with strides (H*W*ld, W*ld, ld, 1)."""
+
+    __slots__ = ("data", "c", "parent", "c0")
+
+    def __init__(self, data: Tensor, c: Optional[int] = None, parent: Optional["Act"] = None, c0: int = 0) -> None:
+        assert data.dtype == torch.bfloat16 and data.dim() == 4 and data.stride(3) == 1
+        self.data = data
+        self.c = data.shape[3] if c is None else c  # logical channels (<= stored, stored is a multiple of 32)
+        self.parent = parent
+        self.c0 = c0
+
+    @staticmethod
+    def empty(n: int, h: int, w: int, c: int, device, zero: bool = False) -> "Act":
+        cp = pad32(c)
+        data = (torch.zeros if zero else torch.empty)((n, h, w, cp), dtype=torch.bfloat16, device=device)
+        return Act(data, c)
+
+    @property
+    def N(self) -> int:
+        return self.data.shape[0]
+
+    @property
+    def H(self) -> int:
+        return self.data.shape[1]
+
+    @property
+    def W(self) -> int:
+        return self.data.shape[2]
+
+    @property
+    def cp(self) -> int:
+        return self.data.shape[3]
+
+    @property
+    def ld(self) -> int:
+        return self.data.stride(2)
+
+    @property
+    def pixels(self) -> int:
+        return self.N * self.H * self.W
+
+    def ptr(self) -> ctypes.c_void_p:
+        return ctypes.c_void_p(self.data.data_ptr())
+
+    def slice(self, c0: int, c1: int) -> "Act":
+        assert c0 % 32 == 0 and c1 % 32 == 0
+        return Act(self.data[..., c0:c1], c1 - c0, parent=self, c0=c0)
+
+    def like(self, zero: bool = False) -> "Act":
+        return Act.empty(self.N, self.H, self.W, self.c, self.data.device, zero)
+
+    def nchw(self) -> Tensor:
+        """(N,C,H,W) channels_last *view* of the logical channels -- what user code sees."""
+        return self.data[..., : self.c].permute(0, 3, 1, 2)
+
+    @staticmethod
+    def from_nchw(x: Tensor) -> "Act":
+        """Any (N,C,H,W) CUDA tensor -> Act (zero-copy when it already is bf16 channels_last with C % 32 == 0)."""
+        n, c, h, w = x.shape
+        nhwc = x.permute(0, 2, 3, 1)
+        if x.dtype == torch.bfloat16 and c % 32 == 0 and nhwc.is_contiguous():
+            return Act(nhwc, c)
+        out = Act.empty(n, h, w, c, x.device, zero=(c % 32 != 0))
+        out.data[..., :c].copy_(nhwc)
+        return out
+
+
+@dataclass(eq=False)
+class BnState:
+    """Folded BatchNorm of one layer for the current step."""
+
+    module: nn.BatchNorm2d
+    scale: Tensor
+    shift: Tensor
+    mean: Optional[Tensor] = None
+    invstd: Optional[Tensor] = None
+    count: int = 0
+
+
+@dataclass(eq=False)
+class Lazy:
+    """``relu?(scale * raw + shift)`` that is never written to HBM: consumers fold it into their operand load."""
+
+    raw: Act
+    bn: BnState
+    relu: bool = True
+
+
+Operand = Union[Act, Lazy]
+
+
+# ---------------------------------------------------------------------------------------------
+# conv layers: geometry + packed weights
+# ---------------------------------------------------------------------------------------------
+class TapLayer:
+    """Geometry and packed bf16 weight images of one nn.Conv2d / nn.ConvTranspose2d parameter."""
+
+    def __init__(self, weight: nn.Parameter, stride_w: int, pad: Tuple[int, int], transposed: bool,
+                 bias: Optional[nn.Parameter] = None, in_perm: Optional[Tuple[int, int]] = None) -> None:
+        self.weight = weight
+        self.bias = bias
+        self.transposed = transposed
+        self.in_perm = in_perm  # (C, taps): MetaKernel fusion conv, reference channel order c*taps+k -> k*Cpad+c
+        cu, cv, kh, kw = weight.shape
+        if in_perm is not None:
+            c, taps = in_perm
+            cv = taps * pad32(c)
+        self.geom = L.TapGeom(kh, kw, stride_w, pad[0], pad[1], cu, cv)
+        self.cu, self.cv = cu, cv
+        self._packed: Dict[str, Tensor] = {}
+        self._version = None
+
+    # forward direction of the torch module: conv = gather, conv-transpose = scatter
+    @property
+    def fwd_form(self) -> str:
+        return "scatter" if self.transposed else "gather"
+
+    @property
+    def c_in(self) -> int:
+        return self.cu if self.transposed else self.cv
+
+    @property
+    def c_out(self) -> int:
+        return self.cv if self.transposed else self.cu
+
+    def _torch_weight(self) -> Tensor:
+        w = self.weight.detach()
+        if self.in_perm is not None:
+            c, taps = self.in_perm
+            cu = w.shape[0]
+            w = w.reshape(cu, c, taps).permute(0, 2, 1)  # [cu][k][c]
+            w = torch.nn.functional.pad(w, (0, pad32(c) - c)).reshape(cu, taps * pad32(c), 1, 1)
+        return w.contiguous().float()
+
+    def unpermute_grad(self, g: Tensor) -> Tensor:
+        """Packed-order gradient [cu][cv_eff][kh][kw] -> the parameter's own layout."""
+        if self.in_perm is None:
+            return g
+        c, taps = self.in_perm
+        cu = g.shape[0]
+        return g.reshape(cu, taps, pad32(c))[..., :c].permute(0, 2, 1).reshape(self.weight.shape).contiguous()
+
+    def packed(self, form: str) -> Tensor:
+        """bf16 weight image for ``form``; re-packed when the parameter changed (optimizer step / load_state_dict)."""
+        ver = (self.weight._version, self.weight.data_ptr())
+        if ver != self._version:
+            self._packed.clear()
+            self._version = ver
+        if form not in self._packed:
+            nbytes = L.load().rv_packed_weight_bytes(ctypes.byref(self.geom))
+            buf = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=self.weight.device)
+            w = self._torch_weight()
+            g, s = (buf, None) if form == "gather" else (None, buf)
+            L.call("rv_pack_weight", ctypes.byref(self.geom), L.ptr(w), L.ptr(g), L.ptr(s), L.stream_ptr())
+            self._packed[form] = buf
+        return self._packed[form]
+
+
+# ---------------------------------------------------------------------------------------------
+# tape
+# ---------------------------------------------------------------------------------------------
+class Tape:
+    """Ops of one forward pass + gradient bookkeeping of the matching backward pass."""
+
+    def __init__(self, training: bool, device) -> None:
+        self.training = training
+        self.device = device
+        self.ops: List["Op"] = []
+        # backward state
+        self.grads: Dict[int, Act] = {}          # id(root Act) -> gradient Act (same padded shape)
+        self.written: set = set()                # ids of gradient Acts (roots) already holding a value
+        self.lazy_in: Dict[int, Tuple[Act, Optional[Act]]] = {}  # id(Lazy) -> (dOut, OUT mask source)
+        self.raw_grad: Dict[int, Act] = {}       # id(raw Act) -> gradient w.r.t. the raw conv output
+        self.param_grads: Dict[int, Tensor] = {}  # id(param) -> fp32 gradient
+        self.params: Dict[int, nn.Parameter] = {}
+
+    # ---- gradient buffers (views follow their parents) ----
+    def grad_buffer(self, a: Act) -> Tuple[Act, bool]:
+        """Gradient Act for ``a`` and whether it already holds a value (=> accumulate)."""
+        root, chain = a, []
+        while root.parent is not None:
+            chain.append(root)
+            root = root.parent
+        key = id(root)
+        if key not in self.grads:
+            self.grads[key] = root.like(zero=bool(chain))  # partial (view) writers need a defined background
+            if chain:
+                self.written.add(key)
+        g = self.grads[key]
+        have = key in self.written
+        for v in reversed(chain):
+            g = g.slice(v.c0, v.c0 + v.cp)
+        return g, have
+
+    def mark_written(self, a: Act) -> None:
+        root = a
+        while root.parent is not None:
+            root = root.parent
+        self.written.add(id(root))
+
+    def set_grad(self, a: Act, g: Act) -> None:
+        assert a.parent is None
+        self.grads[id(a)] = g
+        self.written.add(id(a))
+
+    def add_param_grad(self, p: nn.Parameter, g: Tensor) -> None:
+        k = id(p)
+        self.params[k] = p
+        if k in self.param_grads:
+            self.param_grads[k] = self.param_grads[k] + g
+        else:
+            self.param_grads[k] = g
+
+    def backward(self) -> None:
+        for op in reversed(self.ops):
+            op.backward(self)
+
+
+class Op:
+    def backward(self, t: Tape) -> None:  # pragma: no cover - interface
+        raise NotImplementedError
+
+
+def _operand_parts(x: Operand) -> Tuple[Act, Optional[Tensor], Optional[Tensor], int]:
+    if isinstance(x, Lazy):
+        return x.raw, x.bn.scale, x.bn.shift, L.IN_AFFINE | (L.IN_RELU if x.relu else 0)
+    return x, None, None, 0
+
+
+# ---------------------------------------------------------------------------------------------
+# conv op
+# ---------------------------------------------------------------------------------------------
+class ConvOp(Op):
+    """``out = layer(x)``: tap-conv forward; optional batch statistics, bias, fp32 output."""
+
+    def __init__(self, t: Tape, layer: TapLayer, x: Operand, stats: bool = False, out_f32: bool = False,
+                 out: Optional[Act] = None, need_input_grad: bool = True) -> None:
+        self.layer, self.x, self.need_input_grad = layer, x, need_input_grad
+        src, sc, sh, flags = _operand_parts(x)
+        form = layer.fwd_form
+        g = layer.geom
+        if form == "gather":
+            wv, wu = src.W, src.W // g.stride_w
+            w_out = wu
+        else:
+            wu, wv = src.W, src.W * g.stride_w
+            w_out = wv
+        assert src.cp == pad32(layer.c_in), (src.cp, layer.c_in)
+        self.out_f32 = out_f32
+        if out_f32:
+            self.out_t = torch.empty((src.N, src.H, w_out, pad32(layer.c_out)), dtype=torch.float32, device=t.device)
+            dst_ptr, ld_dst = L.ptr(self.out_t), self.out_t.stride(2)
+            flags |= L.OUT_F32
+            self.out = None
+        else:
+            self.out = out if out is not None else Act.empty(src.N, src.H, w_out, layer.c_out, t.device)
+            dst_ptr, ld_dst = self.out.ptr(), self.out.ld
+        bias = layer.bias
+        if bias is not None:
+            flags |= L.OUT_BIAS
+            bias_p = torch.nn.functional.pad(bias.detach().float(), (0, pad32(layer.c_out) - layer.c_out))
+        else:
+            bias_p = None
+        self.shape = L.TapShape(src.N, src.H, wu, wv, src.ld, ld_dst, flags | (L.OUT_STATS if stats else 0))
+        self.partial = None
+        self.rows = 0
+        if stats:
+            self.rows = L.load().rv_tap_stats_rows(ctypes.byref(g), ctypes.byref(self.shape), 1 if form == "scatter" else 0)
+            if self.rows < 0:
+                raise L.RvError("rv_tap_stats_rows: " + L.load().rv_last_error().decode())
+            self.partial = torch.empty((self.rows + L.STATS_SCRATCH_ROWS, 2, pad32(layer.c_out)), dtype=torch.float32,
+                                       device=t.device)
+        L.call("rv_tap_" + form, ctypes.byref(g), ctypes.byref(self.shape), src.ptr(), L.ptr(sc), L.ptr(sh),
+               L.ptr(layer.packed(form)), L.ptr(bias_p), dst_ptr, L.ptr(self.partial), L.stream_ptr())
+        self.count = src.N * src.H * w_out
+        t.ops.append(self)
+
+    def backward(self, t: Tape) -> None:
+        from . import engine_bwd  # local import: backward kernels are a separate module
+
+        engine_bwd.conv_backward(self, t)
+
+
+# ---------------------------------------------------------------------------------------------
+# batch norm
+# ---------------------------------------------------------------------------------------------
+class BnOp(Op):
+    """Finalise batch statistics (train) or fold running statistics (eval) into scale/shift."""
+
+    def __init__(self, t: Tape, conv: ConvOp, bn: nn.BatchNorm2d, relu: bool = True) -> None:
+        self.conv = conv
+        c = bn.num_features
+        cp = pad32(c)
+        dev = t.device
+        gamma, beta = _padded(bn.weight, cp), _padded(bn.bias, cp)
+        scale = torch.empty(cp, dtype=torch.float32, device=dev)
+        shift = torch.empty(cp, dtype=torch.float32, device=dev)
+        self.gamma_p = gamma
+        if t.training:
+            mean = torch.empty(cp, dtype=torch.float32, device=dev)
+            invstd = torch.empty(cp, dtype=torch.float32, device=dev)
+            rm, rv = _padded(bn.running_mean, cp), _padded(bn.running_var, cp, 1.0)
+            L.call("rv_bn_finalize", L.ptr(conv.partial), L.i32(conv.rows), L.i32(cp), L.i64(conv.count), L.ptr(gamma),
+                   L.ptr(beta), L.f32(bn.eps), L.f32(bn.momentum if bn.momentum is not None else 0.1), L.ptr(rm),
+                   L.ptr(rv), L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd), L.stream_ptr())
+            if bn.running_mean.shape[0] != cp:  # padded copies: write the logical channels back
+                bn.running_mean.copy_(rm[:c])
+                bn.running_var.copy_(rv[:c])
+            bn.num_batches_tracked += 1
+            conv.partial = None
+            self.state = BnState(bn, scale, shift, mean, invstd, conv.count)
+        else:
+            rm, rv = _padded(bn.running_mean, cp), _padded(bn.running_var, cp, 1.0)
+            L.call("rv_bn_fold_eval", L.i32(cp), L.ptr(gamma), L.ptr(beta), L.ptr(rm), L.ptr(rv), L.f32(bn.eps),
+                   L.ptr(scale), L.ptr(shift), L.stream_ptr())
+            self.state = BnState(bn, scale, shift)
+        self.lazy = Lazy(conv.out, self.state, relu)
+        t.ops.append(self)
+
+    def backward(self, t: Tape) -> None:
+        from . import engine_bwd
+
+        engine_bwd.bn_backward(self, t)
+
+
+def _padded(p: Tensor, cp: int, fill: float = 0.0) -> Tensor:
+    p = p.detach()
+    if p.shape[0] == cp:
+        return p if p.dtype == torch.float32 else p.float()
+    out = torch.full((cp,), fill, dtype=torch.float32, device=p.device)
+    out[: p.shape[0]] = p
+    return out
+
+
+def conv_bn(t: Tape, layer: TapLayer, x: Operand, bn: nn.BatchNorm2d, relu: bool = True,
+            need_input_grad: bool = True) -> Lazy:
+    conv = ConvOp(t, layer, x, stats=t.training, need_input_grad=need_input_grad)
+    return BnOp(t, conv, bn, relu).lazy
+
+
+# ---------------------------------------------------------------------------------------------
+# element-wise combine
+# ---------------------------------------------------------------------------------------------
+class CombineOp(Op):
+    """``out = relu?( fa(a) + fb(b) )`` with Lazy operands folded in; materialises a block output."""
+
+    def __init__(self, t: Tape, a: Operand, b: Optional[Operand], relu_out: bool, out: Optional[Act] = None) -> None:
+        self.a, self.b, self.relu_out = a, b, relu_out
+        ra, sa, ta, fa = _operand_parts(a)
+        flags = (L.EW_RELU_A if fa & L.IN_RELU else 0) | (L.EW_RELU_OUT if relu_out else 0)
+        rb = sb = tb = None
+        if b is not None:
+            rb, sb, tb, fb = _operand_parts(b)
+            flags |= L.EW_RELU_B if fb & L.IN_RELU else 0
+            assert rb.cp == ra.cp and rb.pixels == ra.pixels
+        self.out = out if out is not None else ra.like()
+        L.call("rv_ew_combine", L.i64(ra.pixels), L.i32(ra.cp), ra.ptr(), L.i32(ra.ld), L.ptr(sa), L.ptr(ta),
+               rb.ptr() if rb is not None else None, L.i32(rb.ld if rb is not None else 0), L.ptr(sb), L.ptr(tb),
+               self.out.ptr(), L.i32(self.out.ld), L.i32(flags), L.stream_ptr())
+        t.ops.append(self)
+
+    def backward(self, t: Tape) -> None:
+        from . import engine_bwd
+
+        engine_bwd.combine_backward(self, t)
+
+
+# ---------------------------------------------------------------------------------------------
+# MetaKernel pieces
+# ---------------------------------------------------------------------------------------------
+class MetaRelativeOp(Op):
+    """cart (B,3,H,W) fp32 NCHW -> relative neighbour coordinates as an (N,H,9W,32) bf16 image (no gradient)."""
+
+    def __init__(self, t: Tape, cart: Tensor) -> None:
+        n, _, h, w = cart.shape
+        cart = cart.contiguous().float()
+        self.out = Act.empty(n, h, w * 9, 3, t.device)
+        L.call("rv_meta_relative", L.ptr(cart), L.i32(n), L.i32(h), L.i32(w), self.out.ptr(), L.stream_ptr())
+        t.ops.append(self)
+
+    def backward(self, t: Tape) -> None:
+        return None
+
+
+class MetaModulateOp(Op):
+    """geo[n,h,w,k*C+c] = relu(bn(pos))[n,h,w*9+k,c] * feat[n,h+dy_k,w+dx_k,c]."""
+
+    def __init__(self, t: Tape, pos: Lazy, feat: Act) -> None:
+        self.pos, self.feat = pos, feat
+        n, h, w, cp = feat.N, feat.H, feat.W, feat.cp
+        assert pos.raw.W == 9 * w and pos.raw.cp == cp and pos.raw.ld == cp
+        self.out = Act.empty(n, h, w, 9 * cp, t.device)
+        L.call("rv_meta_modulate", pos.raw.ptr(), L.ptr(pos.bn.scale), L.ptr(pos.bn.shift), feat.ptr(), L.i32(feat.ld),
+               L.i32(n), L.i32(h), L.i32(w), L.i32(cp), self.out.ptr(), L.stream_ptr())
+        t.ops.append(self)
+
+    def backward(self, t: Tape) -> None:
+        from . import engine_bwd
+
+        engine_bwd.modulate_backward(self, t)
+
+
+class ConcatOp(Op):
+    """Channel concat through a copy (only when the parts are not multiples of 32 channels: tiny test models)."""
+
+    def __init__(self, t: Tape, parts: Sequence[Act]) -> None:
+        self.parts = list(parts)
+        c = sum(p.c for p in parts)
+        ref = parts[0]
+        self.out = Act.empty(ref.N, ref.H, ref.W, c, t.device, zero=True)
+        o = 0
+        for p in parts:
+            self.out.data[..., o : o + p.c].copy_(p.data[..., : p.c])
+            o += p.c
+        t.ops.append(self)
+
+    def backward(self, t: Tape) -> None:
+        g, have = t.grad_buffer(self.out)
+        if not have:
+            return
+        o = 0
+        for p in self.parts:
+            gp, have_p = t.grad_buffer(p)
+            if have_p:
+                gp.data[..., : p.c].add_(g.data[..., o : o + p.c])
+            else:
+                gp.data.zero_()
+                gp.data[..., : p.c].copy_(g.data[..., o : o + p.c])
+                t.mark_written(p)
+            o += p.c
+
+
+def tap_layer(module: nn.Module, **kw) -> TapLayer:
+    """The (cached) TapLayer of an ``nn.Conv2d`` / ``nn.ConvTranspose2d`` parameter holder."""
+    layer = module.__dict__.get("_rv_layer")
+    if layer is None or layer.weight is not module.weight:
+        kh, kw_ = module.kernel_size
+        sh, sw = module.stride
+        if sh != 1:
+            raise NotImplementedError("vertical stride is 1 everywhere on the range-view path (dla.py:37-63)")
+        if tuple(module.dilation) != (1, 1):
+            raise NotImplementedError("dilation != 1 is not used on the range-view path")
+        if isinstance(module, nn.ConvTranspose2d):
+            pad = tuple(module.padding)
+            layer = TapLayer(module.weight, sw, pad, transposed=True, bias=module.bias, **kw)
+        else:
+            pad = getattr(module, "_rv_same_pad", None)
+            if pad is None:
+                pad = module.padding
+                pad = ((kh - 1) // 2, (kw_ - 1) // 2) if pad == "same" else tuple(pad)
+            layer = TapLayer(module.weight, sw, pad, transposed=False, bias=module.bias, **kw)
+        module.__dict__["_rv_layer"] = layer
+    return layer

@@ -1,0 +1,153 @@
+"""Backward halves of the engine ops (hand-derived; every kernel goes through the C ABI).
+
+Gradient flow on the tape, in reverse op order:
+
+* ``CombineOp``   dOut -> (a) plain operands: ``rv_ew_mask_grad``; (b) Lazy operands: hand
+  ``(dOut, OUT)`` to the BatchNorm that produced them;
+* ``BnOp``        ``rv_bn_bwd_reduce`` -> ``rv_bn_bwd_finalize`` (dgamma, dbeta, coefficients)
+  -> ``rv_bn_bwd_apply`` = gradient w.r.t. the raw conv output (bf16);
+* ``ConvOp``      input gradient = the opposite tap form (gather <-> scatter) on the same
+  geometry; weight gradient = ``rv_tap_wgrad`` (split-K TN GEMM) -> ``rv_unpack_weight_grad``.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib as L
+from . import engine as E
+from .engine import Act, Lazy, Tape, pad32
+
+
+def grad_act_like(o: Act, g: Tensor) -> Act:
+    """Incoming autograd gradient (N,C,H,W), any layout/dtype -> NHWC bf16 Act shaped like ``o``."""
+    nhwc = g.permute(0, 2, 3, 1)
+    if g.dtype == torch.bfloat16 and g.shape[1] == o.cp and nhwc.is_contiguous():
+        return Act(nhwc, o.c)
+    out = Act.empty(o.N, o.H, o.W, o.c, g.device, zero=(g.shape[1] != o.cp))
+    out.data[..., : g.shape[1]].copy_(nhwc)
+    return out
+
+
+def seed_f32_output_grad(t: Tape, op: "E.ConvOp", g: Tensor) -> None:
+    """Gradient of an fp32 conv output (final head conv): bf16 copy for the kernels + the bias gradient."""
+    c = op.layer.c_out
+    n, h, w = op.out_t.shape[:3]
+    act = Act.empty(n, h, w, c, g.device, zero=(c % 32 != 0))
+    act.data[..., :c].copy_(g.permute(0, 2, 3, 1))
+    t.raw_grad[id(op)] = act
+    if op.layer.bias is not None:
+        t.add_param_grad(op.layer.bias, g.float().sum(dim=(0, 2, 3)))
+
+
+def _conv_out_grad(op: "E.ConvOp", t: Tape) -> Optional[Act]:
+    if op.out_f32:
+        return t.raw_grad.get(id(op))
+    g = t.raw_grad.get(id(op.out))
+    if g is None and id(op.out) in t.grads and id(op.out) in t.written:
+        g = t.grads[id(op.out)]
+    return g
+
+
+def conv_backward(op: "E.ConvOp", t: Tape) -> None:
+    dout = _conv_out_grad(op, t)
+    if dout is None:
+        return
+    layer, g = op.layer, op.layer.geom
+    src, sc, sh, in_flags = E._operand_parts(op.x)
+    fwd = layer.fwd_form
+    bwd = "scatter" if fwd == "gather" else "gather"
+    sp = op.shape
+    # ---- input gradient: the opposite tap form -------------------------------------------------
+    if op.need_input_grad:
+        if isinstance(op.x, Lazy):
+            dst, accumulate = src.like(), False
+            t.lazy_in[id(op.x)] = (dst, None)
+        else:
+            dst, accumulate = t.grad_buffer(op.x)
+        shape = L.TapShape(sp.N, sp.H, sp.Wu, sp.Wv, dout.ld, dst.ld, L.OUT_ACCUM if accumulate else 0)
+        L.call("rv_tap_" + bwd, ctypes.byref(g), ctypes.byref(shape), dout.ptr(), None, None, L.ptr(layer.packed(bwd)), None,
+               dst.ptr(), None, L.stream_ptr())
+        if not isinstance(op.x, Lazy):
+            t.mark_written(op.x)
+    # ---- weight gradient ---------------------------------------------------------------------------
+    if fwd == "gather":
+        u, v, v_affine = dout, src, 1
+    else:
+        u, v, v_affine = src, dout, 0
+    wshape = L.TapShape(sp.N, sp.H, sp.Wu, sp.Wv, 0, 0, in_flags)
+    ws_bytes = L.load().rv_tap_wgrad_workspace_bytes(ctypes.byref(g), ctypes.byref(wshape))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=t.device)
+    cu_p, cv_p = pad32(g.cu), pad32(g.cv)
+    packed = torch.empty((g.kh * g.kw, cu_p, cv_p), dtype=torch.float32, device=t.device)
+    L.call("rv_tap_wgrad", ctypes.byref(g), ctypes.byref(wshape), u.ptr(), L.i32(u.ld), v.ptr(), L.i32(v.ld), L.ptr(sc),
+           L.ptr(sh), L.i32(v_affine), L.ptr(packed), L.ptr(ws), L.stream_ptr())
+    grad = torch.empty((g.cu, g.cv, g.kh, g.kw), dtype=torch.float32, device=t.device)
+    L.call("rv_unpack_weight_grad", ctypes.byref(g), L.ptr(packed), L.ptr(grad), L.i32(0), L.stream_ptr())
+    t.add_param_grad(layer.weight, layer.unpermute_grad(grad))
+
+
+def bn_backward(op: "E.BnOp", t: Tape) -> None:
+    lazy = op.lazy
+    entry = t.lazy_in.pop(id(lazy), None)
+    if entry is None:
+        return
+    dout, mask = entry
+    st, raw = lazy.bn, lazy.raw
+    if st.mean is None:
+        raise L.RvError("BatchNorm backward needs batch statistics (module was run in eval mode)")
+    cp, pixels = raw.cp, raw.pixels
+    flags = L.BNB_RELU_Z if lazy.relu else 0
+    rows = L.load().rv_bn_bwd_rows(L.i64(pixels))
+    partial = torch.empty((rows + L.STATS_SCRATCH_ROWS, 2, cp), dtype=torch.float32, device=t.device)
+    common = (L.i64(pixels), L.i32(cp), dout.ptr(), L.i32(dout.ld), mask.ptr() if mask is not None else None,
+              L.i32(mask.ld if mask is not None else 0), raw.ptr(), L.i32(raw.ld), L.ptr(st.scale), L.ptr(st.shift),
+              L.ptr(st.mean), L.ptr(st.invstd))
+    L.call("rv_bn_bwd_reduce", *common, L.i32(flags), L.ptr(partial), L.stream_ptr())
+    dgamma = torch.empty(cp, dtype=torch.float32, device=t.device)
+    dbeta = torch.empty(cp, dtype=torch.float32, device=t.device)
+    coef = torch.empty((3, cp), dtype=torch.float32, device=t.device)
+    L.call("rv_bn_bwd_finalize", L.ptr(partial), L.i32(rows), L.i32(cp), L.i64(st.count), L.ptr(op.gamma_p), L.ptr(st.invstd),
+           L.ptr(dgamma), L.ptr(dbeta), L.i32(0), L.ptr(coef), L.stream_ptr())
+    dy = raw.like()
+    L.call("rv_bn_bwd_apply", *common, L.ptr(coef), L.i32(flags), dy.ptr(), L.i32(dy.ld), None, L.i32(0), L.stream_ptr())
+    t.raw_grad[id(raw)] = dy
+    c = st.module.num_features
+    t.add_param_grad(st.module.weight, dgamma[:c])
+    t.add_param_grad(st.module.bias, dbeta[:c])
+
+
+def combine_backward(op: "E.CombineOp", t: Tape) -> None:
+    gout, have = t.grad_buffer(op.out)
+    if not have:
+        return
+    mask = op.out if op.relu_out else None
+    for x in (op.a, op.b):
+        if x is None:
+            continue
+        if isinstance(x, Lazy):
+            t.lazy_in[id(x)] = (gout, mask)
+        else:
+            g, have_x = t.grad_buffer(x)
+            L.call("rv_ew_mask_grad", L.i64(gout.pixels), L.i32(gout.cp), gout.ptr(), L.i32(gout.ld),
+                   mask.ptr() if mask is not None else None, L.i32(mask.ld if mask is not None else 0), g.ptr(), L.i32(g.ld),
+                   L.i32(1 if have_x else 0), L.stream_ptr())
+            t.mark_written(x)
+
+
+def modulate_backward(op: "E.MetaModulateOp", t: Tape) -> None:
+    g, have = t.grad_buffer(op.out)
+    if not have:
+        return
+    pos, feat = op.pos, op.feat
+    dpos = pos.raw.like()
+    gf, have_f = t.grad_buffer(feat)
+    assert not have_f, "MetaKernel projection output has a single consumer"
+    L.call("rv_meta_modulate_bwd", g.ptr(), pos.raw.ptr(), L.ptr(pos.bn.scale), L.ptr(pos.bn.shift), feat.ptr(), L.i32(feat.ld),
+           L.i32(feat.N), L.i32(feat.H), L.i32(feat.W), L.i32(feat.cp), dpos.ptr(), gf.ptr(), L.i32(gf.ld), L.stream_ptr())
+    t.mark_written(feat)
+    t.lazy_in[id(pos)] = (dpos, None)

@@ -1,0 +1,204 @@
+"""Fused HIP programs of the reference's modules, expressed on the engine tape.
+
+Each ``*_program`` function follows the reference forward it replaces (cited per function)
+but emits fused ops: BatchNorm+ReLU of a producer are folded into the operand load of the
+consuming conv (``Lazy``), block outputs are one element-wise pass, "same" padding lives in
+the tap tables, the channel concat is written in place.  ``run`` wraps a program into ONE
+``torch.autograd.Function`` node whose backward replays the tape in reverse.
+"""
+
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from . import _lib as L
+from . import engine as E
+from .engine import Act, Lazy, Operand, Tape
+
+
+# ---------------------------------------------------------------------------------------------
+# module programs
+# ---------------------------------------------------------------------------------------------
+def basic_block_program(t: Tape, m: nn.Module, x: Operand, out: Optional[Act] = None, need_input_grad: bool = True) -> Act:
+    """``BasicBlock.forward`` (nn/blocks/__init__.py:68-81): relu_(net(x) + proj(x))."""
+    c1, bn1, _, c2, bn2 = m.net
+    h1 = E.conv_bn(t, E.tap_layer(c1.conv), x, bn1, relu=True, need_input_grad=need_input_grad)
+    h2 = E.conv_bn(t, E.tap_layer(c2.conv), h1, bn2, relu=False)
+    if m.projection_block is not None:
+        pc, pbn = m.projection_block
+        res: Operand = E.conv_bn(t, E.tap_layer(pc.conv), x, pbn, relu=False, need_input_grad=need_input_grad)
+    else:
+        if isinstance(x, Lazy):
+            x = E.CombineOp(t, x, None, relu_out=False).out
+        res = x
+    return E.CombineOp(t, h2, res, relu_out=True, out=out).out
+
+
+def residual_block_program(t: Tape, m: nn.Module, x: Operand, out: Optional[Act] = None) -> Act:
+    """``ResidualBlock.forward`` (nn/blocks/__init__.py:123-126)."""
+    blocks = list(m.blocks)
+    for i, b in enumerate(blocks):
+        x = basic_block_program(t, b, x, out=out if i == len(blocks) - 1 else None)
+    return x
+
+
+def aggregation_block_program(t: Tape, m: nn.Module, x1: Act, x2: Act, out: Optional[Act] = None) -> Act:
+    """``AggregationBlock.forward`` (nn/blocks/__init__.py:165-182): x1 + relu(bn(convT(x2))) -> ResidualBlock."""
+    up = E.conv_bn(t, E.tap_layer(m.upscale), x2, m.normalization, relu=True)
+    s = E.CombineOp(t, x1, up, relu_out=False).out
+    return residual_block_program(t, m.block, s, out=out)
+
+
+def meta_kernel_program(t: Tape, m: nn.Module, features: Act, cart: Tensor, out: Optional[Act] = None) -> Act:
+    """``MetaKernel.forward`` (nn/stems/__init__.py:64-85) without materialising either ``F.unfold``."""
+    f = basic_block_program(t, m.projection, features, need_input_grad=False)
+    rel = E.MetaRelativeOp(t, cart).out
+    pos: Operand = rel
+    for i, blk in enumerate(m.positional_kernel):
+        pos = E.conv_bn(t, E.tap_layer(blk[0]), pos, blk[1], relu=True, need_input_grad=(i > 0))
+    geo: Operand = E.MetaModulateOp(t, pos, f).out
+    c = m.out_channels
+    for i, blk in enumerate(m.fusion_kernel):
+        kw = {"in_perm": (c, m.num_neighbors**2)} if i == 0 else {}
+        geo = E.conv_bn(t, E.tap_layer(blk[0], **kw), geo, blk[1], relu=True)
+    return E.CombineOp(t, geo, None, relu_out=False, out=out).out
+
+
+def range_backbone_program(t: Tape, m: nn.Module, stem: Act, feat1: Optional[Act]) -> Dict[int, Act]:
+    """``RangeBackbone.forward`` (nn/backbones/dla.py:110-131)."""
+    res1 = residual_block_program(t, m.res1, stem)
+    res2a = residual_block_program(t, m.res2a, res1)
+    res2 = residual_block_program(t, m.res2, res2a)
+    res3a = residual_block_program(t, m.res3a, res2)
+    res3 = residual_block_program(t, m.res3, res3a)
+    agg2 = aggregation_block_program(t, m.agg2, res2, res3)
+    agg1 = aggregation_block_program(t, m.agg1, res1, res2)
+    agg2a = aggregation_block_program(t, m.agg2a, res2a, agg2)
+    c0 = stem.cp
+    if feat1 is not None:  # concat written in place: stem already sits in channels [0, c0)
+        agg3 = aggregation_block_program(t, m.agg3, agg1, agg2a, out=feat1.slice(c0, 2 * c0))
+        cat = feat1
+        cat.c = 2 * c0
+    else:
+        agg3 = aggregation_block_program(t, m.agg3, agg1, agg2a)
+        cat = E.ConcatOp(t, [stem, agg3]).out
+    return {1: cat, 2: agg2a, 4: agg2, 16: res3}
+
+
+def range_net_program(t: Tape, m: nn.Module, features: Tensor, cart: Tensor) -> Dict[int, Act]:
+    """``RangeNet.forward`` (nn/backbones/dla.py:193-208)."""
+    n, c, h, w = features.shape
+    x = Act.empty(n, h, w, c, t.device, zero=True)
+    feats32 = features.contiguous().float()  # keep the temporary referenced across the launch
+    L.call("rv_nchw_f32_to_nhwc_bf16", L.ptr(feats32), L.i32(n), L.i32(c), L.i32(h), L.i32(w), x.ptr(),
+           L.i32(x.ld), L.i32(0), L.stream_ptr())
+    c0 = m.layers[0]
+    in_place = c0 % 32 == 0
+    feat1 = Act.empty(n, h, w, 2 * c0, t.device) if in_place else None
+    stem_out = feat1.slice(0, c0) if in_place else None
+    if m.stem_type == "META":
+        stem = meta_kernel_program(t, m.stem, x, cart, out=stem_out)
+    elif m.stem_type == "BASIC":
+        stem = basic_block_program(t, m.stem, x, out=stem_out, need_input_grad=False)
+    else:
+        raise NotImplementedError("stem_type RANGE_PARTITION is not selected by any shipped rv-* config")
+    return range_backbone_program(t, m.net, stem, feat1)
+
+
+def dense_head_program(t: Tape, m: nn.Module, x: Act) -> E.ConvOp:
+    """``DenseHead.forward`` (nn/heads/dense_head.py:74-76): towers of conv-BN-ReLU + a biased final conv (fp32 out)."""
+    blocks = list(m.blocks)
+    h: Operand = x
+    for blk in blocks[:-1]:
+        h = E.conv_bn(t, E.tap_layer(blk[0]), h, blk[1], relu=True)
+    return E.ConvOp(t, E.tap_layer(blocks[-1][0]), h, stats=False, out_f32=True)
+
+
+# ---------------------------------------------------------------------------------------------
+# autograd bridge
+# ---------------------------------------------------------------------------------------------
+class _ProgramFn(torch.autograd.Function):
+    """One autograd node for a whole fused program.
+
+    ``build(tape, *tensor_inputs)`` -> (list of input Acts wanting gradients (or None), list of outputs), where an
+    output is an ``Act`` (bf16 NHWC, returned as a channels_last NCHW view) or a ``ConvOp`` with an fp32 result.
+    """
+
+    @staticmethod
+    def forward(ctx, build: Callable, training: bool, n_in: int, *args):
+        inputs = args[:n_in]
+        for x in inputs:
+            if isinstance(x, Tensor):
+                E._require_cuda(x, "input tensor")
+        dev = next(x.device for x in inputs if isinstance(x, Tensor))
+        tape = Tape(training, dev)
+        in_acts, outs = build(tape, *inputs)
+        ctx.tape, ctx.in_acts, ctx.outs, ctx.n_in = tape, in_acts, outs, n_in
+        ctx.params = args[n_in:]
+        ctx.in_meta = [(x.dtype, x.shape) if isinstance(x, Tensor) else None for x in inputs]
+        result = []
+        for o in outs:
+            if isinstance(o, Act):
+                result.append(o.nchw())
+            else:  # fp32 conv output (N,H,W,cp) -> (N,c,H,W) view
+                result.append(o.out_t[..., : o.layer.c_out].permute(0, 3, 1, 2))
+        return tuple(result)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        from . import engine_bwd
+
+        tape: Tape = ctx.tape
+        for o, g in zip(ctx.outs, gouts):
+            if g is None:
+                continue
+            if isinstance(o, Act):
+                tape.set_grad(o, engine_bwd.grad_act_like(o, g))
+            else:
+                engine_bwd.seed_f32_output_grad(tape, o, g)
+        tape.backward()
+        gin: List[Optional[Tensor]] = []
+        for a, meta in zip(ctx.in_acts, ctx.in_meta):
+            if a is None or meta is None or id(a) not in tape.grads:
+                gin.append(None)
+            else:
+                gin.append(tape.grads[id(a)].nchw().to(meta[0]))
+        gparams = [tape.param_grads.get(id(p)) for p in ctx.params]
+        ctx.tape = None  # free activations
+        return (None, None, None, *gin, *gparams)
+
+
+def run(build: Callable, module: nn.Module, inputs: Sequence[Tensor]) -> Tuple[Tensor, ...]:
+    params = [p for p in module.parameters()]
+    return _ProgramFn.apply(build, module.training, len(inputs), *inputs, *params)
+
+
+def standalone(m: nn.Module, *inputs: Tensor):
+    """Run a single block-level module on NCHW tensors (API parity with the reference's per-module ``forward``)."""
+    from .nn.blocks import AggregationBlock, BasicBlock, ResidualBlock
+    from .nn.modules.conv import Conv2dSame
+    from .nn.stems import MetaKernel
+
+    def build(t: Tape, *xs: Tensor):
+        if isinstance(m, MetaKernel):
+            feats, cart = xs
+            n, c, h, w = feats.shape
+            x = Act.empty(n, h, w, c, t.device, zero=True)
+            x.data[..., :c].copy_(feats.permute(0, 2, 3, 1))
+            return [None, None], [meta_kernel_program(t, m, x, cart)]
+        acts = [Act.from_nchw(x) for x in xs]
+        if isinstance(m, Conv2dSame):
+            return acts, [E.ConvOp(t, E.tap_layer(m.conv), acts[0]).out]
+        if isinstance(m, BasicBlock):
+            return acts, [basic_block_program(t, m, acts[0])]
+        if isinstance(m, ResidualBlock):
+            return acts, [residual_block_program(t, m, acts[0])]
+        if isinstance(m, AggregationBlock):
+            return acts, [aggregation_block_program(t, m, acts[0], acts[1])]
+        raise NotImplementedError(type(m))
+
+    out = run(build, m, inputs)
+    return out[0]

@@ -1,0 +1,234 @@
+"""GPU parity of the full detector path: backbone + head + targets + loss + backward, decoder + weighted NMS.
+
+Tolerances: see test_gpu_forward.py / test_gpu_backward.py; additionally
+* dense targets: labels / panoptic ids / point counts bit-exact, regression targets 1e-5;
+* loss scalars vs the oracle evaluated on the HIP path's own logits / regressands: 1e-4;
+* weighted NMS vs the C oracle (declared semantics): kept indices and counts bit-exact, merged rows 1e-6.
+"""
+
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_backward import _cos, _l2
+from test_gpu_forward import DEV, rel_err
+
+pytestmark = pytest.mark.gpu
+
+NCLS = 5
+
+
+def build_tiny(C=16, ncls=NCLS):
+    from range_view_3d_detection_amd.nn.backbones.dla import RangeNet
+    from range_view_3d_detection_amd.nn.heads.detection_head import DetectionHead
+
+    layers = [C] * 5
+    backbone = RangeNet(in_channels=5, layers=layers, out_channels=C, projection_kernel_size=1, dataset_name="av2",
+                        num_neighbors=3, num_layers=2, stem_type="META",
+                        _net={"_target_": "torchbox3d.nn.backbones.dla.RangeBackbone", "in_channels": 5, "layers": layers, "out_channels": C})
+    tasks = {0: [f"C{i}" for i in range(ncls)]}
+    tcfg = {"dataset_name": "av2", "tasks": tasks, "enable_azimuth_invariant_targets": True, "range_partitions": {1: [0.0, math.inf]},
+            "fpn_assignment_method": None, "k": math.inf, "affinity_fn": "GAUSSIAN", "normalize_affinities": False, "sigma": 0.75}
+    head = DetectionHead(fpn={1: 2 * C}, fpn_kernel_sizes={1: [3, 3]}, targets_config=tcfg, num_classification_blocks=4,
+                         num_regression_blocks=4, final_kernel_size=1, tasks_cfg=tasks, task_in_channels=C, classification_weight=1.0,
+                         regression_weight=1.0, coding_weights=[1.0] * 8, classification_head_channels=2 * C,
+                         regression_head_channels=2 * C, classification_normalization_method="FOREGROUND",
+                         _cls_loss={"_target_": "torchbox3d.nn.losses.classification.VarifocalLoss", "alpha": 0.75, "gamma": 2.0, "reduction": "none"},
+                         _regression_loss={"_target_": "torch.nn.L1Loss", "reduction": "none"})
+    return backbone, head
+
+
+def load_tiny(g):
+    backbone, head = build_tiny()
+    sd = g.sub("sd")
+    backbone.load_state_dict({k[len("backbone."):]: v for k, v in sd.items() if k.startswith("backbone.")})
+    head.load_state_dict({k[len("head."):]: v for k, v in sd.items() if k.startswith("head.")})
+    return backbone.to(DEV), head.to(DEV)
+
+
+def test_state_dict_keys_match_reference(golden):
+    g = golden("tiny_model")
+    backbone, head = build_tiny()
+    ref_keys = set(g.sub("sd").keys())
+    ours = {f"backbone.{k}" for k in backbone.state_dict()} | {f"head.{k}" for k in head.state_dict()}
+    assert ours == ref_keys
+
+
+def test_targets_bit_exact(golden):
+    from range_view_3d_detection_amd.nn.heads.detection_head import compute_targets
+
+    g = golden("tiny_model")
+    tasks = {0: ["c"] * NCLS}
+    data = {"cart": g["cart"].to(DEV), "annotations": g["annotations"]}
+    t = compute_targets(data, tasks, [1], {"enable_azimuth_invariant_targets": True, "fpn_assignment_method": None})[1][0]
+    for k in ("classification_labels", "panoptics", "points_per_obj"):
+        assert torch.equal(t[k].cpu(), g[f"targets/{k}"]), k
+    assert rel_err(t["regression_targets"], g["targets/regression_targets"]) < 1e-5
+    assert int(t["num_objects"].item()) == int(g["loss/total_objects"].item())
+
+
+def test_loss_kernel_matches_oracle(golden):
+    """Loss + gradients on the reference's own logits / regressands (fp32 in, fp64 reductions)."""
+    from oracle import targets as otgt
+    from range_view_3d_detection_amd.nn.heads.detection_head import _DetectionLossFn, compute_targets
+
+    g = golden("tiny_model")
+    logits = g["logits"].clone().requires_grad_(True)
+    reg = g["regressands"].clone().requires_grad_(True)
+    tg_o = {k: g[f"targets/{k}"] for k in ("classification_labels", "panoptics", "points_per_obj", "regression_targets")}
+    lo = otgt.detection_loss(logits, reg, g["cart"], g["mask"], tg_o, NCLS)
+    lo["loss"].backward()
+
+    data = {"cart": g["cart"].to(DEV), "annotations": g["annotations"]}
+    t = compute_targets(data, {0: ["c"] * NCLS}, [1], {"enable_azimuth_invariant_targets": True, "fpn_assignment_method": None})[1][0]
+    hp = {"coding_weights": [1.0] * 8, "cls_weight": 1.0, "reg_weight": 1.0, "smoothing": 1.0, "sigma": 0.75, "alpha": 0.75, "gamma": 2.0, "az_inv": True}
+    ld = g["logits"].to(DEV).requires_grad_(True)
+    rd = g["regressands"].to(DEV).requires_grad_(True)
+    loss, sums, soft, fg = _DetectionLossFn.apply(ld, rd, g["cart"].to(DEV), g["mask"].to(DEV), t, hp)
+    loss.backward()
+    assert rel_err(loss.reshape(()), g["loss/loss"].reshape(())) < 1e-4
+    assert rel_err(soft, g["targets/soft"]) < 1e-5
+    assert torch.equal(fg.cpu(), g["aux/foreground"])
+    for key, val in (("classification_loss", sums[0] / sums[13]), ("foreground_loss", sums[1] / sums[13]), ("background_loss", sums[2] / sums[13]),
+                     ("coordinate_loss", sums[4:7].sum() / sums[12]), ("dimension_loss", sums[7:10].sum() / sums[12]),
+                     ("rotation_loss", sums[10:12].sum() / sums[12]), ("total_fg", sums[13]), ("total_objects", sums[12])):
+        assert rel_err(val.reshape(()), g[f"loss/{key}"].reshape(())) < 1e-4, key
+    assert rel_err(ld.grad, logits.grad) < 1e-4
+    assert rel_err(rd.grad, reg.grad) < 1e-4
+
+
+def test_tiny_detector_forward_backward(golden):
+    g = golden("tiny_model")
+    backbone, head = load_tiny(g)
+    backbone.train()
+    head.train()
+    data = {"features": g["features"].to(DEV), "cart": g["cart"].to(DEV), "mask": g["mask"].to(DEV), "annotations": g["annotations"]}
+    from oracle import model as om
+
+    with torch.no_grad():
+        feats_o, logits_o, reg_o = om.detector_forward(g["features"], g["cart"], g.sub("sd"), nm=om.Numerics.bf16(train=True))
+    feats = backbone(data)
+    for s in (1, 2, 4, 16):
+        assert feats[s].shape == g[f"feat/{s}"].shape
+        # ~60 conv+BN layers on 2x8x{4..64} pixels: vs the oracle with the same bf16 storage points, and (looser) vs fp32
+        assert rel_err(feats[s].float(), feats_o[s]) < 6e-2, (s, rel_err(feats[s].float(), feats_o[s]))
+        assert rel_err(feats[s].float(), g[f"feat/{s}"]) < 1.2e-1 and _cos(feats[s].float(), g[f"feat/{s}"]) > 0.999, s
+    outputs, losses = head(feats, data, return_loss=True)
+    assert rel_err(outputs[1][0]["logits"], logits_o) < 6e-2 and rel_err(outputs[1][0]["regressands"], reg_o) < 6e-2
+    assert rel_err(outputs[1][0]["logits"], g["logits"]) < 1.2e-1
+    assert rel_err(outputs[1][0]["regressands"], g["regressands"]) < 1.2e-1
+    for k in ("classification_labels", "panoptics", "points_per_obj"):
+        assert torch.equal(data[1][0][k].cpu(), g[f"targets/{k}"])
+    assert rel_err(losses["loss"].reshape(()), g["loss/loss"].reshape(())) < 3e-2
+    assert losses["loss"].dtype == torch.float64
+    losses["loss"].backward()
+    cos_all, n_bad = [], 0
+    for prefix, mod in (("backbone", backbone), ("head", head)):
+        for k, p in mod.named_parameters():
+            assert p.grad is not None and torch.isfinite(p.grad).all(), k
+            ref = g[f"grad/{prefix}.{k}"]
+            if float(ref.abs().max()) < 1e-6:
+                continue
+            c = _cos(p.grad, ref)
+            cos_all.append(c)
+            n_bad += c < 0.9
+    # deep tiny network (60 BN layers at 2x8x4 .. 2x8x64 pixels): bf16 gate flips make individual small tensors noisy;
+    # the bulk of the gradient must still point the same way as the reference's fp32 gradient
+    assert np.median(cos_all) > 0.97 and n_bad <= len(cos_all) // 10, (np.median(cos_all), n_bad, len(cos_all))
+    # running statistics updated in place
+    sd_after = {**{f"backbone.{k}": v for k, v in backbone.state_dict().items()}, **{f"head.{k}": v for k, v in head.state_dict().items()}}
+    worst = max(rel_err(sd_after[k], v) for k, v in g.sub("sd_after").items())
+    assert worst < 5e-2, worst
+
+
+def test_tiny_detector_eval_and_decode(golden):
+    from range_view_3d_detection_amd.nn.decoders.range_decoder import RangeDecoder
+
+    g = golden("tiny_model")
+    backbone, head = load_tiny(g)
+    backbone.eval()
+    head.eval()
+    data = {"features": g["features"].to(DEV), "cart": g["cart"].to(DEV), "mask": g["mask"].to(DEV)}
+    with torch.no_grad():
+        feats = backbone(data)
+        outputs, _ = head(feats, data, return_loss=False)
+    assert rel_err(outputs[1][0]["logits"], g["eval/logits"]) < 6e-2
+    assert rel_err(outputs[1][0]["regressands"], g["eval/regressands"]) < 6e-2
+    dec = RangeDecoder(True, True, [0, 15, 30], [15, 30, math.inf], [8, 2, 1])
+    post = {"num_pre_nms": 50000, "num_post_nms": 1000, "nms_threshold": 0.3, "min_confidence": 0.1, "nms_mode": "WEIGHTED"}
+    # decoder on the reference's own eval outputs: exact candidate set
+    mo = {1: {"cart": data["cart"], "mask": data["mask"], 0: {"logits": g["eval/logits"].to(DEV), "regressands": g["eval/regressands"].to(DEV)}}}
+    p, s, c, b = dec.decode(mo, post, {0: ["c"] * NCLS}, use_nms=False)
+    assert torch.equal(c.cpu(), g["eval/dec_categories"]) and torch.equal(b.cpu(), g["eval/dec_batch_index"])
+    assert rel_err(p, g["eval/dec_params"]) < 1e-5 and rel_err(s, g["eval/dec_scores"]) < 1e-6
+    # full decode with weighted NMS on the HIP outputs runs and satisfies the wrapper's post-conditions
+    p, s, c, b = dec.decode(outputs, post, {0: ["c"] * NCLS}, use_nms=True)
+    assert p.shape[1] == 10 and p.shape[0] == s.shape[0] == c.shape[0] == b.shape[0] and p.shape[0] > 0
+    assert torch.isfinite(p).all() and (s >= 0).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# weighted NMS
+# ---------------------------------------------------------------------------------------------
+def _random_boxes(n, seed, spread=30.0):
+    g = torch.Generator().manual_seed(seed)
+    ctr = (torch.rand(n, 2, generator=g) - 0.5) * spread
+    lw = 1.0 + 4.0 * torch.rand(n, 2, generator=g)
+    yaw = (torch.rand(n, 1, generator=g) * 2 - 1) * math.pi
+    z = torch.randn(n, 1, generator=g)
+    h = 1.0 + torch.rand(n, 1, generator=g)
+    cub = torch.cat([ctr, z, lw, h, yaw], dim=1)  # x,y,z,l,w,h,yaw
+    scores = torch.rand(n, generator=g) * 0.9 + 0.1
+    return cub, scores
+
+
+@pytest.mark.parametrize("n,spread", [(1, 10.0), (65, 8.0), (700, 30.0), (3000, 60.0)])
+def test_weighted_nms_matches_oracle_bit_exact(n, spread):
+    from oracle import nms as onms
+    from range_view_3d_detection_amd.math.ops import nms as hnms
+
+    cub, scores = _random_boxes(n, n, spread)
+    half = cub[:, 3:5] / 2
+    rect = torch.cat([cub[:, :2] - half, cub[:, :2] + half, cub[:, 6:7]], dim=-1)
+    data = torch.cat([cub[:, :6], cub[:, 6:7].sin(), cub[:, 6:7].cos()], dim=1)
+    keep_o, out_o, cnt_o = onms.weighted_nms(rect, data, scores, 0.3, 0.5)
+    keep, out, cnt = hnms.weighted_nms(rect.to(DEV), data.to(DEV), scores.to(DEV), 0.3, 0.5)
+    assert torch.equal(keep.cpu(), keep_o) and torch.equal(cnt.cpu(), cnt_o)
+    assert torch.equal(out.cpu(), out_o), float((out.cpu() - out_o).abs().max())
+    assert (cnt > 0).all() and int(cnt.sum()) <= n  # nms.py:173-174 post-conditions; clusters are disjoint
+
+
+def test_rotated_iou_matches_oracle():
+    from oracle import nms as onms
+    from range_view_3d_detection_amd import _lib as L
+
+    cub, _ = _random_boxes(200, 3, 12.0)
+    half = cub[:, 3:5] / 2
+    rect = torch.cat([cub[:, :2] - half, cub[:, :2] + half, cub[:, 6:7]], dim=-1).contiguous()
+    ref = onms.pairwise_iou(rect.numpy(), rect.numpy())
+    rd = rect.to(DEV)
+    out = torch.empty((200, 200), dtype=torch.float32, device=DEV)
+    L.call("rv_rotated_iou", L.ptr(rd), L.i64(200), L.ptr(rd), L.i64(200), L.ptr(out), L.stream_ptr())
+    assert np.array_equal(out.cpu().numpy(), ref)
+    assert abs(float(out.diagonal().min()) - 1.0) < 1e-5 and float(out.max()) <= 1.0 + 1e-6
+
+
+def test_batched_multiclass_nms_matches_oracle():
+    from oracle import nms as onms
+    from range_view_3d_detection_amd.math.ops import nms as hnms
+
+    cubs, scs, cats = [], [], []
+    for b in range(2):
+        cub, s = _random_boxes(500, 100 + b, 25.0)
+        cubs.append(cub)
+        scs.append(s * (torch.rand(500, generator=torch.Generator().manual_seed(b)) > 0.3))
+        cats.append(torch.randint(0, 4, (500,), generator=torch.Generator().manual_seed(10 + b)))
+    cub, sc, cat = torch.stack(cubs), torch.stack(scs), torch.stack(cats)
+    bo, so, co, io = onms.batched_multiclass_nms(cub, sc, cat, 50000, 100, 0.3, 0.1)
+    b, s, c, i = hnms.batched_multiclass_nms(cub.to(DEV), sc.to(DEV), cat.to(DEV), 50000, 100, 0.3, 0.1, "weighted")
+    assert b.shape == bo.shape and torch.equal(c.cpu(), co) and torch.equal(i.cpu(), io)
+    assert rel_err(b, bo) < 1e-6 and rel_err(s, so) < 1e-6
