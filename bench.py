@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training-step throughput (sweeps/s, fwd+bwd) of the rv-av2 range-view detector.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic sweeps per GPU: MetaKernel stem +
+DLA backbone + cls/reg towers (forward), device target assignment + varifocal/L1 loss, backward
+through every layer, gradient clipping (35.0) and the AdamW update -- the work of one
+``Detector.training_step`` (nn/arch/detector.py:238-247) with ``conf/experiment/rv-av2.yaml``.
+Inputs are resident in HBM before the timed region.  N > 1: one process per GPU, sweeps sharded
+across ranks (weak scaling, 4 sweeps per GPU), gradient all-reduce through DDP over RCCL overlapped
+with the backward of the earlier stage, BatchNorm statistics all-reduced (SyncBN as in
+conf/trainer/train.yaml:15).
+
+Rank 0 prints ONE JSON line (contract in the task statement) including
+  "roofline":     the dominant kernel (128x128-tile bf16 MFMA tap-conv) against the dense bf16 MFMA peak,
+                  timed live with events around each of its launches inside the timed region;
+  "cpu_baseline": the oracle (CPU restatement of the reference, ``oracle/``) timed on this box's host
+                  cores on a bounded sample (N == 1 only).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 (MI355X_MICROARCH.md: ~2.5 PF dense; 2:1-sparsity figures are not used)
+HBM_PEAK_GBS = 8000.0
+
+AV2_CLASSES = 26
+
+
+def synthetic_batch(B: int, H: int, W: int, seed: int, device, n_feat: int = 5, boxes_per_sweep: int = 16, n_cls: int = AV2_CLASSES):
+    """Synthetic sweeps as SURVEY.md §8d defines them (seeded; built on CPU, then moved to HBM)."""
+    g = torch.Generator().manual_seed(seed)
+    inc = torch.linspace(0.2, -0.4, H).view(1, 1, H, 1)
+    az = torch.linspace(math.pi, -math.pi, W).view(1, 1, 1, W)
+    # piecewise-smooth ranges (so that boxes contain several pixels) + noise, 10 % dropped returns
+    r = 20.0 + 15.0 * torch.sin(3 * az + 1.3 * torch.rand(B, 1, 1, 1, generator=g)) + 10.0 * torch.cos(7 * inc) + torch.rand(B, 1, H, W, generator=g)
+    r = r.clamp(1.5, 80.0)
+    mask = torch.rand(B, 1, H, W, generator=g) >= 0.1
+    cart = torch.cat([r * inc.cos() * az.cos(), r * inc.cos() * az.sin(), r * inc.sin().expand(B, 1, H, W)], dim=1) * mask
+    intensity = torch.rand(B, 1, H, W, generator=g)
+    feats = [intensity, r, cart[:, 0:1], cart[:, 1:2], cart[:, 2:3]]
+    if n_feat == 6:
+        feats = [torch.rand(B, 1, H, W, generator=g)] + feats
+    features = (torch.cat(feats, dim=1) * mask).float()
+    rows = []
+    for b in range(B):
+        valid = mask[b, 0].nonzero()
+        pick = valid[torch.randperm(valid.shape[0], generator=g)[:boxes_per_sweep]]
+        for h, w in pick.tolist():
+            ctr = cart[b, :, h, w].double().tolist()
+            lwh = (torch.tensor([1.0, 1.0, 1.0]) + torch.rand(3, generator=g) * torch.tensor([5.0, 2.0, 2.0])).tolist()
+            yaw = (torch.rand(1, generator=g).item() * 2 - 1) * math.pi
+            cat = int(torch.randint(0, n_cls, (1,), generator=g).item())
+            rows.append(ctr + lwh + [math.cos(yaw / 2), 0.0, 0.0, math.sin(yaw / 2)] + [0.0, float(cat), float(b)])
+    ann = torch.tensor(rows, dtype=torch.float64)
+    return {"features": features.to(device), "cart": cart.float().to(device), "mask": mask.to(device), "annotations": ann}
+
+
+def build_model(widths: str, n_cls: int, in_channels: int = 5):
+    from range_view_3d_detection_amd.nn.backbones.dla import RangeNet
+    from range_view_3d_detection_amd.nn.heads.detection_head import DetectionHead
+
+    if widths == "rv-av2":
+        layers, head_c = [256, 128, 128, 128, 128], 512
+    elif widths == "rv-waymo":
+        layers, head_c = [128] * 5, 256
+    else:  # debug widths "c<int>"
+        c = int(widths[1:])
+        layers, head_c = [c] * 5, 2 * c
+    backbone = RangeNet(in_channels=in_channels, layers=layers, out_channels=layers[0], projection_kernel_size=1, dataset_name="av2",
+                        num_neighbors=3, num_layers=2, stem_type="META",
+                        _net={"_target_": "torchbox3d.nn.backbones.dla.RangeBackbone", "in_channels": in_channels, "layers": layers,
+                              "out_channels": layers[0]})
+    tasks = {0: [f"C{i}" for i in range(n_cls)]}
+    tcfg = {"dataset_name": "av2", "tasks": tasks, "enable_azimuth_invariant_targets": True, "range_partitions": {1: [0.0, math.inf]},
+            "fpn_assignment_method": None, "k": math.inf, "affinity_fn": "GAUSSIAN", "normalize_affinities": False, "sigma": 0.75}
+    head = DetectionHead(fpn={1: 2 * layers[0]}, fpn_kernel_sizes={1: [3, 3]}, targets_config=tcfg, num_classification_blocks=4,
+                         num_regression_blocks=4, final_kernel_size=1, tasks_cfg=tasks, task_in_channels=layers[0],
+                         classification_weight=1.0, regression_weight=1.0, coding_weights=[1.0] * 8,
+                         classification_head_channels=head_c, regression_head_channels=head_c,
+                         classification_normalization_method="FOREGROUND",
+                         _cls_loss={"_target_": "torchbox3d.nn.losses.classification.VarifocalLoss", "alpha": 0.75, "gamma": 2.0, "reduction": "none"},
+                         _regression_loss={"_target_": "torch.nn.L1Loss", "reduction": "none"})
+    return backbone, head
+
+
+class Detector(torch.nn.Module):
+    """``Detector.forward`` (nn/arch/detector.py:196-210): backbone -> head(return_loss) -> loss."""
+
+    def __init__(self, backbone, head) -> None:
+        super().__init__()
+        self.backbone, self.head = backbone, head
+
+    def forward(self, data):
+        feats = self.backbone(data)
+        _, losses = self.head(feats, data, return_loss=True)
+        return losses["loss"]
+
+
+def cpu_baseline(seconds_budget: float = 25.0):
+    """Oracle (``oracle/`` = CPU restatement of the reference, fp32 PyTorch-CPU) fwd+bwd on a bounded sample."""
+    from oracle import model as om
+    from oracle import targets as otgt
+
+    torch.set_num_threads(os.cpu_count() or 1)
+    H, W_full, frac = 64, 2048, 16
+    W = W_full // frac
+    backbone, head = build_model("rv-av2", AV2_CLASSES)
+    sd = {**{f"backbone.{k}": v for k, v in backbone.state_dict().items()}, **{f"head.{k}": v for k, v in head.state_dict().items()}}
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
+    full = {**sd, **params}
+    batch = synthetic_batch(1, H, W, seed=0, device="cpu")
+
+    def step():
+        feats, logits, reg = om.detector_forward(batch["features"], batch["cart"], full, nm=om.Numerics(train=True))
+        tg = otgt.compute_targets(batch["cart"], batch["annotations"], AV2_CLASSES)
+        loss = otgt.detection_loss(logits, reg, batch["cart"], batch["mask"], tg, AV2_CLASSES)["loss"]
+        loss.backward()
+
+    step()  # warm-up (discarded, tools/benchmark.py:120-122 methodology)
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        step()
+        n += 1
+        if time.perf_counter() - t0 > seconds_budget * 0.5 or n >= 3:
+            break
+    dt = (time.perf_counter() - t0) / n
+    return {
+        "value": (1.0 / frac) / dt, "unit": "sweeps/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": f"oracle fwd+loss+bwd, rv-av2 widths, fp32, B=1, one 64x{W}x5 crop (1/{frac} of a 64x2048 sweep), {n} timed iterations",
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4, help="sweeps per GPU")
+    ap.add_argument("--width", type=int, default=2048)
+    ap.add_argument("--height", type=int, default=64)
+    ap.add_argument("--widths", default="rv-av2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sync-bn", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+
+    from range_view_3d_detection_amd import engine as E
+
+    torch.manual_seed(0)
+    backbone, head = build_model(args.widths, AV2_CLASSES)
+    model = Detector(backbone, head).to(dev).train()
+    E.SYNC_BN = world > 1 and not args.no_sync_bn
+    step_model = model
+    if world > 1:
+        step_model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], gradient_as_bucket_view=True, static_graph=True)
+    params = [p for p in model.parameters()]
+    opt = torch.optim.AdamW(params, lr=1e-3)
+    batch = synthetic_batch(args.batch, args.height, args.width, seed=1234 + rank, device=dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = step_model(batch)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 35.0)
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    E.PROFILE = E.KernelProfile()  # events around each tap-conv / wgrad launch inside the timed region
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof = E.PROFILE
+    E.PROFILE = None
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        sweeps = args.batch * world * args.steps
+        out = {
+            "metric": "sweeps/sec (fwd+bwd, 64x2048x5 range image)", "value": sweeps / elapsed, "unit": "sweeps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.widths} full model (MetaKernel stem + DLA backbone/FPN + cls/reg towers + targets + loss), "
+                                   f"fwd+bwd+AdamW, {args.batch} synthetic {args.height}x{args.width}x5 sweeps per GPU (BASELINE configs[2])",
+                       "global_batch": args.batch * world, "sweep": [args.height, args.width, 5], "parallelism": f"dp{world}",
+                       "sync_bn": bool(E.SYNC_BN), "loss": float(loss.detach().item())},
+            "roofline": prof.roofline(MFMA_BF16_PEAK_TFLOPS),
+            "kernels": prof.summary(),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

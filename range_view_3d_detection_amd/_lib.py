@@ -75,12 +75,26 @@ def _as_arg(v):
     return v
 
 
+_DEBUG = bool(int(os.environ.get("RV3D_DEBUG_SYNC", "0")))
+
+
 def call(name: str, *args) -> None:
-    """Invoke an int-returning entry point; raise with rv_last_error() on failure."""
+    """Invoke an int-returning entry point; raise with rv_last_error() on failure.
+
+    ``RV3D_DEBUG_SYNC=1`` prints every call and synchronises after it (locates a faulting launch).
+    """
     fn = getattr(load(), name)
+    if _DEBUG:
+        import sys
+
+        import torch
+
+        print(f"[rv3d] {name}", file=sys.stderr, flush=True)
     rc = fn(*args)
     if rc != 0:
         raise RvError(f"{name} failed: {load().rv_last_error().decode()}")
+    if _DEBUG:
+        torch.cuda.synchronize()
 
 
 def ptr(t) -> ctypes.c_void_p:

@@ -154,11 +154,14 @@ __global__ __launch_bounds__(256, 2) void tapconv_kernel(const TapConvArgs a) {
     const int a_lane = (wm * MT * 16 + l15) * S * kPix + lg * 8;
     const int b_lane = (wn * NT * 16 + l15) * kPix + lg * 8;
 
-    const int nk = a.C_src / 32;
-    load_a(0);
-    load_b(0, 0);
-    write_a();
-    write_b(0);
+    // a phase of a strided scatter can have no tap at all (1x1 stride-2 projection: odd columns receive nothing)
+    const int nk = (T > 0) ? a.C_src / 32 : 0;
+    if (nk > 0) {
+        load_a(0);
+        load_b(0, 0);
+        write_a();
+        write_b(0);
+    }
     __syncthreads();
     int buf = 0;
     for (int kc = 0; kc < nk; ++kc) {
@@ -375,7 +378,7 @@ int rv_build_tap_table(const rvTapGeom* g, bool scatter, TapTable* tt, int* phas
 
 static int tap_launch(const rvTapGeom* g, const rvTapShape* s, bool scatter, const void* src, const float* in_scale,
                       const float* in_shift, const void* w, const float* bias, void* dst, float* stats,
-                      rvStream stream, bool dry_run, int* stats_rows) {
+                      rvStream stream, bool dry_run, int* stats_rows, int* info = nullptr) {
     TapConvArgs a;
     memset(&a, 0, sizeof(a));
     int phases, step;
@@ -430,6 +433,12 @@ static int tap_launch(const rvTapGeom* g, const rvTapShape* s, bool scatter, con
     const int grid_x = a.m_tiles * a.H * a.N * phases;
     const int grid_y = rv_ceil_div(a.C_dst, BN);
     if (stats_rows) *stats_rows = grid_x * 2;
+    if (info) {
+        info[0] = mt;
+        info[1] = nt;
+        info[2] = grid_x;
+        info[3] = grid_y;
+    }
     if (dry_run) return 0;
     hipStream_t st = (hipStream_t)stream;
 #define RV_CASE(M, Nn) \
@@ -445,6 +454,11 @@ int32_t rv_tap_stats_rows(const rvTapGeom* g, const rvTapShape* s, int32_t scatt
     int rows = 0;
     if (tap_launch(g, s, scatter != 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, true, &rows)) return -1;
     return rows;
+}
+
+int rv_tap_launch_info(const rvTapGeom* g, const rvTapShape* s, int32_t scatter, int32_t* host_info) {
+    RV_REQUIRE(g && s && host_info, "rv_tap_launch_info: null argument");
+    return tap_launch(g, s, scatter != 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, true, nullptr, host_info);
 }
 
 int rv_tap_gather(const rvTapGeom* g, const rvTapShape* s, const void* V, const float* in_scale, const float* in_shift,

@@ -23,6 +23,74 @@ from . import _lib as L
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
+# Cross-rank BatchNorm statistics (the reference trains with ``sync_batchnorm: true``, conf/trainer/train.yaml:15):
+# when set and torch.distributed is initialised, the per-channel (sum, sum of squares) / (sum g, sum g*xhat)
+# reductions are all-reduced over RCCL before they are finalised.
+SYNC_BN = False
+
+
+class KernelProfile:
+    """Event pairs around individual kernel launches (bench.py: live per-kernel timing inside the timed region)."""
+
+    def __init__(self) -> None:
+        self.records: List[Tuple[str, float, torch.cuda.Event, torch.cuda.Event]] = []
+
+    def launch(self, name: str, flops: float, fn) -> None:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        self.records.append((name, flops, a, b))
+
+    def summary(self) -> Dict[str, Dict[str, float]]:
+        torch.cuda.synchronize()
+        agg: Dict[str, Dict[str, float]] = {}
+        for name, flops, a, b in self.records:
+            d = agg.setdefault(name, {"launches": 0, "ms": 0.0, "tflop": 0.0})
+            d["launches"] += 1
+            d["ms"] += a.elapsed_time(b)
+            d["tflop"] += flops / 1e12
+        for d in agg.values():
+            d["avg_us"] = 1e3 * d["ms"] / max(d["launches"], 1)
+            d["tflops"] = d["tflop"] / max(d["ms"] * 1e-3, 1e-12)
+        return agg
+
+    def roofline(self, peak_tflops: float) -> Dict[str, object]:
+        agg = self.summary()
+        if not agg:
+            return {}
+        name = max(agg, key=lambda k: agg[k]["ms"])
+        d = agg[name]
+        return {"kernel": name, "bound": "mfma", "achieved": d["tflops"], "peak": peak_tflops, "unit": "TFLOP/s",
+                "frac": d["tflops"] / peak_tflops, "traffic": None, "launches": d["launches"], "avg_launch_us": d["avg_us"],
+                "flops_per_launch": 1e12 * d["tflop"] / max(d["launches"], 1)}
+
+
+PROFILE: Optional[KernelProfile] = None
+
+
+def _launch(name: str, flops: float, fn) -> None:
+    if PROFILE is not None:
+        PROFILE.launch(name, flops, fn)
+    else:
+        fn()
+
+
+def tap_kernel_name(geom, shape, scatter: bool) -> str:
+    info = (ctypes.c_int32 * 4)()
+    L.call("rv_tap_launch_info", ctypes.byref(geom), ctypes.byref(shape), L.i32(1 if scatter else 0), info)
+    return f"tapconv_kernel<{info[0]},{info[1]}>"
+
+
+def tap_flops(geom, shape) -> float:
+    return 2.0 * shape.N * shape.H * shape.Wu * geom.kh * geom.kw * geom.cu * geom.cv
+
+
+def _world() -> int:
+    if SYNC_BN and torch.distributed.is_available() and torch.distributed.is_initialized():
+        return torch.distributed.get_world_size()
+    return 1
+
 
 def pad32(c: int) -> int:
     return (c + 31) // 32 * 32
@@ -312,8 +380,13 @@ class ConvOp(Op):
                 raise L.RvError("rv_tap_stats_rows: " + L.load().rv_last_error().decode())
             self.partial = torch.empty((self.rows + L.STATS_SCRATCH_ROWS, 2, pad32(layer.c_out)), dtype=torch.float32,
                                        device=t.device)
-        L.call("rv_tap_" + form, ctypes.byref(g), ctypes.byref(self.shape), src.ptr(), L.ptr(sc), L.ptr(sh),
-               L.ptr(layer.packed(form)), L.ptr(bias_p), dst_ptr, L.ptr(self.partial), L.stream_ptr())
+        wp = layer.packed(form)
+        call = lambda: L.call("rv_tap_" + form, ctypes.byref(g), ctypes.byref(self.shape), src.ptr(), L.ptr(sc), L.ptr(sh),
+                              L.ptr(wp), L.ptr(bias_p), dst_ptr, L.ptr(self.partial), L.stream_ptr())
+        if PROFILE is not None:
+            _launch(tap_kernel_name(g, self.shape, form == "scatter"), tap_flops(g, self.shape), call)
+        else:
+            call()
         self.count = src.N * src.H * w_out
         t.ops.append(self)
 
@@ -342,6 +415,13 @@ class BnOp(Op):
             mean = torch.empty(cp, dtype=torch.float32, device=dev)
             invstd = torch.empty(cp, dtype=torch.float32, device=dev)
             rm, rv = _padded(bn.running_mean, cp), _padded(bn.running_var, cp, 1.0)
+            world = _world()
+            if world > 1:  # SyncBN: all-reduce (sum, sum of squares) over RCCL, then finalise with the global count
+                tot = conv.partial[: conv.rows].sum(dim=0)
+                torch.distributed.all_reduce(tot)
+                conv.partial = torch.empty((1 + L.STATS_SCRATCH_ROWS, 2, cp), dtype=torch.float32, device=dev)
+                conv.partial[0] = tot
+                conv.rows, conv.count = 1, conv.count * world
             L.call("rv_bn_finalize", L.ptr(conv.partial), L.i32(conv.rows), L.i32(cp), L.i64(conv.count), L.ptr(gamma),
                    L.ptr(beta), L.f32(bn.eps), L.f32(bn.momentum if bn.momentum is not None else 0.1), L.ptr(rm),
                    L.ptr(rv), L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd), L.stream_ptr())

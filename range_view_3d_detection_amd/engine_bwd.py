@@ -70,8 +70,13 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
         else:
             dst, accumulate = t.grad_buffer(op.x)
         shape = L.TapShape(sp.N, sp.H, sp.Wu, sp.Wv, dout.ld, dst.ld, L.OUT_ACCUM if accumulate else 0)
-        L.call("rv_tap_" + bwd, ctypes.byref(g), ctypes.byref(shape), dout.ptr(), None, None, L.ptr(layer.packed(bwd)), None,
-               dst.ptr(), None, L.stream_ptr())
+        wp = layer.packed(bwd)
+        call = lambda: L.call("rv_tap_" + bwd, ctypes.byref(g), ctypes.byref(shape), dout.ptr(), None, None, L.ptr(wp), None,
+                              dst.ptr(), None, L.stream_ptr())
+        if E.PROFILE is not None:
+            E._launch(E.tap_kernel_name(g, shape, bwd == "scatter"), E.tap_flops(g, shape), call)
+        else:
+            call()
         if not isinstance(op.x, Lazy):
             t.mark_written(op.x)
     # ---- weight gradient ---------------------------------------------------------------------------
@@ -84,8 +89,9 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=t.device)
     cu_p, cv_p = pad32(g.cu), pad32(g.cv)
     packed = torch.empty((g.kh * g.kw, cu_p, cv_p), dtype=torch.float32, device=t.device)
-    L.call("rv_tap_wgrad", ctypes.byref(g), ctypes.byref(wshape), u.ptr(), L.i32(u.ld), v.ptr(), L.i32(v.ld), L.ptr(sc),
-           L.ptr(sh), L.i32(v_affine), L.ptr(packed), L.ptr(ws), L.stream_ptr())
+    E._launch("wgrad_kernel(+reduce)", E.tap_flops(g, wshape),
+              lambda: L.call("rv_tap_wgrad", ctypes.byref(g), ctypes.byref(wshape), u.ptr(), L.i32(u.ld), v.ptr(), L.i32(v.ld),
+                             L.ptr(sc), L.ptr(sh), L.i32(v_affine), L.ptr(packed), L.ptr(ws), L.stream_ptr()))
     grad = torch.empty((g.cu, g.cv, g.kh, g.kw), dtype=torch.float32, device=t.device)
     L.call("rv_unpack_weight_grad", ctypes.byref(g), L.ptr(packed), L.ptr(grad), L.i32(0), L.stream_ptr())
     t.add_param_grad(layer.weight, layer.unpermute_grad(grad))
@@ -111,8 +117,20 @@ def bn_backward(op: "E.BnOp", t: Tape) -> None:
     dgamma = torch.empty(cp, dtype=torch.float32, device=t.device)
     dbeta = torch.empty(cp, dtype=torch.float32, device=t.device)
     coef = torch.empty((3, cp), dtype=torch.float32, device=t.device)
-    L.call("rv_bn_bwd_finalize", L.ptr(partial), L.i32(rows), L.i32(cp), L.i64(st.count), L.ptr(op.gamma_p), L.ptr(st.invstd),
-           L.ptr(dgamma), L.ptr(dbeta), L.i32(0), L.ptr(coef), L.stream_ptr())
+    if E._world() > 1:
+        # SyncBN backward: the normalisation coefficients need the GLOBAL (sum g, sum g*xhat) -> RCCL all-reduce;
+        # dgamma / dbeta stay LOCAL sums (DDP averages parameter gradients over ranks, as under torch SyncBatchNorm).
+        tot = partial[:rows].sum(dim=0)
+        dbeta.copy_(tot[0])
+        dgamma.copy_(tot[1])
+        torch.distributed.all_reduce(tot)
+        partial = torch.empty((1 + L.STATS_SCRATCH_ROWS, 2, cp), dtype=torch.float32, device=t.device)
+        partial[0] = tot
+        L.call("rv_bn_bwd_finalize", L.ptr(partial), L.i32(1), L.i32(cp), L.i64(st.count), L.ptr(op.gamma_p), L.ptr(st.invstd),
+               None, None, L.i32(0), L.ptr(coef), L.stream_ptr())
+    else:
+        L.call("rv_bn_bwd_finalize", L.ptr(partial), L.i32(rows), L.i32(cp), L.i64(st.count), L.ptr(op.gamma_p), L.ptr(st.invstd),
+               L.ptr(dgamma), L.ptr(dbeta), L.i32(0), L.ptr(coef), L.stream_ptr())
     dy = raw.like()
     L.call("rv_bn_bwd_apply", *common, L.ptr(coef), L.i32(flags), dy.ptr(), L.i32(dy.ld), None, L.i32(0), L.stream_ptr())
     t.raw_grad[id(raw)] = dy
