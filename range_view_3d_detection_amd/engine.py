@@ -86,6 +86,17 @@ def tap_flops(geom, shape) -> float:
     return 2.0 * shape.N * shape.H * shape.Wu * geom.kh * geom.kw * geom.cu * geom.cv
 
 
+def allreduce_partial_rows(partial: Tensor, rows: int) -> Tensor:
+    """Sum ``rows`` partial-statistics rows locally, then all-reduce the (2, C) totals over the default process group
+    (RCCL on the GPUs; gloo in the CPU tests).  Returns a fresh (1 + scratch, 2, C) buffer whose row 0 holds the
+    global totals, ready for ``rv_bn_finalize`` / ``rv_bn_bwd_finalize`` with ``rows = 1``."""
+    tot = partial[:rows].sum(dim=0)
+    torch.distributed.all_reduce(tot)
+    out = torch.empty((1 + L.STATS_SCRATCH_ROWS,) + tuple(tot.shape), dtype=partial.dtype, device=partial.device)
+    out[0] = tot
+    return out
+
+
 def _world() -> int:
     if SYNC_BN and torch.distributed.is_available() and torch.distributed.is_initialized():
         return torch.distributed.get_world_size()
@@ -417,10 +428,7 @@ class BnOp(Op):
             rm, rv = _padded(bn.running_mean, cp), _padded(bn.running_var, cp, 1.0)
             world = _world()
             if world > 1:  # SyncBN: all-reduce (sum, sum of squares) over RCCL, then finalise with the global count
-                tot = conv.partial[: conv.rows].sum(dim=0)
-                torch.distributed.all_reduce(tot)
-                conv.partial = torch.empty((1 + L.STATS_SCRATCH_ROWS, 2, cp), dtype=torch.float32, device=dev)
-                conv.partial[0] = tot
+                conv.partial = allreduce_partial_rows(conv.partial, conv.rows)
                 conv.rows, conv.count = 1, conv.count * world
             L.call("rv_bn_finalize", L.ptr(conv.partial), L.i32(conv.rows), L.i32(cp), L.i64(conv.count), L.ptr(gamma),
                    L.ptr(beta), L.f32(bn.eps), L.f32(bn.momentum if bn.momentum is not None else 0.1), L.ptr(rm),

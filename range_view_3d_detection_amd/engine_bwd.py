@@ -123,9 +123,7 @@ def bn_backward(op: "E.BnOp", t: Tape) -> None:
         tot = partial[:rows].sum(dim=0)
         dbeta.copy_(tot[0])
         dgamma.copy_(tot[1])
-        torch.distributed.all_reduce(tot)
-        partial = torch.empty((1 + L.STATS_SCRATCH_ROWS, 2, cp), dtype=torch.float32, device=t.device)
-        partial[0] = tot
+        partial = E.allreduce_partial_rows(partial, rows)
         L.call("rv_bn_bwd_finalize", L.ptr(partial), L.i32(1), L.i32(cp), L.i64(st.count), L.ptr(op.gamma_p), L.ptr(st.invstd),
                None, None, L.i32(0), L.ptr(coef), L.stream_ptr())
     else:

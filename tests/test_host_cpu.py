@@ -1,0 +1,165 @@
+"""CPU-side checks of the product: the C-ABI library loads and exports every declared symbol, the host
+logic that needs no GPU (tap geometry, candidate counts, annotation handling, state-dict layout), the
+"fail loudly without a GPU" rule, and the multi-process (gloo, world_size 2) pieces of the N > 1 path."""
+
+from __future__ import annotations
+
+import ctypes
+import math
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="session")
+def lib():
+    from range_view_3d_detection_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "range_view_3d_detection_amd", "csrc"), "-j8"], check=True)
+    return _lib
+
+
+def test_library_exports_every_declared_symbol(lib):
+    handle = lib.load()
+    declared = lib.declared_symbols()
+    assert len(declared) >= 30
+    missing = [s for s in declared if not hasattr(handle, s)]
+    assert not missing, missing
+    assert handle.rv_version() >= 100
+    assert handle.rv_pad_channels(5) == 32 and handle.rv_pad_channels(256) == 256
+
+
+def test_host_side_geometry(lib):
+    h = lib.load()
+    g = lib.TapGeom(3, 3, 1, 1, 1, 256, 256)
+    assert h.rv_packed_weight_bytes(ctypes.byref(g)) == 9 * 256 * 256 * 2
+    s = lib.TapShape(4, 64, 2048, 2048, 256, 256, lib.OUT_STATS)
+    info = (ctypes.c_int32 * 4)()
+    assert h.rv_tap_launch_info(ctypes.byref(g), ctypes.byref(s), 0, info) == 0
+    assert list(info) == [4, 4, 16 * 64 * 4, 2]  # 128x128 tiles, one block per (row segment, n, h), 2 channel tiles
+    assert h.rv_tap_stats_rows(ctypes.byref(g), ctypes.byref(s), 0) == 2 * 16 * 64 * 4
+    # strided conv: Wv must be Wu * stride
+    bad = lib.TapShape(4, 64, 1000, 2048, 256, 256, 0)
+    g2 = lib.TapGeom(3, 3, 2, 1, 1, 128, 128)
+    assert h.rv_tap_launch_info(ctypes.byref(g2), ctypes.byref(bad), 0, info) != 0
+    assert b"stride_w" in h.rv_last_error()
+    # transposed conv (3,8)/s4: four phases
+    g3 = lib.TapGeom(3, 8, 4, 1, 2, 128, 256)
+    s3 = lib.TapShape(4, 64, 512, 2048, 128, 256, 0)
+    assert h.rv_tap_launch_info(ctypes.byref(g3), ctypes.byref(s3), 1, info) == 0 and info[2] == 4 * 4 * 64 * 4
+    rates = (ctypes.c_int32 * 3)(8, 2, 1)
+    assert h.rv_decode_num_candidates(64, 2048, 3, rates) == 64 * (256 + 1024 + 2048)  # 212 992
+    assert h.rv_decode_num_candidates(64, 2048, 0, rates) == 64 * 2048
+    assert h.rv_wnms_workspace_bytes(ctypes.c_int64(50000)) > 2 * 50000 * 782 * 8
+    assert h.rv_bn_bwd_rows(ctypes.c_int64(4 * 64 * 2048)) == 1024
+
+
+def test_null_arguments_fail_with_message(lib):
+    h = lib.load()
+    assert h.rv_ew_combine(ctypes.c_int64(10), 32, None, 32, None, None, None, 0, None, None, None, 32, 0, None) != 0
+    assert b"null" in h.rv_last_error()
+    with pytest.raises(lib.RvError):
+        lib.call("rv_yaw_to_quat", None, ctypes.c_int64(4), ctypes.c_int64(1), None, None)
+
+
+def test_modules_fail_loudly_without_gpu():
+    from range_view_3d_detection_amd import _lib
+    from range_view_3d_detection_amd.math.ops.coding import decode_range_view
+    from range_view_3d_detection_amd.nn.blocks import BasicBlock
+
+    m = BasicBlock(8, 8)
+    with pytest.raises(_lib.RvError, match="no CPU fallback"):
+        m(torch.randn(1, 8, 4, 32))
+    with pytest.raises(_lib.RvError, match="no CPU fallback"):
+        decode_range_view(torch.randn(1, 8, 4, 32), torch.randn(1, 3, 4, 32), True)
+
+
+def test_state_dict_keys_and_init_match_reference(golden):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_model import build_tiny
+
+    g = golden("tiny_model")
+    backbone, head = build_tiny()
+    ref = g.sub("sd")
+    ours = {**{f"backbone.{k}": v for k, v in backbone.state_dict().items()}, **{f"head.{k}": v for k, v in head.state_dict().items()}}
+    assert set(ours) == set(ref)
+    for k, v in ref.items():
+        assert tuple(ours[k].shape) == tuple(v.shape), k
+    # DenseHead init (dense_head.py:62-72): N(0, 0.01) conv weights, focal prior bias on the classification head
+    cls = head.classification_head["1"]["0"]
+    assert abs(float(cls.blocks[-1][0].bias[0]) + math.log((1 - 0.01) / 0.01)) < 1e-6
+    assert 0.005 < float(cls.blocks[0][0].weight.std()) < 0.02
+    assert float(head.regression_head["1"]["0"].blocks[-1][0].bias.abs().max()) == 0.0
+
+
+def test_annotation_table_to_cuboids(golden):
+    from oracle import targets as otgt
+    from range_view_3d_detection_amd.nn.heads.detection_head import annotations_to_cuboids
+
+    ann = golden("tiny_model")["annotations"]
+    ours = annotations_to_cuboids(ann)
+    assert np.allclose(ours, otgt.annotations_to_cuboids(ann).numpy(), rtol=0, atol=1e-12)
+    assert annotations_to_cuboids(np.zeros((0, 13))).shape == (0, 10)
+
+
+def test_weight_permutation_for_metakernel_fusion_conv():
+    """Reference channel order c*9+k (F.unfold) <-> engine order k*Cpad+c, and back for the gradient."""
+    from range_view_3d_detection_amd import engine as E
+
+    w = torch.nn.Parameter(torch.randn(16, 16 * 9, 1, 1))
+    layer = E.TapLayer(w, 1, (0, 0), False, in_perm=(16, 9))
+    tw = layer._torch_weight()
+    assert tw.shape == (16, 9 * 32, 1, 1)
+    assert torch.equal(tw[3, 5 * 32 + 7, 0, 0], w[3, 7 * 9 + 5, 0, 0])
+    assert float(tw[:, 16:32].abs().max()) == 0.0
+    assert torch.equal(layer.unpermute_grad(tw), w.detach())
+
+
+_WORKER = r"""
+import os, sys, json, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+from range_view_3d_detection_amd import engine as E
+import bench
+# (1) sweeps are sharded: every rank draws its own synthetic sweeps
+b = bench.synthetic_batch(2, 8, 32, seed=1234 + rank, device="cpu", boxes_per_sweep=2)
+digest = torch.tensor([float(b["features"].double().sum())], dtype=torch.float64)
+gathered = [torch.zeros_like(digest) for _ in range(world)]
+dist.all_gather(gathered, digest)
+# (2) SyncBN statistics: local partial rows -> global totals, identical on every rank
+g = torch.Generator().manual_seed(rank)
+partial = torch.randn(5 + 128, 2, 32, generator=g)
+tot = E.allreduce_partial_rows(partial, 5)[0]
+ref = torch.stack([torch.randn(5 + 128, 2, 32, generator=torch.Generator().manual_seed(r))[:5].sum(0) for r in range(world)]).sum(0)
+# (3) step time = MAX over ranks (bench.py contract)
+t = torch.tensor([1.0 + rank], dtype=torch.float64)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+out = {"rank": rank, "digests": [float(x) for x in gathered], "stats_err": float((tot - ref).abs().max()), "tmax": float(t)}
+print("RESULT " + json.dumps(out), flush=True)
+dist.destroy_process_group()
+"""
+
+
+def test_two_process_gloo_sharding_and_syncbn_reduction(tmp_path, lib):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    import json
+
+    res = []
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+        res.append(json.loads([ln for ln in o.splitlines() if ln.startswith("RESULT ")][0][7:]))
+    assert res[0]["digests"] == res[1]["digests"] and res[0]["digests"][0] != res[0]["digests"][1]
+    assert all(r["stats_err"] < 1e-4 and r["tmax"] == 2.0 for r in res)
