@@ -96,8 +96,10 @@ typedef struct {
 /* Rows of the partial-statistics buffer ([rows][2][c_pad] fp32) a launch with RV_OUT_STATS
  * writes; `scatter` selects the SCATTER form. */
 int32_t rv_tap_stats_rows(const rvTapGeom* g, const rvTapShape* s, int32_t scatter);
-/* Launch geometry the library picks for a tap op: info = {wave m-tiles MT, wave n-tiles NT, grid.x, grid.y}
- * (block tile = 32*MT pixels x 32*NT channels).  Used by bench.py to label per-kernel timings. */
+/* Launch plan the library picks for a tap op: info = {kernel generation, variant, grid.x, grid.y}:
+ * generation 1 = tapconv_kernel<MT,NT> (variant = 16*MT + NT, block tile 32*MT pixels x 32*NT channels),
+ * generation 2 = tapconv2_kernel<KS> (variant = KS, block tile 2 rows x 64 columns x 128 channels, 32*KS-channel
+ * chunks).  Used by bench.py to label per-kernel timings. */
 int rv_tap_launch_info(const rvTapGeom* g, const rvTapShape* s, int32_t scatter, int32_t* host_info);
 /* Every partial-statistics buffer handed to rv_bn_finalize / rv_bn_bwd_finalize must have room
  * for this many extra rows after its `rows` partial rows (second-stage reduction scratch). */

@@ -30,6 +30,7 @@ struct TapConvArgs {
     int32_t ld_src, ld_dst;
     int32_t phases, step;
     int32_t m_tiles;
+    int32_t h_tiles;  // tapconv2: tiles of two image rows
     int32_t lds_a_elems;
     int32_t flags;
     TapTable tt;
@@ -37,3 +38,7 @@ struct TapConvArgs {
 
 // fills tt (except w_tile), *phases and *step; scatter == false: GATHER form, true: SCATTER form
 int rv_build_tap_table(const rvTapGeom* g, bool scatter, TapTable* tt, int* phases, int* step);
+
+// second-generation kernel (tapconv2.hip): plan returns false when the layer is not eligible
+bool rv_tapconv2_plan(TapConvArgs* a, int* grid_x, int* grid_y, size_t* lds, int* ks);
+int rv_tapconv2_launch(const TapConvArgs& a, int grid_x, int grid_y, size_t lds, int ks, hipStream_t stream);

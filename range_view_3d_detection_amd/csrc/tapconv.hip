@@ -23,6 +23,8 @@
 //     (BatchNorm batch statistics; wave shuffles, one partial row per wave, no atomics =>
 //     bitwise reproducible), then the tile is transposed through LDS and stored as whole
 //     16-byte channel runs (coalesced NHWC rows).
+#include <stdlib.h>
+
 #include "common.h"
 #include "tapconv.h"
 
@@ -400,6 +402,7 @@ static int tap_launch(const rvTapGeom* g, const rvTapShape* s, bool scatter, con
     a.phases = phases;
     a.step = step;
     a.flags = s->flags;
+    if (const char* dbg = getenv("RV3D_DBG_FLAGS")) a.flags |= atoi(dbg);  // timing experiments only
     RV_REQUIRE(!((a.flags & RV_OUT_F32) && (a.flags & RV_OUT_ACCUM)), "RV_OUT_ACCUM needs a bf16 destination");
     RV_REQUIRE(dry_run || !(a.flags & RV_IN_AFFINE) || (in_scale && in_shift), "RV_IN_AFFINE without scale/shift");
     RV_REQUIRE(dry_run || !(a.flags & RV_OUT_BIAS) || bias, "RV_OUT_BIAS without bias");
@@ -412,7 +415,23 @@ static int tap_launch(const rvTapGeom* g, const rvTapShape* s, bool scatter, con
     a.bias = bias;
     a.stats = stats;
 
-    // tile selection: keep the LDS halo small for strided gathers; narrow N tile for thin outputs
+    // fast path: 2-row x 64-column tiles, 64-channel chunks (tapconv2.hip)
+    {
+        int gx, gy, ks;
+        size_t lds2;
+        if (rv_tapconv2_plan(&a, &gx, &gy, &lds2, &ks)) {
+            if (stats_rows) *stats_rows = gx * 2;
+            if (info) {
+                info[0] = 2;
+                info[1] = ks;
+                info[2] = gx;
+                info[3] = gy;
+            }
+            if (dry_run) return 0;
+            return rv_tapconv2_launch(a, gx, gy, lds2, ks, (hipStream_t)stream);
+        }
+    }
+    // generic path -- tile selection: keep the LDS halo small for strided gathers; narrow N tile for thin outputs
     int mt = (step == 1) ? 4 : (step == 2 ? 2 : 1);
     const int wm_total = a.W_dst / phases;
     while (mt > 1 && 32 * mt / 2 >= wm_total) mt >>= 1;  // tiny images (tests)
@@ -434,8 +453,8 @@ static int tap_launch(const rvTapGeom* g, const rvTapShape* s, bool scatter, con
     const int grid_y = rv_ceil_div(a.C_dst, BN);
     if (stats_rows) *stats_rows = grid_x * 2;
     if (info) {
-        info[0] = mt;
-        info[1] = nt;
+        info[0] = 1;
+        info[1] = mt * 16 + nt;
         info[2] = grid_x;
         info[3] = grid_y;
     }

@@ -14,6 +14,8 @@
 //
 // Block = 4 waves (2x2), tile 128(cu) x 128(cv) of ONE tap, one K slice; fp32 partial slabs are
 // summed by a second kernel in a fixed order (bitwise reproducible, no atomics).
+#include <stdlib.h>
+
 #include "common.h"
 #include "tapconv.h"
 
@@ -210,9 +212,188 @@ __global__ void wgrad_reduce_kernel(const float* slabs, int ksplit, int64_t elem
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// wgrad2: stride-1 layers whose width is a multiple of 64.  One block = 8 waves = up to THREE taps of one
+// kernel row x 128(cu) x 128(cv) x one K slice.  A K step is 64 consecutive pixels of one image row: the U tile
+// [64 px][128 cu] and the V halo [64+2 px][128 cv] are staged once and serve all taps of the group (tap j reads
+// the V rows shifted by j), so each staged byte feeds 3x the MFMAs of wgrad_kernel and a step holds 48 MFMAs
+// per wave between barriers instead of 16.
+// ---------------------------------------------------------------------------------------------
+struct Wgrad2Args {
+    const bf16_t* U;
+    const bf16_t* V;
+    const float* scale;
+    const float* shift;
+    float* slabs;
+    int32_t N, H, Wu;
+    int32_t cu_pad, cv_pad, ld_u, ld_v;
+    int32_t taps, groups;
+    int32_t ksplit, chunks_per_split, chunks;  // 64-pixel chunks
+    int32_t tiles_u, tiles_v;
+    int32_t flags, v_affine;
+    int8_t g_first[kMaxTaps], g_count[kMaxTaps];  // tap group -> first tap index / number of taps (<= 3)
+    int8_t dh[kMaxTaps], dw[kMaxTaps];
+};
+
+template <int TG>
+__device__ __forceinline__ void wgrad2_body(const Wgrad2Args& a, bf16_t (*lds)[2][66 * 128]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    int bx = blockIdx.x;
+    const int tv = bx % a.tiles_v;
+    bx /= a.tiles_v;
+    const int tu = bx % a.tiles_u;
+    bx /= a.tiles_u;
+    const int grp = bx % a.groups;
+    const int ks = bx / a.groups;
+    const int u0 = tu * 128, v0 = tv * 128;
+    const int tap0 = a.g_first[grp];
+    const int dh = a.dh[tap0], dw0 = a.dw[tap0];
+    const int wchunks = a.Wu / 64;
+
+    const int c_begin = ks * a.chunks_per_split;
+    const int c_end = (c_begin + a.chunks_per_split < a.chunks) ? c_begin + a.chunks_per_split : a.chunks;
+
+    const int chunk = tid & 15, prow = tid >> 4;  // prow 0..31: rows prow, prow+32 (U) / prow, +32, +64 (V halo)
+    const bool u_ok = (u0 + chunk * 8) < a.cu_pad, v_ok = (v0 + chunk * 8) < a.cv_pad;
+    const bool affine = a.flags & RV_IN_AFFINE, relu = a.flags & RV_IN_RELU;
+    float sc[8], sh[8];
+    if (affine) {
+        const int c0 = (a.v_affine ? v0 : u0) + chunk * 8;
+        const bool ok = a.v_affine ? v_ok : u_ok;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            sc[j] = ok ? a.scale[c0 + j] : 0.f;
+            sh[j] = ok ? a.shift[c0 + j] : 0.f;
+        }
+    }
+    u32x4 ru[2], rv[3];
+    auto load = [&](int c) {
+        const int row = c / wchunks, w0 = (c - row * wchunks) * 64;  // row = n*H + h
+        const int h = row % a.H;
+        const bf16_t* urow = a.U + ((int64_t)row * a.Wu) * a.ld_u + u0 + chunk * 8;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            ru[j] = u32x4{0u, 0u, 0u, 0u};
+            if (u_ok) {
+                ru[j] = *(const u32x4*)(urow + (int64_t)(w0 + prow + 32 * j) * a.ld_u);
+                if ((affine || relu) && !a.v_affine) ru[j] = transform8(ru[j], sc, sh, affine, relu);
+            }
+        }
+        const int hv = h + dh;
+        const bool row_ok = hv >= 0 && hv < a.H;
+        const bf16_t* vrow = a.V + ((int64_t)(row + dh) * a.Wu) * a.ld_v + v0 + chunk * 8;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            rv[j] = u32x4{0u, 0u, 0u, 0u};
+            const int r = prow + 32 * j;  // halo row 0..65(+)
+            const int wv = w0 + r + dw0;
+            if (v_ok && row_ok && r < 64 + TG - 1 && wv >= 0 && wv < a.Wu) {
+                rv[j] = *(const u32x4*)(vrow + (int64_t)wv * a.ld_v);
+                if ((affine || relu) && a.v_affine) rv[j] = transform8(rv[j], sc, sh, affine, relu);
+            }
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = prow + 32 * j;
+            *(u32x4*)(&lds[buf][0][k * 128 + (((chunk >> 1) ^ sigma(k)) << 4) + (chunk & 1) * 8]) = ru[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int k = prow + 32 * j;
+            if (k < 66) *(u32x4*)(&lds[buf][1][k * 128 + (((chunk >> 1) ^ sigma(k)) << 4) + (chunk & 1) * 8]) = rv[j];
+        }
+    };
+
+    f32x4 acc[TG][4][2];
+#pragma unroll
+    for (int t = 0; t < TG; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    auto frag = [&](const bf16_t* tile, int row0, int col0) -> bf16x8 {
+        // rows row0 + 8g + q (+4), columns col0 + 4p .. +3 (before the granule swizzle)
+        const int r_lo = row0 + 8 * g + q, r_hi = r_lo + 4, gran = col0 >> 4;
+        const bf16_t* p_lo = tile + r_lo * 128 + ((gran ^ sigma(r_lo)) << 4) + 4 * p;
+        const bf16_t* p_hi = tile + r_hi * 128 + ((gran ^ sigma(r_hi)) << 4) + 4 * p;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p_lo);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p_hi);
+        const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, both);
+    };
+
+    if (c_begin < c_end) {
+        load(c_begin);
+        store(0);
+        __syncthreads();
+        int buf = 0;
+        for (int c = c_begin; c < c_end; ++c) {
+            const bool has_next = c + 1 < c_end;
+            if (has_next) load(c + 1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {  // two MFMA K-steps of 32 pixels
+                bf16x8 fa[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fa[i] = frag(&lds[buf][0][0], kk * 32, wm * 64 + i * 16);
+#pragma unroll
+                for (int t = 0; t < TG; ++t) {
+                    bf16x8 fb[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) fb[j] = frag(&lds[buf][1][0], kk * 32 + t, wn * 32 + j * 16);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[t][i][j], 0, 0, 0);
+                }
+            }
+            if (has_next) store(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TG; ++t) {
+        float* slab = a.slabs + ((int64_t)ks * a.taps + tap0 + t) * a.cu_pad * a.cv_pad;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int cu = u0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+                if (cu >= a.cu_pad) continue;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int cv = v0 + wn * 32 + j * 16 + (lane & 15);
+                    if (cv < a.cv_pad) slab[(int64_t)cu * a.cv_pad + cv] = acc[t][i][j][r];
+                }
+            }
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void wgrad2_kernel(const Wgrad2Args a) {
+    __shared__ __attribute__((aligned(16))) bf16_t lds[2][2][66 * 128];
+    int bx = blockIdx.x / (a.tiles_v * a.tiles_u);
+    const int cnt = a.g_count[bx % a.groups];  // uniform per block
+    if (cnt == 3)
+        wgrad2_body<3>(a, lds);
+    else if (cnt == 2)
+        wgrad2_body<2>(a, lds);
+    else
+        wgrad2_body<1>(a, lds);
+}
+
 struct WgradPlan {
     int taps, tiles_u, tiles_v, ksplit, k_per_split;
     int64_t elems;
+    bool v2;
+    int groups, chunks, chunks_per_split;
 };
 
 int plan(const rvTapGeom* g, const rvTapShape* s, WgradPlan* p) {
@@ -230,6 +411,18 @@ int plan(const rvTapGeom* g, const rvTapShape* s, WgradPlan* p) {
     p->k_per_split = (int)(per * 32);
     p->ksplit = (int)((chunks + per - 1) / per);
     p->elems = (int64_t)p->taps * cu * cv;
+    // wgrad2: stride 1, whole 64-pixel chunks per image row
+    p->v2 = (g->stride_w == 1) && (s->Wu % 64 == 0) && (getenv("RV3D_NO_WGRAD2") == nullptr);
+    if (p->v2) {
+        p->groups = g->kh * ((g->kw + 2) / 3);
+        p->chunks = (int)(K / 64);
+        const int base2 = p->groups * p->tiles_u * p->tiles_v;
+        int64_t ks2 = (768 + base2 - 1) / base2;  // ~3 blocks of 8 waves per CU in flight over the kernel
+        if (ks2 > p->chunks) ks2 = p->chunks;
+        if (ks2 < 1) ks2 = 1;
+        p->chunks_per_split = (int)((p->chunks + ks2 - 1) / ks2);
+        p->ksplit = (p->chunks + p->chunks_per_split - 1) / p->chunks_per_split;
+    }
     return 0;
 }
 
@@ -250,6 +443,51 @@ extern "C" int rv_tap_wgrad(const rvTapGeom* g, const rvTapShape* s, const void*
     RV_REQUIRE(g->kh * g->kw <= kMaxTaps, "rv_tap_wgrad: kernel %dx%d unsupported", g->kh, g->kw);
     WgradPlan p;
     plan(g, s, &p);
+    if (p.v2) {
+        Wgrad2Args b;
+        memset(&b, 0, sizeof(b));
+        b.U = (const bf16_t*)U;
+        b.V = (const bf16_t*)V;
+        b.scale = in_scale;
+        b.shift = in_shift;
+        b.slabs = (float*)workspace;
+        b.N = s->N;
+        b.H = s->H;
+        b.Wu = s->Wu;
+        b.cu_pad = rv_pad32(g->cu);
+        b.cv_pad = rv_pad32(g->cv);
+        b.ld_u = ld_u;
+        b.ld_v = ld_v;
+        RV_REQUIRE(ld_u >= b.cu_pad && ld_v >= b.cv_pad && ld_u % 8 == 0 && ld_v % 8 == 0, "rv_tap_wgrad: bad channel strides");
+        b.taps = p.taps;
+        b.groups = p.groups;
+        b.ksplit = p.ksplit;
+        b.chunks_per_split = p.chunks_per_split;
+        b.chunks = p.chunks;
+        b.tiles_u = p.tiles_u;
+        b.tiles_v = p.tiles_v;
+        b.flags = s->flags;
+        b.v_affine = v_affine;
+        int gi = 0;
+        for (int ky = 0; ky < g->kh; ++ky)
+            for (int kx = 0; kx < g->kw; ++kx) {
+                b.dh[ky * g->kw + kx] = (int8_t)(ky - g->pad_h);
+                b.dw[ky * g->kw + kx] = (int8_t)(kx - g->pad_w);
+                if (kx % 3 == 0) {
+                    b.g_first[gi] = (int8_t)(ky * g->kw + kx);
+                    b.g_count[gi] = (int8_t)((g->kw - kx) < 3 ? (g->kw - kx) : 3);
+                    ++gi;
+                }
+            }
+        hipStream_t st2 = (hipStream_t)stream;
+        const int grid2 = p.tiles_v * p.tiles_u * p.groups * p.ksplit;
+        hipLaunchKernelGGL(wgrad2_kernel, dim3(grid2), dim3(512), 0, st2, b);
+        RV_CHECK_LAUNCH("wgrad2_kernel");
+        const int rb2 = (int)((p.elems + 255) / 256 < 2048 ? (p.elems + 255) / 256 : 2048);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb2), dim3(256), 0, st2, (const float*)workspace, p.ksplit, p.elems, dT_packed);
+        RV_CHECK_LAUNCH("wgrad_reduce_kernel");
+        return 0;
+    }
     WgradArgs a;
     memset(&a, 0, sizeof(a));
     a.U = (const bf16_t*)U;

@@ -79,7 +79,9 @@ def _launch(name: str, flops: float, fn) -> None:
 def tap_kernel_name(geom, shape, scatter: bool) -> str:
     info = (ctypes.c_int32 * 4)()
     L.call("rv_tap_launch_info", ctypes.byref(geom), ctypes.byref(shape), L.i32(1 if scatter else 0), info)
-    return f"tapconv_kernel<{info[0]},{info[1]}>"
+    if info[0] == 2:
+        return f"tapconv2_kernel<{info[1]}>"
+    return f"tapconv_kernel<{info[1] // 16},{info[1] % 16}>"
 
 
 def tap_flops(geom, shape) -> float:

@@ -22,7 +22,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize(
     "cin,cout,k,stride,H,W",
-    [(40, 24, 3, 1, 5, 48), (32, 32, 3, 2, 4, 64), (64, 48, 1, 2, 3, 96), (128, 160, 3, 1, 4, 128), (256, 128, 3, 1, 2, 256)],
+    [(40, 24, 3, 1, 5, 48), (32, 32, 3, 2, 4, 64), (64, 48, 1, 2, 3, 96), (128, 160, 3, 1, 4, 128), (256, 128, 3, 1, 2, 256),
+     (64, 64, 3, 2, 5, 256), (128, 128, 1, 2, 4, 256), (64, 128, 1, 1, 3, 128)],  # strided layers: bwd-data = tapconv2 scatter phases
 )
 def test_conv_input_and_weight_grad(cin, cout, k, stride, H, W):
     from range_view_3d_detection_amd.nn.modules.conv import Conv2dSame

@@ -67,6 +67,10 @@ def run_conv_f32(module, x, in_affine=None, relu=False):
         (5, 16, 1, 1, 6, 32),      # stem projection: C_in = 5
         (128, 128, 3, 1, 4, 256),  # full 128x128 tile, two K chunks... (4 chunks)
         (96, 160, 3, 1, 2, 128),   # C_out not a multiple of the N tile
+        (64, 128, 3, 1, 5, 192),   # tapconv2: odd H (masked second tile row), 3 column tiles, 64-channel chunks
+        (32, 64, 3, 1, 4, 128),    # tapconv2<1>: 32-channel chunks
+        (128, 64, 1, 1, 6, 128),   # tapconv2: 1x1 => double-buffered A tile
+        (192, 256, 3, 1, 3, 100),  # tapconv2: ragged width (partial column tile), 3 chunks
     ],
 )
 def test_gather_matches_conv2d(cin, cout, k, stride, H, W):
@@ -98,10 +102,12 @@ def test_gather_folded_bn_relu_prologue():
     assert rel_err(out, ref) < 2e-5
 
 
-@pytest.mark.parametrize("kernel,stride,padding,W", [((3, 8), (1, 4), (1, 2), 24), ((3, 4), (1, 2), (1, 1), 40), ((3, 4), (1, 2), (1, 1), 160)])
-def test_scatter_matches_conv_transpose2d(kernel, stride, padding, W):
+@pytest.mark.parametrize("kernel,stride,padding,W,cout", [((3, 8), (1, 4), (1, 2), 24, 40), ((3, 4), (1, 2), (1, 1), 40, 40),
+                                                          ((3, 4), (1, 2), (1, 1), 160, 40), ((3, 8), (1, 4), (1, 2), 64, 96),
+                                                          ((3, 4), (1, 2), (1, 1), 96, 128)])
+def test_scatter_matches_conv_transpose2d(kernel, stride, padding, W, cout):
     g = torch.Generator().manual_seed(W)
-    m = torch.nn.ConvTranspose2d(48, 40, kernel_size=kernel, stride=stride, padding=padding, bias=False)
+    m = torch.nn.ConvTranspose2d(48, cout, kernel_size=kernel, stride=stride, padding=padding, bias=False)
     m.weight.data = bf16r(torch.randn(m.weight.shape, generator=g) * 0.2)
     x = bf16r(torch.randn(2, 48, 5, W, generator=g))
     ref = F.conv_transpose2d(x, m.weight.data, stride=stride, padding=padding)
