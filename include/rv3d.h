@@ -99,7 +99,7 @@ int32_t rv_tap_stats_rows(const rvTapGeom* g, const rvTapShape* s, int32_t scatt
 /* Launch plan the library picks for a tap op: info = {kernel generation, variant, grid.x, grid.y}:
  * generation 1 = tapconv_kernel<MT,NT> (variant = 16*MT + NT, block tile 32*MT pixels x 32*NT channels),
  * generation 2 = tapconv2_kernel<KS> (variant = KS, block tile 2 rows x 64 columns x 128 channels, 32*KS-channel
- * chunks).  Used by bench.py to label per-kernel timings. */
+ * chunks), generation 3 = tapconv3_kernel<KS> (8 waves, 4 rows x 64 columns x 128 channels, 3-tap weight stages).  Used by bench.py to label per-kernel timings. */
 int rv_tap_launch_info(const rvTapGeom* g, const rvTapShape* s, int32_t scatter, int32_t* host_info);
 /* Every partial-statistics buffer handed to rv_bn_finalize / rv_bn_bwd_finalize must have room
  * for this many extra rows after its `rows` partial rows (second-stage reduction scratch). */
@@ -269,6 +269,15 @@ int rv_project_indices(const double* cart, const int32_t* laser, const int32_t* 
 int rv_z_buffer(const int32_t* rows, const int32_t* cols, const double* range, const double* features, int64_t n,
                 int32_t c, int32_t H, int32_t W, double min_range, uint64_t* keys, float* image, int64_t* winner,
                 rvStream stream);
+
+/* Spherical <-> Cartesian (math/conversions.py:28-81, math/numpy/conversions.py:46-103): (n,3) arrays,
+ * [azimuth, inclination, radius] <-> [x, y, z]; is_f64 selects double (numpy twins) or float (torch versions). */
+int rv_cart_to_sph(const void* cart, int64_t n, int32_t is_f64, void* sph, rvStream stream);
+int rv_sph_to_cart(const void* sph, int64_t n, int32_t is_f64, void* cart, rvStream stream);
+/* subsample_range_view's W padding at x_stride 1 (prototype/loader.py:792-815): out (C,H,W+2*pad) = pad(image * mask);
+ * mask (H,W) may be NULL; circular != 0 wraps around in azimuth, else zeros.  AV2 pad 4 (1800 -> 1808), Waymo 3. */
+int rv_pad_range_view(const float* image, const float* mask, int32_t C, int32_t H, int32_t W, int32_t pad,
+                      int32_t circular, float* out, rvStream stream);
 
 /* ---------------------------------------------------------------------------------------
  * Targets + losses on device (nn/heads/detection_head.py:496-665, math/ops/assignment.py:76-161,

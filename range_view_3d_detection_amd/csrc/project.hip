@@ -122,3 +122,83 @@ extern "C" int rv_z_buffer(const int32_t* rows, const int32_t* cols, const doubl
     RV_CHECK_LAUNCH("z_buffer kernels");
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// S1: spherical <-> Cartesian (math/conversions.py:28-81; numpy twins math/numpy/conversions.py:46-103) and
+// R2: the loader's W padding (prototype/loader.py:792-815).  Element-wise, one point / pixel per thread.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+template <typename T>
+__global__ void cart_to_sph_kernel(const T* cart, int64_t n, T* sph) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const T x = cart[3 * i], y = cart[3 * i + 1], z = cart[3 * i + 2];
+        const T hyp = hypot(x, y);
+        sph[3 * i] = atan2(y, x);
+        sph[3 * i + 1] = atan2(z, hyp);
+        sph[3 * i + 2] = hypot(hyp, z);
+    }
+}
+
+template <typename T>
+__global__ void sph_to_cart_kernel(const T* sph, int64_t n, T* cart) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const T az = sph[3 * i], inc = sph[3 * i + 1], r = sph[3 * i + 2];
+        const T rc = r * cos(inc);
+        cart[3 * i] = rc * cos(az);
+        cart[3 * i + 1] = rc * sin(az);
+        cart[3 * i + 2] = r * sin(inc);
+    }
+}
+
+// (C,H,W) -> (C,H,W+2*pad): zeros ("constant") or wrap-around in azimuth ("circular"); optional per-pixel mask multiply
+__global__ void pad_width_kernel(const float* src, const float* mask, int C, int H, int W, int pad, int circular, float* dst) {
+    const int Wp = W + 2 * pad;
+    const int64_t total = (int64_t)C * H * Wp;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int w = (int)(i % Wp);
+        const int64_t ch = i / Wp;  // c*H + h
+        const int h = (int)(ch % H);
+        int ws = w - pad;
+        float v = 0.f;
+        if (circular) ws = (ws % W + W) % W;
+        if (ws >= 0 && ws < W) {
+            v = src[ch * W + ws];
+            if (mask) v *= mask[(int64_t)h * W + ws];
+        }
+        dst[i] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int rv_cart_to_sph(const void* cart, int64_t n, int32_t is_f64, void* sph, rvStream stream) {
+    if (n == 0) return 0;
+    RV_REQUIRE(cart && sph, "rv_cart_to_sph: null argument");
+    if (is_f64)
+        hipLaunchKernelGGL(cart_to_sph_kernel<double>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const double*)cart, n, (double*)sph);
+    else
+        hipLaunchKernelGGL(cart_to_sph_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const float*)cart, n, (float*)sph);
+    RV_CHECK_LAUNCH("cart_to_sph_kernel");
+    return 0;
+}
+
+extern "C" int rv_sph_to_cart(const void* sph, int64_t n, int32_t is_f64, void* cart, rvStream stream) {
+    if (n == 0) return 0;
+    RV_REQUIRE(cart && sph, "rv_sph_to_cart: null argument");
+    if (is_f64)
+        hipLaunchKernelGGL(sph_to_cart_kernel<double>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const double*)sph, n, (double*)cart);
+    else
+        hipLaunchKernelGGL(sph_to_cart_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const float*)sph, n, (float*)cart);
+    RV_CHECK_LAUNCH("sph_to_cart_kernel");
+    return 0;
+}
+
+extern "C" int rv_pad_range_view(const float* image, const float* mask, int32_t C, int32_t H, int32_t W, int32_t pad,
+                                 int32_t circular, float* out, rvStream stream) {
+    RV_REQUIRE(image && out && pad >= 0 && W > 0, "rv_pad_range_view: bad argument");
+    hipLaunchKernelGGL(pad_width_kernel, dim3(grid_for((int64_t)C * H * (W + 2 * pad))), dim3(256), 0, (hipStream_t)stream, image, mask,
+                       C, H, W, pad, circular, out);
+    RV_CHECK_LAUNCH("pad_width_kernel");
+    return 0;
+}

@@ -42,3 +42,7 @@ int rv_build_tap_table(const rvTapGeom* g, bool scatter, TapTable* tt, int* phas
 // second-generation kernel (tapconv2.hip): plan returns false when the layer is not eligible
 bool rv_tapconv2_plan(TapConvArgs* a, int* grid_x, int* grid_y, size_t* lds, int* ks);
 int rv_tapconv2_launch(const TapConvArgs& a, int grid_x, int grid_y, size_t lds, int ks, hipStream_t stream);
+
+// third-generation kernel (tapconv3.hip): 8 waves, 4-row tiles, 3-tap weight stages; stats rows = 4 * grid_x
+bool rv_tapconv3_plan(TapConvArgs* a, int* grid_x, int* grid_y, size_t* lds, int* ks);
+int rv_tapconv3_launch(const TapConvArgs& a, int grid_x, int grid_y, size_t lds, int ks, hipStream_t stream);

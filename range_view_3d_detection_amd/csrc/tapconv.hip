@@ -415,6 +415,23 @@ static int tap_launch(const rvTapGeom* g, const rvTapShape* s, bool scatter, con
     a.bias = bias;
     a.stats = stats;
 
+    // fastest path: 8 waves, 4-row x 64-column tiles, 3-tap weight stages (tapconv3.hip)
+    if (getenv("RV3D_NO_TAPCONV3") == nullptr) {
+        int gx, gy, ks;
+        size_t lds3;
+        TapConvArgs a3 = a;
+        if (rv_tapconv3_plan(&a3, &gx, &gy, &lds3, &ks)) {
+            if (stats_rows) *stats_rows = gx * 4;
+            if (info) {
+                info[0] = 3;
+                info[1] = ks;
+                info[2] = gx;
+                info[3] = gy;
+            }
+            if (dry_run) return 0;
+            return rv_tapconv3_launch(a3, gx, gy, lds3, ks, (hipStream_t)stream);
+        }
+    }
     // fast path: 2-row x 64-column tiles, 64-channel chunks (tapconv2.hip)
     {
         int gx, gy, ks;

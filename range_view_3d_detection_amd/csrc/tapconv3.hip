@@ -1,38 +1,33 @@
-// tapconv2.hip -- second-generation tap-conv kernel for the layers that dominate the step
-// (stride-1 gathers and every scatter form on images at least 64 columns wide, >= 64 output channels).
+// tapconv3.hip -- third-generation tap-conv kernel: 8 wavefronts, 4-row x 64-column x 128-channel tiles,
+// three taps per weight stage.
 //
-// Differences to tapconv_kernel (tapconv.hip), each aimed at a measured bottleneck of round 1
-// (539 TFLOP/s, tap steps of only 16 MFMAs between barriers, 50 % LDS padding):
-//   * output tile = 2 image rows x 64 columns (x 128 channels): the 3x3 halo is 4 rows x 66 px for
-//     128 outputs (2.06x) instead of 3 x 130 (3.05x) => fewer global loads and 41 KB instead of 37 KB of
-//     LDS for TWICE the channel depth per chunk;
-//   * K chunk = 64 channels (two MFMA K-steps per tap): 32 MFMAs per wave between barriers, half the
-//     barriers, prefetch distance of a tap step doubled (covers L2 latency with 2 blocks per CU);
-//   * dense LDS images made of 16-byte chunks: A[halo row][k-group][column (padded to 16)][8], B[k-group][128 n][8].
-//     A fragment read (16 pixels x 4 k-groups) touches slots (column + const) mod 16 within each hardware
-//     service group => conflict-free without padding every pixel row by 50 %;
-//   * staging threads are mapped 8 pixels x 8 k-groups per wave: global reads cover whole 128-byte pixel rows
-//     (coalesced) and every 8-lane ds_write_b128 group writes 128 contiguous bytes (conflict-free);
-//   * 1x1 layers double-buffer the (small) A tile: one barrier per 32-MFMA step instead of two.
-#include <stdlib.h>
-
+// Round-1 experiments on tapconv2 (512->512 3x3, 4x64x2048): 673 TFLOP/s; 910 with the weight loads
+// removed, 1040 with all global loads removed => the per-CU load path (weights re-fetched for every 128
+// output pixels) and the short 32-MFMA barrier interval are the limiters.  This kernel
+//   * doubles the pixels per block (256 = 4 rows x 64 columns, halo 6 x 66 = 1.55x) so every weight byte
+//     fetched from L2 feeds twice the MFMAs;
+//   * stages the weights of up to THREE taps (one kernel row) at once, double-buffered in LDS (2 x 48 KB next to
+//     the 60 KB halo tile): 96 MFMAs per wave between barriers, a whole group of compute to cover the loads;
+//   * keeps tapconv2's dense, conflict-free LDS images and 8-pixel x 8-k-group staging map.
+// One workgroup (512 threads, ~157 KB LDS) per CU, two waves per SIMD.
 #include "common.h"
 #include "tapconv.h"
 
 namespace {
 
 constexpr int kTC = 64;   // tile columns (m positions)
-constexpr int kTR = 2;    // tile rows
+constexpr int kTR = 4;    // tile rows
 constexpr int kBN = 128;  // tile channels
-constexpr int kNa2 = 9;   // max A chunks per thread: 4 rows x 66 px x 8 groups / 256 threads
+constexpr int kNa2 = 7;   // max A chunks per thread: 6 rows x 66 px x 8 groups / 512 threads
+constexpr int kTG = 3;    // taps per weight stage
 
-template <int KS, bool BDMA>  // KS: MFMA K-steps per chunk (chunk = 32*KS channels); BDMA: weights by LDS-DMA
-__global__ __launch_bounds__(256, 2) void tapconv2_kernel(const TapConvArgs a) {
+template <int KS>  // MFMA K-steps per chunk: chunk = 32*KS channels
+__global__ __launch_bounds__(512, 2) void tapconv3_kernel(const TapConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int G = 4 * KS;        // 16-byte k-groups per chunk
     constexpr int BK = 32 * KS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;  // wm = tile row, wn = channel half
+    const int wm = wave >> 1, wn = wave & 1;  // wm = tile row (0..3), wn = channel half
     const int l15 = lane & 15, lg = lane >> 4;
 
     int bx = blockIdx.x;
@@ -58,40 +53,44 @@ __global__ __launch_bounds__(256, 2) void tapconv2_kernel(const TapConvArgs a) {
 
     // ---- staging map -----------------------------------------------------------------------
     const int s_px = tid & 7, s_g = (tid >> 3) & (G - 1), s_hi = tid >> (3 + (KS == 2 ? 3 : 2));
-    const int px_per_iter = 256 / G;  // 32 (KS=2) or 64 (KS=1)
+    const int px_per_iter = 512 / G;  // 64 (KS=2) or 128 (KS=1)
     const int n_px = HR * Wt;
-    int src_off[kNa2];
-    int lds_off[kNa2];
+    // per-slot halo coordinates packed as (valid << 31) | (in_tile << 30) | (hr << 8) | cc  -- offsets are recomputed
+    // from them at load / write time (two multiply-adds) instead of living in 2 x 7 registers across the K loop
+    uint32_t slot[kNa2];
+    const int row_base = h0 + a.tt.dh_min, col_base = m0 + a.tt.dw_min[ph];
 #pragma unroll
     for (int i = 0; i < kNa2; ++i) {
         const int p = i * px_per_iter + s_hi * 8 + s_px;
-        src_off[i] = INT32_MIN;
-        lds_off[i] = -1;
+        slot[i] = 0u;
         if (p < n_px) {
             const int hr = p / Wt, cc = p - hr * Wt;
-            const int hs = h0 + a.tt.dh_min + hr;
-            const int ws = m0 + a.tt.dw_min[ph] + cc;
-            lds_off[i] = ((hr * G + s_g) * Wtp + cc) * 8;
-            if (hs >= 0 && hs < a.H && ws >= 0 && ws < a.W_src) src_off[i] = (hs * a.W_src + ws) * a.ld_src + s_g * 8;
+            const int hs = row_base + hr, ws = col_base + cc;
+            const bool ok = hs >= 0 && hs < a.H && ws >= 0 && ws < a.W_src;
+            slot[i] = (ok ? 0x80000000u : 0u) | 0x40000000u | ((uint32_t)hr << 8) | (uint32_t)cc;
         }
     }
+    auto slot_src = [&](uint32_t sl) { return ((row_base + (int)((sl >> 8) & 0xff)) * a.W_src + col_base + (int)(sl & 0xff)) * a.ld_src + s_g * 8; };
+    auto slot_lds = [&](uint32_t sl) { return (((int)((sl >> 8) & 0xff) * G + s_g) * Wtp + (int)(sl & 0xff)) * 8; };
     // B: 128 n x G groups = 128*G chunks; thread handles n = (q>>... ) with the same 8x8 wave map
-    constexpr int kNb = (kBN * G) / 256;  // 4 (KS=2) or 2 (KS=1)
+    constexpr int kBTap = G * kBN * 8;          // elements of one tap image in LDS
     const int64_t w_img = (int64_t)a.C_dst * a.C_src;
     const int w_base_idx = a.tt.w_first[ph];
 
     u32x4 a_reg[kNa2];
-    u32x4 b_reg[kNb];
-    float sc[8], sh[8];
     const bool affine = a.flags & RV_IN_AFFINE, relu = a.flags & RV_IN_RELU;
 
     auto load_a = [&](int kc) {
 #pragma unroll
         for (int i = 0; i < kNa2; ++i) {
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (src_off[i] != INT32_MIN) v = *(const u32x4*)(src_img + src_off[i] + kc * BK);
+            if (slot[i] & 0x80000000u) v = *(const u32x4*)(src_img + slot_src(slot[i]) + kc * BK);
             a_reg[i] = v;
         }
+    };
+    auto write_a = [&](int abuf, int kc) {
+        bf16_t* base = ldsA + abuf * a_buf_elems;
+        float sc[8], sh[8];
         if (affine) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -99,14 +98,11 @@ __global__ __launch_bounds__(256, 2) void tapconv2_kernel(const TapConvArgs a) {
                 sh[j] = a.in_shift[kc * BK + s_g * 8 + j];
             }
         }
-    };
-    auto write_a = [&](int abuf) {
-        bf16_t* base = ldsA + abuf * a_buf_elems;
 #pragma unroll
         for (int i = 0; i < kNa2; ++i) {
-            if (lds_off[i] < 0) continue;
+            if (!(slot[i] & 0x40000000u)) continue;
             u32x4 v = a_reg[i];
-            if ((affine || relu) && src_off[i] != INT32_MIN) {
+            if ((affine || relu) && (slot[i] & 0x80000000u)) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float lo = bf_lo(v[j]), hi = bf_hi(v[j]);
@@ -121,45 +117,29 @@ __global__ __launch_bounds__(256, 2) void tapconv2_kernel(const TapConvArgs a) {
                     v[j] = pack_bf2(lo, hi);
                 }
             }
-            *(u32x4*)(base + lds_off[i]) = v;
+            *(u32x4*)(base + slot_lds(slot[i])) = v;
         }
     };
-    auto load_b = [&](int kc, int t, int buf_next) {
-        const bf16_t* wt = a.w + (int64_t)(w_base_idx + t) * w_img + kc * BK;
-        if constexpr (BDMA) {
-            // LDS-DMA (global_load_lds_dwordx4): one wave-instruction fills 64 consecutive 16-byte chunks = one
-            // k-group x 64 output channels of the dense B image; no VGPR round trip, no ds_write.
-            constexpr int kInstr = (G * kBN) / 64 / 4;  // instructions per wave (4 or 2)
+    constexpr int kNb = (kTG * kBN * G) / 512;  // 6 (KS=2) or 3 (KS=1): all taps of a stage
+    u32x4 b_reg[kNb];
+    auto load_b = [&](int kc, int t0, int) {  // taps t0 .. t0+kTG-1 (those < T); 8 rows x 8 k-groups per wave-instruction
 #pragma unroll
-            for (int i = 0; i < kInstr; ++i) {
-                const int idx = wave * kInstr + i;
-                const int gg = idx >> 1, nh = idx & 1;
-                const int nn = nh * 64 + lane;
-                bf16_t* dst = ldsB + buf_next * (G * kBN * 8) + (gg * kBN + nh * 64) * 8;  // wave-uniform base
-                if (n0 + nn < a.C_dst)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wt + (int64_t)(n0 + nn) * a.C_src + gg * 8),
-                                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < kNb; ++i) {
-                const int nn = i * px_per_iter + s_hi * 8 + s_px;  // 0..127
-                u32x4 v = {0u, 0u, 0u, 0u};
-                if (n0 + nn < a.C_dst) v = *(const u32x4*)(wt + s_g * 8 + (int64_t)(n0 + nn) * a.C_src);
-                b_reg[i] = v;
-            }
+        for (int i = 0; i < kNb; ++i) {
+            const int q = i * px_per_iter + s_hi * 8 + s_px;  // 0 .. kTG*128-1
+            const int tt = q >> 7, nn = q & 127;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (t0 + tt < T && n0 + nn < a.C_dst)
+                v = *(const u32x4*)(a.w + (int64_t)(w_base_idx + t0 + tt) * w_img + (int64_t)(n0 + nn) * a.C_src + kc * BK + s_g * 8);
+            b_reg[i] = v;
         }
     };
     auto write_b = [&](int buf) {
-        if constexpr (BDMA) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed; the barrier publishes them
-        } else {
-            bf16_t* base = ldsB + buf * (G * kBN * 8);
+        bf16_t* base = ldsB + buf * (kTG * kBTap);
 #pragma unroll
-            for (int i = 0; i < kNb; ++i) {
-                const int nn = i * px_per_iter + s_hi * 8 + s_px;
-                *(u32x4*)(base + (s_g * kBN + nn) * 8) = b_reg[i];
-            }
+        for (int i = 0; i < kNb; ++i) {
+            const int q = i * px_per_iter + s_hi * 8 + s_px;
+            const int tt = q >> 7, nn = q & 127;
+            *(u32x4*)(base + tt * kBTap + (s_g * kBN + nn) * 8) = b_reg[i];
         }
     };
 
@@ -170,30 +150,33 @@ __global__ __launch_bounds__(256, 2) void tapconv2_kernel(const TapConvArgs a) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = (T > 0) ? a.C_src / BK : 0;
+    const int ngroups = (T + kTG - 1) / kTG;
     if (nk > 0) {
         load_a(0);
         load_b(0, 0, 0);
-        write_a(0);
+        write_a(0, 0);
         write_b(0);
     }
     __syncthreads();
     int buf = 0, abuf = 0;
     for (int kc = 0; kc < nk; ++kc) {
         const bool next_chunk = kc + 1 < nk;
-        if (next_chunk && !(a.flags & (1 << 29))) load_a(kc + 1);
-        for (int t = 0; t < T; ++t) {
-            const bool last_tap = (t == T - 1);
-            const bool has_next = !last_tap || next_chunk;
-            if (has_next && !(a.flags & (1 << 30))) load_b(last_tap ? kc + 1 : kc, last_tap ? 0 : t + 1, buf ^ 1);
-            {
+        const bool dbg_nomem = a.flags & (1 << 28);
+        if (next_chunk && !dbg_nomem) load_a(kc + 1);
+        for (int gi = 0; gi < ngroups; ++gi) {
+            const bool last_g = (gi == ngroups - 1);
+            const bool has_next = !last_g || next_chunk;
+            if (has_next && !dbg_nomem) load_b(last_g ? kc + 1 : kc, last_g ? 0 : (gi + 1) * kTG, buf ^ 1);
+            const int t0 = gi * kTG;
+            const int tn = (T - t0) < kTG ? (T - t0) : kTG;
+            for (int tt = 0; tt < tn; ++tt) {
+                const int t = t0 + tt;
                 const int hr = wm + (a.tt.dh[ph][t] - a.tt.dh_min);
                 const int c0 = a.tt.dw[ph][t] - a.tt.dw_min[ph];
                 const bf16_t* pa = ldsA + abuf * a_buf_elems + ((hr * G + lg) * Wtp + c0 + l15) * 8;
-                const bf16_t* pb = ldsB + buf * (G * kBN * 8) + (lg * kBN + wn * 64 + l15) * 8;
+                const bf16_t* pb = ldsB + buf * (kTG * kBTap) + tt * kBTap + (lg * kBN + wn * 64 + l15) * 8;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    // all eight fragment reads of the K-step are issued before its 16 MFMAs: one exposed LDS latency per
-                    // K-step (covered by the partner wave on the same SIMD) instead of one per group of four MFMAs
                     bf16x8 fb[4], fa[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) fb[j] = *(const bf16x8*)(pb + (ks * 4 * kBN + j * 16) * 8);
@@ -211,14 +194,15 @@ __global__ __launch_bounds__(256, 2) void tapconv2_kernel(const TapConvArgs a) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            if (dbg_nomem) continue;
             if (has_next) write_b(buf ^ 1);
-            if (last_tap && next_chunk) {
+            if (last_g && next_chunk) {
                 if (a_double) {
-                    write_a(abuf ^ 1);
+                    write_a(abuf ^ 1, kc + 1);
                     abuf ^= 1;
                 } else {
                     __syncthreads();
-                    write_a(0);
+                    write_a(0, kc + 1);
                 }
             }
             __syncthreads();
@@ -242,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void tapconv2_kernel(const TapConvArgs a) {
             }
         }
     if (a.flags & RV_OUT_STATS) {
-        float* prow = a.stats + ((int64_t)(blockIdx.x * 2 + wm) * 2) * a.C_dst;
+        float* prow = a.stats + ((int64_t)(blockIdx.x * kTR + wm) * 2) * a.C_dst;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float s = 0.f, q = 0.f;
@@ -309,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void tapconv2_kernel(const TapConvArgs a) {
     __syncthreads();
     constexpr int kChunks = kBN / 8;
     const bool accum = a.flags & RV_OUT_ACCUM;
-    for (int q = tid; q < kTR * kTC * kChunks; q += 256) {
+    for (int q = tid; q < kTR * kTC * kChunks; q += 512) {
         const int pm = q / kChunks, c8 = q - pm * kChunks;
         const int rr = pm / kTC, mm = pm - rr * kTC;
         const int m = m0 + mm, c = n0 + c8 * 8, hh = h0 + rr;
@@ -328,10 +312,12 @@ __global__ __launch_bounds__(256, 2) void tapconv2_kernel(const TapConvArgs a) {
 }  // namespace
 
 // returns false when the layer is not eligible (caller falls back to tapconv_kernel)
-bool rv_tapconv2_plan(TapConvArgs* a, int* grid_x, int* grid_y, size_t* lds, int* ks) {
+bool rv_tapconv3_plan(TapConvArgs* a, int* grid_x, int* grid_y, size_t* lds, int* ks) {
     if (a->step != 1) return false;
     const int wm_total = a->W_dst / a->phases;
-    if (wm_total < kTC || a->C_dst < 64 || a->H < 2) return false;
+    if (wm_total < kTC || a->C_dst < 64 || a->H < kTR) return false;
+    for (int r = 0; r < a->phases; ++r)
+        if (a->tt.ntaps[r] < 2) return false;  // single-tap (1x1) phases: the smaller tapconv2 tile measured faster
     int a_max = 0;
     bool any_single_tap = true;
     const int KS = (a->C_src % 64 == 0) ? 2 : 1;
@@ -342,7 +328,7 @@ bool rv_tapconv2_plan(TapConvArgs* a, int* grid_x, int* grid_y, size_t* lds, int
         const int wtp = (a->tt.w_tile[r] + 15) & ~15;
         const int e = HR * G * wtp * 8;
         a_max = a_max > e ? a_max : e;
-        if (HR * a->tt.w_tile[r] > kNa2 * (256 / G)) return false;
+        if (HR * a->tt.w_tile[r] > kNa2 * (512 / G)) return false;
         if (a->tt.ntaps[r] != 1) any_single_tap = false;
     }
     // the A tile is double-buffered by phases with a single tap; size the region for it when any phase needs it
@@ -350,38 +336,31 @@ bool rv_tapconv2_plan(TapConvArgs* a, int* grid_x, int* grid_y, size_t* lds, int
     for (int r = 0; r < a->phases; ++r) some_single |= (a->tt.ntaps[r] == 1);
     (void)any_single_tap;
     a->lds_a_elems = a_max * (some_single ? 2 : 1);
-    size_t bytes = (size_t)(a->lds_a_elems + 2 * G * kBN * 8) * sizeof(bf16_t);
+    size_t bytes = (size_t)(a->lds_a_elems + 2 * kTG * G * kBN * 8) * sizeof(bf16_t);
     const size_t epi = (size_t)kTR * kTC * (kBN + 8) * sizeof(bf16_t);
     if (bytes < epi) bytes = epi;
-    if (bytes > 80 * 1024) return false;  // keep two workgroups per CU
+    if (bytes > 160 * 1024) return false;  // one workgroup per CU
     a->m_tiles = rv_ceil_div(wm_total, kTC);
     a->h_tiles = rv_ceil_div(a->H, kTR);
     *grid_x = a->m_tiles * a->h_tiles * a->N * a->phases;
     *grid_y = rv_ceil_div(a->C_dst, kBN);
+    if ((int64_t)*grid_x * *grid_y < 512) return false;  // too few 256-pixel tiles to fill 256 CUs: use tapconv2
     *lds = bytes;
     *ks = KS;
     return true;
 }
 
-int rv_tapconv2_launch(const TapConvArgs& a, int grid_x, int grid_y, size_t lds, int ks, hipStream_t stream) {
+int rv_tapconv3_launch(const TapConvArgs& a, int grid_x, int grid_y, size_t lds, int ks, hipStream_t stream) {
     static bool attr_set = false;
-    static bool dma = true;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)tapconv2_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)tapconv2_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)tapconv2_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)tapconv2_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        dma = getenv("RV3D_NO_BDMA") == nullptr;
+        (void)hipFuncSetAttribute((const void*)tapconv3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)tapconv3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    if (ks == 2 && dma)
-        hipLaunchKernelGGL((tapconv2_kernel<2, true>), dim3(grid_x, grid_y), dim3(256), lds, stream, a);
-    else if (ks == 2)
-        hipLaunchKernelGGL((tapconv2_kernel<2, false>), dim3(grid_x, grid_y), dim3(256), lds, stream, a);
-    else if (dma)
-        hipLaunchKernelGGL((tapconv2_kernel<1, true>), dim3(grid_x, grid_y), dim3(256), lds, stream, a);
+    if (ks == 2)
+        hipLaunchKernelGGL((tapconv3_kernel<2>), dim3(grid_x, grid_y), dim3(512), lds, stream, a);
     else
-        hipLaunchKernelGGL((tapconv2_kernel<1, false>), dim3(grid_x, grid_y), dim3(256), lds, stream, a);
-    RV_CHECK_LAUNCH("tapconv2_kernel");
+        hipLaunchKernelGGL((tapconv3_kernel<1>), dim3(grid_x, grid_y), dim3(512), lds, stream, a);
+    RV_CHECK_LAUNCH("tapconv3_kernel");
     return 0;
 }

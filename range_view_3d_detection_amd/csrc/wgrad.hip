@@ -417,9 +417,21 @@ int plan(const rvTapGeom* g, const rvTapShape* s, WgradPlan* p) {
         p->groups = g->kh * ((g->kw + 2) / 3);
         p->chunks = (int)(K / 64);
         const int base2 = p->groups * p->tiles_u * p->tiles_v;
-        int64_t ks2 = (768 + base2 - 1) / base2;  // ~3 blocks of 8 waves per CU in flight over the kernel
-        if (ks2 > p->chunks) ks2 = p->chunks;
-        if (ks2 < 1) ks2 = 1;
+        // split-K factor: whole rounds of 256 CUs (a 2.06-round grid ran 30 % slower than a 3-round one), at least 32
+        // K chunks per block so that the fp32 slab traffic stays small next to the MFMA work
+        int64_t ks_max = p->chunks / 32;
+        if (ks_max < 1) ks_max = 1;
+        if (ks_max * base2 > 1024) ks_max = 1024 / base2 > 0 ? 1024 / base2 : 1;
+        int64_t ks2 = 1;
+        double best = -1.0;
+        for (int64_t k = 1; k <= ks_max; ++k) {
+            const int64_t grid = k * base2, rounds = (grid + 255) / 256;
+            const double eff = (double)grid / (double)(rounds * 256) + 1e-6 * (double)grid;
+            if (eff > best) {
+                best = eff;
+                ks2 = k;
+            }
+        }
         p->chunks_per_split = (int)((p->chunks + ks2 - 1) / ks2);
         p->ksplit = (p->chunks + p->chunks_per_split - 1) / p->chunks_per_split;
     }

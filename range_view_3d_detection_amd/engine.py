@@ -12,6 +12,7 @@ through ``_lib`` -- there is no PyTorch/CPU fallback for any of them.
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple, Union
 
@@ -79,9 +80,10 @@ def _launch(name: str, flops: float, fn) -> None:
 def tap_kernel_name(geom, shape, scatter: bool) -> str:
     info = (ctypes.c_int32 * 4)()
     L.call("rv_tap_launch_info", ctypes.byref(geom), ctypes.byref(shape), L.i32(1 if scatter else 0), info)
-    if info[0] == 2:
-        return f"tapconv2_kernel<{info[1]}>"
-    return f"tapconv_kernel<{info[1] // 16},{info[1] % 16}>"
+    name = f"tapconv{info[0]}_kernel<{info[1]}>" if info[0] in (2, 3) else f"tapconv_kernel<{info[1] // 16},{info[1] % 16}>"
+    if os.environ.get("RV3D_PROFILE_SHAPES"):
+        name += f" {'S' if scatter else 'G'} k{geom.kh}x{geom.kw}s{geom.stride_w} {geom.cu}<->{geom.cv} {shape.N}x{shape.H}x{shape.Wu} f{shape.flags}"
+    return name
 
 
 def tap_flops(geom, shape) -> float:

@@ -89,7 +89,12 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=t.device)
     cu_p, cv_p = pad32(g.cu), pad32(g.cv)
     packed = torch.empty((g.kh * g.kw, cu_p, cv_p), dtype=torch.float32, device=t.device)
-    E._launch("wgrad_kernel(+reduce)", E.tap_flops(g, wshape),
+    import os
+
+    wname = "wgrad_kernel(+reduce)"
+    if os.environ.get("RV3D_PROFILE_SHAPES"):
+        wname += f" k{g.kh}x{g.kw}s{g.stride_w} {g.cu}<->{g.cv} {wshape.N}x{wshape.H}x{wshape.Wu}"
+    E._launch(wname, E.tap_flops(g, wshape),
               lambda: L.call("rv_tap_wgrad", ctypes.byref(g), ctypes.byref(wshape), u.ptr(), L.i32(u.ld), v.ptr(), L.i32(v.ld),
                              L.ptr(sc), L.ptr(sh), L.i32(v_affine), L.ptr(packed), L.ptr(ws), L.stream_ptr()))
     grad = torch.empty((g.cu, g.cv, g.kh, g.kw), dtype=torch.float32, device=t.device)

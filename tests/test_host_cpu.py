@@ -43,8 +43,8 @@ def test_host_side_geometry(lib):
     s = lib.TapShape(4, 64, 2048, 2048, 256, 256, lib.OUT_STATS)
     info = (ctypes.c_int32 * 4)()
     assert h.rv_tap_launch_info(ctypes.byref(g), ctypes.byref(s), 0, info) == 0
-    assert list(info) == [2, 2, 32 * 32 * 4, 2]  # tapconv2<2>: (2 rows x 64 cols) tiles, 2 channel tiles of 128
-    assert h.rv_tap_stats_rows(ctypes.byref(g), ctypes.byref(s), 0) == 2 * 32 * 32 * 4
+    assert list(info) == [3, 2, 32 * 16 * 4, 2]  # tapconv3<2>: (4 rows x 64 cols) tiles, 2 channel tiles of 128
+    assert h.rv_tap_stats_rows(ctypes.byref(g), ctypes.byref(s), 0) == 4 * 32 * 16 * 4
     # strided conv: Wv must be Wu * stride
     bad = lib.TapShape(4, 64, 1000, 2048, 256, 256, 0)
     g2 = lib.TapGeom(3, 3, 2, 1, 1, 128, 128)
@@ -53,7 +53,7 @@ def test_host_side_geometry(lib):
     # transposed conv (3,8)/s4: four phases
     g3 = lib.TapGeom(3, 8, 4, 1, 2, 128, 256)
     s3 = lib.TapShape(4, 64, 512, 2048, 128, 256, 0)
-    assert h.rv_tap_launch_info(ctypes.byref(g3), ctypes.byref(s3), 1, info) == 0 and info[2] == 4 * 8 * 32 * 4
+    assert h.rv_tap_launch_info(ctypes.byref(g3), ctypes.byref(s3), 1, info) == 0 and info[2] == 4 * 8 * 16 * 4
     rates = (ctypes.c_int32 * 3)(8, 2, 1)
     assert h.rv_decode_num_candidates(64, 2048, 3, rates) == 64 * (256 + 1024 + 2048)  # 212 992
     assert h.rv_decode_num_candidates(64, 2048, 0, rates) == 64 * 2048
