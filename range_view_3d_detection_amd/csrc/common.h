@@ -51,6 +51,11 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
     return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
 }
 
+// Opaque pass-through: consumers of `v` cannot be scheduled above this point.  Used on prefetch registers so that
+// hipcc does not hoist the unpack/transform of freshly loaded data (and with it an s_waitcnt vmcnt(0)) in front of
+// the MFMA section the loads are supposed to overlap with.
+__device__ __forceinline__ void pin_here(u32x4& v) { asm volatile("" : "+v"(v)); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

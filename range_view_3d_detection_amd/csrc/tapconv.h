@@ -30,8 +30,10 @@ struct TapConvArgs {
     int32_t ld_src, ld_dst;
     int32_t phases, step;
     int32_t m_tiles;
-    int32_t h_tiles;  // tapconv2: tiles of two image rows
+    int32_t h_tiles;  // tapconv2/3: tiles of two / four image rows
+    int32_t total_tiles, n_tiles, tiles_per_xcd;  // tapconv3: XCD-aware 1-D grid
     int32_t lds_a_elems;
+    int32_t lds_tab_offset;  // byte offset of the per-tap offset table in dynamic LDS
     int32_t flags;
     TapTable tt;
 };

@@ -59,6 +59,11 @@ __global__ __launch_bounds__(256, 2) void tapconv_kernel(const TapConvArgs a) {
     bf16_t* ldsB = ldsA + a.lds_a_elems;
 
     const bf16_t* src_row = a.src + ((int64_t)(n * a.H + h) * a.W_src) * a.ld_src;
+    // per-tap LDS offsets from an LDS table (a runtime-indexed kernarg lookup would be a vector load whose vmcnt(0)
+    // wait drains the prefetch loads -- see tapconv3.hip)
+    int* tap_tab = (int*)(smem + a.lds_tab_offset);
+    if (tid < T) tap_tab[tid] = ((a.tt.dh[ph][tid] - a.tt.dh_min) * Wt + (a.tt.dw[ph][tid] - a.tt.dw_min[ph])) * kPix;
+
 
     // ---- per-thread A-halo slots (fixed for the whole K loop) ------------------------------
     int src_off[kNaMax];
@@ -110,6 +115,7 @@ __global__ __launch_bounds__(256, 2) void tapconv_kernel(const TapConvArgs a) {
 #pragma unroll
         for (int i = 0; i < kNaMax; ++i) {
             if (lds_off[i] < 0) continue;
+            pin_here(a_reg[i]);
             u32x4 v = a_reg[i];
             if ((affine || relu) && src_off[i] != INT32_MIN) {
 #pragma unroll
@@ -142,6 +148,8 @@ __global__ __launch_bounds__(256, 2) void tapconv_kernel(const TapConvArgs a) {
     auto write_b = [&](int buf) {
         if (b_active) {
             bf16_t* p = ldsB + buf * (BN * kPix) + b_row * kPix + b_half * 16;
+            pin_here(b_reg[0]);
+            pin_here(b_reg[1]);
             *(u32x4*)p = b_reg[0];
             *(u32x4*)(p + 8) = b_reg[1];
         }
@@ -168,15 +176,14 @@ __global__ __launch_bounds__(256, 2) void tapconv_kernel(const TapConvArgs a) {
     int buf = 0;
     for (int kc = 0; kc < nk; ++kc) {
         const bool next_chunk = kc + 1 < nk;
-        if (next_chunk) load_a(kc + 1);
+        load_a(next_chunk ? kc + 1 : kc);  // unconditional (see tapconv3.hip)
         for (int t = 0; t < T; ++t) {
             const bool last_tap = (t == T - 1);
             const bool has_next = !last_tap || next_chunk;
-            if (has_next) load_b(last_tap ? kc + 1 : kc, last_tap ? 0 : t + 1);
+            load_b(has_next ? (last_tap ? kc + 1 : kc) : kc, has_next ? (last_tap ? 0 : t + 1) : t);
             // ---- MFMAs of tap t on chunk kc ----
             {
-                const int tap_off =
-                    ((a.tt.dh[ph][t] - a.tt.dh_min) * Wt + (a.tt.dw[ph][t] - a.tt.dw_min[ph])) * kPix;
+                const int tap_off = tap_tab[t];
                 const bf16_t* pa = ldsA + tap_off + a_lane;
                 const bf16_t* pb = ldsB + buf * (BN * kPix) + b_lane;
                 bf16x8 fb[NT];
@@ -190,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void tapconv_kernel(const TapConvArgs a) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[j], acc[i][j], 0, 0, 0);
                 }
             }
-            if (has_next) write_b(buf ^ 1);
+            write_b(buf ^ 1);
             if (last_tap && next_chunk) {
                 __syncthreads();
                 write_a();
@@ -465,6 +472,9 @@ static int tap_launch(const rvTapGeom* g, const rvTapShape* s, bool scatter, con
     size_t lds = (size_t)(a_elems + 2 * BN * kPix) * sizeof(bf16_t);
     const size_t epi = (size_t)BM * (BN + 8) * sizeof(bf16_t);
     if (lds < epi) lds = epi;
+    lds = (lds + 15) & ~(size_t)15;
+    a.lds_tab_offset = (int32_t)lds;
+    lds += 128;
     a.m_tiles = rv_ceil_div(wm_total, BM);
     const int grid_x = a.m_tiles * a.H * a.N * phases;
     const int grid_y = rv_ceil_div(a.C_dst, BN);

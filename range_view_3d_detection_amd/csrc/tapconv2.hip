@@ -56,6 +56,14 @@ __global__ __launch_bounds__(256, 2) void tapconv2_kernel(const TapConvArgs a) {
 
     const bf16_t* src_img = a.src + ((int64_t)n * a.H * a.W_src) * a.ld_src;
 
+    // Per-tap (halo row, halo column) offsets live in LDS.  Indexing the kernel-argument tap table with the runtime
+    // tap index makes hipcc emit a VECTOR load (global_load_sbyte) inside the K loop, and the s_waitcnt vmcnt(0) for
+    // its result drains every prefetch load issued just before it (vmcnt counts in order) -- in round 1 that
+    // serialised all global loads with the MFMAs.  An LDS lookup waits on lgkmcnt only.
+    int* tap_tab = (int*)(smem + a.lds_tab_offset);
+    if (tid < T) tap_tab[tid] = ((a.tt.dh[ph][tid] - a.tt.dh_min) << 16) | (a.tt.dw[ph][tid] - a.tt.dw_min[ph]);
+
+
     // ---- staging map -----------------------------------------------------------------------
     const int s_px = tid & 7, s_g = (tid >> 3) & (G - 1), s_hi = tid >> (3 + (KS == 2 ? 3 : 2));
     const int px_per_iter = 256 / G;  // 32 (KS=2) or 64 (KS=1)
@@ -105,6 +113,7 @@ __global__ __launch_bounds__(256, 2) void tapconv2_kernel(const TapConvArgs a) {
 #pragma unroll
         for (int i = 0; i < kNa2; ++i) {
             if (lds_off[i] < 0) continue;
+            pin_here(a_reg[i]);
             u32x4 v = a_reg[i];
             if ((affine || relu) && src_off[i] != INT32_MIN) {
 #pragma unroll
@@ -158,6 +167,7 @@ __global__ __launch_bounds__(256, 2) void tapconv2_kernel(const TapConvArgs a) {
 #pragma unroll
             for (int i = 0; i < kNb; ++i) {
                 const int nn = i * px_per_iter + s_hi * 8 + s_px;
+                pin_here(b_reg[i]);
                 *(u32x4*)(base + (s_g * kBN + nn) * 8) = b_reg[i];
             }
         }
@@ -180,14 +190,14 @@ __global__ __launch_bounds__(256, 2) void tapconv2_kernel(const TapConvArgs a) {
     int buf = 0, abuf = 0;
     for (int kc = 0; kc < nk; ++kc) {
         const bool next_chunk = kc + 1 < nk;
-        if (next_chunk && !(a.flags & (1 << 29))) load_a(kc + 1);
+        load_a(next_chunk ? kc + 1 : kc);  // unconditional (see tapconv3.hip): no register merge => no early vmcnt(0)
         for (int t = 0; t < T; ++t) {
             const bool last_tap = (t == T - 1);
             const bool has_next = !last_tap || next_chunk;
-            if (has_next && !(a.flags & (1 << 30))) load_b(last_tap ? kc + 1 : kc, last_tap ? 0 : t + 1, buf ^ 1);
+            load_b(has_next ? (last_tap ? kc + 1 : kc) : kc, has_next ? (last_tap ? 0 : t + 1) : t, buf ^ 1);
             {
-                const int hr = wm + (a.tt.dh[ph][t] - a.tt.dh_min);
-                const int c0 = a.tt.dw[ph][t] - a.tt.dw_min[ph];
+                const int ti = tap_tab[t];
+                const int hr = wm + (ti >> 16), c0 = ti & 0xffff;
                 const bf16_t* pa = ldsA + abuf * a_buf_elems + ((hr * G + lg) * Wtp + c0 + l15) * 8;
                 const bf16_t* pb = ldsB + buf * (G * kBN * 8) + (lg * kBN + wn * 64 + l15) * 8;
 #pragma unroll
@@ -211,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void tapconv2_kernel(const TapConvArgs a) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if (has_next) write_b(buf ^ 1);
+            write_b(buf ^ 1);
             if (last_tap && next_chunk) {
                 if (a_double) {
                     write_a(abuf ^ 1);
@@ -353,6 +363,9 @@ bool rv_tapconv2_plan(TapConvArgs* a, int* grid_x, int* grid_y, size_t* lds, int
     size_t bytes = (size_t)(a->lds_a_elems + 2 * G * kBN * 8) * sizeof(bf16_t);
     const size_t epi = (size_t)kTR * kTC * (kBN + 8) * sizeof(bf16_t);
     if (bytes < epi) bytes = epi;
+    bytes = (bytes + 15) & ~(size_t)15;
+    a->lds_tab_offset = (int32_t)bytes;
+    bytes += 128;  // per-tap offset table (<= 24 ints)
     if (bytes > 80 * 1024) return false;  // keep two workgroups per CU
     a->m_tiles = rv_ceil_div(wm_total, kTC);
     a->h_tiles = rv_ceil_div(a->H, kTR);

@@ -30,14 +30,21 @@ __global__ __launch_bounds__(512, 2) void tapconv3_kernel(const TapConvArgs a) {
     const int wm = wave >> 1, wn = wave & 1;  // wm = tile row (0..3), wn = channel half
     const int l15 = lane & 15, lg = lane >> 4;
 
-    int bx = blockIdx.x;
+    // XCD-aware block order: workgroups are dealt round-robin over the 8 XCDs (private L2 each), so block b runs on
+    // XCD b % 8.  Each XCD gets a contiguous range of pixel tiles and walks the channel tiles of one pixel tile
+    // back to back: the gy blocks that read the same input halo run at the same time on the same L2.
+    const int gy = a.n_tiles;
+    const int xcd = blockIdx.x & 7, xslot = blockIdx.x >> 3;
+    const int tile = xcd * a.tiles_per_xcd + xslot / gy;
+    if (tile >= a.total_tiles) return;
+    const int n0 = (xslot % gy) * kBN;
+    int bx = tile;
     const int tc = bx % a.m_tiles;
     bx /= a.m_tiles;
     const int th = bx % a.h_tiles;
     bx /= a.h_tiles;
     const int n = bx % a.N;
     const int ph = bx / a.N;
-    const int n0 = blockIdx.y * kBN;
     const int m0 = tc * kTC, h0 = th * kTR;
     const int T = a.tt.ntaps[ph];
     const int Wt = a.tt.w_tile[ph];           // halo columns actually staged
@@ -50,6 +57,14 @@ __global__ __launch_bounds__(512, 2) void tapconv3_kernel(const TapConvArgs a) {
     bf16_t* ldsB = ldsA + a.lds_a_elems;  // host: lds_a_elems = (a_double ? 2 : 1) * max a_buf_elems
 
     const bf16_t* src_img = a.src + ((int64_t)n * a.H * a.W_src) * a.ld_src;
+
+    // Per-tap (halo row, halo column) offsets live in LDS.  Indexing the kernel-argument tap table with the runtime
+    // tap index makes hipcc emit a VECTOR load (global_load_sbyte) inside the K loop, and the s_waitcnt vmcnt(0) for
+    // its result drains every prefetch load issued just before it (vmcnt counts in order) -- in round 1 that
+    // serialised all global loads with the MFMAs.  An LDS lookup waits on lgkmcnt only.
+    int* tap_tab = (int*)(smem + a.lds_tab_offset);
+    if (tid < T) tap_tab[tid] = ((a.tt.dh[ph][tid] - a.tt.dh_min) << 16) | (a.tt.dw[ph][tid] - a.tt.dw_min[ph]);
+
 
     // ---- staging map -----------------------------------------------------------------------
     const int s_px = tid & 7, s_g = (tid >> 3) & (G - 1), s_hi = tid >> (3 + (KS == 2 ? 3 : 2));
@@ -101,6 +116,7 @@ __global__ __launch_bounds__(512, 2) void tapconv3_kernel(const TapConvArgs a) {
 #pragma unroll
         for (int i = 0; i < kNa2; ++i) {
             if (!(slot[i] & 0x40000000u)) continue;
+            pin_here(a_reg[i]);
             u32x4 v = a_reg[i];
             if ((affine || relu) && (slot[i] & 0x80000000u)) {
 #pragma unroll
@@ -139,6 +155,7 @@ __global__ __launch_bounds__(512, 2) void tapconv3_kernel(const TapConvArgs a) {
         for (int i = 0; i < kNb; ++i) {
             const int q = i * px_per_iter + s_hi * 8 + s_px;
             const int tt = q >> 7, nn = q & 127;
+            pin_here(b_reg[i]);
             *(u32x4*)(base + tt * kBTap + (s_g * kBN + nn) * 8) = b_reg[i];
         }
     };
@@ -162,17 +179,20 @@ __global__ __launch_bounds__(512, 2) void tapconv3_kernel(const TapConvArgs a) {
     for (int kc = 0; kc < nk; ++kc) {
         const bool next_chunk = kc + 1 < nk;
         const bool dbg_nomem = a.flags & (1 << 28);
-        if (next_chunk && !dbg_nomem) load_a(kc + 1);
+        // Prefetch loads are issued UNCONDITIONALLY (the final ones re-fetch the current tile, harmlessly): a conditional
+        // load leaves hipcc with a register merge of "loaded" and "not loaded" values at the join, and the v_mov it emits
+        // there needs the data => s_waitcnt vmcnt(0) right after the loads, in front of the MFMAs they should overlap.
+        load_a(next_chunk ? kc + 1 : kc);
         for (int gi = 0; gi < ngroups; ++gi) {
             const bool last_g = (gi == ngroups - 1);
             const bool has_next = !last_g || next_chunk;
-            if (has_next && !dbg_nomem) load_b(last_g ? kc + 1 : kc, last_g ? 0 : (gi + 1) * kTG, buf ^ 1);
+            load_b(has_next ? (last_g ? kc + 1 : kc) : kc, has_next ? (last_g ? 0 : (gi + 1) * kTG) : gi * kTG, buf ^ 1);
             const int t0 = gi * kTG;
             const int tn = (T - t0) < kTG ? (T - t0) : kTG;
             for (int tt = 0; tt < tn; ++tt) {
                 const int t = t0 + tt;
-                const int hr = wm + (a.tt.dh[ph][t] - a.tt.dh_min);
-                const int c0 = a.tt.dw[ph][t] - a.tt.dw_min[ph];
+                const int ti = tap_tab[t];
+                const int hr = wm + (ti >> 16), c0 = ti & 0xffff;
                 const bf16_t* pa = ldsA + abuf * a_buf_elems + ((hr * G + lg) * Wtp + c0 + l15) * 8;
                 const bf16_t* pb = ldsB + buf * (kTG * kBTap) + tt * kBTap + (lg * kBN + wn * 64 + l15) * 8;
 #pragma unroll
@@ -195,7 +215,7 @@ __global__ __launch_bounds__(512, 2) void tapconv3_kernel(const TapConvArgs a) {
                 }
             }
             if (dbg_nomem) continue;
-            if (has_next) write_b(buf ^ 1);
+            write_b(buf ^ 1);
             if (last_g && next_chunk) {
                 if (a_double) {
                     write_a(abuf ^ 1, kc + 1);
@@ -226,7 +246,7 @@ __global__ __launch_bounds__(512, 2) void tapconv3_kernel(const TapConvArgs a) {
             }
         }
     if (a.flags & RV_OUT_STATS) {
-        float* prow = a.stats + ((int64_t)(blockIdx.x * kTR + wm) * 2) * a.C_dst;
+        float* prow = a.stats + ((int64_t)(tile * kTR + wm) * 2) * a.C_dst;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float s = 0.f, q = 0.f;
@@ -339,11 +359,17 @@ bool rv_tapconv3_plan(TapConvArgs* a, int* grid_x, int* grid_y, size_t* lds, int
     size_t bytes = (size_t)(a->lds_a_elems + 2 * kTG * G * kBN * 8) * sizeof(bf16_t);
     const size_t epi = (size_t)kTR * kTC * (kBN + 8) * sizeof(bf16_t);
     if (bytes < epi) bytes = epi;
+    bytes = (bytes + 15) & ~(size_t)15;
+    a->lds_tab_offset = (int32_t)bytes;
+    bytes += 128;  // per-tap offset table (<= 24 ints)
     if (bytes > 160 * 1024) return false;  // one workgroup per CU
     a->m_tiles = rv_ceil_div(wm_total, kTC);
     a->h_tiles = rv_ceil_div(a->H, kTR);
-    *grid_x = a->m_tiles * a->h_tiles * a->N * a->phases;
-    *grid_y = rv_ceil_div(a->C_dst, kBN);
+    a->total_tiles = a->m_tiles * a->h_tiles * a->N * a->phases;
+    a->n_tiles = rv_ceil_div(a->C_dst, kBN);
+    a->tiles_per_xcd = rv_ceil_div(a->total_tiles, 8);
+    *grid_x = a->total_tiles;  // (stats rows = 4 * grid_x); the launch uses 8 * tiles_per_xcd * n_tiles blocks
+    *grid_y = a->n_tiles;
     if ((int64_t)*grid_x * *grid_y < 512) return false;  // too few 256-pixel tiles to fill 256 CUs: use tapconv2
     *lds = bytes;
     *ks = KS;
@@ -358,9 +384,9 @@ int rv_tapconv3_launch(const TapConvArgs& a, int grid_x, int grid_y, size_t lds,
         attr_set = true;
     }
     if (ks == 2)
-        hipLaunchKernelGGL((tapconv3_kernel<2>), dim3(grid_x, grid_y), dim3(512), lds, stream, a);
+        hipLaunchKernelGGL((tapconv3_kernel<2>), dim3(8 * a.tiles_per_xcd * a.n_tiles), dim3(512), lds, stream, a);
     else
-        hipLaunchKernelGGL((tapconv3_kernel<1>), dim3(grid_x, grid_y), dim3(512), lds, stream, a);
+        hipLaunchKernelGGL((tapconv3_kernel<1>), dim3(8 * a.tiles_per_xcd * a.n_tiles), dim3(512), lds, stream, a);
     RV_CHECK_LAUNCH("tapconv3_kernel");
     return 0;
 }

@@ -106,21 +106,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
         pw[j] = (int)(r - (int64_t)phh[j] * a.Wu);
     }
     u32x4 ru[2], rv[2];
+    bool ru_ok[2], rv_ok[2];
     auto load = [&](int64_t kbase) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int64_t k = kbase + prow + 16 * j;
             ru[j] = u32x4{0u, 0u, 0u, 0u};
             rv[j] = u32x4{0u, 0u, 0u, 0u};
+            ru_ok[j] = false;
+            rv_ok[j] = false;
             if (k < k_end) {
                 if (u_ok) {
+                    ru_ok[j] = true;
                     ru[j] = *(const u32x4*)(a.U + ((int64_t)(pn[j] * a.H + phh[j]) * a.Wu + pw[j]) * a.ld_u + u0 + chunk * 8);
-                    if ((affine || relu) && !a.v_affine) ru[j] = transform8(ru[j], sc, sh, affine, relu);
                 }
                 const int hv = phh[j] + dh, wv = pw[j] * a.stride_w + dw;
                 if (v_ok && hv >= 0 && hv < a.H && wv >= 0 && wv < a.Wv) {
+                    rv_ok[j] = true;
                     rv[j] = *(const u32x4*)(a.V + ((int64_t)(pn[j] * a.H + hv) * a.Wv + wv) * a.ld_v + v0 + chunk * 8);
-                    if ((affine || relu) && a.v_affine) rv[j] = transform8(rv[j], sc, sh, affine, relu);
                 }
             }
             // advance this row by 32 pixels
@@ -139,6 +142,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
         for (int j = 0; j < 2; ++j) {
             const int k = prow + 16 * j;
             const int off = k * 128 + (((chunk >> 1) ^ sigma(k)) << 4) + (chunk & 1) * 8;
+            pin_here(ru[j]);
+            pin_here(rv[j]);
+            // zero-filled (out-of-range) slots hold exact zeros; relu(shift) must not leak into them
+            if ((affine || relu) && !a.v_affine && ru_ok[j]) ru[j] = transform8(ru[j], sc, sh, affine, relu);
+            if ((affine || relu) && a.v_affine && rv_ok[j]) rv[j] = transform8(rv[j], sc, sh, affine, relu);
             *(u32x4*)(&lds[buf][0][off]) = ru[j];
             *(u32x4*)(&lds[buf][1][off]) = rv[j];
         }
@@ -269,6 +277,7 @@ __device__ __forceinline__ void wgrad2_body(const Wgrad2Args& a, bf16_t (*lds)[2
         }
     }
     u32x4 ru[2], rv[3];
+    bool rv_ok[3];
     auto load = [&](int c) {
         const int row = c / wchunks, w0 = (c - row * wchunks) * 64;  // row = n*H + h
         const int h = row % a.H;
@@ -276,10 +285,7 @@ __device__ __forceinline__ void wgrad2_body(const Wgrad2Args& a, bf16_t (*lds)[2
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             ru[j] = u32x4{0u, 0u, 0u, 0u};
-            if (u_ok) {
-                ru[j] = *(const u32x4*)(urow + (int64_t)(w0 + prow + 32 * j) * a.ld_u);
-                if ((affine || relu) && !a.v_affine) ru[j] = transform8(ru[j], sc, sh, affine, relu);
-            }
+            if (u_ok) ru[j] = *(const u32x4*)(urow + (int64_t)(w0 + prow + 32 * j) * a.ld_u);
         }
         const int hv = h + dh;
         const bool row_ok = hv >= 0 && hv < a.H;
@@ -289,21 +295,23 @@ __device__ __forceinline__ void wgrad2_body(const Wgrad2Args& a, bf16_t (*lds)[2
             rv[j] = u32x4{0u, 0u, 0u, 0u};
             const int r = prow + 32 * j;  // halo row 0..65(+)
             const int wv = w0 + r + dw0;
-            if (v_ok && row_ok && r < 64 + TG - 1 && wv >= 0 && wv < a.Wu) {
-                rv[j] = *(const u32x4*)(vrow + (int64_t)wv * a.ld_v);
-                if ((affine || relu) && a.v_affine) rv[j] = transform8(rv[j], sc, sh, affine, relu);
-            }
+            rv_ok[j] = v_ok && row_ok && r < 64 + TG - 1 && wv >= 0 && wv < a.Wu;
+            if (rv_ok[j]) rv[j] = *(const u32x4*)(vrow + (int64_t)wv * a.ld_v);
         }
     };
     auto store = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int k = prow + 32 * j;
+            pin_here(ru[j]);
+            if ((affine || relu) && !a.v_affine && u_ok) ru[j] = transform8(ru[j], sc, sh, affine, relu);
             *(u32x4*)(&lds[buf][0][k * 128 + (((chunk >> 1) ^ sigma(k)) << 4) + (chunk & 1) * 8]) = ru[j];
         }
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int k = prow + 32 * j;
+            pin_here(rv[j]);
+            if ((affine || relu) && a.v_affine && rv_ok[j]) rv[j] = transform8(rv[j], sc, sh, affine, relu);
             if (k < 66) *(u32x4*)(&lds[buf][1][k * 128 + (((chunk >> 1) ^ sigma(k)) << 4) + (chunk & 1) * 8]) = rv[j];
         }
     };
