@@ -93,7 +93,6 @@ __global__ __launch_bounds__(256, 2) void tapconv_kernel(const TapConvArgs a) {
 
     u32x4 a_reg[kNaMax];
     u32x4 b_reg[2];
-    float sc[8], sh[8];
 
     auto load_a = [&](int kc) {
 #pragma unroll
@@ -102,16 +101,17 @@ __global__ __launch_bounds__(256, 2) void tapconv_kernel(const TapConvArgs a) {
             if (src_off[i] != INT32_MIN) v = *(const u32x4*)(src_row + src_off[i] + kc * 32);
             a_reg[i] = v;
         }
-        if (a.flags & RV_IN_AFFINE) {
+    };
+    auto write_a = [&](int kc) {
+        const bool affine = a.flags & RV_IN_AFFINE, relu = a.flags & RV_IN_RELU;
+        float sc[8], sh[8];
+        if (affine) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 sc[j] = a.in_scale[kc * 32 + oct * 8 + j];
                 sh[j] = a.in_shift[kc * 32 + oct * 8 + j];
             }
         }
-    };
-    auto write_a = [&]() {
-        const bool affine = a.flags & RV_IN_AFFINE, relu = a.flags & RV_IN_RELU;
 #pragma unroll
         for (int i = 0; i < kNaMax; ++i) {
             if (lds_off[i] < 0) continue;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void tapconv_kernel(const TapConvArgs a) {
     if (nk > 0) {
         load_a(0);
         load_b(0, 0);
-        write_a();
+        write_a(0);
         write_b(0);
     }
     __syncthreads();
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void tapconv_kernel(const TapConvArgs a) {
             write_b(buf ^ 1);
             if (last_tap && next_chunk) {
                 __syncthreads();
-                write_a();
+                write_a(kc + 1);
             }
             __syncthreads();
             buf ^= 1;

@@ -90,7 +90,6 @@ __global__ __launch_bounds__(256, 2) void tapconv2_kernel(const TapConvArgs a) {
 
     u32x4 a_reg[kNa2];
     u32x4 b_reg[kNb];
-    float sc[8], sh[8];
     const bool affine = a.flags & RV_IN_AFFINE, relu = a.flags & RV_IN_RELU;
 
     auto load_a = [&](int kc) {
@@ -100,16 +99,17 @@ __global__ __launch_bounds__(256, 2) void tapconv2_kernel(const TapConvArgs a) {
             if (src_off[i] != INT32_MIN) v = *(const u32x4*)(src_img + src_off[i] + kc * BK);
             a_reg[i] = v;
         }
-        if (affine) {
+    };
+    auto write_a = [&](int abuf, int kc) {
+        bf16_t* base = ldsA + abuf * a_buf_elems;
+        float sc[8], sh[8];
+        if (affine) {  // loaded here, after the MFMA section: a wait for these would drain the prefetch loads too
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 sc[j] = a.in_scale[kc * BK + s_g * 8 + j];
                 sh[j] = a.in_shift[kc * BK + s_g * 8 + j];
             }
         }
-    };
-    auto write_a = [&](int abuf) {
-        bf16_t* base = ldsA + abuf * a_buf_elems;
 #pragma unroll
         for (int i = 0; i < kNa2; ++i) {
             if (lds_off[i] < 0) continue;
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void tapconv2_kernel(const TapConvArgs a) {
     if (nk > 0) {
         load_a(0);
         load_b(0, 0, 0);
-        write_a(0);
+        write_a(0, 0);
         write_b(0);
     }
     __syncthreads();
@@ -209,7 +209,8 @@ __global__ __launch_bounds__(256, 2) void tapconv2_kernel(const TapConvArgs a) {
                     for (int j = 0; j < 4; ++j) fb[j] = *(const bf16x8*)(pb + (ks * 4 * kBN + j * 16) * 8);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) fa[i] = *(const bf16x8*)(pa + (ks * 4 * Wtp + i * 16) * 8);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    // all 8 reads are issued first (sched_barrier pins that); hipcc's own counted lgkmcnt waits then let the
+                    // first MFMA group start as soon as its operands (5 of the 8 reads) have landed
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -224,11 +225,11 @@ __global__ __launch_bounds__(256, 2) void tapconv2_kernel(const TapConvArgs a) {
             write_b(buf ^ 1);
             if (last_tap && next_chunk) {
                 if (a_double) {
-                    write_a(abuf ^ 1);
+                    write_a(abuf ^ 1, kc + 1);
                     abuf ^= 1;
                 } else {
                     __syncthreads();
-                    write_a(0);
+                    write_a(0, kc + 1);
                 }
             }
             __syncthreads();

@@ -202,7 +202,8 @@ __global__ __launch_bounds__(512, 2) void tapconv3_kernel(const TapConvArgs a) {
                     for (int j = 0; j < 4; ++j) fb[j] = *(const bf16x8*)(pb + (ks * 4 * kBN + j * 16) * 8);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) fa[i] = *(const bf16x8*)(pa + (ks * 4 * Wtp + i * 16) * 8);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    // all 8 reads are issued first (sched_barrier pins that); hipcc's own counted lgkmcnt waits then let the
+                    // first MFMA group start as soon as its operands (5 of the 8 reads) have landed
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -337,7 +338,7 @@ bool rv_tapconv3_plan(TapConvArgs* a, int* grid_x, int* grid_y, size_t* lds, int
     const int wm_total = a->W_dst / a->phases;
     if (wm_total < kTC || a->C_dst < 64 || a->H < kTR) return false;
     for (int r = 0; r < a->phases; ++r)
-        if (a->tt.ntaps[r] < 2) return false;  // single-tap (1x1) phases: the smaller tapconv2 tile measured faster
+        if (a->tt.ntaps[r] < 2 && getenv("RV3D_V3_1X1") == nullptr) return false;  // single-tap (1x1) phases: the smaller tapconv2 tile measured faster
     int a_max = 0;
     bool any_single_tap = true;
     const int KS = (a->C_src % 64 == 0) ? 2 : 1;

@@ -107,7 +107,7 @@ def bn_backward(op: "E.BnOp", t: Tape) -> None:
     entry = t.lazy_in.pop(id(lazy), None)
     if entry is None:
         return
-    dout, mask = entry
+    dout, mask, res = entry if len(entry) == 3 else (entry[0], entry[1], None)
     st, raw = lazy.bn, lazy.raw
     if st.mean is None:
         raise L.RvError("BatchNorm backward needs batch statistics (module was run in eval mode)")
@@ -135,7 +135,12 @@ def bn_backward(op: "E.BnOp", t: Tape) -> None:
         L.call("rv_bn_bwd_finalize", L.ptr(partial), L.i32(rows), L.i32(cp), L.i64(st.count), L.ptr(op.gamma_p), L.ptr(st.invstd),
                L.ptr(dgamma), L.ptr(dbeta), L.i32(0), L.ptr(coef), L.stream_ptr())
     dy = raw.like()
-    L.call("rv_bn_bwd_apply", *common, L.ptr(coef), L.i32(flags), dy.ptr(), L.i32(dy.ld), None, L.i32(0), L.stream_ptr())
+    if res is not None:
+        rg, racc = res
+        L.call("rv_bn_bwd_apply", *common, L.ptr(coef), L.i32(flags | (L.BNB_RES_ACCUM if racc else 0)), dy.ptr(), L.i32(dy.ld),
+               rg.ptr(), L.i32(rg.ld), L.stream_ptr())
+    else:
+        L.call("rv_bn_bwd_apply", *common, L.ptr(coef), L.i32(flags), dy.ptr(), L.i32(dy.ld), None, L.i32(0), L.stream_ptr())
     t.raw_grad[id(raw)] = dy
     c = st.module.num_features
     t.add_param_grad(st.module.weight, dgamma[:c])
@@ -147,17 +152,26 @@ def combine_backward(op: "E.CombineOp", t: Tape) -> None:
     if not have:
         return
     mask = op.out if op.relu_out else None
-    for x in (op.a, op.b):
-        if x is None:
-            continue
-        if isinstance(x, Lazy):
-            t.lazy_in[id(x)] = (gout, mask)
-        else:
-            g, have_x = t.grad_buffer(x)
-            L.call("rv_ew_mask_grad", L.i64(gout.pixels), L.i32(gout.cp), gout.ptr(), L.i32(gout.ld),
-                   mask.ptr() if mask is not None else None, L.i32(mask.ld if mask is not None else 0), g.ptr(), L.i32(g.ld),
-                   L.i32(1 if have_x else 0), L.stream_ptr())
-            t.mark_written(x)
+    lazies = [x for x in (op.a, op.b) if isinstance(x, Lazy)]
+    plains = [x for x in (op.a, op.b) if x is not None and not isinstance(x, Lazy)]
+    # out = relu(bn(y) + x): the residual gradient dOut*[out>0] is exactly the `g` the BatchNorm-backward apply pass
+    # already forms, so that pass also writes it (rv_bn_bwd_apply's dres output) instead of a separate masking pass.
+    fuse_res = len(lazies) == 1 and len(plains) == 1 and not lazies[0].relu and t.training
+    for x in lazies:
+        res = None
+        if fuse_res:
+            g, have_x = t.grad_buffer(plains[0])
+            res = (g, have_x)
+            t.mark_written(plains[0])
+        t.lazy_in[id(x)] = (gout, mask, res)
+    if fuse_res:
+        return
+    for x in plains:
+        g, have_x = t.grad_buffer(x)
+        L.call("rv_ew_mask_grad", L.i64(gout.pixels), L.i32(gout.cp), gout.ptr(), L.i32(gout.ld),
+               mask.ptr() if mask is not None else None, L.i32(mask.ld if mask is not None else 0), g.ptr(), L.i32(g.ld),
+               L.i32(1 if have_x else 0), L.stream_ptr())
+        t.mark_written(x)
 
 
 def modulate_backward(op: "E.MetaModulateOp", t: Tape) -> None:
