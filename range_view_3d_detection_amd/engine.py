@@ -69,6 +69,19 @@ class KernelProfile:
 
 PROFILE: Optional[KernelProfile] = None
 
+# Weight gradients run on a second HIP stream: wgrad(L) is independent of the main backward chain
+# (dgrad(L) -> BatchNorm backward(L-1) -> dgrad(L-1) ...), and the MFMA-bound wgrad kernels overlap with the
+# HBM-bound BatchNorm-backward / element-wise passes on the main stream instead of queueing behind them.
+OVERLAP_WGRAD = os.environ.get("RV3D_NO_OVERLAP") is None
+_SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
+
+
+def side_stream(device) -> "torch.cuda.Stream":
+    idx = torch.device(device).index or 0
+    if idx not in _SIDE_STREAMS:
+        _SIDE_STREAMS[idx] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[idx]
+
 
 def _launch(name: str, flops: float, fn) -> None:
     if PROFILE is not None:
@@ -298,6 +311,7 @@ class Tape:
         self.raw_grad: Dict[int, Act] = {}       # id(raw Act) -> gradient w.r.t. the raw conv output
         self.param_grads: Dict[int, Tensor] = {}  # id(param) -> fp32 gradient
         self.params: Dict[int, nn.Parameter] = {}
+        self.used_side_stream = False
 
     # ---- gradient buffers (views follow their parents) ----
     def grad_buffer(self, a: Act) -> Tuple[Act, bool]:
@@ -339,6 +353,8 @@ class Tape:
     def backward(self) -> None:
         for op in reversed(self.ops):
             op.backward(self)
+        if self.used_side_stream:  # parameter gradients (and the buffers the side stream read) are final after this
+            torch.cuda.current_stream().wait_stream(side_stream(self.device))
 
 
 class Op:

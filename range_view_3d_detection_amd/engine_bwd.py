@@ -13,6 +13,7 @@ Gradient flow on the tape, in reverse op order:
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -85,21 +86,32 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
     else:
         u, v, v_affine = src, dout, 0
     wshape = L.TapShape(sp.N, sp.H, sp.Wu, sp.Wv, 0, 0, in_flags)
-    ws_bytes = L.load().rv_tap_wgrad_workspace_bytes(ctypes.byref(g), ctypes.byref(wshape))
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=t.device)
-    cu_p, cv_p = pad32(g.cu), pad32(g.cv)
-    packed = torch.empty((g.kh * g.kw, cu_p, cv_p), dtype=torch.float32, device=t.device)
-    import os
 
-    wname = "wgrad_kernel(+reduce)"
-    if os.environ.get("RV3D_PROFILE_SHAPES"):
-        wname += f" k{g.kh}x{g.kw}s{g.stride_w} {g.cu}<->{g.cv} {wshape.N}x{wshape.H}x{wshape.Wu}"
-    E._launch(wname, E.tap_flops(g, wshape),
-              lambda: L.call("rv_tap_wgrad", ctypes.byref(g), ctypes.byref(wshape), u.ptr(), L.i32(u.ld), v.ptr(), L.i32(v.ld),
-                             L.ptr(sc), L.ptr(sh), L.i32(v_affine), L.ptr(packed), L.ptr(ws), L.stream_ptr()))
-    grad = torch.empty((g.cu, g.cv, g.kh, g.kw), dtype=torch.float32, device=t.device)
-    L.call("rv_unpack_weight_grad", ctypes.byref(g), L.ptr(packed), L.ptr(grad), L.i32(0), L.stream_ptr())
-    t.add_param_grad(layer.weight, layer.unpermute_grad(grad))
+    def run_wgrad() -> None:
+        ws_bytes = L.load().rv_tap_wgrad_workspace_bytes(ctypes.byref(g), ctypes.byref(wshape))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=t.device)
+        cu_p, cv_p = pad32(g.cu), pad32(g.cv)
+        packed = torch.empty((g.kh * g.kw, cu_p, cv_p), dtype=torch.float32, device=t.device)
+        wname = "wgrad_kernel(+reduce)"
+        if os.environ.get("RV3D_PROFILE_SHAPES"):
+            wname += f" k{g.kh}x{g.kw}s{g.stride_w} {g.cu}<->{g.cv} {wshape.N}x{wshape.H}x{wshape.Wu}"
+        E._launch(wname, E.tap_flops(g, wshape),
+                  lambda: L.call("rv_tap_wgrad", ctypes.byref(g), ctypes.byref(wshape), u.ptr(), L.i32(u.ld), v.ptr(), L.i32(v.ld),
+                                 L.ptr(sc), L.ptr(sh), L.i32(v_affine), L.ptr(packed), L.ptr(ws), L.stream_ptr()))
+        grad = torch.empty((g.cu, g.cv, g.kh, g.kw), dtype=torch.float32, device=t.device)
+        L.call("rv_unpack_weight_grad", ctypes.byref(g), L.ptr(packed), L.ptr(grad), L.i32(0), L.stream_ptr())
+        t.add_param_grad(layer.weight, layer.unpermute_grad(grad))
+
+    if E.OVERLAP_WGRAD:
+        side = E.side_stream(t.device)
+        ready = torch.cuda.Event()
+        ready.record()  # dout (and everything before it on the main stream) is complete at this point of the main stream
+        side.wait_event(ready)
+        with torch.cuda.stream(side):
+            run_wgrad()
+        t.used_side_stream = True
+    else:
+        run_wgrad()
 
 
 def bn_backward(op: "E.BnOp", t: Tape) -> None:

@@ -130,23 +130,89 @@ def test_tiny_detector_forward_backward(golden):
     assert rel_err(losses["loss"].reshape(()), g["loss/loss"].reshape(())) < 3e-2
     assert losses["loss"].dtype == torch.float64
     losses["loss"].backward()
-    cos_all, n_bad = [], 0
+    # Gradients of THIS fixture are not comparable across precisions: its BatchNorms see as few as 64 values per channel
+    # (2 x 8 x 4 pixels), and even the CPU oracle with bf16 storage emulation only reaches a median cosine of 0.68
+    # against the reference's fp32 gradients.  Gradient parity of the composed model is checked on a better conditioned
+    # model in test_detector_gradients_vs_oracle; here: every parameter gets a finite gradient.
     for prefix, mod in (("backbone", backbone), ("head", head)):
         for k, p in mod.named_parameters():
             assert p.grad is not None and torch.isfinite(p.grad).all(), k
-            ref = g[f"grad/{prefix}.{k}"]
-            if float(ref.abs().max()) < 1e-6:
-                continue
-            c = _cos(p.grad, ref)
-            cos_all.append(c)
-            n_bad += c < 0.9
-    # deep tiny network (60 BN layers at 2x8x4 .. 2x8x64 pixels): bf16 gate flips make individual small tensors noisy;
-    # the bulk of the gradient must still point the same way as the reference's fp32 gradient
-    assert np.median(cos_all) > 0.97 and n_bad <= len(cos_all) // 10, (np.median(cos_all), n_bad, len(cos_all))
     # running statistics updated in place
     sd_after = {**{f"backbone.{k}": v for k, v in backbone.state_dict().items()}, **{f"head.{k}": v for k, v in head.state_dict().items()}}
     worst = max(rel_err(sd_after[k], v) for k, v in g.sub("sd_after").items())
     assert worst < 5e-2, worst
+
+
+@pytest.mark.parametrize("bn_bias_shift", [6.0, 3.0, 0.0])
+def test_detector_gradients_vs_oracle(bn_bias_shift):
+    """Composed model (stem + backbone + towers + targets + loss), forward AND backward, against the pinned oracle.
+
+    32-channel model on 2 x 16 x 256 sweeps.  HIP (bf16 storage) vs the oracle in fp32 and vs the oracle with bf16 storage
+    emulation: per-parameter gradient cosine.
+
+    Conditioning: with bf16 storage a ReLU gate whose pre-activation is within rounding error of zero flips, and a flipped
+    gate is an all-or-nothing gradient error.  Over the ~45 BN-ReLU layers of this model that makes the randomly
+    initialised network's gradient ill conditioned -- the CPU oracle's own bf16 emulation only reaches a median cosine of
+    ~0.6 against its fp32 gradients.  So the composition (tape order, residual sums, gradient routing, every backward
+    kernel in its place) is checked where the problem is well conditioned -- BatchNorm biases shifted so that (nearly)
+    all / most gates are firmly open -- and in the natural regime (shift 0) the HIP path is required to be at least as
+    close to the fp32 oracle as the CPU bf16 emulation is.  Gate masks themselves are checked exactly in
+    test_gpu_backward.py.
+    """
+    from bench import Detector, build_model, synthetic_batch
+    from oracle import model as om
+    from oracle import targets as otgt
+
+    torch.manual_seed(0)
+    n_cls = 5
+    backbone, head = build_model("c32", n_cls)
+    gen = torch.Generator().manual_seed(1)
+    for m in list(backbone.modules()) + list(head.modules()):
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data = 0.5 + torch.rand(m.weight.shape, generator=gen)
+            m.bias.data = 0.2 * torch.randn(m.bias.shape, generator=gen) + bn_bias_shift
+    sd = {**{f"backbone.{k}": v.clone() for k, v in backbone.state_dict().items()}, **{f"head.{k}": v.clone() for k, v in head.state_dict().items()}}
+    batch = synthetic_batch(2, 16, 256, seed=3, device="cpu", boxes_per_sweep=8, n_cls=n_cls)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+
+    def oracle_grads(nm):
+        params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
+        _, logits, reg = om.detector_forward(batch["features"], batch["cart"], {**sd, **params}, nm=nm)
+        tg = otgt.compute_targets(batch["cart"], batch["annotations"], n_cls)
+        loss = otgt.detection_loss(logits, reg, batch["cart"], batch["mask"], tg, n_cls)["loss"]
+        loss.backward()
+        return float(loss.detach()), {k: p.grad for k, p in params.items()}
+
+    loss32, g32 = oracle_grads(om.Numerics(train=True))
+    loss16, g16 = oracle_grads(om.Numerics.bf16(train=True))
+    model = Detector(backbone, head).to(DEV).train()
+    data = {k: (v.to(DEV) if k != "annotations" else v) for k, v in batch.items()}
+    loss = model(data)
+    loss.backward()
+    assert abs(float(loss) - loss32) / abs(loss32) < 2e-2, (float(loss), loss32, loss16)
+    cos32, cos16, cos_emu, names = [], [], [], []
+    for k, p in model.named_parameters():
+        ref = g32[k]
+        assert torch.isfinite(p.grad).all(), k
+        if float(ref.norm()) < 1e-9:
+            continue
+        names.append(k)
+        cos32.append(_cos(p.grad, ref))
+        cos16.append(_cos(p.grad, g16[k]))
+        cos_emu.append(_cos(g16[k], ref))
+    cos32, cos_emu = np.array(cos32), np.array(cos_emu)
+    med32, med16, med_emu = np.median(cos32), np.median(cos16), np.median(cos_emu)
+    print(f"[shift {bn_bias_shift}] {len(cos32)} parameters; gradient cosine medians: HIP~fp32 {med32:.4f}  HIP~bf16-emulation {med16:.4f}  "
+          f"emulation~fp32 {med_emu:.4f}; min {cos32.min():.4f} {min(cos16):.4f} {cos_emu.min():.4f}")
+    for i in np.argsort(cos32)[:4]:
+        print(f"    worst: {names[i]:56s} HIP~fp32 {cos32[i]:.4f}  emulation~fp32 {cos_emu[i]:.4f}  |g| {float(g32[names[i]].norm()):.2e}")
+    # never worse than what bf16 storage costs the CPU emulation of the same model
+    q32, q_emu = np.quantile(cos32, 0.05), np.quantile(cos_emu, 0.05)
+    assert med32 > med_emu - 0.03 and q32 > q_emu - 0.05, (med32, med_emu, q32, q_emu)
+    if bn_bias_shift >= 6.0:
+        assert med32 > 0.995 and q32 > 0.99, (med32, q32)
+    elif bn_bias_shift >= 3.0:
+        assert med32 > 0.98 and q32 > 0.9, (med32, q32)
 
 
 def test_tiny_detector_eval_and_decode(golden):
