@@ -157,6 +157,28 @@ def cpu_baseline(seconds_budget: float = 20.0):
     }
 
 
+def roofline(prof, iso) -> dict:
+    """Dominant kernel of the timed region against the dense bf16 MFMA peak; ``traffic`` = HBM bytes per launch of that
+    kernel from the committed PMC passes over this same command (profiles/r01_pmc_traffic.json, made by
+    profiles/pmc_traffic.py: FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate passes); ``isolated`` = the same kernel's
+    launches timed with nothing else on the GPU (side stream off, outside the timed region)."""
+    r = prof.roofline(MFMA_BF16_PEAK_TFLOPS)
+    if not r:
+        return r
+    d = iso.summary().get(r["kernel"])
+    if d:
+        r["isolated"] = {"achieved": d["tflops"], "frac": d["tflops"] / MFMA_BF16_PEAK_TFLOPS, "avg_launch_us": d["avg_us"]}
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")) as f:
+            k = json.load(f)["kernels"].get(r["kernel"])
+        if k:
+            r["traffic"] = k["hbm_bytes_per_launch"]
+            r["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 gfx950 correction)"
+    except OSError:
+        pass
+    return r
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -220,6 +242,15 @@ def main() -> None:
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     prof = E.PROFILE
+    # the same per-kernel events once more, outside the timed region, with the weight-gradient side stream off: with
+    # it on, kernels of the two streams share the CUs and each one's event-to-event time includes its neighbour's
+    iso = E.KernelProfile()
+    E.PROFILE, overlap = iso, E.OVERLAP_WGRAD
+    E.OVERLAP_WGRAD = False
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    E.OVERLAP_WGRAD = overlap
     E.PROFILE = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -236,7 +267,7 @@ def main() -> None:
                                    f"fwd+bwd+AdamW, {args.batch} synthetic {args.height}x{args.width}x5 sweeps per GPU (BASELINE configs[2])",
                        "global_batch": args.batch * world, "sweep": [args.height, args.width, 5], "parallelism": f"dp{world}",
                        "sync_bn": bool(E.SYNC_BN), "loss": float(loss.detach().item())},
-            "roofline": prof.roofline(MFMA_BF16_PEAK_TFLOPS),
+            "roofline": roofline(prof, iso),
             "kernels": prof.summary(),
         }
         if world == 1 and not args.no_cpu_baseline:

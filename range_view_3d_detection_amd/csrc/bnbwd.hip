@@ -42,14 +42,24 @@ __device__ __forceinline__ u32x4 pack8(const float* f) {
 }
 
 // g = dout * [out > 0] * [scale*y+shift > 0]; xhat = (y - mean) * invstd
-__device__ __forceinline__ void masked_grad(const BnbArgs& a, int64_t px, int c0, const float* sc, const float* sh,
+struct BnbLoad {
+    u32x4 d, y, o;
+};
+__device__ __forceinline__ BnbLoad load_px(const BnbArgs& a, int64_t px, int c0) {
+    BnbLoad r;
+    r.d = *(const u32x4*)(a.dout + px * a.ld_dout + c0);
+    r.y = *(const u32x4*)(a.y + px * a.ld_y + c0);
+    if (a.out) r.o = *(const u32x4*)(a.out + px * a.ld_out + c0);
+    return r;
+}
+__device__ __forceinline__ void masked_grad(const BnbArgs& a, const BnbLoad& r, const float* sc, const float* sh,
                                             const float* mu, const float* is, float* g, float* xhat) {
     float d[8], yv[8];
-    unpack8(*(const u32x4*)(a.dout + px * a.ld_dout + c0), d);
-    unpack8(*(const u32x4*)(a.y + px * a.ld_y + c0), yv);
+    unpack8(r.d, d);
+    unpack8(r.y, yv);
     if (a.out) {
         float o[8];
-        unpack8(*(const u32x4*)(a.out + px * a.ld_out + c0), o);
+        unpack8(r.o, o);
 #pragma unroll
         for (int j = 0; j < 8; ++j) d[j] = o[j] > 0.f ? d[j] : 0.f;
     }
@@ -61,6 +71,8 @@ __device__ __forceinline__ void masked_grad(const BnbArgs& a, int64_t px, int c0
     }
 }
 
+// Thread layout shared by both passes: thread = (pixel lane, channel octet), so a thread keeps one octet for the whole
+// launch and its per-channel constants live in registers; consecutive threads read consecutive 16-byte octets.
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnbArgs a) {
     __shared__ float red[256][17];
     const int tid = threadIdx.x;
@@ -80,16 +92,34 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnbArgs a) {
     }
     const int64_t p0 = (int64_t)blockIdx.x * kPixPerBlock;
     const int64_t p1 = p0 + kPixPerBlock < a.pixels ? p0 + kPixPerBlock : a.pixels;
-    if (active)
-        for (int64_t px = p0 + pl; px < p1; px += lanes_px) {
+    if (active) {
+        int64_t px = p0 + pl;
+        // four pixels (8-12 16-byte loads) in flight per thread
+        for (; px + 3 * lanes_px < p1; px += 4 * lanes_px) {
+            BnbLoad r[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) r[u] = load_px(a, px + u * lanes_px, c0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float g[8], xh[8];
+                masked_grad(a, r[u], sc, sh, mu, is, g, xh);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    s0[j] += g[j];
+                    s1[j] += g[j] * xh[j];
+                }
+            }
+        }
+        for (; px < p1; px += lanes_px) {
             float g[8], xh[8];
-            masked_grad(a, px, c0, sc, sh, mu, is, g, xh);
+            masked_grad(a, load_px(a, px, c0), sc, sh, mu, is, g, xh);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 s0[j] += g[j];
                 s1[j] += g[j] * xh[j];
             }
         }
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         red[tid][j] = s0[j];
@@ -122,34 +152,60 @@ __global__ void bn_bwd_finalize_kernel(const double* red, int groups, int c, dou
     coef[2 * c + ch] = (float)(s1 * inv_count);
 }
 
+__device__ __forceinline__ void apply_px(const BnbArgs& a, int64_t px, int c0, const BnbLoad& r, const u32x4 old,
+                                         const float* sc, const float* sh, const float* mu, const float* is,
+                                         const float* k0, const float* k1, const float* k2) {
+    float g[8], xh[8], o[8];
+    masked_grad(a, r, sc, sh, mu, is, g, xh);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = k0[j] * (g[j] - k1[j] - xh[j] * k2[j]);
+    *(u32x4*)(a.dy + px * a.ld_dy + c0) = pack8(o);
+    if (a.dres) {
+        if (a.flags & RV_BNB_RES_ACCUM) {
+            float prev[8];
+            unpack8(old, prev);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[j] += prev[j];
+        }
+        *(u32x4*)(a.dres + px * a.ld_dres + c0) = pack8(g);
+    }
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnbArgs a) {
-    const int64_t total = a.pixels * a.c8;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t px = i / a.c8;
-        const int c0 = (int)(i - px * a.c8) * 8;
-        float sc[8], sh[8], mu[8], is[8], g[8], xh[8], o[8];
+    const int tid = threadIdx.x;
+    const int lanes_px = 256 / a.c8;
+    const int oct = tid % a.c8, pl = tid / a.c8;
+    if (pl >= lanes_px) return;
+    const int c0 = oct * 8;
+    float sc[8], sh[8], mu[8], is[8], k0[8], k1[8], k2[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            sc[j] = a.scale[c0 + j];
-            sh[j] = a.shift[c0 + j];
-            mu[j] = a.mean[c0 + j];
-            is[j] = a.invstd[c0 + j];
+    for (int j = 0; j < 8; ++j) {
+        sc[j] = a.scale[c0 + j];
+        sh[j] = a.shift[c0 + j];
+        mu[j] = a.mean[c0 + j];
+        is[j] = a.invstd[c0 + j];
+        k0[j] = a.coef[c0 + j];
+        k1[j] = a.coef[a.c + c0 + j];
+        k2[j] = a.coef[2 * a.c + c0 + j];
+    }
+    const bool acc = a.dres && (a.flags & RV_BNB_RES_ACCUM);
+    const int64_t step = (int64_t)gridDim.x * lanes_px;
+    int64_t px = (int64_t)blockIdx.x * lanes_px + pl;
+    for (; px + step < a.pixels; px += 2 * step) {
+        const BnbLoad r0 = load_px(a, px, c0), r1 = load_px(a, px + step, c0);
+        u32x4 o0 = {}, o1 = {};
+        if (acc) {
+            o0 = *(const u32x4*)(a.dres + px * a.ld_dres + c0);
+            o1 = *(const u32x4*)(a.dres + (px + step) * a.ld_dres + c0);
         }
-        masked_grad(a, px, c0, sc, sh, mu, is, g, xh);
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            o[j] = a.coef[c0 + j] * (g[j] - a.coef[a.c + c0 + j] - xh[j] * a.coef[2 * a.c + c0 + j]);
-        *(u32x4*)(a.dy + px * a.ld_dy + c0) = pack8(o);
-        if (a.dres) {
-            bf16_t* p = a.dres + px * a.ld_dres + c0;
-            if (a.flags & RV_BNB_RES_ACCUM) {
-                float old[8];
-                unpack8(*(const u32x4*)p, old);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) g[j] += old[j];
-            }
-            *(u32x4*)p = pack8(g);
-        }
+        apply_px(a, px, c0, r0, o0, sc, sh, mu, is, k0, k1, k2);
+        apply_px(a, px + step, c0, r1, o1, sc, sh, mu, is, k0, k1, k2);
+    }
+    if (px < a.pixels) {
+        const BnbLoad r0 = load_px(a, px, c0);
+        u32x4 o0 = {};
+        if (acc) o0 = *(const u32x4*)(a.dres + px * a.ld_dres + c0);
+        apply_px(a, px, c0, r0, o0, sc, sh, mu, is, k0, k1, k2);
     }
 }
 
@@ -248,7 +304,10 @@ extern "C" int rv_bn_bwd_apply(int64_t pixels, int32_t c, const void* dout, int3
     a.ld_dy = ld_dy;
     a.dres = (bf16_t*)dres;
     a.ld_dres = ld_dres;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(pixels * (c / 8))), dim3(256), 0, (hipStream_t)stream, a);
+    const int lanes_px = 256 / a.c8;
+    int64_t blocks = (pixels + lanes_px - 1) / lanes_px;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, a);
     RV_CHECK_LAUNCH("bn_bwd_apply_kernel");
     return 0;
 }

@@ -48,3 +48,7 @@ int rv_tapconv2_launch(const TapConvArgs& a, int grid_x, int grid_y, size_t lds,
 // third-generation kernel (tapconv3.hip): 8 waves, 4-row tiles, 3-tap weight stages; stats rows = 4 * grid_x
 bool rv_tapconv3_plan(TapConvArgs* a, int* grid_x, int* grid_y, size_t* lds, int* ks);
 int rv_tapconv3_launch(const TapConvArgs& a, int grid_x, int grid_y, size_t lds, int ks, hipStream_t stream);
+
+// fourth-generation kernel (tapconv4.hip): 256 x 256 tiles, LDS-DMA staging, counted waits; stats rows = 2 * tiles
+bool rv_tapconv4_plan(TapConvArgs* a, int* tiles, size_t* lds);
+int rv_tapconv4_launch(const TapConvArgs& a, size_t lds, hipStream_t stream);

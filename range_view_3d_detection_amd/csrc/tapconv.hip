@@ -422,7 +422,24 @@ static int tap_launch(const rvTapGeom* g, const rvTapShape* s, bool scatter, con
     a.bias = bias;
     a.stats = stats;
 
-    // fastest path: 8 waves, 4-row x 64-column tiles, 3-tap weight stages (tapconv3.hip)
+    // fastest path: 256 x 256 tiles streamed by LDS-DMA, counted waits (tapconv4.hip); plain bf16 inputs only
+    if (getenv("RV3D_NO_TAPCONV4") == nullptr) {
+        int tiles;
+        size_t lds4;
+        TapConvArgs a4 = a;
+        if (rv_tapconv4_plan(&a4, &tiles, &lds4)) {
+            if (stats_rows) *stats_rows = tiles * 2;
+            if (info) {
+                info[0] = 4;
+                info[1] = 0;
+                info[2] = tiles;
+                info[3] = a4.n_tiles;
+            }
+            if (dry_run) return 0;
+            return rv_tapconv4_launch(a4, lds4, (hipStream_t)stream);
+        }
+    }
+    // 8 waves, 4-row x 64-column x 128-channel tiles, 3-tap weight stages, register staging (tapconv3.hip)
     if (getenv("RV3D_NO_TAPCONV3") == nullptr) {
         int gx, gy, ks;
         size_t lds3;

@@ -1,0 +1,333 @@
+// tapconv4.hip -- fourth-generation tap-conv kernel: 256 pixels x 256 channels per workgroup, 64-channel K tiles,
+// operands streamed global -> LDS by LDS-DMA (global_load_lds_dwordx4) that stays in flight across barriers.
+//
+// Why: tapconv3 (register staging, 128-channel tiles, ds_write pass, __syncthreads) tops out at ~900-970 TFLOP/s on the
+// 512->512 3x3 layers; every K step waits for its staging loads at the barrier.  Here nothing on the K loop passes
+// through VGPRs on its way to LDS, the only waits are COUNTED (s_waitcnt vmcnt(8): four 16 KB pieces stay in flight
+// over every barrier), and the two halves of the workgroup run one barrier apart, so one wave of each SIMD issues
+// MFMAs while the other reads its fragments.
+//
+// Tile: 4 image rows x 64 columns (M = 256) x 256 output channels; 8 waves as 2 (M) x 4 (N), 128 x 64 outputs per wave
+// (acc = 128 VGPRs).  One K tile = one tap x 64 input channels = four 16 KB pieces in LDS (two buffers, 128 KiB):
+//     X0  input rows {0, 2} of the tile   (first 64 M rows of each wave pair)      read in phase 0
+//     X1  weights, first 32 channels of each wave's 64                              read in phase 0
+//     X2  weights, last 32 channels                                                 read in phase 1
+//     X3  input rows {1, 3}                                                         read in phase 2
+// A K tile is four phases of 16 MFMAs per wave (one 64 x 32 quadrant x K = 64); each phase issues one piece:
+//     phase 0: X2(kt+1)   phase 1: X3(kt+1)   phase 2: X0(kt+2)   phase 3: X1(kt+2)
+// i.e. a piece is re-staged two or three phases after its last read and lands five phases before its first.
+// Each piece is a [128 rows][64 k] bf16 image (128-byte rows) written lane-linearly by the DMA; the XOR swizzle that
+// makes the ds_read_b128 fragment reads conflict-free (16-byte slot = k-chunk ^ (row & 7)) is applied to the per-lane
+// SOURCE address.  Zero padding: lanes whose pixel falls outside the image read a zero page instead.
+//
+// Eligible layers: stride-1 phases with >= 2 taps, C_src % 64 == 0, C_dst % 256 == 0, plain bf16 input (no folded
+// BatchNorm on the way in -- the DMA bypasses the registers), bf16 output (+ stats / bias / accumulate).
+#include "common.h"
+#include "tapconv.h"
+
+namespace {
+
+constexpr int kTC = 64;    // tile columns
+constexpr int kTR = 4;     // tile rows
+constexpr int kBN4 = 256;  // tile channels
+constexpr int kBK = 64;    // K tile (channels of one tap)
+constexpr int kPiece = 128 * 128;    // bytes of one piece
+constexpr int kBuf = 4 * kPiece;     // one K tile
+constexpr int kTabOffset = 2 * kBuf; // tap table behind the two buffers
+
+__device__ __attribute__((aligned(256))) uint32_t g_zero_page[64];
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+struct Staged {   // the K tile a piece belongs to
+    int aoff;     // element offset of (tap, channel chunk) in the source image
+    int woff;     // element offset of (tap image, channel chunk) in the packed weight
+    uint32_t vb;  // validity of the thread's four tile rows under this tap
+};
+
+__global__ __launch_bounds__(512, 2) void tapconv4_kernel(const TapConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int l15 = lane & 15, lg = lane >> 4;
+
+    // XCD-aware block order (see tapconv3.hip)
+    const int gy = a.n_tiles;
+    const int xcd = blockIdx.x & 7, xslot = blockIdx.x >> 3;
+    const int tile = xcd * a.tiles_per_xcd + xslot / gy;
+    if (tile >= a.total_tiles) return;
+    const int n0 = (xslot % gy) * kBN4;
+    int bx = tile;
+    const int tc = bx % a.m_tiles;
+    bx /= a.m_tiles;
+    const int th = bx % a.h_tiles;
+    bx /= a.h_tiles;
+    const int n = bx % a.N;
+    const int ph = bx / a.N;
+    const int m0 = tc * kTC, h0 = th * kTR;
+    const int T = a.tt.ntaps[ph];
+    const int nkc = a.C_src / kBK;
+    const int nkt = T * nkc;
+
+    const bf16_t* src_img = a.src + ((int64_t)n * a.H * a.W_src) * a.ld_src;
+    int* tap_tab = (int*)(smem + kTabOffset);
+    if (tid < T) tap_tab[tid] = (a.tt.dh[ph][tid] * a.W_src + a.tt.dw[ph][tid]) * a.ld_src;
+
+    // ---- staging map: thread = (tile column, 16-byte slot); two rows per piece ------------------------------
+    const int s_c = tid >> 3, s_slot = tid & 7;
+    const int kq = s_slot ^ (s_c & 7);  // logical k-chunk held by LDS slot s_slot of rows == s_c (mod 8)
+    uint64_t vmask = 0;
+    for (int t = 0; t < T; ++t) {
+        const int dh = a.tt.dh[ph][t], dw = a.tt.dw[ph][t];
+        const int ws = m0 + s_c + dw;
+        const bool cok = ws >= 0 && ws < a.W_src;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int hs = h0 + rr + dh;
+            if (cok && hs >= 0 && hs < a.H) vmask |= 1ull << (t * 4 + rr);
+        }
+    }
+    const int row_stride = a.W_src * a.ld_src;
+    const int a_base = (h0 * a.W_src + m0 + s_c) * a.ld_src + kq * 8;
+    // weights: piece row = (wave column wcc, channel jl of its 32); rows tid>>3 and 64 + tid>>3
+    const int b_base = (n0 + ((s_c >> 5) * 64) + (s_c & 31)) * a.C_src + kq * 8;
+    const int64_t w_img = (int64_t)a.C_dst * a.C_src;
+    const bf16_t* w_ph = a.w + (int64_t)a.tt.w_first[ph] * w_img;
+    const bf16_t* zero = (const bf16_t*)g_zero_page + s_slot * 8;
+    const int lds_lane_base = wave * 1024;  // this wave's 1 KiB of each 8 KiB half piece
+
+    __syncthreads();  // tap table visible
+
+    auto make_staged = [&](int q) {
+        q = q < nkt ? q : nkt - 1;  // pieces past the last K tile re-fetch it (never read; keeps the wait counts uniform)
+        const int kc = q / T, t = q - kc * T;
+        Staged s;
+        s.aoff = tap_tab[t] + kc * kBK;
+        s.woff = t * (int)w_img + kc * kBK;
+        s.vb = (uint32_t)(vmask >> (t * 4)) & 15u;
+        return s;
+    };
+    auto stage_a = [&](int piece_byte, int mq, const Staged& s) {  // rows {mq, mq + 2} of the tile
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rr = 2 * i + mq;
+            const bf16_t* p = ((s.vb >> rr) & 1u) ? src_img + (a_base + rr * row_stride + s.aoff) : zero;
+            __builtin_amdgcn_global_load_lds((glb_void_t*)p, (lds_void_t*)(smem + piece_byte + i * 8192 + lds_lane_base), 16, 0, 0);
+        }
+    };
+    auto stage_b = [&](int piece_byte, int nq, const Staged& s) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bf16_t* p = w_ph + (s.woff + b_base + (i * 128 + nq * 32) * a.C_src);
+            __builtin_amdgcn_global_load_lds((glb_void_t*)p, (lds_void_t*)(smem + piece_byte + i * 8192 + lds_lane_base), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment reads -------------------------------------------------------------------------------------
+    const int swz = (lg ^ (l15 & 7)) * 16;                       // k-chunk lg of the first 32 k; ^64 for the second
+    const int a_rd = (wr * 64 + l15) * 128 + swz;                // + i * 2048 per m-frag
+    const int b_rd = (wc * 32 + l15) * 128 + swz;                // + jj * 2048 per n-frag
+    bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+    auto read_a = [&](int piece_byte) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fa[i][ks] = *(const bf16x8*)(smem + piece_byte + i * 2048 + (a_rd ^ (ks * 64)));
+    };
+    auto read_b = [&](bf16x8 (&fb)[2][2], int piece_byte) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fb[jj][ks] = *(const bf16x8*)(smem + piece_byte + jj * 2048 + (b_rd ^ (ks * 64)));
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#define RV_MFMA_QUADRANT(MQ, NQ, FB)                                                                               \
+    __builtin_amdgcn_s_setprio(1);                                                                                 \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i)                 \
+        _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) acc[(MQ) * 4 + i][(NQ) * 2 + jj] =                        \
+            __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], FB[jj][ks], acc[(MQ) * 4 + i][(NQ) * 2 + jj], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);
+#define RV_WAIT_PIECES() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
+#define RV_PHASE_SYNC()                                 \
+    __builtin_amdgcn_s_barrier();                       \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  \
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- prologue: K tile 0 complete, X0 / X1 of K tile 1 ---------------------------------------------------
+    Staged scur = make_staged(0);
+    stage_a(0 * kPiece, 0, scur);
+    stage_b(1 * kPiece, 0, scur);
+    stage_b(2 * kPiece, 1, scur);
+    stage_a(3 * kPiece, 1, scur);
+    scur = make_staged(1);
+    stage_a(kBuf + 0 * kPiece, 0, scur);
+    stage_b(kBuf + 1 * kPiece, 0, scur);
+    RV_WAIT_PIECES();
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();  // the second half of the workgroup runs one barrier behind the first
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int rb = (kt & 1) * kBuf, ob = kBuf - rb;
+        const Staged snext = make_staged(kt + 2);  // its tap-table read lands long before phase 2 needs it
+        // phase 0
+        read_b(fb0, rb + 1 * kPiece);
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(rb + 0 * kPiece);
+        stage_b(ob + 2 * kPiece, 1, scur);
+        RV_WAIT_PIECES();
+        RV_PHASE_SYNC();
+        RV_MFMA_QUADRANT(0, 0, fb0);
+        __builtin_amdgcn_s_barrier();
+        // phase 1
+        read_b(fb1, rb + 2 * kPiece);
+        stage_a(ob + 3 * kPiece, 1, scur);
+        RV_WAIT_PIECES();
+        RV_PHASE_SYNC();
+        RV_MFMA_QUADRANT(0, 1, fb1);
+        __builtin_amdgcn_s_barrier();
+        // phase 2
+        scur = snext;
+        read_a(rb + 3 * kPiece);
+        stage_a(rb + 0 * kPiece, 0, scur);
+        RV_PHASE_SYNC();
+        RV_MFMA_QUADRANT(1, 1, fb1);
+        __builtin_amdgcn_s_barrier();
+        // phase 3
+        stage_b(rb + 1 * kPiece, 0, scur);
+        RV_WAIT_PIECES();
+        RV_PHASE_SYNC();
+        RV_MFMA_QUADRANT(1, 0, fb0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#undef RV_MFMA_QUADRANT
+#undef RV_WAIT_PIECES
+#undef RV_PHASE_SYNC
+
+    // ------------------------------------ epilogue --------------------------------------------
+    // acc[mq*4+i][nq*2+jj][r]: tile row 2*wr + mq, column i*16 + lg*4 + r, channel n0 + wc*64 + nq*32 + jj*16 + l15
+    const int Wm = a.W_dst / a.phases;
+#pragma unroll
+    for (int mq = 0; mq < 2; ++mq) {
+        const bool row_ok = h0 + 2 * wr + mq < a.H;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + i * 16 + lg * 4 + r;
+                if (m >= Wm || !row_ok) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[mq * 4 + i][j][r] = 0.f;
+                }
+            }
+    }
+    if (a.flags & RV_OUT_STATS) {
+        float* prow = a.stats + ((int64_t)(tile * 2 + wr) * 2) * a.C_dst;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = acc[i][j][r];
+                    s += v;
+                    q += v * v;
+                }
+            s += __shfl_xor(s, 16, 64);
+            q += __shfl_xor(q, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            q += __shfl_xor(q, 32, 64);
+            const int c = n0 + wc * 64 + j * 16 + l15;
+            if (lg == 0) {
+                prow[c] = s;
+                prow[a.C_dst + c] = q;
+            }
+        }
+    }
+    if (a.flags & RV_OUT_BIAS) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float b = a.bias[n0 + wc * 64 + j * 16 + l15];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] += b;
+        }
+    }
+    constexpr int kEpi = kBN4 + 8;
+    bf16_t* epi = (bf16_t*)smem;  // [4 rows * 64 cols][kEpi]
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int pm = (2 * wr + (i >> 2)) * kTC + (i & 3) * 16 + lg * 4 + r;
+                const int pc = wc * 64 + j * 16 + l15;
+                epi[pm * kEpi + pc] = f2bf(acc[i][j][r]);
+            }
+    __syncthreads();
+    constexpr int kChunks = kBN4 / 8;
+    const bool accum = a.flags & RV_OUT_ACCUM;
+    for (int q = tid; q < kTR * kTC * kChunks; q += 512) {
+        const int pm = q / kChunks, c8 = q - pm * kChunks;
+        const int rr = pm / kTC, mm = pm - rr * kTC;
+        const int m = m0 + mm, c = n0 + c8 * 8, hh = h0 + rr;
+        if (m >= Wm || hh >= a.H) continue;
+        u32x4 v = *(const u32x4*)(epi + pm * kEpi + c8 * 8);
+        bf16_t* p = (bf16_t*)a.dst + (((int64_t)(n * a.H + hh) * a.W_dst) + (a.phases * m + ph)) * a.ld_dst + c;
+        if (accum) {
+            const u32x4 o = *(const u32x4*)p;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = pack_bf2(bf_lo(v[j]) + bf_lo(o[j]), bf_hi(v[j]) + bf_hi(o[j]));
+        }
+        *(u32x4*)p = v;
+    }
+}
+
+}  // namespace
+
+// returns false when the layer is not eligible (caller falls back to tapconv3 / tapconv2 / the generic kernel)
+bool rv_tapconv4_plan(TapConvArgs* a, int* tiles, size_t* lds) {
+    if (a->step != 1) return false;
+    if (a->flags & (RV_IN_AFFINE | RV_IN_RELU | RV_OUT_F32)) return false;  // the DMA path has no register prologue
+    if (a->C_src % kBK != 0 || a->C_dst % kBN4 != 0) return false;
+    const int wm_total = a->W_dst / a->phases;
+    if (wm_total < kTC || a->H < kTR) return false;
+    for (int r = 0; r < a->phases; ++r)
+        if (a->tt.ntaps[r] < 2 || a->tt.ntaps[r] > 16) return false;
+    if ((int64_t)a->H * a->W_src * a->ld_src >= (1ll << 31) || (int64_t)kMaxTaps * a->C_dst * a->C_src >= (1ll << 31)) return false;
+    a->m_tiles = rv_ceil_div(wm_total, kTC);
+    a->h_tiles = rv_ceil_div(a->H, kTR);
+    a->total_tiles = a->m_tiles * a->h_tiles * a->N * a->phases;
+    a->n_tiles = a->C_dst / kBN4;
+    a->tiles_per_xcd = rv_ceil_div(a->total_tiles, 8);
+    if ((int64_t)a->total_tiles * a->n_tiles < 256) return false;  // too few tiles to fill the chip
+    *tiles = a->total_tiles;  // stats rows = 2 * tiles
+    *lds = (size_t)kTabOffset + 128;
+    const size_t epi = (size_t)kTR * kTC * (kBN4 + 8) * sizeof(bf16_t);
+    if (*lds < epi) *lds = epi;
+    return true;
+}
+
+int rv_tapconv4_launch(const TapConvArgs& a, size_t lds, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)tapconv4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(tapconv4_kernel, dim3(8 * a.tiles_per_xcd * a.n_tiles), dim3(512), lds, stream, a);
+    RV_CHECK_LAUNCH("tapconv4_kernel");
+    return 0;
+}

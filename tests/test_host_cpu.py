@@ -43,8 +43,13 @@ def test_host_side_geometry(lib):
     s = lib.TapShape(4, 64, 2048, 2048, 256, 256, lib.OUT_STATS)
     info = (ctypes.c_int32 * 4)()
     assert h.rv_tap_launch_info(ctypes.byref(g), ctypes.byref(s), 0, info) == 0
-    assert list(info) == [3, 2, 32 * 16 * 4, 2]  # tapconv3<2>: (4 rows x 64 cols) tiles, 2 channel tiles of 128
-    assert h.rv_tap_stats_rows(ctypes.byref(g), ctypes.byref(s), 0) == 4 * 32 * 16 * 4
+    assert list(info) == [4, 0, 32 * 16 * 4, 1]  # tapconv4: (4 rows x 64 cols) pixel tiles x one 256-channel tile
+    assert h.rv_tap_stats_rows(ctypes.byref(g), ctypes.byref(s), 0) == 2 * 32 * 16 * 4
+    # a folded BatchNorm on the way in needs the register-staged kernel
+    s_aff = lib.TapShape(4, 64, 2048, 2048, 256, 256, lib.OUT_STATS | lib.IN_AFFINE | lib.IN_RELU)
+    assert h.rv_tap_launch_info(ctypes.byref(g), ctypes.byref(s_aff), 0, info) == 0
+    assert list(info) == [3, 2, 32 * 16 * 4, 2]  # tapconv3<2>: 2 channel tiles of 128
+    assert h.rv_tap_stats_rows(ctypes.byref(g), ctypes.byref(s_aff), 0) == 4 * 32 * 16 * 4
     # strided conv: Wv must be Wu * stride
     bad = lib.TapShape(4, 64, 1000, 2048, 256, 256, 0)
     g2 = lib.TapGeom(3, 3, 2, 1, 1, 128, 128)
