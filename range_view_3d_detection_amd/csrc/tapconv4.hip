@@ -46,6 +46,7 @@ struct Staged {   // the K tile a piece belongs to
     uint32_t vb;  // validity of the thread's four tile rows under this tap
 };
 
+template <int V>  // V: schedule variant (A/B experiments; 0 ships)
 __global__ __launch_bounds__(512, 2) void tapconv4_kernel(const TapConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -69,18 +70,28 @@ __global__ __launch_bounds__(512, 2) void tapconv4_kernel(const TapConvArgs a) {
     const int m0 = tc * kTC, h0 = th * kTR;
     const int T = a.tt.ntaps[ph];
     const int nkc = a.C_src / kBK;
-    const int nkt = T * nkc;
+    const int nkt = (a.flags & (1 << 28)) ? 2 : T * nkc;  // bit 28: timing experiment (two K tiles only)
 
     const bf16_t* src_img = a.src + ((int64_t)n * a.H * a.W_src) * a.ld_src;
+    // per-tap tables in LDS: element offset of the tap, and its (dh, dw).  Each of the first T threads fetches its own
+    // tap from the kernel arguments (one load latency for the whole table); nothing below indexes the arguments with a
+    // runtime tap number, which would cost a dependent global load per tap and thread.
     int* tap_tab = (int*)(smem + kTabOffset);
-    if (tid < T) tap_tab[tid] = (a.tt.dh[ph][tid] * a.W_src + a.tt.dw[ph][tid]) * a.ld_src;
+    int* tap_dhw = tap_tab + 32;
+    if (tid < T) {
+        const int dh = a.tt.dh[ph][tid], dw = a.tt.dw[ph][tid];
+        tap_tab[tid] = (dh * a.W_src + dw) * a.ld_src;
+        tap_dhw[tid] = (dh << 16) | (dw & 0xffff);
+    }
+    __syncthreads();
 
     // ---- staging map: thread = (tile column, 16-byte slot); two rows per piece ------------------------------
     const int s_c = tid >> 3, s_slot = tid & 7;
     const int kq = s_slot ^ (s_c & 7);  // logical k-chunk held by LDS slot s_slot of rows == s_c (mod 8)
     uint64_t vmask = 0;
     for (int t = 0; t < T; ++t) {
-        const int dh = a.tt.dh[ph][t], dw = a.tt.dw[ph][t];
+        const int e = tap_dhw[t];
+        const int dh = e >> 16, dw = (int)(int16_t)(e & 0xffff);
         const int ws = m0 + s_c + dw;
         const bool cok = ws >= 0 && ws < a.W_src;
 #pragma unroll
@@ -97,8 +108,6 @@ __global__ __launch_bounds__(512, 2) void tapconv4_kernel(const TapConvArgs a) {
     const bf16_t* w_ph = a.w + (int64_t)a.tt.w_first[ph] * w_img;
     const bf16_t* zero = (const bf16_t*)g_zero_page + s_slot * 8;
     const int lds_lane_base = wave * 1024;  // this wave's 1 KiB of each 8 KiB half piece
-
-    __syncthreads();  // tap table visible
 
     auto make_staged = [&](int q) {
         q = q < nkt ? q : nkt - 1;  // pieces past the last K tile re-fetch it (never read; keeps the wait counts uniform)
@@ -149,17 +158,28 @@ __global__ __launch_bounds__(512, 2) void tapconv4_kernel(const TapConvArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-#define RV_MFMA_QUADRANT(MQ, NQ, FB)                                                                               \
-    __builtin_amdgcn_s_setprio(1);                                                                                 \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i)                 \
-        _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) acc[(MQ) * 4 + i][(NQ) * 2 + jj] =                        \
-            __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], FB[jj][ks], acc[(MQ) * 4 + i][(NQ) * 2 + jj], 0, 0, 0); \
-    __builtin_amdgcn_s_setprio(0);
-#define RV_WAIT_PIECES() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
-#define RV_PHASE_SYNC()                                 \
-    __builtin_amdgcn_s_barrier();                       \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  \
-    __builtin_amdgcn_sched_barrier(0);
+// One phase: [fragment reads] (counted wait) barrier | 8 MFMAs, this phase's piece (two DMA instructions), 8 MFMAs | barrier.
+// The DMA instructions are issued from INSIDE the MFMA cluster: issuing one costs the wave ~60 cycles there against
+// 100-185 in the read section (MI355X_MICROARCH.md, LDS-DMA issue cost), and the read section is what the other half of
+// the workgroup's MFMAs have to cover.
+#define RV_MFMA_HALF(MQ, NQ, FB, KS)                                                                               \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                 \
+        acc[(MQ) * 4 + i][(NQ) * 2 + jj] =                                                                         \
+            __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][KS], FB[jj][KS], acc[(MQ) * 4 + i][(NQ) * 2 + jj], 0, 0, 0);
+#define RV_PHASE_COMPUTE(MQ, NQ, FB, STAGE)                \
+    __builtin_amdgcn_s_barrier();                          \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+    __builtin_amdgcn_sched_barrier(0);                     \
+    __builtin_amdgcn_s_setprio(1);                         \
+    RV_MFMA_HALF(MQ, NQ, FB, 0)                            \
+    __builtin_amdgcn_sched_barrier(0);                     \
+    STAGE;                                                 \
+    __builtin_amdgcn_sched_barrier(0);                     \
+    RV_MFMA_HALF(MQ, NQ, FB, 1)                            \
+    __builtin_amdgcn_s_setprio(0);                         \
+    __builtin_amdgcn_sched_barrier(0);                     \
+    __builtin_amdgcn_s_barrier();
+#define RV_WAIT_PIECES(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 
     // ---- prologue: K tile 0 complete, X0 / X1 of K tile 1 ---------------------------------------------------
     Staged scur = make_staged(0);
@@ -170,49 +190,55 @@ __global__ __launch_bounds__(512, 2) void tapconv4_kernel(const TapConvArgs a) {
     scur = make_staged(1);
     stage_a(kBuf + 0 * kPiece, 0, scur);
     stage_b(kBuf + 1 * kPiece, 0, scur);
-    RV_WAIT_PIECES();
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // X0(0), X1(0) landed; four pieces in flight
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();  // the second half of the workgroup runs one barrier behind the first
 
     for (int kt = 0; kt < nkt; ++kt) {
         const int rb = (kt & 1) * kBuf, ob = kBuf - rb;
         const Staged snext = make_staged(kt + 2);  // its tap-table read lands long before phase 2 needs it
-        // phase 0
-        read_b(fb0, rb + 1 * kPiece);
-        __builtin_amdgcn_sched_barrier(0);
-        read_a(rb + 0 * kPiece);
-        stage_b(ob + 2 * kPiece, 1, scur);
-        RV_WAIT_PIECES();
-        RV_PHASE_SYNC();
-        RV_MFMA_QUADRANT(0, 0, fb0);
-        __builtin_amdgcn_s_barrier();
-        // phase 1
-        read_b(fb1, rb + 2 * kPiece);
-        stage_a(ob + 3 * kPiece, 1, scur);
-        RV_WAIT_PIECES();
-        RV_PHASE_SYNC();
-        RV_MFMA_QUADRANT(0, 1, fb1);
-        __builtin_amdgcn_s_barrier();
-        // phase 2
-        scur = snext;
-        read_a(rb + 3 * kPiece);
-        stage_a(rb + 0 * kPiece, 0, scur);
-        RV_PHASE_SYNC();
-        RV_MFMA_QUADRANT(1, 1, fb1);
-        __builtin_amdgcn_s_barrier();
-        // phase 3
-        stage_b(rb + 1 * kPiece, 0, scur);
-        RV_WAIT_PIECES();
-        RV_PHASE_SYNC();
-        RV_MFMA_QUADRANT(1, 0, fb0);
-        __builtin_amdgcn_s_barrier();
+        if constexpr (V == 0) {
+            // the piece is issued in the read section, before the counted wait: four pieces in flight
+            read_b(fb0, rb + 1 * kPiece);
+            __builtin_amdgcn_sched_barrier(0);
+            read_a(rb + 0 * kPiece);
+            stage_b(ob + 2 * kPiece, 1, scur);
+            RV_WAIT_PIECES(8);
+            RV_PHASE_COMPUTE(0, 0, fb0, (void)0);
+            read_b(fb1, rb + 2 * kPiece);
+            stage_a(ob + 3 * kPiece, 1, scur);
+            RV_WAIT_PIECES(8);
+            RV_PHASE_COMPUTE(0, 1, fb1, (void)0);
+            scur = snext;
+            read_a(rb + 3 * kPiece);
+            stage_a(rb + 0 * kPiece, 0, scur);
+            RV_PHASE_COMPUTE(1, 1, fb1, (void)0);
+            stage_b(rb + 1 * kPiece, 0, scur);
+            RV_WAIT_PIECES(8);
+            RV_PHASE_COMPUTE(1, 0, fb0, (void)0);
+        } else {
+            // the piece is issued from inside the MFMA cluster: three pieces in flight at the waits
+            read_b(fb0, rb + 1 * kPiece);
+            __builtin_amdgcn_sched_barrier(0);
+            read_a(rb + 0 * kPiece);
+            RV_WAIT_PIECES(6);
+            RV_PHASE_COMPUTE(0, 0, fb0, stage_b(ob + 2 * kPiece, 1, scur));
+            read_b(fb1, rb + 2 * kPiece);
+            RV_WAIT_PIECES(6);
+            RV_PHASE_COMPUTE(0, 1, fb1, stage_a(ob + 3 * kPiece, 1, scur));
+            scur = snext;
+            read_a(rb + 3 * kPiece);
+            RV_PHASE_COMPUTE(1, 1, fb1, stage_a(rb + 0 * kPiece, 0, scur));
+            RV_WAIT_PIECES(6);
+            RV_PHASE_COMPUTE(1, 0, fb0, stage_b(rb + 1 * kPiece, 0, scur));
+        }
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-#undef RV_MFMA_QUADRANT
+#undef RV_MFMA_HALF
+#undef RV_PHASE_COMPUTE
 #undef RV_WAIT_PIECES
-#undef RV_PHASE_SYNC
 
     // ------------------------------------ epilogue --------------------------------------------
     // acc[mq*4+i][nq*2+jj][r]: tile row 2*wr + mq, column i*16 + lg*4 + r, channel n0 + wc*64 + nq*32 + jj*16 + l15
@@ -265,6 +291,7 @@ __global__ __launch_bounds__(512, 2) void tapconv4_kernel(const TapConvArgs a) {
                 for (int r = 0; r < 4; ++r) acc[i][j][r] += b;
         }
     }
+    if (a.flags & (1 << 30)) return;  // timing experiment: no output
     constexpr int kEpi = kBN4 + 8;
     bf16_t* epi = (bf16_t*)smem;  // [4 rows * 64 cols][kEpi]
 #pragma unroll
@@ -278,6 +305,7 @@ __global__ __launch_bounds__(512, 2) void tapconv4_kernel(const TapConvArgs a) {
                 epi[pm * kEpi + pc] = f2bf(acc[i][j][r]);
             }
     __syncthreads();
+    if (a.flags & (1 << 29)) return;  // timing experiment: no global stores
     constexpr int kChunks = kBN4 / 8;
     const bool accum = a.flags & RV_OUT_ACCUM;
     for (int q = tid; q < kTR * kTC * kChunks; q += 512) {
@@ -315,7 +343,7 @@ bool rv_tapconv4_plan(TapConvArgs* a, int* tiles, size_t* lds) {
     a->tiles_per_xcd = rv_ceil_div(a->total_tiles, 8);
     if ((int64_t)a->total_tiles * a->n_tiles < 256) return false;  // too few tiles to fill the chip
     *tiles = a->total_tiles;  // stats rows = 2 * tiles
-    *lds = (size_t)kTabOffset + 128;
+    *lds = (size_t)kTabOffset + 256;
     const size_t epi = (size_t)kTR * kTC * (kBN4 + 8) * sizeof(bf16_t);
     if (*lds < epi) *lds = epi;
     return true;
@@ -324,10 +352,15 @@ bool rv_tapconv4_plan(TapConvArgs* a, int* tiles, size_t* lds) {
 int rv_tapconv4_launch(const TapConvArgs& a, size_t lds, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)tapconv4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)tapconv4_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)tapconv4_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(tapconv4_kernel, dim3(8 * a.tiles_per_xcd * a.n_tiles), dim3(512), lds, stream, a);
+    const char* v = getenv("RV3D_TC4_VARIANT");
+    if (v && atoi(v) == 1)
+        hipLaunchKernelGGL(tapconv4_kernel<1>, dim3(8 * a.tiles_per_xcd * a.n_tiles), dim3(512), lds, stream, a);
+    else
+        hipLaunchKernelGGL(tapconv4_kernel<0>, dim3(8 * a.tiles_per_xcd * a.n_tiles), dim3(512), lds, stream, a);
     RV_CHECK_LAUNCH("tapconv4_kernel");
     return 0;
 }

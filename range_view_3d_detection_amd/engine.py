@@ -93,7 +93,12 @@ def _launch(name: str, flops: float, fn) -> None:
 def tap_kernel_name(geom, shape, scatter: bool) -> str:
     info = (ctypes.c_int32 * 4)()
     L.call("rv_tap_launch_info", ctypes.byref(geom), ctypes.byref(shape), L.i32(1 if scatter else 0), info)
-    name = f"tapconv{info[0]}_kernel<{info[1]}>" if info[0] in (2, 3) else f"tapconv_kernel<{info[1] // 16},{info[1] % 16}>"
+    if info[0] == 4:
+        name = "tapconv4_kernel"
+    elif info[0] in (2, 3):
+        name = f"tapconv{info[0]}_kernel<{info[1]}>"
+    else:
+        name = f"tapconv_kernel<{info[1] // 16},{info[1] % 16}>"
     if os.environ.get("RV3D_PROFILE_SHAPES"):
         name += f" {'S' if scatter else 'G'} k{geom.kh}x{geom.kw}s{geom.stride_w} {geom.cu}<->{geom.cv} {shape.N}x{shape.H}x{shape.Wu} f{shape.flags}"
     return name
@@ -222,9 +227,31 @@ class Lazy:
     raw: Act
     bn: BnState
     relu: bool = True
+    plain: Optional[Act] = None  # written out once when a consumer cannot fold it (see ConvOp)
+
+    def materialized(self) -> Act:
+        if self.plain is None:
+            out = self.raw.like()
+            L.call("rv_ew_combine", L.i64(self.raw.pixels), L.i32(self.raw.cp), self.raw.ptr(), L.i32(self.raw.ld), L.ptr(self.bn.scale),
+                   L.ptr(self.bn.shift), None, L.i32(0), None, None, out.ptr(), L.i32(out.ld), L.i32(L.EW_RELU_A if self.relu else 0),
+                   L.stream_ptr())
+            self.plain = out
+        return self.plain
 
 
 Operand = Union[Act, Lazy]
+
+# The LDS-DMA tap-conv (tapconv4) streams its operands global -> LDS without passing through registers, so it cannot
+# apply a folded BatchNorm(+ReLU) on the way in.  On the layers it is eligible for it is enough faster than the
+# register-staged kernels (3x3 512 -> 512: 1330 vs 980 TFLOP/s, one box) to pay for writing the operand out once
+# (one HBM-bound pass); forward conv, and the weight gradient in backward, then both read the plain tensor.
+MATERIALIZE_FOR_DMA = os.environ.get("RV3D_NO_MATERIALIZE") is None
+
+
+def _dma_eligible(geom, n: int, h: int, wu: int, wv: int, ld_src: int, ld_dst: int, scatter: bool) -> bool:
+    info = (ctypes.c_int32 * 4)()
+    shape = L.TapShape(n, h, wu, wv, ld_src, ld_dst, 0)
+    return L.load().rv_tap_launch_info(ctypes.byref(geom), ctypes.byref(shape), 1 if scatter else 0, info) == 0 and info[0] == 4
 
 
 # ---------------------------------------------------------------------------------------------
@@ -387,6 +414,12 @@ class ConvOp(Op):
             wu, wv = src.W, src.W * g.stride_w
             w_out = wv
         assert src.cp == pad32(layer.c_in), (src.cp, layer.c_in)
+        self.x_plain = None
+        if (isinstance(x, Lazy) and MATERIALIZE_FOR_DMA and not out_f32
+                and _dma_eligible(g, src.N, src.H, wu, wv, src.ld, pad32(layer.c_out), form == "scatter")):
+            self.x_plain = src = x.materialized()
+            sc = sh = None
+            flags = 0
         self.out_f32 = out_f32
         if out_f32:
             self.out_t = torch.empty((src.N, src.H, w_out, pad32(layer.c_out)), dtype=torch.float32, device=t.device)

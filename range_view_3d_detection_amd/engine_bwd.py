@@ -60,6 +60,8 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
         return
     layer, g = op.layer, op.layer.geom
     src, sc, sh, in_flags = E._operand_parts(op.x)
+    if op.x_plain is not None:  # the forward pass wrote relu(bn(.)) out for the DMA kernel: the weight gradient reads it too
+        src, sc, sh, in_flags = op.x_plain, None, None, 0
     fwd = layer.fwd_form
     bwd = "scatter" if fwd == "gather" else "gather"
     sp = op.shape
