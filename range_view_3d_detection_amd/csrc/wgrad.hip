@@ -397,6 +397,171 @@ __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const Wgrad2Args a) {
         wgrad2_body<1>(a, lds);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// wgrad3: wgrad2's tiling (128 cu x 128 cv x up to 3 taps of one kernel row, 64-pixel chunks, 8 waves) with the operands
+// streamed global -> LDS by LDS-DMA into a ring of FOUR chunk buffers: the chunk three iterations ahead is issued before
+// each compute step, the only waits are counted (s_waitcnt vmcnt(10): two chunks stay in flight across the barrier) and
+// there is one raw barrier per chunk.  Plain bf16 operands only (the DMA bypasses the registers, so no folded
+// BatchNorm on the way in) -- which is what the engine provides on the wide layers (engine.py, MATERIALIZE_FOR_DMA).
+// The 32-byte granule swizzle sigma() is applied to the per-lane SOURCE address (the DMA writes LDS lane-linearly).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kW3U = 64 * 256;        // bytes: 64 pixel rows x 128 channels
+constexpr int kW3V = 68 * 256;        // 66 halo rows (+2 so that the last DMA instruction is whole)
+constexpr int kW3Buf = kW3U + kW3V;   // 33 792
+constexpr int kW3Ring = 4;
+
+__device__ __attribute__((aligned(256))) uint32_t g_wgrad_zero_page[64];
+
+template <int TG>
+__device__ __forceinline__ void wgrad3_body(const Wgrad2Args& a, uint8_t* smem) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    int bx = blockIdx.x;
+    const int tv = bx % a.tiles_v;
+    bx /= a.tiles_v;
+    const int tu = bx % a.tiles_u;
+    bx /= a.tiles_u;
+    const int grp = bx % a.groups;
+    const int ks = bx / a.groups;
+    const int u0 = tu * 128, v0 = tv * 128;
+    const int tap0 = a.g_first[grp];
+    const int dh = a.dh[tap0], dw0 = a.dw[tap0];
+    const int wchunks = a.Wu / 64;
+    const int c_begin = ks * a.chunks_per_split;
+    const int c_end = (c_begin + a.chunks_per_split < a.chunks) ? c_begin + a.chunks_per_split : a.chunks;
+
+    // DMA map: one wave-instruction = 4 pixel rows x 16 chunks of 16 bytes; wave w owns rows 8w .. 8w+7 of both tiles
+    const int d_row = lane >> 4, d_c16 = lane & 15;
+    typedef const __attribute__((address_space(1))) void glb_t;
+    typedef __attribute__((address_space(3))) void lds_t;
+    const bf16_t* zero = (const bf16_t*)g_wgrad_zero_page + (d_c16 & 7) * 8;
+    auto src_chunk = [&](int k) { return ((((d_c16 >> 1) ^ sigma(k)) << 1) | (d_c16 & 1)) * 8; };  // logical channel offset
+    auto issue = [&](int c) {
+        uint8_t* buf = smem + (c & (kW3Ring - 1)) * kW3Buf;
+        c = c < c_end ? c : c_end - 1;  // past the end: re-fetch the last chunk (never read; keeps the wait counts uniform)
+        const int row = c / wchunks, w0 = (c - row * wchunks) * 64;  // row = n*H + h
+        const int h = row % a.H;
+        const bf16_t* urow = a.U + ((int64_t)row * a.Wu + w0) * a.ld_u + u0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = wave * 8 + j * 4 + d_row;
+            __builtin_amdgcn_global_load_lds((glb_t*)(urow + (int64_t)k * a.ld_u + src_chunk(k)), (lds_t*)(buf + (wave * 8 + j * 4) * 256), 16, 0, 0);
+        }
+        const int hv = h + dh;
+        const bool row_ok = hv >= 0 && hv < a.H;
+        const bf16_t* vrow = a.V + ((int64_t)(row + dh) * a.Wu) * a.ld_v + v0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int k0 = (j < 2) ? wave * 8 + j * 4 : 64;  // the third instruction of every wave fetches halo rows 64..67
+            const int k = k0 + d_row;
+            const int wv = w0 + k + dw0;
+            const bool ok = row_ok && k < 64 + TG - 1 && wv >= 0 && wv < a.Wu;
+            const bf16_t* p = ok ? vrow + (int64_t)wv * a.ld_v + src_chunk(k) : zero;
+            __builtin_amdgcn_global_load_lds((glb_t*)p, (lds_t*)(buf + kW3U + k0 * 256), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[TG][4][2];
+#pragma unroll
+    for (int t = 0; t < TG; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // Transposed fragment reads as inline asm: hipcc (ROCm 7.2) puts an s_waitcnt vmcnt(0) in front of the
+    // ds_read_tr16_b64 BUILTIN whenever an LDS-DMA is in flight (it cannot tell the DMA's LDS destination from the read's
+    // source), which would drain the ring every chunk.  The price: the compiler does not see these reads, so their
+    // lgkmcnt waits are placed by hand (and pinned with sched_barrier, cdna_hip_programming.md rule 18).
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
+    auto frag = [&](uint32_t tile_byte, int row0, int col0) -> bf16x8 {
+        // rows row0 + 8g + q (+4), columns col0 + 4p .. +3 (before the granule swizzle)
+        const int r_lo = row0 + 8 * g + q, r_hi = r_lo + 4, gran = col0 >> 4;
+        const uint32_t a_lo = tile_byte + (uint32_t)(r_lo * 128 + ((gran ^ sigma(r_lo)) << 4) + 4 * p) * 2u;
+        const uint32_t a_hi = tile_byte + (uint32_t)(r_hi * 128 + ((gran ^ sigma(r_hi)) << 4) + 4 * p) * 2u;
+        s16x4 lo, hi;
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a_lo));
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a_hi));
+        const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, both);
+    };
+
+    auto read_frags = [&](bf16x8 (&fa)[4], bf16x8 (&fb)[TG][2], uint32_t tu_, uint32_t tv_, int kk) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = frag(tu_, kk * 32, wm * 64 + i * 16);
+#pragma unroll
+        for (int t = 0; t < TG; ++t)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[t][j] = frag(tv_, kk * 32 + t, wn * 32 + j * 16);
+    };
+    if (c_begin < c_end) {
+        issue(c_begin);
+        issue(c_begin + 1);
+        issue(c_begin + 2);
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int c = c_begin; c < c_end; ++c) {
+            issue(c + 3);  // into the buffer chunk c-1 was read from; the barrier that ended that iteration orders it
+            const uint32_t tu_ = lds0 + (uint32_t)((c & (kW3Ring - 1)) * kW3Buf), tv_ = tu_ + kW3U;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 fa[4], fb[TG][2];
+                read_frags(fa, fb, tu_, tv_, kk);
+#pragma unroll
+                for (int t = 0; t < TG; ++t) {
+                    // 8 + 4*TG reads were issued in order; tap t needs all but the last 4*(TG-1-t)
+                    if (TG - 1 - t == 2)
+                        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+                    else if (TG - 1 - t == 1)
+                        asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                    else
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[t][j], acc[t][i][j], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // chunk c+1 landed; c+2 and c+3 stay in flight
+            __builtin_amdgcn_s_barrier();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#pragma unroll
+    for (int t = 0; t < TG; ++t) {
+        float* slab = a.slabs + ((int64_t)ks * a.taps + tap0 + t) * a.cu_pad * a.cv_pad;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int cu = u0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int cv = v0 + wn * 32 + j * 16 + (lane & 15);
+                    slab[(int64_t)cu * a.cv_pad + cv] = acc[t][i][j][r];
+                }
+            }
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void wgrad3_kernel(const Wgrad2Args a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t w3_smem[];
+    int bx = blockIdx.x / (a.tiles_v * a.tiles_u);
+    const int cnt = a.g_count[bx % a.groups];  // uniform per block
+    if (cnt == 3)
+        wgrad3_body<3>(a, w3_smem);
+    else if (cnt == 2)
+        wgrad3_body<2>(a, w3_smem);
+    else
+        wgrad3_body<1>(a, w3_smem);
+}
+
 struct WgradPlan {
     int taps, tiles_u, tiles_v, ksplit, k_per_split;
     int64_t elems;
@@ -501,8 +666,20 @@ extern "C" int rv_tap_wgrad(const rvTapGeom* g, const rvTapShape* s, const void*
             }
         hipStream_t st2 = (hipStream_t)stream;
         const int grid2 = p.tiles_v * p.tiles_u * p.groups * p.ksplit;
-        hipLaunchKernelGGL(wgrad2_kernel, dim3(grid2), dim3(512), 0, st2, b);
-        RV_CHECK_LAUNCH("wgrad2_kernel");
+        const bool dma = !(s->flags & (RV_IN_AFFINE | RV_IN_RELU)) && b.cu_pad % 128 == 0 && b.cv_pad % 128 == 0 &&
+                         getenv("RV3D_NO_WGRAD3") == nullptr;
+        if (dma) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute((const void*)wgrad3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(wgrad3_kernel, dim3(grid2), dim3(512), kW3Ring * kW3Buf, st2, b);
+            RV_CHECK_LAUNCH("wgrad3_kernel");
+        } else {
+            hipLaunchKernelGGL(wgrad2_kernel, dim3(grid2), dim3(512), 0, st2, b);
+            RV_CHECK_LAUNCH("wgrad2_kernel");
+        }
         const int rb2 = (int)((p.elems + 255) / 256 < 2048 ? (p.elems + 255) / 256 : 2048);
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb2), dim3(256), 0, st2, (const float*)workspace, p.ksplit, p.elems, dT_packed);
         RV_CHECK_LAUNCH("wgrad_reduce_kernel");

@@ -415,7 +415,8 @@ class ConvOp(Op):
             w_out = wv
         assert src.cp == pad32(layer.c_in), (src.cp, layer.c_in)
         self.x_plain = None
-        if (isinstance(x, Lazy) and MATERIALIZE_FOR_DMA and not out_f32
+        # (not for 1x1 layers: there the extra pass costs what the faster kernel saves)
+        if (isinstance(x, Lazy) and MATERIALIZE_FOR_DMA and not out_f32 and g.kh * g.kw > 1
                 and _dma_eligible(g, src.N, src.H, wu, wv, src.ld, pad32(layer.c_out), form == "scatter")):
             self.x_plain = src = x.materialized()
             sc = sh = None

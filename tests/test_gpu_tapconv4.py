@@ -41,13 +41,22 @@ def _run(module, x, stats=False, expect_kernel=4):
                                                  (128, 512, 2, 64, 256, True),   # two channel tiles, two K chunks, bias
                                                  (192, 256, 4, 17, 1030, False)])  # three K chunks, one-row last tile
 def test_gather_3x3_exact(cin, cout, N, H, W, bias):
+    _gather_exact(cin, cout, 3, N, H, W, bias)
+
+
+@pytest.mark.parametrize("cin,cout,N,H,W", [(256, 256, 4, 32, 520), (64, 512, 2, 64, 300), (576, 256, 2, 33, 1000)])
+def test_gather_1x1_exact(cin, cout, N, H, W):
+    _gather_exact(cin, cout, 1, N, H, W, False)
+
+
+def _gather_exact(cin, cout, k, N, H, W, bias):
     g = torch.Generator().manual_seed(cin + W)
-    m = torch.nn.Conv2d(cin, cout, 3, padding=1, bias=bias)
+    m = torch.nn.Conv2d(cin, cout, k, padding=k // 2, bias=bias)
     m.weight.data = _ints(m.weight.shape, g, -2, 3)
     if bias:
         m.bias.data = _ints(m.bias.shape, g, -8, 9)
     x = _ints((N, cin, H, W), g)
-    ref = F.conv2d(x, m.weight.data, m.bias.data if bias else None, padding=1)
+    ref = F.conv2d(x, m.weight.data, m.bias.data if bias else None, padding=k // 2)
     out, op = _run(m.to(DEV), x.to(DEV), stats=not bias)
     assert torch.equal(out.cpu(), ref.bfloat16().float())
     if not bias:
