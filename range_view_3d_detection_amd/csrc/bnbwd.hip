@@ -136,15 +136,23 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnbArgs a) {
     }
 }
 
-__global__ void bn_bwd_finalize_kernel(const double* red, int groups, int c, double inv_count, const float* gamma,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* red, int groups, int c, double inv_count, const float* gamma,
                                        const float* invstd, float* dgamma, float* dbeta, int accumulate, float* coef) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= c) return;
+    __shared__ double part[2][4][64];
+    const int cl = threadIdx.x & 63, gl = threadIdx.x >> 6;
+    const int ch = blockIdx.x * 64 + cl;
     double s0 = 0.0, s1 = 0.0;
-    for (int g = 0; g < groups; ++g) {
-        s0 += red[(int64_t)g * 2 * c + ch];
-        s1 += red[(int64_t)g * 2 * c + c + ch];
-    }
+    if (ch < c)
+        for (int g = gl; g < groups; g += 4) {
+            s0 += red[(int64_t)g * 2 * c + ch];
+            s1 += red[(int64_t)g * 2 * c + c + ch];
+        }
+    part[0][gl][cl] = s0;
+    part[1][gl][cl] = s1;
+    __syncthreads();
+    if (gl != 0 || ch >= c) return;
+    s0 = (part[0][0][cl] + part[0][1][cl]) + (part[0][2][cl] + part[0][3][cl]);
+    s1 = (part[1][0][cl] + part[1][1][cl]) + (part[1][2][cl] + part[1][3][cl]);
     if (dgamma) dgamma[ch] = (float)((accumulate ? (double)dgamma[ch] : 0.0) + s1);
     if (dbeta) dbeta[ch] = (float)((accumulate ? (double)dbeta[ch] : 0.0) + s0);
     coef[ch] = gamma[ch] * invstd[ch];
@@ -286,7 +294,7 @@ extern "C" int rv_bn_bwd_finalize(const float* partial, int32_t rows, int32_t c,
     double* scratch = (double*)(partial + (int64_t)rows * 2 * c);
     int groups;
     if (rv_col_reduce(partial, rows, 2 * c, scratch, &groups, (hipStream_t)stream)) return 1;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(rv_ceil_div(c, 64)), dim3(64), 0, (hipStream_t)stream, scratch, groups, c,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(rv_ceil_div(c, 64)), dim3(256), 0, (hipStream_t)stream, scratch, groups, c,
                        1.0 / (double)count, gamma, invstd, dgamma, dbeta, accumulate, coef);
     RV_CHECK_LAUNCH("bn_bwd_finalize_kernel");
     return 0;

@@ -146,17 +146,26 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* in, int ro
     }
 }
 
-__global__ void bn_finalize_kernel(const double* red, int groups, int c, double inv_count, double unbias,
+// 256 threads = 64 channels x 4 group lanes: the (at most 64) fp64 group rows of a channel are summed by four threads
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* red, int groups, int c, double inv_count, double unbias,
                                    const float* gamma, const float* beta, float eps, float momentum,
                                    float* running_mean, float* running_var, float* scale, float* shift, float* mean_out,
                                    float* invstd_out) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= c) return;
+    __shared__ double part[2][4][64];
+    const int cl = threadIdx.x & 63, gl = threadIdx.x >> 6;
+    const int ch = blockIdx.x * 64 + cl;
     double s = 0.0, q = 0.0;
-    for (int g = 0; g < groups; ++g) {
-        s += red[(int64_t)g * 2 * c + ch];
-        q += red[(int64_t)g * 2 * c + c + ch];
-    }
+    if (ch < c)
+        for (int g = gl; g < groups; g += 4) {
+            s += red[(int64_t)g * 2 * c + ch];
+            q += red[(int64_t)g * 2 * c + c + ch];
+        }
+    part[0][gl][cl] = s;
+    part[1][gl][cl] = q;
+    __syncthreads();
+    if (gl != 0 || ch >= c) return;
+    s = (part[0][0][cl] + part[0][1][cl]) + (part[0][2][cl] + part[0][3][cl]);
+    q = (part[1][0][cl] + part[1][1][cl]) + (part[1][2][cl] + part[1][3][cl]);
     const double mean = s * inv_count;
     double var = q * inv_count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -201,7 +210,7 @@ extern "C" int rv_bn_finalize(const float* partial, int32_t rows, int32_t c, int
     int groups;
     if (rv_col_reduce(partial, rows, 2 * c, scratch, &groups, (hipStream_t)stream)) return 1;
     const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(rv_ceil_div(c, 64)), dim3(64), 0, (hipStream_t)stream, scratch, groups, c,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(rv_ceil_div(c, 64)), dim3(256), 0, (hipStream_t)stream, scratch, groups, c,
                        1.0 / (double)count, unbias, gamma, beta, eps, momentum, running_mean, running_var, scale, shift,
                        mean, invstd);
     RV_CHECK_LAUNCH("bn_finalize_kernel");

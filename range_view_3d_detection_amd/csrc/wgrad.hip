@@ -212,11 +212,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
         }
 }
 
-__global__ void wgrad_reduce_kernel(const float* slabs, int ksplit, int64_t elems, float* out) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < elems; i += (int64_t)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int k = 0; k < ksplit; ++k) s += slabs[(int64_t)k * elems + i];
-        out[i] = s;
+// sum of the split-K slabs in slab order (bitwise reproducible); elems is a multiple of 1024 (padded channel counts)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, int ksplit, int64_t elems, float* out) {
+    const int64_t n4 = elems >> 2;
+    const f32x4* in = (const f32x4*)slabs;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 s = in[i];
+        int k = 1;
+        for (; k + 3 < ksplit; k += 4) {
+            const f32x4 a = in[(int64_t)k * n4 + i], b = in[(int64_t)(k + 1) * n4 + i], c = in[(int64_t)(k + 2) * n4 + i],
+                        d = in[(int64_t)(k + 3) * n4 + i];
+            s = (((s + a) + b) + c) + d;
+        }
+        for (; k < ksplit; ++k) s += in[(int64_t)k * n4 + i];
+        ((f32x4*)out)[i] = s;
     }
 }
 
@@ -680,7 +689,7 @@ extern "C" int rv_tap_wgrad(const rvTapGeom* g, const rvTapShape* s, const void*
             hipLaunchKernelGGL(wgrad2_kernel, dim3(grid2), dim3(512), 0, st2, b);
             RV_CHECK_LAUNCH("wgrad2_kernel");
         }
-        const int rb2 = (int)((p.elems + 255) / 256 < 2048 ? (p.elems + 255) / 256 : 2048);
+        const int rb2 = (int)((p.elems / 4 + 255) / 256 < 4096 ? (p.elems / 4 + 255) / 256 : 4096);
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb2), dim3(256), 0, st2, (const float*)workspace, p.ksplit, p.elems, dT_packed);
         RV_CHECK_LAUNCH("wgrad_reduce_kernel");
         return 0;
@@ -718,7 +727,7 @@ extern "C" int rv_tap_wgrad(const rvTapGeom* g, const rvTapShape* s, const void*
     const int grid = p.tiles_v * p.tiles_u * p.taps * p.ksplit;
     hipLaunchKernelGGL(wgrad_kernel, dim3(grid), dim3(256), 0, st, a);
     RV_CHECK_LAUNCH("wgrad_kernel");
-    const int rb = (int)((p.elems + 255) / 256 < 2048 ? (p.elems + 255) / 256 : 2048);
+    const int rb = (int)((p.elems / 4 + 255) / 256 < 4096 ? (p.elems / 4 + 255) / 256 : 4096);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, st, (const float*)workspace, p.ksplit, p.elems, dT_packed);
     RV_CHECK_LAUNCH("wgrad_reduce_kernel");
     return 0;

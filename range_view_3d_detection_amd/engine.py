@@ -339,6 +339,7 @@ class Tape:
         self.param_grads: Dict[int, Tensor] = {}  # id(param) -> fp32 gradient
         self.params: Dict[int, nn.Parameter] = {}
         self.used_side_stream = False
+        self.bn_counters: List[Tensor] = []
 
     # ---- gradient buffers (views follow their parents) ----
     def grad_buffer(self, a: Act) -> Tuple[Act, bool]:
@@ -490,7 +491,7 @@ class BnOp(Op):
             if bn.running_mean.shape[0] != cp:  # padded copies: write the logical channels back
                 bn.running_mean.copy_(rm[:c])
                 bn.running_var.copy_(rv[:c])
-            bn.num_batches_tracked += 1
+            t.bn_counters.append(bn.num_batches_tracked)  # incremented together at the end of the forward pass
             conv.partial = None
             self.state = BnState(bn, scale, shift, mean, invstd, conv.count)
         else:

@@ -136,6 +136,9 @@ class _ProgramFn(torch.autograd.Function):
         dev = next(x.device for x in inputs if isinstance(x, Tensor))
         tape = Tape(training, dev)
         in_acts, outs = build(tape, *inputs)
+        if tape.bn_counters:
+            torch._foreach_add_(tape.bn_counters, 1)  # num_batches_tracked of every BatchNorm on the tape, one launch
+            tape.bn_counters = []
         ctx.tape, ctx.in_acts, ctx.outs, ctx.n_in = tape, in_acts, outs, n_in
         ctx.params = args[n_in:]
         ctx.in_meta = [(x.dtype, x.shape) if isinstance(x, Tensor) else None for x in inputs]
