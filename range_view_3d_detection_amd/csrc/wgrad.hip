@@ -249,6 +249,7 @@ struct Wgrad2Args {
     int32_t ksplit, chunks_per_split, chunks;  // 64-pixel chunks
     int32_t tiles_u, tiles_v;
     int32_t flags, v_affine;
+    int32_t xcd_remap;
     int8_t g_first[kMaxTaps], g_count[kMaxTaps];  // tap group -> first tap index / number of taps (<= 3)
     int8_t dh[kMaxTaps], dw[kMaxTaps];
 };
@@ -426,7 +427,14 @@ __device__ __forceinline__ void wgrad3_body(const Wgrad2Args& a, uint8_t* smem) 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
+    // XCD-aware block order: workgroups are dealt round-robin over the 8 XCDs (one L2 each).  Blocks that share a K slice
+    // read the same pixels of U and V, so each XCD gets a CONTIGUOUS range of the (K-slice-major) block list: a slice is
+    // then fetched into one or two L2s instead of all eight (bijective for any grid size).
     int bx = blockIdx.x;
+    if (a.xcd_remap) {
+        const int total = gridDim.x, q = total >> 3, r = total & 7, xcd = bx & 7;
+        bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bx >> 3);
+    }
     const int tv = bx % a.tiles_v;
     bx /= a.tiles_v;
     const int tu = bx % a.tiles_u;
@@ -561,7 +569,12 @@ __device__ __forceinline__ void wgrad3_body(const Wgrad2Args& a, uint8_t* smem) 
 
 __global__ __launch_bounds__(512, 2) void wgrad3_kernel(const Wgrad2Args a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t w3_smem[];
-    int bx = blockIdx.x / (a.tiles_v * a.tiles_u);
+    int bx = blockIdx.x;
+    if (a.xcd_remap) {
+        const int total = gridDim.x, q = total >> 3, r = total & 7, xcd = bx & 7;
+        bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bx >> 3);
+    }
+    bx /= (a.tiles_v * a.tiles_u);
     const int cnt = a.g_count[bx % a.groups];  // uniform per block
     if (cnt == 3)
         wgrad3_body<3>(a, w3_smem);
@@ -662,6 +675,7 @@ extern "C" int rv_tap_wgrad(const rvTapGeom* g, const rvTapShape* s, const void*
         b.tiles_v = p.tiles_v;
         b.flags = s->flags;
         b.v_affine = v_affine;
+        b.xcd_remap = getenv("RV3D_NO_WGRAD_XCD") == nullptr;
         int gi = 0;
         for (int ky = 0; ky < g->kh; ++ky)
             for (int kx = 0; kx < g->kw; ++kx) {
