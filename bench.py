@@ -187,7 +187,9 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=4, help="sweeps per GPU")
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--height", type=int, default=64)
-    ap.add_argument("--widths", default="rv-av2")
+    ap.add_argument("--widths", default="rv-av2", help="rv-av2 (the metric's configuration), rv-waymo, or c<int> debug widths")
+    ap.add_argument("--features", type=int, default=5, help="input channels: 5 (AV2) or 6 (Waymo)")
+    ap.add_argument("--classes", type=int, default=AV2_CLASSES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sync-bn", action="store_true")
     args = ap.parse_args()
@@ -208,7 +210,7 @@ def main() -> None:
     from range_view_3d_detection_amd import engine as E
 
     torch.manual_seed(0)
-    backbone, head = build_model(args.widths, AV2_CLASSES)
+    backbone, head = build_model(args.widths, args.classes, args.features)
     model = Detector(backbone, head).to(dev).train()
     E.SYNC_BN = world > 1 and not args.no_sync_bn
     step_model = model
@@ -216,7 +218,7 @@ def main() -> None:
         step_model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], gradient_as_bucket_view=True, static_graph=True)
     params = [p for p in model.parameters()]
     opt = torch.optim.AdamW(params, lr=1e-3)
-    batch = synthetic_batch(args.batch, args.height, args.width, seed=1234 + rank, device=dev)
+    batch = synthetic_batch(args.batch, args.height, args.width, seed=1234 + rank, device=dev, n_feat=args.features, n_cls=args.classes)
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -264,8 +266,9 @@ def main() -> None:
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.widths} full model (MetaKernel stem + DLA backbone/FPN + cls/reg towers + targets + loss), "
-                                   f"fwd+bwd+AdamW, {args.batch} synthetic {args.height}x{args.width}x5 sweeps per GPU (BASELINE configs[2])",
-                       "global_batch": args.batch * world, "sweep": [args.height, args.width, 5], "parallelism": f"dp{world}",
+                                   f"fwd+bwd+AdamW, {args.batch} synthetic {args.height}x{args.width}x{args.features} sweeps per GPU"
+                                   + (" (BASELINE configs[2])" if (args.widths, args.width, args.height, args.batch) == ("rv-av2", 2048, 64, 4) else ""),
+                       "global_batch": args.batch * world, "sweep": [args.height, args.width, args.features], "parallelism": f"dp{world}",
                        "sync_bn": bool(E.SYNC_BN), "loss": float(loss.detach().item())},
             "roofline": roofline(prof, iso),
             "kernels": prof.summary(),

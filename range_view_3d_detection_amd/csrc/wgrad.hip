@@ -268,7 +268,7 @@ __device__ __forceinline__ void wgrad2_body(const Wgrad2Args& a, bf16_t (*lds)[2
     const int u0 = tu * 128, v0 = tv * 128;
     const int tap0 = a.g_first[grp];
     const int dh = a.dh[tap0], dw0 = a.dw[tap0];
-    const int wchunks = a.Wu / 64;
+    const int wchunks = (a.Wu + 63) / 64;  // the last chunk of an image row may be partial (W = 1808, 2656 ...): zero-filled
 
     const int c_begin = ks * a.chunks_per_split;
     const int c_end = (c_begin + a.chunks_per_split < a.chunks) ? c_begin + a.chunks_per_split : a.chunks;
@@ -295,7 +295,7 @@ __device__ __forceinline__ void wgrad2_body(const Wgrad2Args& a, bf16_t (*lds)[2
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             ru[j] = u32x4{0u, 0u, 0u, 0u};
-            if (u_ok) ru[j] = *(const u32x4*)(urow + (int64_t)(w0 + prow + 32 * j) * a.ld_u);
+            if (u_ok && w0 + prow + 32 * j < a.Wu) ru[j] = *(const u32x4*)(urow + (int64_t)(w0 + prow + 32 * j) * a.ld_u);
         }
         const int hv = h + dh;
         const bool row_ok = hv >= 0 && hv < a.H;
@@ -444,7 +444,7 @@ __device__ __forceinline__ void wgrad3_body(const Wgrad2Args& a, uint8_t* smem) 
     const int u0 = tu * 128, v0 = tv * 128;
     const int tap0 = a.g_first[grp];
     const int dh = a.dh[tap0], dw0 = a.dw[tap0];
-    const int wchunks = a.Wu / 64;
+    const int wchunks = (a.Wu + 63) / 64;  // the last chunk of an image row may be partial (W = 1808, 2656 ...): zero-filled
     const int c_begin = ks * a.chunks_per_split;
     const int c_end = (c_begin + a.chunks_per_split < a.chunks) ? c_begin + a.chunks_per_split : a.chunks;
 
@@ -463,7 +463,8 @@ __device__ __forceinline__ void wgrad3_body(const Wgrad2Args& a, uint8_t* smem) 
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int k = wave * 8 + j * 4 + d_row;
-            __builtin_amdgcn_global_load_lds((glb_t*)(urow + (int64_t)k * a.ld_u + src_chunk(k)), (lds_t*)(buf + (wave * 8 + j * 4) * 256), 16, 0, 0);
+            const bf16_t* pu = (w0 + k < a.Wu) ? urow + (int64_t)k * a.ld_u + src_chunk(k) : zero;
+            __builtin_amdgcn_global_load_lds((glb_t*)pu, (lds_t*)(buf + (wave * 8 + j * 4) * 256), 16, 0, 0);
         }
         const int hv = h + dh;
         const bool row_ok = hv >= 0 && hv < a.H;
@@ -607,10 +608,10 @@ int plan(const rvTapGeom* g, const rvTapShape* s, WgradPlan* p) {
     p->ksplit = (int)((chunks + per - 1) / per);
     p->elems = (int64_t)p->taps * cu * cv;
     // wgrad2: stride 1, whole 64-pixel chunks per image row
-    p->v2 = (g->stride_w == 1) && (s->Wu % 64 == 0) && (getenv("RV3D_NO_WGRAD2") == nullptr);
+    p->v2 = (g->stride_w == 1) && (s->Wu >= 64) && (getenv("RV3D_NO_WGRAD2") == nullptr);
     if (p->v2) {
         p->groups = g->kh * ((g->kw + 2) / 3);
-        p->chunks = (int)(K / 64);
+        p->chunks = s->N * s->H * ((s->Wu + 63) / 64);
         const int base2 = p->groups * p->tiles_u * p->tiles_v;
         // split-K factor: whole rounds of 256 CUs (a 2.06-round grid ran 30 % slower than a 3-round one), at least 32
         // K chunks per block so that the fp32 slab traffic stays small next to the MFMA work

@@ -23,7 +23,8 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize(
     "cin,cout,k,stride,H,W",
     [(40, 24, 3, 1, 5, 48), (32, 32, 3, 2, 4, 64), (64, 48, 1, 2, 3, 96), (128, 160, 3, 1, 4, 128), (256, 128, 3, 1, 2, 256),
-     (64, 64, 3, 2, 5, 256), (128, 128, 1, 2, 4, 256), (64, 128, 1, 1, 3, 128)],  # strided layers: bwd-data = tapconv2 scatter phases
+     (64, 64, 3, 2, 5, 256), (128, 128, 1, 2, 4, 256), (64, 128, 1, 1, 3, 128),  # strided layers: bwd-data = tapconv2 scatter phases
+     (128, 128, 3, 1, 3, 200), (64, 96, 3, 1, 4, 136), (256, 256, 1, 1, 2, 226)],  # widths that are not multiples of the 64-pixel chunk: wgrad3 (DMA), wgrad2, 1x1
 )
 def test_conv_input_and_weight_grad(cin, cout, k, stride, H, W):
     from range_view_3d_detection_amd.nn.modules.conv import Conv2dSame
@@ -41,10 +42,12 @@ def test_conv_input_and_weight_grad(cin, cout, k, stride, H, W):
     m = m.to(DEV)
     xd = x.detach().to(DEV).requires_grad_(True)
     yd = m(xd)
-    assert rel_err(yd.float(), bf16r(y.detach())) < 4e-3
+    # stored bf16 results: one ulp.  A bf16 ulp is 2^-8 .. 2^-7 of the value, so relative to the tensor's maximum a
+    # single value that rounds to the neighbouring bf16 shows up as at most 7.8e-3.
+    assert rel_err(yd.float(), bf16r(y.detach())) < 8e-3
     (yd.float() * probe.to(DEV)).sum().backward()
     assert rel_err(m.conv.weight.grad, w.grad) < 2e-5
-    assert rel_err(xd.grad, bf16r(x.grad)) < 4e-3
+    assert rel_err(xd.grad, bf16r(x.grad)) < 8e-3
 
 
 @pytest.mark.parametrize("kernel,stride,padding,W", [((3, 8), (1, 4), (1, 2), 24), ((3, 4), (1, 2), (1, 1), 80)])
