@@ -127,6 +127,9 @@ int rv_tap_scatter(const rvTapGeom* g, const rvTapShape* s, const void* U, const
  * s->flags applies to V when v_affine != 0, else to U).
  * Replaces cuDNN conv2d backward-weight / ATen conv_transpose2d backward-weight. */
 int64_t rv_tap_wgrad_workspace_bytes(const rvTapGeom* g, const rvTapShape* s);
+/* host-side introspection (bench / tests): info[0] = kernel generation that rv_tap_wgrad will launch for (g, s)
+ * (1 generic, 2 register-staged 3-tap groups, 3 LDS-DMA ring), info[1] = split-K factor, info[2] = workgroups */
+int rv_tap_wgrad_info(const rvTapGeom* g, const rvTapShape* s, int32_t* host_info);
 int rv_tap_wgrad(const rvTapGeom* g, const rvTapShape* s, const void* U, int32_t ld_u, const void* V, int32_t ld_v,
                  const float* in_scale, const float* in_shift, int32_t v_affine, float* dT_packed,
                  void* workspace, rvStream stream);

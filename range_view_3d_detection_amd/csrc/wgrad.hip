@@ -642,6 +642,21 @@ extern "C" int64_t rv_tap_wgrad_workspace_bytes(const rvTapGeom* g, const rvTapS
     return p.elems * p.ksplit * (int64_t)sizeof(float);
 }
 
+static bool wgrad_dma_eligible(const rvTapGeom* g, const rvTapShape* s) {
+    return !(s->flags & (RV_IN_AFFINE | RV_IN_RELU)) && rv_pad32(g->cu) % 128 == 0 && rv_pad32(g->cv) % 128 == 0 &&
+           getenv("RV3D_NO_WGRAD3") == nullptr;
+}
+
+extern "C" int rv_tap_wgrad_info(const rvTapGeom* g, const rvTapShape* s, int32_t* host_info) {
+    RV_REQUIRE(g && s && host_info, "rv_tap_wgrad_info: null argument");
+    WgradPlan p;
+    plan(g, s, &p);
+    host_info[0] = p.v2 ? (wgrad_dma_eligible(g, s) ? 3 : 2) : 1;
+    host_info[1] = p.ksplit;
+    host_info[2] = p.v2 ? p.tiles_v * p.tiles_u * p.groups * p.ksplit : p.tiles_v * p.tiles_u * p.taps * p.ksplit;
+    return 0;
+}
+
 extern "C" int rv_tap_wgrad(const rvTapGeom* g, const rvTapShape* s, const void* U, int32_t ld_u, const void* V,
                             int32_t ld_v, const float* in_scale, const float* in_shift, int32_t v_affine,
                             float* dT_packed, void* workspace, rvStream stream) {
@@ -690,8 +705,7 @@ extern "C" int rv_tap_wgrad(const rvTapGeom* g, const rvTapShape* s, const void*
             }
         hipStream_t st2 = (hipStream_t)stream;
         const int grid2 = p.tiles_v * p.tiles_u * p.groups * p.ksplit;
-        const bool dma = !(s->flags & (RV_IN_AFFINE | RV_IN_RELU)) && b.cu_pad % 128 == 0 && b.cv_pad % 128 == 0 &&
-                         getenv("RV3D_NO_WGRAD3") == nullptr;
+        const bool dma = wgrad_dma_eligible(g, s);
         if (dma) {
             static bool attr_set = false;
             if (!attr_set) {

@@ -56,11 +56,12 @@ class KernelProfile:
             d["tflops"] = d["tflop"] / max(d["ms"] * 1e-3, 1e-12)
         return agg
 
-    def roofline(self, peak_tflops: float) -> Dict[str, object]:
+    def roofline(self, peak_tflops: float, name: Optional[str] = None) -> Dict[str, object]:
         agg = self.summary()
         if not agg:
             return {}
-        name = max(agg, key=lambda k: agg[k]["ms"])
+        if name is None or name not in agg:
+            name = max(agg, key=lambda k: agg[k]["ms"])
         d = agg[name]
         return {"kernel": name, "bound": "mfma", "achieved": d["tflops"], "peak": peak_tflops, "unit": "TFLOP/s",
                 "frac": d["tflops"] / peak_tflops, "traffic": None, "launches": d["launches"], "avg_launch_us": d["avg_us"],

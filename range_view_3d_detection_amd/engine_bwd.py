@@ -95,6 +95,10 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
         cu_p, cv_p = pad32(g.cu), pad32(g.cv)
         packed = torch.empty((g.kh * g.kw, cu_p, cv_p), dtype=torch.float32, device=t.device)
         wname = "wgrad_kernel(+reduce)"
+        if E.PROFILE is not None:
+            winfo = (ctypes.c_int32 * 4)()
+            L.call("rv_tap_wgrad_info", ctypes.byref(g), ctypes.byref(wshape), winfo)
+            wname = ("wgrad_kernel", "wgrad_kernel", "wgrad2_kernel", "wgrad3_kernel")[winfo[0]] + "(+reduce)"
         if os.environ.get("RV3D_PROFILE_SHAPES"):
             wname += f" k{g.kh}x{g.kw}s{g.stride_w} {g.cu}<->{g.cv} {wshape.N}x{wshape.H}x{wshape.Wu}"
         E._launch(wname, E.tap_flops(g, wshape),
