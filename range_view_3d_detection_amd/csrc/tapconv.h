@@ -50,5 +50,5 @@ bool rv_tapconv3_plan(TapConvArgs* a, int* grid_x, int* grid_y, size_t* lds, int
 int rv_tapconv3_launch(const TapConvArgs& a, int grid_x, int grid_y, size_t lds, int ks, hipStream_t stream);
 
 // fourth-generation kernel (tapconv4.hip): 256 x 256 tiles, LDS-DMA staging, counted waits; stats rows = 2 * tiles
-bool rv_tapconv4_plan(TapConvArgs* a, int* tiles, size_t* lds);
-int rv_tapconv4_launch(const TapConvArgs& a, size_t lds, hipStream_t stream);
+bool rv_tapconv4_plan(TapConvArgs* a, int* tiles, size_t* lds, int* bn);
+int rv_tapconv4_launch(const TapConvArgs& a, size_t lds, int bn, hipStream_t stream);

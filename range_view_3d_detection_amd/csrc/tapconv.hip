@@ -409,7 +409,6 @@ static int tap_launch(const rvTapGeom* g, const rvTapShape* s, bool scatter, con
     a.phases = phases;
     a.step = step;
     a.flags = s->flags;
-    if (const char* dbg = getenv("RV3D_DBG_FLAGS")) a.flags |= atoi(dbg);  // timing experiments only
     RV_REQUIRE(!((a.flags & RV_OUT_F32) && (a.flags & RV_OUT_ACCUM)), "RV_OUT_ACCUM needs a bf16 destination");
     RV_REQUIRE(dry_run || !(a.flags & RV_IN_AFFINE) || (in_scale && in_shift), "RV_IN_AFFINE without scale/shift");
     RV_REQUIRE(dry_run || !(a.flags & RV_OUT_BIAS) || bias, "RV_OUT_BIAS without bias");
@@ -424,19 +423,19 @@ static int tap_launch(const rvTapGeom* g, const rvTapShape* s, bool scatter, con
 
     // fastest path: 256 x 256 tiles streamed by LDS-DMA, counted waits (tapconv4.hip); plain bf16 inputs only
     if (getenv("RV3D_NO_TAPCONV4") == nullptr) {
-        int tiles;
+        int tiles, bn;
         size_t lds4;
         TapConvArgs a4 = a;
-        if (rv_tapconv4_plan(&a4, &tiles, &lds4)) {
+        if (rv_tapconv4_plan(&a4, &tiles, &lds4, &bn)) {
             if (stats_rows) *stats_rows = tiles * 2;
             if (info) {
                 info[0] = 4;
-                info[1] = 0;
+                info[1] = bn;
                 info[2] = tiles;
                 info[3] = a4.n_tiles;
             }
             if (dry_run) return 0;
-            return rv_tapconv4_launch(a4, lds4, (hipStream_t)stream);
+            return rv_tapconv4_launch(a4, lds4, bn, (hipStream_t)stream);
         }
     }
     // 8 waves, 4-row x 64-column x 128-channel tiles, 3-tap weight stages, register staging (tapconv3.hip)

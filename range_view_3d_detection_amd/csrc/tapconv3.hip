@@ -178,7 +178,6 @@ __global__ __launch_bounds__(512, 2) void tapconv3_kernel(const TapConvArgs a) {
     int buf = 0, abuf = 0;
     for (int kc = 0; kc < nk; ++kc) {
         const bool next_chunk = kc + 1 < nk;
-        const bool dbg_nomem = a.flags & (1 << 28);
         // Prefetch loads are issued UNCONDITIONALLY (the final ones re-fetch the current tile, harmlessly): a conditional
         // load leaves hipcc with a register merge of "loaded" and "not loaded" values at the join, and the v_mov it emits
         // there needs the data => s_waitcnt vmcnt(0) right after the loads, in front of the MFMAs they should overlap.
@@ -215,7 +214,6 @@ __global__ __launch_bounds__(512, 2) void tapconv3_kernel(const TapConvArgs a) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if (dbg_nomem) continue;
             write_b(buf ^ 1);
             if (last_g && next_chunk) {
                 if (a_double) {
@@ -338,7 +336,7 @@ bool rv_tapconv3_plan(TapConvArgs* a, int* grid_x, int* grid_y, size_t* lds, int
     const int wm_total = a->W_dst / a->phases;
     if (wm_total < kTC || a->C_dst < 64 || a->H < kTR) return false;
     for (int r = 0; r < a->phases; ++r)
-        if (a->tt.ntaps[r] < 2 && getenv("RV3D_V3_1X1") == nullptr) return false;  // single-tap (1x1) phases: the smaller tapconv2 tile measured faster
+        if (a->tt.ntaps[r] < 2) return false;  // single-tap (1x1) phases: the smaller tapconv2 tile measured faster
     int a_max = 0;
     bool any_single_tap = true;
     const int KS = (a->C_src % 64 == 0) ? 2 : 1;

@@ -29,7 +29,6 @@ namespace {
 
 constexpr int kTC = 64;    // tile columns
 constexpr int kTR = 4;     // tile rows
-constexpr int kBN4 = 256;  // tile channels
 constexpr int kBK = 64;    // K tile (channels of one tap)
 constexpr int kPiece = 128 * 128;    // bytes of one piece
 constexpr int kBuf = 4 * kPiece;     // one K tile
@@ -46,7 +45,9 @@ struct Staged {   // the K tile a piece belongs to
     uint32_t vb;  // validity of the thread's four tile rows under this tap
 };
 
+template <int BN>  // channels per workgroup tile: 256 (two 16 KB weight pieces per K tile) or 128 (one)
 __global__ __launch_bounds__(512, 2) void tapconv4_kernel(const TapConvArgs a) {
+    constexpr int NJ = BN / 64;  // 16-channel accumulator fragments per wave (wave tile = 128 pixels x BN/4 channels)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(512, 2) void tapconv4_kernel(const TapConvArgs a) {
     const int xcd = blockIdx.x & 7, xslot = blockIdx.x >> 3;
     const int tile = xcd * a.tiles_per_xcd + xslot / gy;
     if (tile >= a.total_tiles) return;
-    const int n0 = (xslot % gy) * kBN4;
+    const int n0 = (xslot % gy) * BN;
     int bx = tile;
     const int tc = bx % a.m_tiles;
     bx /= a.m_tiles;
@@ -69,13 +70,14 @@ __global__ __launch_bounds__(512, 2) void tapconv4_kernel(const TapConvArgs a) {
     const int m0 = tc * kTC, h0 = th * kTR;
     const int T = a.tt.ntaps[ph];
     const int nkc = a.C_src / kBK;
-    const int nkt = (a.flags & (1 << 28)) ? 2 : T * nkc;  // bit 28: timing experiment (two K tiles only)
+    const int nkt = T * nkc;
 
     const bf16_t* src_img = a.src + ((int64_t)n * a.H * a.W_src) * a.ld_src;
     // per-tap tables in LDS: element offset of the tap, and its (dh, dw).  Each of the first T threads fetches its own
     // tap from the kernel arguments (one load latency for the whole table); nothing below indexes the arguments with a
     // runtime tap number, which would cost a dependent global load per tap and thread.
-    int* tap_tab = (int*)(smem + kTabOffset);
+    constexpr int kTab = (BN == 256) ? kTabOffset : 9 * kPiece;  // behind two 64 KB buffers / three 48 KB buffers
+    int* tap_tab = (int*)(smem + kTab);
     int* tap_dhw = tap_tab + 32;
     if (tid < T) {
         const int dh = a.tt.dh[ph][tid], dw = a.tt.dw[ph][tid];
@@ -101,8 +103,8 @@ __global__ __launch_bounds__(512, 2) void tapconv4_kernel(const TapConvArgs a) {
     }
     const int row_stride = a.W_src * a.ld_src;
     const int a_base = (h0 * a.W_src + m0 + s_c) * a.ld_src + kq * 8;
-    // weights: piece row = (wave column wcc, channel jl of its 32); rows tid>>3 and 64 + tid>>3
-    const int b_base = (n0 + ((s_c >> 5) * 64) + (s_c & 31)) * a.C_src + kq * 8;
+    // weights: piece row = (wave column wcc, channel jl of the 32 it reads per piece); rows tid>>3 and 64 + tid>>3
+    const int b_base = (n0 + ((s_c >> 5) * (BN / 4)) + (s_c & 31)) * a.C_src + kq * 8;
     const int64_t w_img = (int64_t)a.C_dst * a.C_src;
     const bf16_t* w_ph = a.w + (int64_t)a.tt.w_first[ph] * w_img;
     const bf16_t* zero = (const bf16_t*)g_zero_page + s_slot * 8;
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(512, 2) void tapconv4_kernel(const TapConvArgs a) {
     auto stage_b = [&](int piece_byte, int nq, const Staged& s) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const bf16_t* p = w_ph + (s.woff + b_base + (i * 128 + nq * 32) * a.C_src);
+            const bf16_t* p = w_ph + (s.woff + b_base + (i * (BN / 2) + nq * 32) * a.C_src);
             __builtin_amdgcn_global_load_lds((glb_void_t*)p, (lds_void_t*)(smem + piece_byte + i * 8192 + lds_lane_base), 16, 0, 0);
         }
     };
@@ -151,11 +153,11 @@ __global__ __launch_bounds__(512, 2) void tapconv4_kernel(const TapConvArgs a) {
             for (int ks = 0; ks < 2; ++ks) fb[jj][ks] = *(const bf16x8*)(smem + piece_byte + jj * 2048 + (b_rd ^ (ks * 64)));
     };
 
-    f32x4 acc[8][4];
+    f32x4 acc[8][NJ];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 // One phase: [fragment reads, this phase's piece (two DMA instructions), counted wait] barrier | 16 MFMAs | barrier.
 #define RV_MFMA_HALF(MQ, NQ, FB, KS)                                                                               \
@@ -177,42 +179,77 @@ __global__ __launch_bounds__(512, 2) void tapconv4_kernel(const TapConvArgs a) {
     __builtin_amdgcn_s_barrier();
 #define RV_WAIT_PIECES(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 
-    // ---- prologue: K tile 0 complete, X0 / X1 of K tile 1 ---------------------------------------------------
-    Staged scur = make_staged(0);
-    stage_a(0 * kPiece, 0, scur);
-    stage_b(1 * kPiece, 0, scur);
-    stage_b(2 * kPiece, 1, scur);
-    stage_a(3 * kPiece, 1, scur);
-    scur = make_staged(1);
-    stage_a(kBuf + 0 * kPiece, 0, scur);
-    stage_b(kBuf + 1 * kPiece, 0, scur);
-    RV_WAIT_PIECES(8);  // X0(0), X1(0) landed; four pieces in flight
-    __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();  // the second half of the workgroup runs one barrier behind the first
+    if constexpr (BN == 256) {
+        // ---- prologue: K tile 0 complete, X0 / X1 of K tile 1 ---------------------------------------------------
+        Staged scur = make_staged(0);
+        stage_a(0 * kPiece, 0, scur);
+        stage_b(1 * kPiece, 0, scur);
+        stage_b(2 * kPiece, 1, scur);
+        stage_a(3 * kPiece, 1, scur);
+        scur = make_staged(1);
+        stage_a(kBuf + 0 * kPiece, 0, scur);
+        stage_b(kBuf + 1 * kPiece, 0, scur);
+        RV_WAIT_PIECES(8);  // X0(0), X1(0) landed; four pieces in flight
+        __builtin_amdgcn_s_barrier();
+        if (wr == 1) __builtin_amdgcn_s_barrier();  // the second half of the workgroup runs one barrier behind the first
 
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int rb = (kt & 1) * kBuf, ob = kBuf - rb;
-        const Staged snext = make_staged(kt + 2);  // its tap-table read lands long before phase 2 needs it
-        // The piece of each phase is issued in its read section, before the counted wait: four pieces stay in flight.
-        // Measured and dropped (same process, same device): issuing the DMA from inside the MFMA cluster (-5 %); a 4-byte
-        // DMA per K tile that warms L2 with the next channel chunk's input lines (-3..5 %).
-        read_b(fb0, rb + 1 * kPiece);
-        __builtin_amdgcn_sched_barrier(0);
-        read_a(rb + 0 * kPiece);
-        stage_b(ob + 2 * kPiece, 1, scur);
-        RV_WAIT_PIECES(8);
-        RV_PHASE_COMPUTE(0, 0, fb0, (void)0);
-        read_b(fb1, rb + 2 * kPiece);
-        stage_a(ob + 3 * kPiece, 1, scur);
-        RV_WAIT_PIECES(8);
-        RV_PHASE_COMPUTE(0, 1, fb1, (void)0);
-        scur = snext;
-        read_a(rb + 3 * kPiece);
-        stage_a(rb + 0 * kPiece, 0, scur);
-        RV_PHASE_COMPUTE(1, 1, fb1, (void)0);
-        stage_b(rb + 1 * kPiece, 0, scur);
-        RV_WAIT_PIECES(8);
-        RV_PHASE_COMPUTE(1, 0, fb0, (void)0);
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int rb = (kt & 1) * kBuf, ob = kBuf - rb;
+            const Staged snext = make_staged(kt + 2);  // its tap-table read lands long before phase 2 needs it
+            // The piece of each phase is issued in its read section, before the counted wait: four pieces stay in flight.
+            // Measured and dropped (same process, same device): issuing the DMA from inside the MFMA cluster (-5 %); a 4-byte
+            // DMA per K tile that warms L2 with the next channel chunk's input lines (-3..5 %).
+            read_b(fb0, rb + 1 * kPiece);
+            __builtin_amdgcn_sched_barrier(0);
+            read_a(rb + 0 * kPiece);
+            stage_b(ob + 2 * kPiece, 1, scur);
+            RV_WAIT_PIECES(8);
+            RV_PHASE_COMPUTE(0, 0, fb0, (void)0);
+            read_b(fb1, rb + 2 * kPiece);
+            stage_a(ob + 3 * kPiece, 1, scur);
+            RV_WAIT_PIECES(8);
+            RV_PHASE_COMPUTE(0, 1, fb1, (void)0);
+            scur = snext;
+            read_a(rb + 3 * kPiece);
+            stage_a(rb + 0 * kPiece, 0, scur);
+            RV_PHASE_COMPUTE(1, 1, fb1, (void)0);
+            stage_b(rb + 1 * kPiece, 0, scur);
+            RV_WAIT_PIECES(8);
+            RV_PHASE_COMPUTE(1, 0, fb0, (void)0);
+        }
+    } else {
+        // BN = 128: a K tile is THREE pieces (input rows {0,2}, weights, input rows {1,3}; 48 KB) and two phases; the
+        // ring holds three K tiles.  Phase 0 of K tile kt issues A0 and B of kt+2 (their regions of that buffer were last
+        // read two phases earlier), phase 1 issues A1 of kt+2; the waits leave 10 / 8 DMA instructions in flight.
+        constexpr int kBuf3 = 3 * kPiece;
+        Staged scur = make_staged(0);
+        stage_a(0 * kPiece, 0, scur);
+        stage_b(1 * kPiece, 0, scur);
+        stage_a(2 * kPiece, 1, scur);
+        scur = make_staged(1);
+        stage_a(kBuf3 + 0 * kPiece, 0, scur);
+        stage_b(kBuf3 + 1 * kPiece, 0, scur);
+        stage_a(kBuf3 + 2 * kPiece, 1, scur);
+        RV_WAIT_PIECES(8);  // A0(0), B(0) landed
+        __builtin_amdgcn_s_barrier();
+        if (wr == 1) __builtin_amdgcn_s_barrier();
+        int rb = 0, sb = 2 * kBuf3;  // buffers of K tile kt and kt+2
+        for (int kt = 0; kt < nkt; ++kt) {
+            scur = make_staged(kt + 2);
+            read_b(fb0, rb + 1 * kPiece);
+            __builtin_amdgcn_sched_barrier(0);
+            read_a(rb + 0 * kPiece);
+            stage_a(sb + 0 * kPiece, 0, scur);
+            stage_b(sb + 1 * kPiece, 0, scur);
+            RV_WAIT_PIECES(10);  // A1(kt) landed
+            RV_PHASE_COMPUTE(0, 0, fb0, (void)0);
+            read_a(rb + 2 * kPiece);
+            stage_a(sb + 2 * kPiece, 1, scur);
+            RV_WAIT_PIECES(8);  // A0(kt+1), B(kt+1) landed
+            RV_PHASE_COMPUTE(1, 0, fb0, (void)0);
+            rb = (rb == 2 * kBuf3) ? 0 : rb + kBuf3;
+            sb = (sb == 2 * kBuf3) ? 0 : sb + kBuf3;
+        }
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -222,7 +259,8 @@ __global__ __launch_bounds__(512, 2) void tapconv4_kernel(const TapConvArgs a) {
 #undef RV_WAIT_PIECES
 
     // ------------------------------------ epilogue --------------------------------------------
-    // acc[mq*4+i][nq*2+jj][r]: tile row 2*wr + mq, column i*16 + lg*4 + r, channel n0 + wc*64 + nq*32 + jj*16 + l15
+    // acc[mq*4+i][j][r]: tile row 2*wr + mq, column i*16 + lg*4 + r, channel n0 + wc*(BN/4) + j*16 + l15
+    constexpr int WN = BN / 4;
     const int Wm = a.W_dst / a.phases;
 #pragma unroll
     for (int mq = 0; mq < 2; ++mq) {
@@ -234,14 +272,14 @@ __global__ __launch_bounds__(512, 2) void tapconv4_kernel(const TapConvArgs a) {
                 const int m = m0 + i * 16 + lg * 4 + r;
                 if (m >= Wm || !row_ok) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[mq * 4 + i][j][r] = 0.f;
+                    for (int j = 0; j < NJ; ++j) acc[mq * 4 + i][j][r] = 0.f;
                 }
             }
     }
     if (a.flags & RV_OUT_STATS) {
         float* prow = a.stats + ((int64_t)(tile * 2 + wr) * 2) * a.C_dst;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             float s = 0.f, q = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i)
@@ -255,7 +293,7 @@ __global__ __launch_bounds__(512, 2) void tapconv4_kernel(const TapConvArgs a) {
             q += __shfl_xor(q, 16, 64);
             s += __shfl_xor(s, 32, 64);
             q += __shfl_xor(q, 32, 64);
-            const int c = n0 + wc * 64 + j * 16 + l15;
+            const int c = n0 + wc * WN + j * 16 + l15;
             if (lg == 0) {
                 prow[c] = s;
                 prow[a.C_dst + c] = q;
@@ -264,30 +302,28 @@ __global__ __launch_bounds__(512, 2) void tapconv4_kernel(const TapConvArgs a) {
     }
     if (a.flags & RV_OUT_BIAS) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float b = a.bias[n0 + wc * 64 + j * 16 + l15];
+        for (int j = 0; j < NJ; ++j) {
+            const float b = a.bias[n0 + wc * WN + j * 16 + l15];
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][j][r] += b;
         }
     }
-    if (a.flags & (1 << 30)) return;  // timing experiment: no output
-    constexpr int kEpi = kBN4 + 8;
+    constexpr int kEpi = BN + 8;
     bf16_t* epi = (bf16_t*)smem;  // [4 rows * 64 cols][kEpi]
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int pm = (2 * wr + (i >> 2)) * kTC + (i & 3) * 16 + lg * 4 + r;
-                const int pc = wc * 64 + j * 16 + l15;
+                const int pc = wc * WN + j * 16 + l15;
                 epi[pm * kEpi + pc] = f2bf(acc[i][j][r]);
             }
     __syncthreads();
-    if (a.flags & (1 << 29)) return;  // timing experiment: no global stores
-    constexpr int kChunks = kBN4 / 8;
+    constexpr int kChunks = BN / 8;
     const bool accum = a.flags & RV_OUT_ACCUM;
     for (int q = tid; q < kTR * kTC * kChunks; q += 512) {
         const int pm = q / kChunks, c8 = q - pm * kChunks;
@@ -308,10 +344,11 @@ __global__ __launch_bounds__(512, 2) void tapconv4_kernel(const TapConvArgs a) {
 }  // namespace
 
 // returns false when the layer is not eligible (caller falls back to tapconv3 / tapconv2 / the generic kernel)
-bool rv_tapconv4_plan(TapConvArgs* a, int* tiles, size_t* lds) {
+bool rv_tapconv4_plan(TapConvArgs* a, int* tiles, size_t* lds, int* bn) {
     if (a->step != 1) return false;
     if (a->flags & (RV_IN_AFFINE | RV_IN_RELU | RV_OUT_F32)) return false;  // the DMA path has no register prologue
-    if (a->C_src % kBK != 0 || a->C_dst % kBN4 != 0) return false;
+    if (a->C_src % kBK != 0 || a->C_dst % 128 != 0) return false;
+    const int BN = (a->C_dst % 256 == 0) ? 256 : 128;
     const int wm_total = a->W_dst / a->phases;
     if (wm_total < kTC || a->H < kTR) return false;
     for (int r = 0; r < a->phases; ++r)
@@ -320,23 +357,28 @@ bool rv_tapconv4_plan(TapConvArgs* a, int* tiles, size_t* lds) {
     a->m_tiles = rv_ceil_div(wm_total, kTC);
     a->h_tiles = rv_ceil_div(a->H, kTR);
     a->total_tiles = a->m_tiles * a->h_tiles * a->N * a->phases;
-    a->n_tiles = a->C_dst / kBN4;
+    a->n_tiles = a->C_dst / BN;
     a->tiles_per_xcd = rv_ceil_div(a->total_tiles, 8);
     if ((int64_t)a->total_tiles * a->n_tiles < 256) return false;  // too few tiles to fill the chip
     *tiles = a->total_tiles;  // stats rows = 2 * tiles
-    *lds = (size_t)kTabOffset + 256;
-    const size_t epi = (size_t)kTR * kTC * (kBN4 + 8) * sizeof(bf16_t);
+    *bn = BN;
+    *lds = (size_t)(BN == 256 ? kTabOffset : 9 * kPiece) + 256;
+    const size_t epi = (size_t)kTR * kTC * (BN + 8) * sizeof(bf16_t);
     if (*lds < epi) *lds = epi;
     return true;
 }
 
-int rv_tapconv4_launch(const TapConvArgs& a, size_t lds, hipStream_t stream) {
+int rv_tapconv4_launch(const TapConvArgs& a, size_t lds, int bn, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)tapconv4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)tapconv4_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)tapconv4_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(tapconv4_kernel, dim3(8 * a.tiles_per_xcd * a.n_tiles), dim3(512), lds, stream, a);
+    if (bn == 256)
+        hipLaunchKernelGGL(tapconv4_kernel<256>, dim3(8 * a.tiles_per_xcd * a.n_tiles), dim3(512), lds, stream, a);
+    else
+        hipLaunchKernelGGL(tapconv4_kernel<128>, dim3(8 * a.tiles_per_xcd * a.n_tiles), dim3(512), lds, stream, a);
     RV_CHECK_LAUNCH("tapconv4_kernel");
     return 0;
 }

@@ -691,7 +691,7 @@ extern "C" int rv_tap_wgrad(const rvTapGeom* g, const rvTapShape* s, const void*
         b.tiles_v = p.tiles_v;
         b.flags = s->flags;
         b.v_affine = v_affine;
-        b.xcd_remap = getenv("RV3D_NO_WGRAD_XCD") == nullptr;
+        b.xcd_remap = 1;
         int gi = 0;
         for (int ky = 0; ky < g->kh; ++ky)
             for (int kx = 0; kx < g->kw; ++kx) {

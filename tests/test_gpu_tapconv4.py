@@ -39,12 +39,14 @@ def _run(module, x, stats=False, expect_kernel=4):
 
 @pytest.mark.parametrize("cin,cout,N,H,W,bias", [(64, 256, 4, 30, 520, False),   # ragged rows and columns, one channel tile
                                                  (128, 512, 2, 64, 256, True),   # two channel tiles, two K chunks, bias
-                                                 (192, 256, 4, 17, 1030, False)])  # three K chunks, one-row last tile
+                                                 (192, 256, 4, 17, 1030, False),  # three K chunks, one-row last tile
+                                                 (64, 128, 4, 30, 520, False),    # 128-channel variant (three-piece K tiles)
+                                                 (128, 384, 3, 32, 300, True)])   # 128-channel variant, three channel tiles, bias
 def test_gather_3x3_exact(cin, cout, N, H, W, bias):
     _gather_exact(cin, cout, 3, N, H, W, bias)
 
 
-@pytest.mark.parametrize("cin,cout,N,H,W", [(256, 256, 4, 32, 520), (64, 512, 2, 64, 300), (576, 256, 2, 33, 1000)])
+@pytest.mark.parametrize("cin,cout,N,H,W", [(256, 256, 4, 32, 520), (64, 512, 2, 64, 300), (576, 256, 2, 33, 1000), (128, 128, 4, 32, 520)])
 def test_gather_1x1_exact(cin, cout, N, H, W):
     _gather_exact(cin, cout, 1, N, H, W, False)
 
@@ -65,11 +67,11 @@ def _gather_exact(cin, cout, k, N, H, W, bias):
         assert torch.allclose(rows[1, :cout], (ref.double() ** 2).sum(dim=(0, 2, 3)), rtol=1e-5)
 
 
-@pytest.mark.parametrize("kernel,stride,padding,N,H,W", [((3, 4), (1, 2), (1, 1), 4, 16, 512), ((3, 8), (1, 4), (1, 2), 4, 16, 256),
-                                                         ((3, 4), (1, 2), (1, 1), 3, 21, 600)])
-def test_scatter_conv_transpose_exact(kernel, stride, padding, N, H, W):
+@pytest.mark.parametrize("kernel,stride,padding,N,H,W,cout", [((3, 4), (1, 2), (1, 1), 4, 16, 512, 256), ((3, 8), (1, 4), (1, 2), 4, 16, 256, 256),
+                                                              ((3, 4), (1, 2), (1, 1), 3, 21, 600, 256), ((3, 8), (1, 4), (1, 2), 4, 16, 300, 128)])
+def test_scatter_conv_transpose_exact(kernel, stride, padding, N, H, W, cout):
     g = torch.Generator().manual_seed(W)
-    m = torch.nn.ConvTranspose2d(64, 256, kernel_size=kernel, stride=stride, padding=padding, bias=False)
+    m = torch.nn.ConvTranspose2d(64, cout, kernel_size=kernel, stride=stride, padding=padding, bias=False)
     m.weight.data = _ints(m.weight.shape, g, -2, 3)
     x = _ints((N, 64, H, W), g)
     ref = F.conv_transpose2d(x, m.weight.data, stride=stride, padding=padding)
@@ -77,14 +79,15 @@ def test_scatter_conv_transpose_exact(kernel, stride, padding, N, H, W):
     assert torch.equal(out.cpu(), ref.bfloat16().float())
 
 
-def test_input_gradient_and_accumulate_exact():
+@pytest.mark.parametrize("cin", [256, 128])
+def test_input_gradient_and_accumulate_exact(cin):
     """Backward-data of a 3x3 conv is the scatter form with one phase (plain bf16 gradient in => this kernel), once into a
     fresh buffer and once accumulating into an existing gradient (RV_OUT_ACCUM: bf16(bf16(conv) + old))."""
     from range_view_3d_detection_amd import _lib as L
     from range_view_3d_detection_amd import engine as E
 
     g = torch.Generator().manual_seed(5)
-    N, H, W, cin, cout = 4, 32, 512, 256, 64
+    N, H, W, cout = 4, 32, 512, 64
     m = torch.nn.Conv2d(cin, cout, 3, padding=1, bias=False)
     m.weight.data = _ints(m.weight.shape, g, -2, 3)
     dy = _ints((N, cout, H, W), g)

@@ -43,7 +43,7 @@ def test_host_side_geometry(lib):
     s = lib.TapShape(4, 64, 2048, 2048, 256, 256, lib.OUT_STATS)
     info = (ctypes.c_int32 * 4)()
     assert h.rv_tap_launch_info(ctypes.byref(g), ctypes.byref(s), 0, info) == 0
-    assert list(info) == [4, 0, 32 * 16 * 4, 1]  # tapconv4: (4 rows x 64 cols) pixel tiles x one 256-channel tile
+    assert list(info) == [4, 256, 32 * 16 * 4, 1]  # tapconv4<256>: (4 rows x 64 cols) pixel tiles x one 256-channel tile
     assert h.rv_tap_stats_rows(ctypes.byref(g), ctypes.byref(s), 0) == 2 * 32 * 16 * 4
     # a folded BatchNorm on the way in needs the register-staged kernel
     s_aff = lib.TapShape(4, 64, 2048, 2048, 256, 256, lib.OUT_STATS | lib.IN_AFFINE | lib.IN_RELU)
