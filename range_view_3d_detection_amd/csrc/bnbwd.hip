@@ -5,6 +5,8 @@
 //
 // Replaces cuDNN batch-norm backward + ReLU backward + add backward of
 // nn/blocks/__init__.py:41-51,63,78-81,158-180 (and the Conv2dNormActivation triples).
+#include <stdlib.h>
+
 #include "common.h"
 
 int rv_col_reduce(const float* partial, int rows, int cols, double* scratch, int* groups, hipStream_t st);
@@ -160,6 +162,50 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* red,
     coef[2 * c + ch] = (float)(s1 * inv_count);
 }
 
+// single-launch variant of col_reduce + finalize (see bn_reduce_finalize_kernel in misc.hip)
+__global__ __launch_bounds__(1024) void bn_bwd_reduce_finalize_kernel(const float* partial, int rows, int c, double inv_count, const float* gamma,
+                                                                      const float* invstd, float* dgamma, float* dbeta, int accumulate,
+                                                                      float* coef) {
+    __shared__ double red[2][64][17];
+    const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int ch = blockIdx.x * 16 + cx;
+    double s0 = 0.0, s1 = 0.0;
+    if (ch < c) {
+        const float* p = partial + ch;
+        int r = ry;
+        for (; r + 192 < rows; r += 256) {
+            const float a0 = p[(int64_t)r * 2 * c], b0 = p[(int64_t)r * 2 * c + c];
+            const float a1 = p[(int64_t)(r + 64) * 2 * c], b1 = p[(int64_t)(r + 64) * 2 * c + c];
+            const float a2 = p[(int64_t)(r + 128) * 2 * c], b2 = p[(int64_t)(r + 128) * 2 * c + c];
+            const float a3 = p[(int64_t)(r + 192) * 2 * c], b3 = p[(int64_t)(r + 192) * 2 * c + c];
+            s0 += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+            s1 += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+        }
+        for (; r < rows; r += 64) {
+            s0 += (double)p[(int64_t)r * 2 * c];
+            s1 += (double)p[(int64_t)r * 2 * c + c];
+        }
+    }
+    red[0][ry][cx] = s0;
+    red[1][ry][cx] = s1;
+    __syncthreads();
+    for (int half = 32; half > 0; half >>= 1) {
+        if (ry < half) {
+            red[0][ry][cx] += red[0][ry + half][cx];
+            red[1][ry][cx] += red[1][ry + half][cx];
+        }
+        __syncthreads();
+    }
+    if (ry != 0 || ch >= c) return;
+    s0 = red[0][0][cx];
+    s1 = red[1][0][cx];
+    if (dgamma) dgamma[ch] = (float)((accumulate ? (double)dgamma[ch] : 0.0) + s1);
+    if (dbeta) dbeta[ch] = (float)((accumulate ? (double)dbeta[ch] : 0.0) + s0);
+    coef[ch] = gamma[ch] * invstd[ch];
+    coef[c + ch] = (float)(s0 * inv_count);
+    coef[2 * c + ch] = (float)(s1 * inv_count);
+}
+
 __device__ __forceinline__ void apply_px(const BnbArgs& a, int64_t px, int c0, const BnbLoad& r, const u32x4 old,
                                          const float* sc, const float* sh, const float* mu, const float* is,
                                          const float* k0, const float* k1, const float* k2) {
@@ -291,6 +337,12 @@ extern "C" int rv_bn_bwd_finalize(const float* partial, int32_t rows, int32_t c,
                                   const float* invstd, float* dgamma, float* dbeta, int32_t accumulate, float* coef,
                                   rvStream stream) {
     RV_REQUIRE(partial && gamma && invstd && coef, "rv_bn_bwd_finalize: null argument");
+    if (getenv("RV3D_NO_FUSED_FINALIZE") == nullptr) {
+        hipLaunchKernelGGL(bn_bwd_reduce_finalize_kernel, dim3(rv_ceil_div(c, 16)), dim3(1024), 0, (hipStream_t)stream, partial, rows, c,
+                           1.0 / (double)count, gamma, invstd, dgamma, dbeta, accumulate, coef);
+        RV_CHECK_LAUNCH("bn_bwd_reduce_finalize_kernel");
+        return 0;
+    }
     double* scratch = (double*)(partial + (int64_t)rows * 2 * c);
     int groups;
     if (rv_col_reduce(partial, rows, 2 * c, scratch, &groups, (hipStream_t)stream)) return 1;

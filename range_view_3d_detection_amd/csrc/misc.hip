@@ -2,6 +2,8 @@
 // layout conversion kernels (all HBM-bound byte movers: coalesced 16-byte accesses, no MFMA).
 #include <stdarg.h>
 
+#include <stdlib.h>
+
 #include "common.h"
 #include "tapconv.h"
 
@@ -179,6 +181,58 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* red, int
     if (running_var) running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * var * unbias);
 }
 
+// One launch instead of col_reduce + finalize: a block of 1024 threads = 16 channels x 64 row lanes sums the partial rows
+// of its channels in fp64 (64-byte row segments, 128 loads in flight per thread pair), then finalises them.
+__global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const float* partial, int rows, int c, double inv_count, double unbias,
+                                                                  const float* gamma, const float* beta, float eps, float momentum,
+                                                                  float* running_mean, float* running_var, float* scale, float* shift,
+                                                                  float* mean_out, float* invstd_out) {
+    __shared__ double red[2][64][17];
+    const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int ch = blockIdx.x * 16 + cx;
+    double s = 0.0, q = 0.0;
+    if (ch < c) {
+        const float* p = partial + ch;
+        int r = ry;
+        for (; r + 192 < rows; r += 256) {  // four independent row pairs per iteration
+            const float a0 = p[(int64_t)r * 2 * c], b0 = p[(int64_t)r * 2 * c + c];
+            const float a1 = p[(int64_t)(r + 64) * 2 * c], b1 = p[(int64_t)(r + 64) * 2 * c + c];
+            const float a2 = p[(int64_t)(r + 128) * 2 * c], b2 = p[(int64_t)(r + 128) * 2 * c + c];
+            const float a3 = p[(int64_t)(r + 192) * 2 * c], b3 = p[(int64_t)(r + 192) * 2 * c + c];
+            s += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+            q += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+        }
+        for (; r < rows; r += 64) {
+            s += (double)p[(int64_t)r * 2 * c];
+            q += (double)p[(int64_t)r * 2 * c + c];
+        }
+    }
+    red[0][ry][cx] = s;
+    red[1][ry][cx] = q;
+    __syncthreads();
+    for (int half = 32; half > 0; half >>= 1) {
+        if (ry < half) {
+            red[0][ry][cx] += red[0][ry + half][cx];
+            red[1][ry][cx] += red[1][ry + half][cx];
+        }
+        __syncthreads();
+    }
+    if (ry != 0 || ch >= c) return;
+    s = red[0][0][cx];
+    q = red[1][0][cx];
+    const double mean = s * inv_count;
+    double var = q * inv_count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    const double sc = (double)gamma[ch] * invstd;
+    scale[ch] = (float)sc;
+    shift[ch] = (float)((double)beta[ch] - mean * sc);
+    if (mean_out) mean_out[ch] = (float)mean;
+    if (invstd_out) invstd_out[ch] = (float)invstd;
+    if (running_mean) running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * mean);
+    if (running_var) running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * var * unbias);
+}
+
 __global__ void bn_fold_eval_kernel(int c, const float* gamma, const float* beta, const float* rm, const float* rv,
                                     float eps, float* scale, float* shift) {
     const int ch = blockIdx.x * blockDim.x + threadIdx.x;
@@ -206,10 +260,16 @@ extern "C" int rv_bn_finalize(const float* partial, int32_t rows, int32_t c, int
                               float* scale, float* shift, float* mean, float* invstd, rvStream stream) {
     RV_REQUIRE(partial && gamma && beta && scale && shift, "rv_bn_finalize: null argument");
     RV_REQUIRE(rows > 0 && c > 0 && count > 0, "rv_bn_finalize: empty reduction");
+    const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
+    if (getenv("RV3D_NO_FUSED_FINALIZE") == nullptr) {
+        hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3(rv_ceil_div(c, 16)), dim3(1024), 0, (hipStream_t)stream, partial, rows, c,
+                           1.0 / (double)count, unbias, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, invstd);
+        RV_CHECK_LAUNCH("bn_reduce_finalize_kernel");
+        return 0;
+    }
     double* scratch = (double*)(partial + (int64_t)rows * 2 * c);
     int groups;
     if (rv_col_reduce(partial, rows, 2 * c, scratch, &groups, (hipStream_t)stream)) return 1;
-    const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(rv_ceil_div(c, 64)), dim3(256), 0, (hipStream_t)stream, scratch, groups, c,
                        1.0 / (double)count, unbias, gamma, beta, eps, momentum, running_mean, running_var, scale, shift,
                        mean, invstd);
