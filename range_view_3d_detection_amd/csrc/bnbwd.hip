@@ -337,7 +337,7 @@ extern "C" int rv_bn_bwd_finalize(const float* partial, int32_t rows, int32_t c,
                                   const float* invstd, float* dgamma, float* dbeta, int32_t accumulate, float* coef,
                                   rvStream stream) {
     RV_REQUIRE(partial && gamma && invstd && coef, "rv_bn_bwd_finalize: null argument");
-    if (getenv("RV3D_NO_FUSED_FINALIZE") == nullptr) {
+    if (rows <= 1024 && getenv("RV3D_NO_FUSED_FINALIZE") == nullptr) {
         hipLaunchKernelGGL(bn_bwd_reduce_finalize_kernel, dim3(rv_ceil_div(c, 16)), dim3(1024), 0, (hipStream_t)stream, partial, rows, c,
                            1.0 / (double)count, gamma, invstd, dgamma, dbeta, accumulate, coef);
         RV_CHECK_LAUNCH("bn_bwd_reduce_finalize_kernel");

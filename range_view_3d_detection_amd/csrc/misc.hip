@@ -261,7 +261,9 @@ extern "C" int rv_bn_finalize(const float* partial, int32_t rows, int32_t c, int
     RV_REQUIRE(partial && gamma && beta && scale && shift, "rv_bn_finalize: null argument");
     RV_REQUIRE(rows > 0 && c > 0 && count > 0, "rv_bn_finalize: empty reduction");
     const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
-    if (getenv("RV3D_NO_FUSED_FINALIZE") == nullptr) {
+    // few partial rows: one launch reduces and finalises; many (4096 rows behind a 512-channel tapconv4 launch): the
+    // 64-group column reduction spreads them over the chip first (29 us vs 14 us measured for the single launch)
+    if (rows <= 1024 && getenv("RV3D_NO_FUSED_FINALIZE") == nullptr) {
         hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3(rv_ceil_div(c, 16)), dim3(1024), 0, (hipStream_t)stream, partial, rows, c,
                            1.0 / (double)count, unbias, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, invstd);
         RV_CHECK_LAUNCH("bn_reduce_finalize_kernel");
