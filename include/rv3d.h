@@ -180,6 +180,16 @@ int rv_bn_bwd_apply(int64_t pixels, int32_t c, const void* dout, int32_t ld_dout
                     const void* y, int32_t ld_y, const float* scale, const float* shift, const float* mean,
                     const float* invstd, const float* coef, int32_t flags, void* dy, int32_t ld_dy, void* dres,
                     int32_t ld_dres, rvStream stream);
+/* Small-K layers whose input needs no gradient (1x1 conv with cin <= 8 followed by BatchNorm: the stem's 3 -> C positional
+ * conv, the 5/6 -> C feature projections): BatchNorm backward AND the conv's weight gradient from one pass over
+ * (dOut, y, v) -- dy is never written.  v = the conv input (bf16 NHWC, >= 8 stored channels), w_packed = the layer's packed
+ * gather image (bf16 [c][ld_w]); dW is fp32 [c][cin].  Replaces cuDNN BatchNorm backward + conv2d backward-weight. */
+int64_t rv_bn_bwd_smallk_workspace_bytes(int64_t pixels, int32_t c, int32_t cin);
+int rv_bn_bwd_smallk(int64_t pixels, int32_t c, const void* dout, int32_t ld_dout, const void* out, int32_t ld_out,
+                     const void* y, int32_t ld_y, const float* scale, const float* shift, const float* mean,
+                     const float* invstd, int32_t flags, const void* v, int32_t ld_v, int32_t cin, const void* w_packed,
+                     int32_t ld_w, const float* gamma, int64_t count, float* dgamma, float* dbeta, float* dW,
+                     void* workspace, rvStream stream);
 /* gradient of rv_ew_combine's plain (non-BN) inputs: d (+)= dOut * [OUT > 0 if out != NULL] */
 int rv_ew_mask_grad(int64_t pixels, int32_t c, const void* dout, int32_t ld_dout, const void* out, int32_t ld_out,
                     void* d, int32_t ld_d, int32_t accumulate, rvStream stream);

@@ -289,6 +289,152 @@ __global__ __launch_bounds__(256) void ew_mask_grad_kernel(int64_t pixels, int c
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Small-K layers without an input gradient (the stem's 3 -> C positional conv on the 9x unfolded grid, the 5 -> C
+// feature projections): BatchNorm backward AND the 1x1 conv's weight gradient from ONE pass over (dOut, y, v).
+//   dy = k0 (g - S0/n - xhat S1/n),  k0 = gamma*invstd,  S0 = sum g,  S1 = sum g*xhat
+//   dW[c][d] = sum_p dy[p,c] v[p,d]
+//            = k0 ( R[c][d] - (S0/n) m1[d] - (S1/n) invstd_c ( sum_e W[c,e] M2[e][d] - mean_c m1[d] ) )
+// with R[c][d] = sum_p g[p,c] v[p,d] and the data moments m1 = sum_p v, M2 = sum_p v v^T (y = W v is linear in v).
+// So dy is never written (2.4 GB on the stem) and the separate apply and weight-gradient passes disappear.
+// ---------------------------------------------------------------------------------------------
+template <int CIN>
+__global__ __launch_bounds__(256) void bn_bwd_smallk_reduce_kernel(const BnbArgs a, const bf16_t* v, int ld_v) {
+    __shared__ float red[256][9];
+    const int tid = threadIdx.x;
+    const int lanes_px = 256 / a.c8;
+    const int oct = tid % a.c8, pl = tid / a.c8;
+    const bool active = pl < lanes_px;
+    const int c0 = oct * 8;
+    float sc[8], sh[8], mu[8], is[8], s0[8], s1[8], r[CIN][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        sc[j] = a.scale[c0 + j];
+        sh[j] = a.shift[c0 + j];
+        mu[j] = a.mean[c0 + j];
+        is[j] = a.invstd[c0 + j];
+        s0[j] = 0.f;
+        s1[j] = 0.f;
+#pragma unroll
+        for (int d = 0; d < CIN; ++d) r[d][j] = 0.f;
+    }
+    const int64_t p0 = (int64_t)blockIdx.x * kPixPerBlock;
+    const int64_t p1 = p0 + kPixPerBlock < a.pixels ? p0 + kPixPerBlock : a.pixels;
+    if (active) {
+        int64_t px = p0 + pl;
+        for (; px + lanes_px < p1; px += 2 * lanes_px) {
+            const BnbLoad l0 = load_px(a, px, c0), l1 = load_px(a, px + lanes_px, c0);
+            const u32x4 w0 = *(const u32x4*)(v + px * ld_v), w1 = *(const u32x4*)(v + (px + lanes_px) * ld_v);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float g[8], xh[8], vv[8];
+                masked_grad(a, u ? l1 : l0, sc, sh, mu, is, g, xh);
+                unpack8(u ? w1 : w0, vv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    s0[j] += g[j];
+                    s1[j] += g[j] * xh[j];
+#pragma unroll
+                    for (int d = 0; d < CIN; ++d) r[d][j] += g[j] * vv[d];
+                }
+            }
+        }
+        for (; px < p1; px += lanes_px) {
+            float g[8], xh[8], vv[8];
+            masked_grad(a, load_px(a, px, c0), sc, sh, mu, is, g, xh);
+            unpack8(*(const u32x4*)(v + px * ld_v), vv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                s0[j] += g[j];
+                s1[j] += g[j] * xh[j];
+#pragma unroll
+                for (int d = 0; d < CIN; ++d) r[d][j] += g[j] * vv[d];
+            }
+        }
+    }
+    // planes 0 (S0), 1 (S1), 2 + d (R[.][d]): block sums over the pixel lanes, one plane at a time through LDS
+    for (int plane = 0; plane < 2 + CIN; ++plane) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float val = plane == 0 ? s0[j] : (plane == 1 ? s1[j] : 0.f);
+#pragma unroll
+            for (int d = 0; d < CIN; ++d)
+                if (plane == 2 + d) val = r[d][j];
+            red[tid][j] = val;
+        }
+        __syncthreads();
+        for (int i = tid; i < a.c8 * 8; i += 256) {
+            const int o = i >> 3, j = i & 7;
+            float s = 0.f;
+            for (int l = 0; l < lanes_px; ++l) s += red[l * a.c8 + o][j];
+            a.partial[((int64_t)blockIdx.x * (2 + CIN) + plane) * a.c + o * 8 + j] = s;
+        }
+        __syncthreads();
+    }
+}
+
+// data moments of the conv input: per block one row of CIN + CIN*CIN sums (m1, M2 row-major)
+template <int CIN>
+__global__ __launch_bounds__(256) void smallk_moments_kernel(const bf16_t* v, int ld_v, int64_t pixels, float* partial) {
+    __shared__ float red[256];
+    float m[CIN + CIN * CIN];
+#pragma unroll
+    for (int i = 0; i < CIN + CIN * CIN; ++i) m[i] = 0.f;
+    const int64_t per = (pixels + gridDim.x - 1) / gridDim.x;
+    const int64_t p0 = blockIdx.x * per, p1 = p0 + per < pixels ? p0 + per : pixels;
+    for (int64_t px = p0 + threadIdx.x; px < p1; px += 256) {
+        float vv[8];
+        unpack8(*(const u32x4*)(v + px * ld_v), vv);
+#pragma unroll
+        for (int d = 0; d < CIN; ++d) {
+            m[d] += vv[d];
+#pragma unroll
+            for (int e = 0; e < CIN; ++e) m[CIN + d * CIN + e] += vv[d] * vv[e];
+        }
+    }
+    for (int i = 0; i < CIN + CIN * CIN; ++i) {
+        red[threadIdx.x] = m[i];
+        __syncthreads();
+        for (int h = 128; h > 0; h >>= 1) {
+            if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * (CIN + CIN * CIN) + i] = red[0];
+        __syncthreads();
+    }
+}
+
+// red_g: [groups][(2+CIN)*c] fp64, red_m: [groups_m][CIN+CIN*CIN] fp64, w: bf16 [c][ld_w] (the packed gather image)
+template <int CIN>
+__global__ void bn_bwd_smallk_finalize_kernel(const double* red_g, int groups, const double* red_m, int groups_m, int c, int cin,
+                                              double inv_count, const float* gamma, const float* mean, const float* invstd,
+                                              const bf16_t* w, int ld_w, float* dgamma, float* dbeta, float* dW) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    double S[2 + CIN];
+    for (int p = 0; p < 2 + CIN; ++p) {
+        double s = 0.0;
+        for (int g = 0; g < groups; ++g) s += red_g[(int64_t)g * (2 + CIN) * c + (int64_t)p * c + ch];
+        S[p] = s;
+    }
+    double m[CIN + CIN * CIN];
+    for (int i = 0; i < CIN + CIN * CIN; ++i) {
+        double s = 0.0;
+        for (int g = 0; g < groups_m; ++g) s += red_m[(int64_t)g * (CIN + CIN * CIN) + i];
+        m[i] = s;
+    }
+    dbeta[ch] = (float)S[0];
+    dgamma[ch] = (float)S[1];
+    const double k0 = (double)gamma[ch] * (double)invstd[ch];
+    const double k1 = S[0] * inv_count, k2 = S[1] * inv_count;
+    for (int d = 0; d < cin; ++d) {
+        double ym = 0.0;  // sum_p y[p,ch] v[p,d] = sum_e W[ch,e] M2[e][d]
+        for (int e = 0; e < cin; ++e) ym += (double)bf2f(w[(int64_t)ch * ld_w + e]) * m[CIN + e * CIN + d];
+        const double xv = (double)invstd[ch] * (ym - (double)mean[ch] * m[d]);
+        dW[(int64_t)ch * cin + d] = (float)(k0 * (S[2 + d] - k1 * m[d] - k2 * xv));
+    }
+}
+
 int grid_for(int64_t work) {
     int64_t b = (work + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -379,5 +525,52 @@ extern "C" int rv_ew_mask_grad(int64_t pixels, int32_t c, const void* dout, int3
     hipLaunchKernelGGL(ew_mask_grad_kernel, dim3(grid_for(pixels * (c / 8))), dim3(256), 0, (hipStream_t)stream, pixels,
                        c / 8, (const bf16_t*)dout, ld_dout, (const bf16_t*)out, ld_out, (bf16_t*)d, ld_d, accumulate);
     RV_CHECK_LAUNCH("ew_mask_grad_kernel");
+    return 0;
+}
+
+extern "C" int64_t rv_bn_bwd_smallk_workspace_bytes(int64_t pixels, int32_t c, int32_t cin) {
+    const int CIN = cin <= 4 ? 4 : 8;
+    const int64_t rows = rv_bn_bwd_rows(pixels);
+    const int64_t planes = 2 + CIN, mcols = CIN + CIN * CIN;
+    // partial rows + fp64 group scratch for both reductions
+    return ((rows + 2 * 64) * planes * c + (1024 + 2 * 64) * mcols) * (int64_t)sizeof(float) + 256;
+}
+
+extern "C" int rv_bn_bwd_smallk(int64_t pixels, int32_t c, const void* dout, int32_t ld_dout, const void* out, int32_t ld_out,
+                                const void* y, int32_t ld_y, const float* scale, const float* shift, const float* mean,
+                                const float* invstd, int32_t flags, const void* v, int32_t ld_v, int32_t cin, const void* w_packed,
+                                int32_t ld_w, const float* gamma, int64_t count, float* dgamma, float* dbeta, float* dW,
+                                void* workspace, rvStream stream) {
+    BnbArgs a;
+    if (fill(&a, pixels, c, dout, ld_dout, out, ld_out, y, ld_y, scale, shift, mean, invstd, flags)) return 1;
+    RV_REQUIRE(v && w_packed && gamma && dgamma && dbeta && dW && workspace, "rv_bn_bwd_smallk: null argument");
+    RV_REQUIRE(cin >= 1 && cin <= 8 && ld_v % 8 == 0 && ld_v >= 8, "rv_bn_bwd_smallk: 1 <= cin <= 8, input rows of at least 8 channels");
+    const int CIN = cin <= 4 ? 4 : 8;
+    const int rows = rv_bn_bwd_rows(pixels), planes = 2 + CIN, mcols = CIN + CIN * CIN;
+    float* part_g = (float*)workspace;
+    double* scr_g = (double*)(part_g + (int64_t)rows * planes * c);
+    float* part_m = (float*)(scr_g + (int64_t)64 * planes * c);
+    const int mblocks = pixels >= 1024 * 256 ? 1024 : (int)((pixels + 255) / 256);
+    double* scr_m = (double*)(part_m + (int64_t)1024 * mcols + ((((int64_t)1024 * mcols) & 1) ? 1 : 0));
+    hipStream_t st = (hipStream_t)stream;
+    a.partial = part_g;
+    if (CIN == 4) {
+        hipLaunchKernelGGL(bn_bwd_smallk_reduce_kernel<4>, dim3(rows), dim3(256), 0, st, a, (const bf16_t*)v, ld_v);
+        hipLaunchKernelGGL(smallk_moments_kernel<4>, dim3(mblocks), dim3(256), 0, st, (const bf16_t*)v, ld_v, pixels, part_m);
+    } else {
+        hipLaunchKernelGGL(bn_bwd_smallk_reduce_kernel<8>, dim3(rows), dim3(256), 0, st, a, (const bf16_t*)v, ld_v);
+        hipLaunchKernelGGL(smallk_moments_kernel<8>, dim3(mblocks), dim3(256), 0, st, (const bf16_t*)v, ld_v, pixels, part_m);
+    }
+    RV_CHECK_LAUNCH("bn_bwd_smallk reduce kernels");
+    int groups_g, groups_m;
+    if (rv_col_reduce(part_g, rows, planes * c, scr_g, &groups_g, st)) return 1;
+    if (rv_col_reduce(part_m, mblocks, mcols, scr_m, &groups_m, st)) return 1;
+    if (CIN == 4)
+        hipLaunchKernelGGL(bn_bwd_smallk_finalize_kernel<4>, dim3(rv_ceil_div(c, 64)), dim3(64), 0, st, scr_g, groups_g, scr_m, groups_m, c, cin,
+                           1.0 / (double)count, gamma, mean, invstd, (const bf16_t*)w_packed, ld_w, dgamma, dbeta, dW);
+    else
+        hipLaunchKernelGGL(bn_bwd_smallk_finalize_kernel<8>, dim3(rv_ceil_div(c, 64)), dim3(64), 0, st, scr_g, groups_g, scr_m, groups_m, c, cin,
+                           1.0 / (double)count, gamma, mean, invstd, (const bf16_t*)w_packed, ld_w, dgamma, dbeta, dW);
+    RV_CHECK_LAUNCH("bn_bwd_smallk_finalize_kernel");
     return 0;
 }

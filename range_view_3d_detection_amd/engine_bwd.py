@@ -120,6 +120,9 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
         run_wgrad()
 
 
+SMALLK_FUSION = os.environ.get("RV3D_NO_SMALLK") is None
+
+
 def bn_backward(op: "E.BnOp", t: Tape) -> None:
     lazy = op.lazy
     entry = t.lazy_in.pop(id(lazy), None)
@@ -131,6 +134,28 @@ def bn_backward(op: "E.BnOp", t: Tape) -> None:
         raise L.RvError("BatchNorm backward needs batch statistics (module was run in eval mode)")
     cp, pixels = raw.cp, raw.pixels
     flags = L.BNB_RELU_Z if lazy.relu else 0
+    conv = op.conv
+    lay, geo = conv.layer, conv.layer.geom
+    if (SMALLK_FUSION and res is None and E._world() == 1 and not conv.need_input_grad and not conv.out_f32 and not isinstance(conv.x, Lazy)
+            and geo.kh == 1 and geo.kw == 1 and geo.stride_w == 1 and lay.fwd_form == "gather" and lay.c_in <= 8 and lay.in_perm is None
+            and lay.bias is None):
+        # 1x1 conv with a handful of input channels and no input gradient (stem): BatchNorm backward and the conv's
+        # weight gradient from one pass over (dOut, y, input) -- neither dy nor a separate wgrad pass (rv_bn_bwd_smallk)
+        v, cin = conv.x, lay.c_in
+        ws = torch.empty(L.load().rv_bn_bwd_smallk_workspace_bytes(L.i64(pixels), L.i32(cp), L.i32(cin)), dtype=torch.uint8, device=t.device)
+        dgamma = torch.empty(cp, dtype=torch.float32, device=t.device)
+        dbeta = torch.empty(cp, dtype=torch.float32, device=t.device)
+        dw = torch.empty((cp, cin), dtype=torch.float32, device=t.device)
+        wp = lay.packed("gather")
+        L.call("rv_bn_bwd_smallk", L.i64(pixels), L.i32(cp), dout.ptr(), L.i32(dout.ld), mask.ptr() if mask is not None else None,
+               L.i32(mask.ld if mask is not None else 0), raw.ptr(), L.i32(raw.ld), L.ptr(st.scale), L.ptr(st.shift), L.ptr(st.mean),
+               L.ptr(st.invstd), L.i32(flags), v.ptr(), L.i32(v.ld), L.i32(cin), L.ptr(wp), L.i32(E.pad32(cin)), L.ptr(op.gamma_p),
+               L.i64(st.count), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dw), L.ptr(ws), L.stream_ptr())
+        c = st.module.num_features
+        t.add_param_grad(st.module.weight, dgamma[:c])
+        t.add_param_grad(st.module.bias, dbeta[:c])
+        t.add_param_grad(lay.weight, lay.unpermute_grad(dw[: lay.c_out].reshape(lay.c_out, cin, 1, 1).contiguous()))
+        return
     rows = L.load().rv_bn_bwd_rows(L.i64(pixels))
     partial = torch.empty((rows + L.STATS_SCRATCH_ROWS, 2, cp), dtype=torch.float32, device=t.device)
     common = (L.i64(pixels), L.i32(cp), dout.ptr(), L.i32(dout.ld), mask.ptr() if mask is not None else None,
