@@ -188,8 +188,32 @@ int64_t rv_bn_bwd_smallk_workspace_bytes(int64_t pixels, int32_t c, int32_t cin)
 int rv_bn_bwd_smallk(int64_t pixels, int32_t c, const void* dout, int32_t ld_dout, const void* out, int32_t ld_out,
                      const void* y, int32_t ld_y, const float* scale, const float* shift, const float* mean,
                      const float* invstd, int32_t flags, const void* v, int32_t ld_v, int32_t cin, const void* w_packed,
-                     int32_t ld_w, const float* gamma, int64_t count, float* dgamma, float* dbeta, float* dW,
-                     void* workspace, rvStream stream);
+                     int32_t ld_w, const float* gamma, const float* stat_mean, const float* stat_invstd, int64_t count,
+                     float* dgamma, float* dbeta, float* dW, void* workspace, rvStream stream);
+/* The same in two phases, for SyncBN: (A) this rank's sums -- sums[(2 + cin_pad) * c] = planes (sum g, sum g*xhat,
+ * sum g*v_d), moms[cin_pad + cin_pad^2] = (sum v, sum v v^T) -- then the caller all-reduces sums[0 : 2c] into global_s01
+ * and (B) forms the gradients (global_s01 == NULL: single rank). */
+int rv_bn_bwd_smallk_sums(int64_t pixels, int32_t c, const void* dout, int32_t ld_dout, const void* out, int32_t ld_out,
+                          const void* y, int32_t ld_y, const float* scale, const float* shift, const float* mean,
+                          const float* invstd, int32_t flags, const void* v, int32_t ld_v, int32_t cin, double* sums,
+                          double* moms, void* workspace, rvStream stream);
+int rv_bn_bwd_smallk_from_sums(int32_t c, int32_t cin, const double* sums, const double* moms, const double* global_s01,
+                               const void* w_packed, int32_t ld_w, const float* gamma, const float* stat_mean,
+                               const float* stat_invstd, int64_t count, float* dgamma, float* dbeta, float* dW,
+                               rvStream stream);
+/* Forward of the same layers: h = relu?(BatchNorm(W v)) as ONE element-wise pass; in training the batch statistics come
+ * in closed form from the data moments (m1 = sum v, M2 = sum v v^T: rv_smallk_moments writes cin_pad + cin_pad^2 doubles,
+ * cin_pad = 4 or 8; the caller all-reduces them under SyncBN), so neither the raw conv output nor a statistics pass over
+ * it exists.  moments == NULL: eval, scale/shift are inputs (rv_bn_fold_eval).  For the backward of such a layer call
+ * rv_bn_bwd_smallk with y = h, scale = 1, shift = 0, mean = beta, invstd = 1/gamma, stat_* = the batch statistics.
+ * Replaces cuDNN conv2d + BatchNorm + ReLU (nn/stems/__init__.py:40-57, nn/blocks/__init__.py:38-51 on 5/6-channel input). */
+int64_t rv_smallk_forward_workspace_bytes(int32_t cin);
+int rv_smallk_moments(const void* v, int32_t ld_v, int64_t pixels, int32_t cin, double* moments, void* workspace,
+                      rvStream stream);
+int rv_smallk_forward(const void* v, int32_t ld_v, int64_t pixels, int32_t cin, const void* w_packed, int32_t ld_w,
+                      int32_t c, const double* moments, int64_t count, const float* gamma, const float* beta, float eps,
+                      float momentum, float* running_mean, float* running_var, float* scale, float* shift, float* mean,
+                      float* invstd, int32_t relu, void* h, int32_t ld_h, rvStream stream);
 /* gradient of rv_ew_combine's plain (non-BN) inputs: d (+)= dOut * [OUT > 0 if out != NULL] */
 int rv_ew_mask_grad(int64_t pixels, int32_t c, const void* dout, int32_t ld_dout, const void* out, int32_t ld_out,
                     void* d, int32_t ld_d, int32_t accumulate, rvStream stream);

@@ -408,7 +408,8 @@ __global__ __launch_bounds__(256) void smallk_moments_kernel(const bf16_t* v, in
 template <int CIN>
 __global__ void bn_bwd_smallk_finalize_kernel(const double* red_g, int groups, const double* red_m, int groups_m, int c, int cin,
                                               double inv_count, const float* gamma, const float* mean, const float* invstd,
-                                              const bf16_t* w, int ld_w, float* dgamma, float* dbeta, float* dW) {
+                                              const bf16_t* w, int ld_w, const double* global_s01, float* dgamma, float* dbeta,
+                                              float* dW) {
     const int ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= c) return;
     double S[2 + CIN];
@@ -426,12 +427,93 @@ __global__ void bn_bwd_smallk_finalize_kernel(const double* red_g, int groups, c
     dbeta[ch] = (float)S[0];
     dgamma[ch] = (float)S[1];
     const double k0 = (double)gamma[ch] * (double)invstd[ch];
-    const double k1 = S[0] * inv_count, k2 = S[1] * inv_count;
+    // SyncBN: the normalisation coefficients use the all-reduced (sum g, sum g*xhat); everything else stays this rank's
+    const double k1 = (global_s01 ? global_s01[ch] : S[0]) * inv_count, k2 = (global_s01 ? global_s01[c + ch] : S[1]) * inv_count;
     for (int d = 0; d < cin; ++d) {
         double ym = 0.0;  // sum_p y[p,ch] v[p,d] = sum_e W[ch,e] M2[e][d]
         for (int e = 0; e < cin; ++e) ym += (double)bf2f(w[(int64_t)ch * ld_w + e]) * m[CIN + e * CIN + d];
         const double xv = (double)invstd[ch] * (ym - (double)mean[ch] * m[d]);
         dW[(int64_t)ch * cin + d] = (float)(k0 * (S[2 + d] - k1 * m[d] - k2 * xv));
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Small-K forward: h = relu?(BatchNorm(W v)) for a 1x1 conv with cin <= 8.  K is so small that the layer is an
+// element-wise map writing C channels per pixel, and its batch statistics follow in closed form from the data moments
+//   mean_c = w_c . m1 / n,   E[y_c^2] = w_c^T M2 w_c / n      (m1 = sum_p v, M2 = sum_p v v^T)
+// so there is no statistics pass over the (9x unfolded, 2.4 GB) output and no raw conv output in HBM at all.
+// ---------------------------------------------------------------------------------------------
+template <int CIN>
+__global__ void smallk_stats_kernel(const double* red_m, int groups_m, int c, int cin, const bf16_t* w, int ld_w, double inv_count,
+                                    double unbias, const float* gamma, const float* beta, float eps, float momentum,
+                                    float* running_mean, float* running_var, float* scale, float* shift, float* mean_out,
+                                    float* invstd_out) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    double m[CIN + CIN * CIN];
+    for (int i = 0; i < CIN + CIN * CIN; ++i) {
+        double s = 0.0;
+        for (int g = 0; g < groups_m; ++g) s += red_m[(int64_t)g * (CIN + CIN * CIN) + i];
+        m[i] = s;
+    }
+    double wv[CIN];
+    for (int e = 0; e < CIN; ++e) wv[e] = e < cin ? (double)bf2f(w[(int64_t)ch * ld_w + e]) : 0.0;
+    double s1 = 0.0, s2 = 0.0;
+    for (int e = 0; e < cin; ++e) {
+        s1 += wv[e] * m[e];
+        for (int f = 0; f < cin; ++f) s2 += wv[e] * wv[f] * m[CIN + e * CIN + f];
+    }
+    const double mean = s1 * inv_count;
+    double var = s2 * inv_count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    const double sc = (double)gamma[ch] * invstd;
+    scale[ch] = (float)sc;
+    shift[ch] = (float)((double)beta[ch] - mean * sc);
+    if (mean_out) mean_out[ch] = (float)mean;
+    if (invstd_out) invstd_out[ch] = (float)invstd;
+    if (running_mean) running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * mean);
+    if (running_var) running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * var * unbias);
+}
+
+template <int CIN>
+__global__ __launch_bounds__(256) void smallk_apply_kernel(const bf16_t* v, int ld_v, int64_t pixels, int c8, const bf16_t* w, int ld_w,
+                                                           const float* scale, const float* shift, int relu, bf16_t* h, int ld_h) {
+    const int tid = threadIdx.x;
+    const int lanes_px = 256 / c8;
+    const int oct = tid % c8, pl = tid / c8;
+    if (pl >= lanes_px) return;
+    const int c0 = oct * 8;
+    float wt[8][CIN], sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        sc[j] = scale[c0 + j];
+        sh[j] = shift[c0 + j];
+#pragma unroll
+        for (int e = 0; e < CIN; ++e) wt[j][e] = bf2f(w[(int64_t)(c0 + j) * ld_w + e]);
+    }
+    const int64_t step = (int64_t)gridDim.x * lanes_px;
+    for (int64_t px = (int64_t)blockIdx.x * lanes_px + pl; px < pixels; px += step) {
+        float vv[8], o[8];
+        unpack8(*(const u32x4*)(v + px * ld_v), vv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float y = 0.f;
+#pragma unroll
+            for (int e = 0; e < CIN; ++e) y += wt[j][e] * vv[e];
+            y = y * sc[j] + sh[j];
+            o[j] = relu ? fmaxf(y, 0.f) : y;
+        }
+        *(u32x4*)(h + px * ld_h + c0) = pack8(o);
+    }
+}
+
+__global__ void sum_rows_f64_kernel(const double* rows, int n_rows, int cols, double* out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cols; i += gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int r = 0; r < n_rows; ++r) s += rows[(int64_t)r * cols + i];
+        out[i] = s;
     }
 }
 
@@ -533,17 +615,19 @@ extern "C" int64_t rv_bn_bwd_smallk_workspace_bytes(int64_t pixels, int32_t c, i
     const int64_t rows = rv_bn_bwd_rows(pixels);
     const int64_t planes = 2 + CIN, mcols = CIN + CIN * CIN;
     // partial rows + fp64 group scratch for both reductions
-    return ((rows + 2 * 64) * planes * c + (1024 + 2 * 64) * mcols) * (int64_t)sizeof(float) + 256;
+    int64_t bytes = ((rows + 2 * 64) * planes * c + (1024 + 2 * 64) * mcols) * (int64_t)sizeof(float) + 256;
+    bytes = (bytes + 7) & ~(int64_t)7;
+    return bytes + (planes * c + 80) * 8;  // + the reduced sums and moments (fp64) of the single-call form
 }
 
-extern "C" int rv_bn_bwd_smallk(int64_t pixels, int32_t c, const void* dout, int32_t ld_dout, const void* out, int32_t ld_out,
-                                const void* y, int32_t ld_y, const float* scale, const float* shift, const float* mean,
-                                const float* invstd, int32_t flags, const void* v, int32_t ld_v, int32_t cin, const void* w_packed,
-                                int32_t ld_w, const float* gamma, int64_t count, float* dgamma, float* dbeta, float* dW,
-                                void* workspace, rvStream stream) {
+// phase A: local sums.  sums = (2 + CIN) * c doubles (planes S0, S1, R[.][d]), moms = CIN + CIN*CIN doubles.
+extern "C" int rv_bn_bwd_smallk_sums(int64_t pixels, int32_t c, const void* dout, int32_t ld_dout, const void* out, int32_t ld_out,
+                                     const void* y, int32_t ld_y, const float* scale, const float* shift, const float* mean,
+                                     const float* invstd, int32_t flags, const void* v, int32_t ld_v, int32_t cin, double* sums,
+                                     double* moms, void* workspace, rvStream stream) {
     BnbArgs a;
     if (fill(&a, pixels, c, dout, ld_dout, out, ld_out, y, ld_y, scale, shift, mean, invstd, flags)) return 1;
-    RV_REQUIRE(v && w_packed && gamma && dgamma && dbeta && dW && workspace, "rv_bn_bwd_smallk: null argument");
+    RV_REQUIRE(v && sums && moms && workspace, "rv_bn_bwd_smallk_sums: null argument");
     RV_REQUIRE(cin >= 1 && cin <= 8 && ld_v % 8 == 0 && ld_v >= 8, "rv_bn_bwd_smallk: 1 <= cin <= 8, input rows of at least 8 channels");
     const int CIN = cin <= 4 ? 4 : 8;
     const int rows = rv_bn_bwd_rows(pixels), planes = 2 + CIN, mcols = CIN + CIN * CIN;
@@ -551,7 +635,7 @@ extern "C" int rv_bn_bwd_smallk(int64_t pixels, int32_t c, const void* dout, int
     double* scr_g = (double*)(part_g + (int64_t)rows * planes * c);
     float* part_m = (float*)(scr_g + (int64_t)64 * planes * c);
     const int mblocks = pixels >= 1024 * 256 ? 1024 : (int)((pixels + 255) / 256);
-    double* scr_m = (double*)(part_m + (int64_t)1024 * mcols + ((((int64_t)1024 * mcols) & 1) ? 1 : 0));
+    double* scr_m = (double*)(part_m + (int64_t)1024 * mcols);
     hipStream_t st = (hipStream_t)stream;
     a.partial = part_g;
     if (CIN == 4) {
@@ -565,12 +649,110 @@ extern "C" int rv_bn_bwd_smallk(int64_t pixels, int32_t c, const void* dout, int
     int groups_g, groups_m;
     if (rv_col_reduce(part_g, rows, planes * c, scr_g, &groups_g, st)) return 1;
     if (rv_col_reduce(part_m, mblocks, mcols, scr_m, &groups_m, st)) return 1;
-    if (CIN == 4)
-        hipLaunchKernelGGL(bn_bwd_smallk_finalize_kernel<4>, dim3(rv_ceil_div(c, 64)), dim3(64), 0, st, scr_g, groups_g, scr_m, groups_m, c, cin,
-                           1.0 / (double)count, gamma, mean, invstd, (const bf16_t*)w_packed, ld_w, dgamma, dbeta, dW);
+    hipLaunchKernelGGL(sum_rows_f64_kernel, dim3(rv_ceil_div(planes * c, 128)), dim3(128), 0, st, scr_g, groups_g, planes * c, sums);
+    hipLaunchKernelGGL(sum_rows_f64_kernel, dim3(1), dim3(128), 0, st, scr_m, groups_m, mcols, moms);
+    RV_CHECK_LAUNCH("sum_rows_f64_kernel");
+    return 0;
+}
+
+// phase B: gradients from the sums.  global_s01 (2 * c doubles, optional): all-reduced (sum g, sum g*xhat) under SyncBN.
+extern "C" int rv_bn_bwd_smallk_from_sums(int32_t c, int32_t cin, const double* sums, const double* moms, const double* global_s01,
+                                          const void* w_packed, int32_t ld_w, const float* gamma, const float* stat_mean,
+                                          const float* stat_invstd, int64_t count, float* dgamma, float* dbeta, float* dW,
+                                          rvStream stream) {
+    RV_REQUIRE(sums && moms && w_packed && gamma && stat_mean && stat_invstd && dgamma && dbeta && dW, "rv_bn_bwd_smallk_from_sums: null argument");
+    RV_REQUIRE(cin >= 1 && cin <= 8 && count > 0, "rv_bn_bwd_smallk_from_sums: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    if (cin <= 4)
+        hipLaunchKernelGGL(bn_bwd_smallk_finalize_kernel<4>, dim3(rv_ceil_div(c, 64)), dim3(64), 0, st, sums, 1, moms, 1, c, cin, 1.0 / (double)count,
+                           gamma, stat_mean, stat_invstd, (const bf16_t*)w_packed, ld_w, global_s01, dgamma, dbeta, dW);
     else
-        hipLaunchKernelGGL(bn_bwd_smallk_finalize_kernel<8>, dim3(rv_ceil_div(c, 64)), dim3(64), 0, st, scr_g, groups_g, scr_m, groups_m, c, cin,
-                           1.0 / (double)count, gamma, mean, invstd, (const bf16_t*)w_packed, ld_w, dgamma, dbeta, dW);
+        hipLaunchKernelGGL(bn_bwd_smallk_finalize_kernel<8>, dim3(rv_ceil_div(c, 64)), dim3(64), 0, st, sums, 1, moms, 1, c, cin, 1.0 / (double)count,
+                           gamma, stat_mean, stat_invstd, (const bf16_t*)w_packed, ld_w, global_s01, dgamma, dbeta, dW);
     RV_CHECK_LAUNCH("bn_bwd_smallk_finalize_kernel");
+    return 0;
+}
+
+extern "C" int rv_bn_bwd_smallk(int64_t pixels, int32_t c, const void* dout, int32_t ld_dout, const void* out, int32_t ld_out,
+                                const void* y, int32_t ld_y, const float* scale, const float* shift, const float* mean,
+                                const float* invstd, int32_t flags, const void* v, int32_t ld_v, int32_t cin, const void* w_packed,
+                                int32_t ld_w, const float* gamma, const float* stat_mean, const float* stat_invstd, int64_t count,
+                                float* dgamma, float* dbeta, float* dW, void* workspace, rvStream stream) {
+    // (mean, invstd) drive the per-pixel xhat = (y - mean) * invstd; (stat_mean, stat_invstd) are the layer's batch
+    // statistics used in the closed-form terms.  They differ when y is the ACTIVATED output h = relu(gamma*xhat + beta)
+    // (rv_smallk_forward): then the caller passes scale = 1, shift = 0, mean = beta, invstd = 1/gamma.
+    RV_REQUIRE(workspace, "rv_bn_bwd_smallk: null workspace");
+    const int CIN = cin <= 4 ? 4 : 8;
+    double* sums = (double*)((uint8_t*)workspace + rv_bn_bwd_smallk_workspace_bytes(pixels, c, cin) - (int64_t)((2 + CIN) * c + 80) * 8);
+    double* moms = sums + (int64_t)(2 + CIN) * c;
+    if (rv_bn_bwd_smallk_sums(pixels, c, dout, ld_dout, out, ld_out, y, ld_y, scale, shift, mean, invstd, flags, v, ld_v, cin, sums, moms,
+                              workspace, stream))
+        return 1;
+    return rv_bn_bwd_smallk_from_sums(c, cin, sums, moms, nullptr, w_packed, ld_w, gamma, stat_mean ? stat_mean : mean,
+                                      stat_invstd ? stat_invstd : invstd, count, dgamma, dbeta, dW, stream);
+}
+
+extern "C" int64_t rv_smallk_forward_workspace_bytes(int32_t cin) {
+    const int CIN = cin <= 4 ? 4 : 8;
+    return (int64_t)(1024 + 2 * 64) * (CIN + CIN * CIN) * (int64_t)sizeof(float) + 256;
+}
+
+/* moments of v (device, fp64 group rows in the workspace); groups returned through *groups_m */
+static int smallk_moments(const void* v, int32_t ld_v, int64_t pixels, int CIN, void* workspace, double** scr_m, int* groups_m,
+                          hipStream_t st) {
+    const int mcols = CIN + CIN * CIN;
+    float* part_m = (float*)workspace;
+    const int mblocks = pixels >= 1024 * 256 ? 1024 : (int)((pixels + 255) / 256);
+    *scr_m = (double*)(part_m + (int64_t)1024 * mcols);
+    if (CIN == 4)
+        hipLaunchKernelGGL(smallk_moments_kernel<4>, dim3(mblocks), dim3(256), 0, st, (const bf16_t*)v, ld_v, pixels, part_m);
+    else
+        hipLaunchKernelGGL(smallk_moments_kernel<8>, dim3(mblocks), dim3(256), 0, st, (const bf16_t*)v, ld_v, pixels, part_m);
+    RV_CHECK_LAUNCH("smallk_moments_kernel");
+    return rv_col_reduce(part_m, mblocks, mcols, *scr_m, groups_m, st);
+}
+
+extern "C" int rv_smallk_moments(const void* v, int32_t ld_v, int64_t pixels, int32_t cin, double* moments, void* workspace,
+                                 rvStream stream) {
+    RV_REQUIRE(v && moments && workspace && cin >= 1 && cin <= 8 && ld_v % 8 == 0 && ld_v >= 8, "rv_smallk_moments: bad argument");
+    const int CIN = cin <= 4 ? 4 : 8;
+    double* scr;
+    int groups;
+    if (smallk_moments(v, ld_v, pixels, CIN, workspace, &scr, &groups, (hipStream_t)stream)) return 1;
+    // sum the (at most 64) group rows into `moments` (CIN + CIN*CIN doubles): reuse the column reducer's layout
+    hipLaunchKernelGGL(sum_rows_f64_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, scr, groups, CIN + CIN * CIN, moments);
+    RV_CHECK_LAUNCH("sum_rows_f64_kernel");
+    return 0;
+}
+
+extern "C" int rv_smallk_forward(const void* v, int32_t ld_v, int64_t pixels, int32_t cin, const void* w_packed, int32_t ld_w,
+                                 int32_t c, const double* moments, int64_t count, const float* gamma, const float* beta, float eps,
+                                 float momentum, float* running_mean, float* running_var, float* scale, float* shift, float* mean,
+                                 float* invstd, int32_t relu, void* h, int32_t ld_h, rvStream stream) {
+    RV_REQUIRE(v && w_packed && scale && shift && h, "rv_smallk_forward: null argument");
+    RV_REQUIRE(cin >= 1 && cin <= 8 && ld_v % 8 == 0 && ld_v >= 8 && c % 8 == 0 && c / 8 <= 256 && ld_h % 8 == 0, "rv_smallk_forward: bad shape");
+    const int CIN = cin <= 4 ? 4 : 8;
+    hipStream_t st = (hipStream_t)stream;
+    if (moments) {  // training: batch statistics in closed form from the moments (already all-reduced by the caller under SyncBN)
+        RV_REQUIRE(gamma && beta && count > 0, "rv_smallk_forward: statistics need gamma, beta and the pixel count");
+        const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
+        if (CIN == 4)
+            hipLaunchKernelGGL(smallk_stats_kernel<4>, dim3(rv_ceil_div(c, 64)), dim3(64), 0, st, moments, 1, c, cin, (const bf16_t*)w_packed, ld_w,
+                               1.0 / (double)count, unbias, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, invstd);
+        else
+            hipLaunchKernelGGL(smallk_stats_kernel<8>, dim3(rv_ceil_div(c, 64)), dim3(64), 0, st, moments, 1, c, cin, (const bf16_t*)w_packed, ld_w,
+                               1.0 / (double)count, unbias, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, invstd);
+        RV_CHECK_LAUNCH("smallk_stats_kernel");
+    }
+    const int c8 = c / 8, lanes_px = 256 / c8;
+    int64_t blocks = (pixels + lanes_px - 1) / lanes_px;
+    if (blocks > 8192) blocks = 8192;
+    if (CIN == 4)
+        hipLaunchKernelGGL(smallk_apply_kernel<4>, dim3((int)blocks), dim3(256), 0, st, (const bf16_t*)v, ld_v, pixels, c8, (const bf16_t*)w_packed, ld_w,
+                           scale, shift, relu, (bf16_t*)h, ld_h);
+    else
+        hipLaunchKernelGGL(smallk_apply_kernel<8>, dim3((int)blocks), dim3(256), 0, st, (const bf16_t*)v, ld_v, pixels, c8, (const bf16_t*)w_packed, ld_w,
+                           scale, shift, relu, (bf16_t*)h, ld_h);
+    RV_CHECK_LAUNCH("smallk_apply_kernel");
     return 0;
 }

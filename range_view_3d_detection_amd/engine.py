@@ -519,8 +519,70 @@ def _padded(p: Tensor, cp: int, fill: float = 0.0) -> Tensor:
     return out
 
 
+SMALLK_FORWARD = os.environ.get("RV3D_NO_SMALLK_FWD") is None
+
+
+class SmallKOp(Op):
+    """``h = relu(BatchNorm(conv1x1(x)))`` for a conv with at most 8 input channels whose input needs no gradient (the
+    stem's 3 -> C positional conv on the 9x unfolded grid, the 5/6 -> C feature projection): one element-wise pass
+    writes the ACTIVATED output, the batch statistics come in closed form from the moments of ``x``
+    (``rv_smallk_forward``), and backward is ``rv_bn_bwd_smallk`` (BatchNorm backward + weight gradient in one pass).
+    Returns a plain ``Act`` -- the consumer conv then runs on the LDS-DMA kernels."""
+
+    def __init__(self, t: Tape, layer: TapLayer, x: Act, bn: nn.BatchNorm2d) -> None:
+        self.layer, self.x, self.bn = layer, x, bn
+        c, cin = bn.num_features, layer.c_in
+        cp = pad32(c)
+        dev = t.device
+        self.gamma_p, self.beta_p = _padded(bn.weight, cp), _padded(bn.bias, cp)
+        scale = torch.empty(cp, dtype=torch.float32, device=dev)
+        shift = torch.empty(cp, dtype=torch.float32, device=dev)
+        self.out = Act.empty(x.N, x.H, x.W, c, dev)
+        wp = layer.packed("gather")
+        rm, rv = _padded(bn.running_mean, cp), _padded(bn.running_var, cp, 1.0)
+        self.count = x.pixels
+        if t.training:
+            self.mean = torch.empty(cp, dtype=torch.float32, device=dev)
+            self.invstd = torch.empty(cp, dtype=torch.float32, device=dev)
+            ws = torch.empty(L.load().rv_smallk_forward_workspace_bytes(L.i32(cin)), dtype=torch.uint8, device=dev)
+            moments = torch.empty(72, dtype=torch.float64, device=dev)
+            L.call("rv_smallk_moments", x.ptr(), L.i32(x.ld), L.i64(x.pixels), L.i32(cin), L.ptr(moments), L.ptr(ws), L.stream_ptr())
+            world = _world()
+            if world > 1:  # SyncBN: the moments are sums over pixels -> all-reduce them, then the closed form is global
+                torch.distributed.all_reduce(moments)
+                self.count = x.pixels * world
+            L.call("rv_smallk_forward", x.ptr(), L.i32(x.ld), L.i64(x.pixels), L.i32(cin), L.ptr(wp), L.i32(pad32(cin)), L.i32(cp),
+                   L.ptr(moments), L.i64(self.count), L.ptr(self.gamma_p), L.ptr(self.beta_p), L.f32(bn.eps),
+                   L.f32(bn.momentum if bn.momentum is not None else 0.1), L.ptr(rm), L.ptr(rv), L.ptr(scale), L.ptr(shift),
+                   L.ptr(self.mean), L.ptr(self.invstd), L.i32(1), self.out.ptr(), L.i32(self.out.ld), L.stream_ptr())
+            if bn.running_mean.shape[0] != cp:
+                bn.running_mean.copy_(rm[:c])
+                bn.running_var.copy_(rv[:c])
+            t.bn_counters.append(bn.num_batches_tracked)
+        else:
+            L.call("rv_bn_fold_eval", L.i32(cp), L.ptr(self.gamma_p), L.ptr(self.beta_p), L.ptr(rm), L.ptr(rv), L.f32(bn.eps),
+                   L.ptr(scale), L.ptr(shift), L.stream_ptr())
+            L.call("rv_smallk_forward", x.ptr(), L.i32(x.ld), L.i64(x.pixels), L.i32(cin), L.ptr(wp), L.i32(pad32(cin)), L.i32(cp),
+                   None, L.i64(self.count), None, None, L.f32(bn.eps), L.f32(0.1), None, None, L.ptr(scale), L.ptr(shift), None, None,
+                   L.i32(1), self.out.ptr(), L.i32(self.out.ld), L.stream_ptr())
+        t.ops.append(self)
+
+    def backward(self, t: Tape) -> None:
+        from . import engine_bwd
+
+        engine_bwd.smallk_backward(self, t)
+
+
+def _smallk_eligible(layer: TapLayer, x: Operand, relu: bool, need_input_grad: bool) -> bool:
+    g = layer.geom
+    return (SMALLK_FORWARD and relu and not need_input_grad and isinstance(x, Act) and layer.fwd_form == "gather" and g.kh == 1
+            and g.kw == 1 and g.stride_w == 1 and layer.c_in <= 8 and layer.in_perm is None and layer.bias is None)
+
+
 def conv_bn(t: Tape, layer: TapLayer, x: Operand, bn: nn.BatchNorm2d, relu: bool = True,
-            need_input_grad: bool = True) -> Lazy:
+            need_input_grad: bool = True) -> Operand:
+    if _smallk_eligible(layer, x, relu, need_input_grad):
+        return SmallKOp(t, layer, x, bn).out
     conv = ConvOp(t, layer, x, stats=t.training, need_input_grad=need_input_grad)
     return BnOp(t, conv, bn, relu).lazy
 

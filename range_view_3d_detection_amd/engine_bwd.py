@@ -120,6 +120,35 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
         run_wgrad()
 
 
+def _smallk_grads(t: Tape, pixels: int, cp: int, dout: Act, mask: Optional[Act], y: Act, scale, shift, mean, invstd, flags: int, v: Act,
+                  lay, gamma_p, stat_mean, stat_invstd, count: int):
+    """(dgamma, dbeta, dW) of a small-K conv + BatchNorm from one pass (``rv_bn_bwd_smallk``); under SyncBN the two-phase
+    form with the all-reduce of (sum g, sum g*xhat) in between."""
+    cin = lay.c_in
+    dev = t.device
+    ws = torch.empty(L.load().rv_bn_bwd_smallk_workspace_bytes(L.i64(pixels), L.i32(cp), L.i32(cin)), dtype=torch.uint8, device=dev)
+    dgamma = torch.empty(cp, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(cp, dtype=torch.float32, device=dev)
+    dw = torch.empty((cp, cin), dtype=torch.float32, device=dev)
+    wp = lay.packed("gather")
+    head = (L.i64(pixels), L.i32(cp), dout.ptr(), L.i32(dout.ld), mask.ptr() if mask is not None else None,
+            L.i32(mask.ld if mask is not None else 0), y.ptr(), L.i32(y.ld), L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd),
+            L.i32(flags), v.ptr(), L.i32(v.ld), L.i32(cin))
+    if E._world() > 1:
+        cin_pad = 4 if cin <= 4 else 8
+        sums = torch.empty((2 + cin_pad) * cp, dtype=torch.float64, device=dev)
+        moms = torch.empty(cin_pad + cin_pad * cin_pad, dtype=torch.float64, device=dev)
+        L.call("rv_bn_bwd_smallk_sums", *head, L.ptr(sums), L.ptr(moms), L.ptr(ws), L.stream_ptr())
+        g01 = sums[: 2 * cp].clone()
+        torch.distributed.all_reduce(g01)  # SyncBN: global (sum g, sum g*xhat); the other sums stay this rank's
+        L.call("rv_bn_bwd_smallk_from_sums", L.i32(cp), L.i32(cin), L.ptr(sums), L.ptr(moms), L.ptr(g01), L.ptr(wp), L.i32(E.pad32(cin)),
+               L.ptr(gamma_p), L.ptr(stat_mean), L.ptr(stat_invstd), L.i64(count), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dw), L.stream_ptr())
+    else:
+        L.call("rv_bn_bwd_smallk", *head, L.ptr(wp), L.i32(E.pad32(cin)), L.ptr(gamma_p), L.ptr(stat_mean), L.ptr(stat_invstd), L.i64(count),
+               L.ptr(dgamma), L.ptr(dbeta), L.ptr(dw), L.ptr(ws), L.stream_ptr())
+    return dgamma, dbeta, dw
+
+
 SMALLK_FUSION = os.environ.get("RV3D_NO_SMALLK") is None
 
 
@@ -136,22 +165,14 @@ def bn_backward(op: "E.BnOp", t: Tape) -> None:
     flags = L.BNB_RELU_Z if lazy.relu else 0
     conv = op.conv
     lay, geo = conv.layer, conv.layer.geom
-    if (SMALLK_FUSION and res is None and E._world() == 1 and not conv.need_input_grad and not conv.out_f32 and not isinstance(conv.x, Lazy)
+    if (SMALLK_FUSION and res is None and not conv.need_input_grad and not conv.out_f32 and not isinstance(conv.x, Lazy)
             and geo.kh == 1 and geo.kw == 1 and geo.stride_w == 1 and lay.fwd_form == "gather" and lay.c_in <= 8 and lay.in_perm is None
             and lay.bias is None):
         # 1x1 conv with a handful of input channels and no input gradient (stem): BatchNorm backward and the conv's
         # weight gradient from one pass over (dOut, y, input) -- neither dy nor a separate wgrad pass (rv_bn_bwd_smallk)
-        v, cin = conv.x, lay.c_in
-        ws = torch.empty(L.load().rv_bn_bwd_smallk_workspace_bytes(L.i64(pixels), L.i32(cp), L.i32(cin)), dtype=torch.uint8, device=t.device)
-        dgamma = torch.empty(cp, dtype=torch.float32, device=t.device)
-        dbeta = torch.empty(cp, dtype=torch.float32, device=t.device)
-        dw = torch.empty((cp, cin), dtype=torch.float32, device=t.device)
-        wp = lay.packed("gather")
-        L.call("rv_bn_bwd_smallk", L.i64(pixels), L.i32(cp), dout.ptr(), L.i32(dout.ld), mask.ptr() if mask is not None else None,
-               L.i32(mask.ld if mask is not None else 0), raw.ptr(), L.i32(raw.ld), L.ptr(st.scale), L.ptr(st.shift), L.ptr(st.mean),
-               L.ptr(st.invstd), L.i32(flags), v.ptr(), L.i32(v.ld), L.i32(cin), L.ptr(wp), L.i32(E.pad32(cin)), L.ptr(op.gamma_p),
-               L.i64(st.count), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dw), L.ptr(ws), L.stream_ptr())
-        c = st.module.num_features
+        dgamma, dbeta, dw = _smallk_grads(t, pixels, cp, dout, mask, raw, st.scale, st.shift, st.mean, st.invstd, flags, conv.x, lay,
+                                          op.gamma_p, st.mean, st.invstd, st.count)
+        c, cin = st.module.num_features, lay.c_in
         t.add_param_grad(st.module.weight, dgamma[:c])
         t.add_param_grad(st.module.bias, dbeta[:c])
         t.add_param_grad(lay.weight, lay.unpermute_grad(dw[: lay.c_out].reshape(lay.c_out, cin, 1, 1).contiguous()))
@@ -229,3 +250,24 @@ def modulate_backward(op: "E.MetaModulateOp", t: Tape) -> None:
            L.i32(feat.N), L.i32(feat.H), L.i32(feat.W), L.i32(feat.cp), dpos.ptr(), gf.ptr(), L.i32(gf.ld), L.stream_ptr())
     t.mark_written(feat)
     t.lazy_in[id(pos)] = (dpos, None)
+
+
+def smallk_backward(op: "E.SmallKOp", t: Tape) -> None:
+    """Backward of ``h = relu(bn(W x))`` from the activated output: mask = [h > 0], xhat = (h - beta) / gamma there."""
+    dout, have = t.grad_buffer(op.out)
+    if not have:
+        return
+    if not t.training:
+        raise L.RvError("BatchNorm backward needs batch statistics (module was run in eval mode)")
+    lay, bn, h, v = op.layer, op.bn, op.out, op.x
+    cp, cin, pixels = h.cp, lay.c_in, h.pixels
+    ones = torch.ones(cp, dtype=torch.float32, device=t.device)
+    zeros = torch.zeros(cp, dtype=torch.float32, device=t.device)
+    safe_gamma = torch.where(op.gamma_p.abs() < 1e-20, torch.full_like(op.gamma_p, 1e-20), op.gamma_p)
+    inv_gamma = 1.0 / safe_gamma
+    dgamma, dbeta, dw = _smallk_grads(t, pixels, cp, dout, None, h, ones, zeros, op.beta_p, inv_gamma, L.BNB_RELU_Z, v, lay, op.gamma_p,
+                                      op.mean, op.invstd, op.count)
+    c = bn.num_features
+    t.add_param_grad(bn.weight, dgamma[:c])
+    t.add_param_grad(bn.bias, dbeta[:c])
+    t.add_param_grad(lay.weight, lay.unpermute_grad(dw[: lay.c_out].reshape(lay.c_out, cin, 1, 1).contiguous()))

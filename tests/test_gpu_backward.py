@@ -195,10 +195,15 @@ def test_meta_kernel_backward(golden):
         assert _cos(p.grad, ref) > 0.97 and _l2(p.grad, ref) < 0.25, (k, _cos(p.grad, ref), _l2(p.grad, ref))
 
 
-def test_small_k_fused_bn_backward_matches_unfused_and_fp64():
-    """rv_bn_bwd_smallk (BatchNorm backward + 1x1 weight gradient in one pass, dy never written) against (a) the
-    reduce / apply / wgrad path it replaces and (b) an fp64 evaluation of the same formulas, on the stem's MetaKernel
-    (3 -> C positional conv on the 9x grid, 5 -> C feature projections)."""
+def test_small_k_fused_paths_match_unfused_and_oracle():
+    """rv_smallk_forward (activated output in one element-wise pass, closed-form batch statistics) and rv_bn_bwd_smallk
+    (BatchNorm backward + 1x1 weight gradient in one pass, dy never written) against the conv / statistics / reduce /
+    apply / wgrad kernels they replace and against the fp32 oracle, on the stem's MetaKernel (3 -> C positional conv on
+    the 9x grid, 5 -> C feature projection).  BatchNorm biases are shifted so that most ReLU gates are firmly open:
+    with gates flipping under bf16 rounding every variant sits ~10 % (max-abs) from the fp32 gradients of this randomly
+    initialised stem and nothing tight can be said (see test_gpu_model.py::test_detector_gradients_vs_oracle)."""
+    from oracle import model as om
+    from range_view_3d_detection_amd import engine as E
     from range_view_3d_detection_amd import engine_bwd
     from range_view_3d_detection_amd.nn.stems import MetaKernel
 
@@ -208,24 +213,35 @@ def test_small_k_fused_bn_backward_matches_unfused_and_fp64():
     for mod in m.modules():
         if isinstance(mod, torch.nn.BatchNorm2d):
             mod.weight.data = (0.5 + torch.rand(mod.weight.shape, generator=gen)).to(DEV)
-            mod.bias.data = (0.3 * torch.randn(mod.bias.shape, generator=gen) + 1.0).to(DEV)
-    feats = torch.randn(2, 5, 16, 96, generator=gen).to(DEV)
-    cart = (torch.randn(2, 3, 16, 96, generator=gen) * 5).to(DEV)
-    probe = torch.randn(2, 64, 16, 96, generator=gen).to(DEV)
+            mod.bias.data = (0.3 * torch.randn(mod.bias.shape, generator=gen) + 3.0).to(DEV)
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    feats = torch.randn(2, 5, 16, 96, generator=gen)
+    cart = torch.randn(2, 3, 16, 96, generator=gen) * 5
+    probe = torch.randn(2, 64, 16, 96, generator=gen)
 
-    def grads(fused: bool):
+    def run(fused: bool):
         engine_bwd.SMALLK_FUSION = fused
+        E.SMALLK_FORWARD = fused
         try:
+            m.load_state_dict(sd)
             m.zero_grad(set_to_none=True)
-            (m(feats, cart).float() * probe).sum().backward()
-            return {k: p.grad.clone() for k, p in m.named_parameters()}
+            out = m(feats.to(DEV), cart.to(DEV)).float()
+            (out * probe.to(DEV)).sum().backward()
+            stats = {k: v.detach().cpu().clone() for k, v in m.state_dict().items() if "running_" in k}
+            return out.detach().cpu(), {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()}, stats
         finally:
             engine_bwd.SMALLK_FUSION = True
+            E.SMALLK_FORWARD = True
 
-    a, b = grads(True), grads(False)
-    small = [k for k in a if k.startswith("positional_kernel.0.") or k.startswith("projection.net.0.") or k.startswith("projection.net.1.")
-             or k.startswith("projection.projection_block.")]
-    assert small, list(a)
+    out_a, a, st_a = run(True)
+    out_b, b, st_b = run(False)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k}
+    out_o = om.meta_kernel(feats, cart, {"m." + k: v for k, v in {**sd, **params}.items()}, "m", nm=om.Numerics(train=True))
+    (out_o * probe).sum().backward()
+    assert rel_err(out_a, out_b) < 2e-2 and rel_err(out_a, out_o) < 2e-2
+    for k in st_a:  # closed-form batch statistics == statistics of the conv output
+        assert rel_err(st_a[k], st_b[k]) < 1e-3, (k, rel_err(st_a[k], st_b[k]))
     for k in a:
-        tol = 2e-2 if k in small else 1e-6  # the fused path keeps dy in fp32/fp64 instead of rounding it to bf16
-        assert rel_err(a[k], b[k]) <= tol, (k, rel_err(a[k], b[k]))
+        ref = params[k].grad
+        assert _cos(a[k], ref) > 0.985 and _cos(a[k], b[k]) > 0.99, (k, _cos(a[k], ref), _cos(a[k], b[k]))
+        assert rel_err(a[k], ref) < max(2.0 * rel_err(b[k], ref), 2e-2), (k, rel_err(a[k], ref), rel_err(b[k], ref))
