@@ -163,25 +163,25 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* red,
 }
 
 // single-launch variant of col_reduce + finalize (see bn_reduce_finalize_kernel in misc.hip)
-__global__ __launch_bounds__(1024) void bn_bwd_reduce_finalize_kernel(const float* partial, int rows, int c, double inv_count, const float* gamma,
+__global__ __launch_bounds__(256) void bn_bwd_reduce_finalize_kernel(const float* partial, int rows, int c, double inv_count, const float* gamma,
                                                                       const float* invstd, float* dgamma, float* dbeta, int accumulate,
                                                                       float* coef) {
-    __shared__ double red[2][64][17];
+    __shared__ double red[2][16][17];
     const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
     const int ch = blockIdx.x * 16 + cx;
     double s0 = 0.0, s1 = 0.0;
     if (ch < c) {
         const float* p = partial + ch;
         int r = ry;
-        for (; r + 192 < rows; r += 256) {
+        for (; r + 48 < rows; r += 64) {
             const float a0 = p[(int64_t)r * 2 * c], b0 = p[(int64_t)r * 2 * c + c];
-            const float a1 = p[(int64_t)(r + 64) * 2 * c], b1 = p[(int64_t)(r + 64) * 2 * c + c];
-            const float a2 = p[(int64_t)(r + 128) * 2 * c], b2 = p[(int64_t)(r + 128) * 2 * c + c];
-            const float a3 = p[(int64_t)(r + 192) * 2 * c], b3 = p[(int64_t)(r + 192) * 2 * c + c];
+            const float a1 = p[(int64_t)(r + 16) * 2 * c], b1 = p[(int64_t)(r + 16) * 2 * c + c];
+            const float a2 = p[(int64_t)(r + 32) * 2 * c], b2 = p[(int64_t)(r + 32) * 2 * c + c];
+            const float a3 = p[(int64_t)(r + 48) * 2 * c], b3 = p[(int64_t)(r + 48) * 2 * c + c];
             s0 += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
             s1 += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
         }
-        for (; r < rows; r += 64) {
+        for (; r < rows; r += 16) {
             s0 += (double)p[(int64_t)r * 2 * c];
             s1 += (double)p[(int64_t)r * 2 * c + c];
         }
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_reduce_finalize_kernel(const floa
     red[0][ry][cx] = s0;
     red[1][ry][cx] = s1;
     __syncthreads();
-    for (int half = 32; half > 0; half >>= 1) {
+    for (int half = 8; half > 0; half >>= 1) {
         if (ry < half) {
             red[0][ry][cx] += red[0][ry + half][cx];
             red[1][ry][cx] += red[1][ry + half][cx];
@@ -566,7 +566,7 @@ extern "C" int rv_bn_bwd_finalize(const float* partial, int32_t rows, int32_t c,
                                   rvStream stream) {
     RV_REQUIRE(partial && gamma && invstd && coef, "rv_bn_bwd_finalize: null argument");
     if (rows <= 1024 && getenv("RV3D_NO_FUSED_FINALIZE") == nullptr) {
-        hipLaunchKernelGGL(bn_bwd_reduce_finalize_kernel, dim3(rv_ceil_div(c, 16)), dim3(1024), 0, (hipStream_t)stream, partial, rows, c,
+        hipLaunchKernelGGL(bn_bwd_reduce_finalize_kernel, dim3(rv_ceil_div(c, 16)), dim3(256), 0, (hipStream_t)stream, partial, rows, c,
                            1.0 / (double)count, gamma, invstd, dgamma, dbeta, accumulate, coef);
         RV_CHECK_LAUNCH("bn_bwd_reduce_finalize_kernel");
         return 0;

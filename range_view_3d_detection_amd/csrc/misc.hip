@@ -181,28 +181,29 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* red, int
     if (running_var) running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * var * unbias);
 }
 
-// One launch instead of col_reduce + finalize: a block of 1024 threads = 16 channels x 64 row lanes sums the partial rows
+// One launch instead of col_reduce + finalize: a block of 256 threads = 16 channels x 16 row lanes (small blocks: a 1024-thread block cannot co-reside with a
+// 512-thread MFMA block of the weight-gradient stream on one CU and waited ~90 us for a free CU) sums the partial rows
 // of its channels in fp64 (64-byte row segments, 128 loads in flight per thread pair), then finalises them.
-__global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const float* partial, int rows, int c, double inv_count, double unbias,
+__global__ __launch_bounds__(256) void bn_reduce_finalize_kernel(const float* partial, int rows, int c, double inv_count, double unbias,
                                                                   const float* gamma, const float* beta, float eps, float momentum,
                                                                   float* running_mean, float* running_var, float* scale, float* shift,
                                                                   float* mean_out, float* invstd_out) {
-    __shared__ double red[2][64][17];
+    __shared__ double red[2][16][17];
     const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
     const int ch = blockIdx.x * 16 + cx;
     double s = 0.0, q = 0.0;
     if (ch < c) {
         const float* p = partial + ch;
         int r = ry;
-        for (; r + 192 < rows; r += 256) {  // four independent row pairs per iteration
+        for (; r + 48 < rows; r += 64) {  // four independent row pairs per iteration
             const float a0 = p[(int64_t)r * 2 * c], b0 = p[(int64_t)r * 2 * c + c];
-            const float a1 = p[(int64_t)(r + 64) * 2 * c], b1 = p[(int64_t)(r + 64) * 2 * c + c];
-            const float a2 = p[(int64_t)(r + 128) * 2 * c], b2 = p[(int64_t)(r + 128) * 2 * c + c];
-            const float a3 = p[(int64_t)(r + 192) * 2 * c], b3 = p[(int64_t)(r + 192) * 2 * c + c];
+            const float a1 = p[(int64_t)(r + 16) * 2 * c], b1 = p[(int64_t)(r + 16) * 2 * c + c];
+            const float a2 = p[(int64_t)(r + 32) * 2 * c], b2 = p[(int64_t)(r + 32) * 2 * c + c];
+            const float a3 = p[(int64_t)(r + 48) * 2 * c], b3 = p[(int64_t)(r + 48) * 2 * c + c];
             s += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
             q += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
         }
-        for (; r < rows; r += 64) {
+        for (; r < rows; r += 16) {
             s += (double)p[(int64_t)r * 2 * c];
             q += (double)p[(int64_t)r * 2 * c + c];
         }
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const float* p
     red[0][ry][cx] = s;
     red[1][ry][cx] = q;
     __syncthreads();
-    for (int half = 32; half > 0; half >>= 1) {
+    for (int half = 8; half > 0; half >>= 1) {
         if (ry < half) {
             red[0][ry][cx] += red[0][ry + half][cx];
             red[1][ry][cx] += red[1][ry + half][cx];
@@ -264,7 +265,7 @@ extern "C" int rv_bn_finalize(const float* partial, int32_t rows, int32_t c, int
     // few partial rows: one launch reduces and finalises; many (4096 rows behind a 512-channel tapconv4 launch): the
     // 64-group column reduction spreads them over the chip first (29 us vs 14 us measured for the single launch)
     if (rows <= 1024 && getenv("RV3D_NO_FUSED_FINALIZE") == nullptr) {
-        hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3(rv_ceil_div(c, 16)), dim3(1024), 0, (hipStream_t)stream, partial, rows, c,
+        hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3(rv_ceil_div(c, 16)), dim3(256), 0, (hipStream_t)stream, partial, rows, c,
                            1.0 / (double)count, unbias, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, invstd);
         RV_CHECK_LAUNCH("bn_reduce_finalize_kernel");
         return 0;

@@ -95,7 +95,7 @@ def tap_kernel_name(geom, shape, scatter: bool) -> str:
     info = (ctypes.c_int32 * 4)()
     L.call("rv_tap_launch_info", ctypes.byref(geom), ctypes.byref(shape), L.i32(1 if scatter else 0), info)
     if info[0] == 4:
-        name = "tapconv4_kernel"
+        name = f"tapconv4_kernel<{info[1]}>"
     elif info[0] in (2, 3):
         name = f"tapconv{info[0]}_kernel<{info[1]}>"
     else:
