@@ -143,8 +143,9 @@ def test_tiny_detector_forward_backward(golden):
     assert worst < 5e-2, worst
 
 
-@pytest.mark.parametrize("bn_bias_shift", [6.0, 3.0, 0.0])
-def test_detector_gradients_vs_oracle(bn_bias_shift):
+@pytest.mark.parametrize("bn_bias_shift,n_feat,n_cls,width", [(6.0, 5, 5, 256), (3.0, 5, 5, 256), (0.0, 5, 5, 256),
+                                                               (3.0, 6, 3, 336)])  # Waymo-like: 6 features, 3 classes, W % 64 != 0
+def test_detector_gradients_vs_oracle(bn_bias_shift, n_feat, n_cls, width):
     """Composed model (stem + backbone + towers + targets + loss), forward AND backward, against the pinned oracle.
 
     32-channel model on 2 x 16 x 256 sweeps.  HIP (bf16 storage) vs the oracle in fp32 and vs the oracle with bf16 storage
@@ -164,15 +165,14 @@ def test_detector_gradients_vs_oracle(bn_bias_shift):
     from oracle import targets as otgt
 
     torch.manual_seed(0)
-    n_cls = 5
-    backbone, head = build_model("c32", n_cls)
+    backbone, head = build_model("c32", n_cls, n_feat)
     gen = torch.Generator().manual_seed(1)
     for m in list(backbone.modules()) + list(head.modules()):
         if isinstance(m, torch.nn.BatchNorm2d):
             m.weight.data = 0.5 + torch.rand(m.weight.shape, generator=gen)
             m.bias.data = 0.2 * torch.randn(m.bias.shape, generator=gen) + bn_bias_shift
     sd = {**{f"backbone.{k}": v.clone() for k, v in backbone.state_dict().items()}, **{f"head.{k}": v.clone() for k, v in head.state_dict().items()}}
-    batch = synthetic_batch(2, 16, 256, seed=3, device="cpu", boxes_per_sweep=8, n_cls=n_cls)
+    batch = synthetic_batch(2, 16, width, seed=3, device="cpu", n_feat=n_feat, boxes_per_sweep=8, n_cls=n_cls)
     torch.set_num_threads(min(16, torch.get_num_threads()))
 
     def oracle_grads(nm):
