@@ -247,7 +247,6 @@ Operand = Union[Act, Lazy]
 # register-staged kernels (3x3 512 -> 512: 1330 vs 980 TFLOP/s, one box) to pay for writing the operand out once
 # (one HBM-bound pass); forward conv, and the weight gradient in backward, then both read the plain tensor.
 MATERIALIZE_FOR_DMA = os.environ.get("RV3D_NO_MATERIALIZE") is None
-MATERIALIZE_1X1 = os.environ.get("RV3D_MAT_1X1") is not None
 
 
 def _dma_eligible(geom, n: int, h: int, wu: int, wv: int, ld_src: int, ld_dst: int, scatter: bool) -> bool:
@@ -419,7 +418,7 @@ class ConvOp(Op):
         assert src.cp == pad32(layer.c_in), (src.cp, layer.c_in)
         self.x_plain = None
         # (not for 1x1 layers: there the extra pass costs what the faster kernel saves)
-        if (isinstance(x, Lazy) and MATERIALIZE_FOR_DMA and not out_f32 and (g.kh * g.kw > 1 or MATERIALIZE_1X1)
+        if (isinstance(x, Lazy) and MATERIALIZE_FOR_DMA and not out_f32 and g.kh * g.kw > 1
                 and _dma_eligible(g, src.N, src.H, wu, wv, src.ld, pad32(layer.c_out), form == "scatter")):
             self.x_plain = src = x.materialized()
             sc = sh = None
