@@ -168,3 +168,31 @@ def test_two_process_gloo_sharding_and_syncbn_reduction(tmp_path, lib):
         res.append(json.loads([ln for ln in o.splitlines() if ln.startswith("RESULT ")][0][7:]))
     assert res[0]["digests"] == res[1]["digests"] and res[0]["digests"][0] != res[0]["digests"][1]
     assert all(r["stats_err"] < 1e-4 and r["tmax"] == 2.0 for r in res)
+
+
+def test_detections_table_and_feather_files(tmp_path):
+    """``build_dataframe`` / per-sweep feather files: schema, join rules and file layout."""
+    import pyarrow as pa
+    import pyarrow.feather as feather
+    import torch
+
+    from range_view_3d_detection_amd.math.ops.coding import build_dataframe, write_detections
+
+    g = torch.Generator().manual_seed(0)
+    params = torch.randn(7, 10, generator=g)
+    scores = torch.rand(7, generator=g)
+    categories = torch.tensor([0.0, 2.0, 1.0, 2.0, 0.0, 1.0, 2.0])  # floats, as the decoder returns them
+    batch_index = torch.tensor([0.0, 0.0, 1.0, 1.0, 1.0, 0.0, 5.0])  # batch 5 has no uuid -> dropped by the inner join
+    uuids = {"batch_index": [0, 1], "log_id": ["logA", "logB"], "timestamp_ns": [315969904359876000, 315969904459876000]}
+    t = build_dataframe(params, scores, categories, batch_index, uuids, ["REGULAR_VEHICLE", "PEDESTRIAN", "BUS"])
+    assert t.column_names == ["tx_m", "ty_m", "tz_m", "length_m", "width_m", "height_m", "qw", "qx", "qy", "qz", "score", "batch_index",
+                              "log_id", "timestamp_ns", "category"]
+    assert [str(f.type) for f in t.schema] == ["float"] * 11 + ["int32", "string", "int64", "string"]
+    assert t.num_rows == 6
+    assert t.column("category").to_pylist() == ["REGULAR_VEHICLE", "BUS", "PEDESTRIAN", "BUS", "REGULAR_VEHICLE", "PEDESTRIAN"]
+    assert t.column("log_id").to_pylist() == ["logA", "logA", "logB", "logB", "logB", "logA"]
+    assert torch.equal(torch.tensor(t.column("length_m").to_pylist()), params[:6, 3])
+    paths = write_detections(t, str(tmp_path), "run0")
+    assert [p.split("predictions/")[1] for p in paths] == ["run0/logA/315969904359876000.feather", "run0/logB/315969904459876000.feather"]
+    a = feather.read_table(paths[0])
+    assert a.schema == t.schema and a.num_rows == 3 and a.column("score").to_pylist() == [t.column("score")[i].as_py() for i in (0, 1, 5)]
