@@ -12,6 +12,8 @@ import os
 import re
 from typing import Dict, List, Optional
 
+import torch
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librv3d_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "rv3d.h")
@@ -54,6 +56,12 @@ def load() -> ctypes.CDLL:
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
         )
+    # Load order matters on a GPU box: the library registers its code objects with the HIP runtime when it is loaded, and
+    # it must find the runtime PyTorch already initialised (loaded the other way round -- e.g. build() followed by
+    # smoke() in one process -- its launches failed with "no ROCm-capable device is detected").  device_count() does not
+    # touch the GPU, so CPU-only boxes (the build check) pass through.
+    if torch.cuda.device_count() > 0 and torch.cuda.is_available():
+        torch.cuda.init()
     lib = ctypes.CDLL(LIB_PATH)
     lib.rv_last_error.restype = ctypes.c_char_p
     for name in ("rv_packed_weight_bytes", "rv_decode_num_candidates", "rv_wnms_workspace_bytes", "rv_tap_wgrad_workspace_bytes", "rv_bn_bwd_smallk_workspace_bytes", "rv_smallk_forward_workspace_bytes"):
