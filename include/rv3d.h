@@ -287,6 +287,12 @@ int rv_yaw_to_quat(const float* yaw, int64_t n, int64_t yaw_stride, float* quat,
 int64_t rv_wnms_workspace_bytes(int64_t n);
 int rv_wnms(const float* boxes, const float* data, int64_t n, int32_t d, float nms_thresh, float merge_thresh,
             float* output, int64_t* keep, int64_t* count, void* workspace, int64_t* host_num_out, rvStream stream);
+/* The same with a class id per box (cats, i32, may be NULL): boxes of different classes neither suppress nor merge, so ONE
+ * call does what the reference's per-class loop does (weighted_multiclass_nms, math/ops/nms.py:64-123) -- identical rows
+ * per class, since classes do not interact and the score order within a class is preserved. */
+int rv_wnms_classes(const float* boxes, const float* data, const int32_t* cats, int64_t n, int32_t d, float nms_thresh,
+                    float merge_thresh, float* output, int64_t* keep, int64_t* count, void* workspace,
+                    int64_t* host_num_out, rvStream stream);
 /* pairwise rotated BEV IoU (n x m), exposed for tests */
 int rv_rotated_iou(const float* a, int64_t n, const float* b, int64_t m, float* out, rvStream stream);
 

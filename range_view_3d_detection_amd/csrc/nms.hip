@@ -83,15 +83,19 @@ __global__ void sincos_kernel(const float* boxes, int64_t n, float* sc) {
 }
 
 // grid (col_block, row_block); only col_block >= row_block does work
-__global__ __launch_bounds__(64) void iou_mask_kernel(const float* boxes, const float* sc, int64_t n, int cb, float nms_t,
-                                                      float merge_t, unsigned long long* nms_mask,
+// cats (optional): class id per box -- boxes of different classes neither suppress nor merge (all classes of a sweep in
+// one launch instead of the reference's per-class loop)
+__global__ __launch_bounds__(64) void iou_mask_kernel(const float* boxes, const float* sc, const int32_t* cats, int64_t n, int cb,
+                                                      float nms_t, float merge_t, unsigned long long* nms_mask,
                                                       unsigned long long* merge_mask) {
     const int col = blockIdx.x, row = blockIdx.y;
     if (col < row) return;
     __shared__ float cbox[64][7];
+    __shared__ int32_t ccat[64];
     const int t = threadIdx.x;
     const int64_t j0 = (int64_t)col * 64;
     if (j0 + t < n) {
+        ccat[t] = cats ? cats[j0 + t] : 0;
 #pragma unroll
         for (int k = 0; k < 5; ++k) cbox[t][k] = boxes[(j0 + t) * 5 + k];
         cbox[t][5] = sc[2 * (j0 + t)];
@@ -104,10 +108,11 @@ __global__ __launch_bounds__(64) void iou_mask_kernel(const float* boxes, const 
 #pragma unroll
     for (int k = 0; k < 5; ++k) a[k] = boxes[i * 5 + k];
     const float sa = sc[2 * i], ca = sc[2 * i + 1];
+    const int32_t cat_i = cats ? cats[i] : 0;
     unsigned long long bits_n = 0ull, bits_m = 0ull;
     const int jn = (int)((n - j0) < 64 ? (n - j0) : 64);
     for (int j = 0; j < jn; ++j) {
-        if (j0 + j <= i) continue;
+        if (j0 + j <= i || ccat[j] != cat_i) continue;
         const float iou = rotated_iou(a, sa, ca, cbox[j], cbox[j][5], cbox[j][6]);
         if (iou > nms_t) bits_n |= 1ull << j;
         if (iou > merge_t) bits_m |= 1ull << j;
@@ -190,6 +195,12 @@ extern "C" int64_t rv_wnms_workspace_bytes(int64_t n) {
 extern "C" int rv_wnms(const float* boxes, const float* data, int64_t n, int32_t d, float nms_thresh, float merge_thresh,
                        float* output, int64_t* keep, int64_t* count, void* workspace, int64_t* host_num_out,
                        rvStream stream) {
+    return rv_wnms_classes(boxes, data, nullptr, n, d, nms_thresh, merge_thresh, output, keep, count, workspace, host_num_out, stream);
+}
+
+extern "C" int rv_wnms_classes(const float* boxes, const float* data, const int32_t* cats, int64_t n, int32_t d, float nms_thresh,
+                               float merge_thresh, float* output, int64_t* keep, int64_t* count, void* workspace,
+                               int64_t* host_num_out, rvStream stream) {
     RV_REQUIRE(host_num_out, "rv_wnms: null host_num_out");
     *host_num_out = 0;
     if (n == 0) return 0;
@@ -205,7 +216,7 @@ extern "C" int rv_wnms(const float* boxes, const float* data, int64_t n, int32_t
     float* sc = (float*)(ws + 2 * align256(n * cb64 * 8));
     long long* num_out = (long long*)(ws + 2 * align256(n * cb64 * 8) + align256(n * 2 * 4));
     hipLaunchKernelGGL(sincos_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, boxes, n, sc);
-    hipLaunchKernelGGL(iou_mask_kernel, dim3(cb, cb), dim3(64), 0, st, boxes, sc, n, cb, nms_thresh, merge_thresh, nms_mask,
+    hipLaunchKernelGGL(iou_mask_kernel, dim3(cb, cb), dim3(64), 0, st, boxes, sc, cats, n, cb, nms_thresh, merge_thresh, nms_mask,
                        merge_mask);
     static bool attr = false;
     if (!attr) {
