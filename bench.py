@@ -277,7 +277,8 @@ def main() -> None:
                                    f"fwd+bwd+AdamW, {args.batch} synthetic {args.height}x{args.width}x{args.features} sweeps per GPU"
                                    + (" (BASELINE configs[2])" if (args.widths, args.width, args.height, args.batch) == ("rv-av2", 2048, 64, 4) else ""),
                        "global_batch": args.batch * world, "sweep": [args.height, args.width, args.features], "parallelism": f"dp{world}",
-                       "sync_bn": bool(E.SYNC_BN), "loss": float(loss.detach().item())},
+                       "sync_bn": bool(E.SYNC_BN), "loss": float(loss.detach().item()),
+                       "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 2)},
             "roofline": roofline(prof, iso),
             "kernels": prof.summary(),
         }
