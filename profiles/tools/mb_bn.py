@@ -20,7 +20,7 @@ for (px, c, with_out, with_res) in [(4*64*2048, 512, False, False), (4*64*2048, 
     coef = torch.rand(3, c, device=dev)
     dy = torch.empty_like(dout); dres = torch.zeros_like(dout) if with_res else None
     common = [L.i64(px), L.i32(c), L.ptr(dout), L.i32(c), L.ptr(out) if out is not None else None, L.i32(c), L.ptr(y), L.i32(c), L.ptr(sc), L.ptr(sh), L.ptr(mu), L.ptr(isd)]
-    for extra, label in ((0, "plain"), (1 << 20, "nt-load"), (1 << 21, "nt-store"), (3 << 20, "nt-both")):
+    for extra, label in ((0, ""),):
         flags = L.BNB_RELU_Z | extra
         t_r = bench(lambda: L.call("rv_bn_bwd_reduce", *common, L.i32(flags), L.ptr(partial), L.stream_ptr()))
         t_a = bench(lambda: L.call("rv_bn_bwd_apply", *common, L.ptr(coef), L.i32(flags | (L.BNB_RES_ACCUM if with_res else 0)), L.ptr(dy), L.i32(c), L.ptr(dres) if with_res else None, L.i32(c), L.stream_ptr()))
