@@ -101,6 +101,11 @@ int32_t rv_tap_stats_rows(const rvTapGeom* g, const rvTapShape* s, int32_t scatt
  * generation 2 = tapconv2_kernel<KS> (variant = KS, block tile 2 rows x 64 columns x 128 channels, 32*KS-channel
  * chunks), generation 3 = tapconv3_kernel<KS> (8 waves, 4 rows x 64 columns x 128 channels, 3-tap weight stages).  Used by bench.py to label per-kernel timings. */
 int rv_tap_launch_info(const rvTapGeom* g, const rvTapShape* s, int32_t scatter, int32_t* host_info);
+/* Process-wide kernel-selection knob (speed heuristics only, never results).  Returns the previous value, -1 for an
+ * unknown key.  Keys: "tapconv4_min_blocks" -- smallest grid the LDS-DMA tap-conv (generation 4) is chosen for
+ * (default 256 = one round of CUs); the parity tests set 1 so that crops the CPU oracle can afford run the same
+ * kernels as the full-size sweeps. */
+int32_t rv_set_option(const char* key, int32_t value);
 /* Every partial-statistics buffer handed to rv_bn_finalize / rv_bn_bwd_finalize must have room
  * for this many extra rows after its `rows` partial rows (second-stage reduction scratch). */
 #define RV_STATS_SCRATCH_ROWS 128
@@ -299,6 +304,9 @@ int rv_rotated_iou(const float* a, int64_t n, const float* b, int64_t m, float* 
 /* ---------------------------------------------------------------------------------------
  * Range-image projection (converters/av2/utils.py:108-208 == math/numpy/conversions.py:9-128).
  * ------------------------------------------------------------------------------------- */
+/* Correctly rounded (round-to-nearest-even) fp64 atan2, elementwise -- the azimuth rv_project_indices bins with
+ * (np.arctan2 at converters/av2/utils.py:172; see csrc/project.hip for why the device value must be THE rounded one). */
+int rv_atan2_cr(const double* y, const double* x, int64_t n, double* out, rvStream stream);
 /* cart (n,3) f64 -> rows/cols (i32) + range (f64); variant 0 = converter binning
  * (col = W - round((az+pi)*W/tau)), 1 = library binning (col = round(W - (az+pi)*W/tau - 1));
  * round-half-to-even, clip to [0, W-1] before the integer cast; row = H - laser_mapping[laser] - 1. */

@@ -16,7 +16,90 @@
 // Pass 2: atomicMax(winner[p], i) over L.       Pass 3: gather the owner's features.
 #include "common.h"
 
+#include "atan_table.h"
+
 namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// Correctly rounded fp64 atan2.  The column of a point is W - rint((az + pi) * W / tau): integer work that must be
+// bit-exact (BASELINE.json north_star), so the azimuth must be a function of (x, y) alone -- the device libm's atan2 is
+// within 1-2 ulp, as is numpy's SIMD arctan2 (which differs from glibc's in ~1 % of inputs), and a last-bit difference
+// moves points that sit on a half-bin boundary.  This one returns THE round-to-nearest-even value of atan2(y, x):
+// 128-bit fixed-point CORDIC (Q.124, table from gen_atan_table.py; accumulated error < 2^-116 against an ulp of
+// >= 2^-83 on this path), a two-term series in double-double for tiny positive-x angles, libm for the exact special
+// cases (zeros, infinities, NaN).  Witness: oracle/project.py::atan2_cr (80-bit atan2l + exact decimal fallback).
+// ---------------------------------------------------------------------------------------------------------------
+typedef __int128 i128_t;
+typedef unsigned __int128 u128_t;
+struct Q128 { uint64_t hi, lo; };
+__constant__ Q128 c_atan_q[RV_ATAN_N] = RV_ATAN_TABLE_INIT;
+
+__device__ __forceinline__ void frexp_bits(double v, uint64_t* mant53, int* exp2) {  // v = mant53 * 2^exp2, mant53 in [2^52, 2^53)
+    const uint64_t b = (uint64_t)__double_as_longlong(v) & 0x7fffffffffffffffull;
+    int e = (int)(b >> 52);
+    uint64_t m = b & 0xfffffffffffffull;
+    if (e == 0) {  // subnormal: normalise
+        const int sh = __clzll((long long)m) - 11;
+        m <<= sh;
+        e = 1 - sh;
+    } else {
+        m |= 1ull << 52;
+    }
+    *mant53 = m;
+    *exp2 = e - 1075;
+}
+
+__device__ double round_q124(u128_t z) {  // non-negative Q.124 -> nearest-even double
+    if (z == 0) return 0.0;
+    const uint64_t hi = (uint64_t)(z >> 64), lo = (uint64_t)z;
+    const int p = hi ? 127 - __clzll((long long)hi) : 63 - __clzll((long long)lo);
+    if (p <= 52) return ldexp((double)lo, -RV_ATAN_FRAC);
+    const int sh = p - 52;
+    uint64_t mant = (uint64_t)(z >> sh);
+    const u128_t rem = z & ((((u128_t)1) << sh) - 1), half = ((u128_t)1) << (sh - 1);
+    if (rem > half || (rem == half && (mant & 1))) ++mant;
+    return ldexp((double)mant, sh - RV_ATAN_FRAC);  // mant <= 2^53: exact conversion
+}
+
+__device__ double atan2_cr(double y, double x) {
+    const double ax = fabs(x), ay = fabs(y);
+    if (ax == 0.0 || ay == 0.0 || !isfinite(ax) || !isfinite(ay)) return atan2(y, x);  // exact special values
+    if (x > 0.0 && ay < ax * 0x1p-30) {
+        // atan(q) = q - q^3/3 + O(q^5), q = ay/ax < 2^-30: the q^5 term is < 2^-122 relative
+        const double qh = ay / ax;
+        const double ql = fma(-qh, ax, ay) / ax;
+        const double corr = -(qh * qh * qh) / 3.0;
+        return copysign(qh + (ql + corr), y);
+    }
+    uint64_t mx, my;
+    int ex, ey;
+    frexp_bits(ax, &mx, &ex);
+    frexp_bits(ay, &my, &ey);
+    const int e = ex > ey ? ex : ey;
+    i128_t X = (e - ex < 128) ? (i128_t)((((u128_t)mx) << 72) >> (e - ex)) : (i128_t)0;
+    i128_t Y = (e - ey < 128) ? (i128_t)((((u128_t)my) << 72) >> (e - ey)) : (i128_t)0;
+    i128_t z = 0;
+    for (int i = 0; i < RV_ATAN_N; ++i) {
+        const i128_t a = (i128_t)((((u128_t)c_atan_q[i].hi) << 64) | c_atan_q[i].lo);
+        const i128_t xs = X >> i, ys = Y >> i;  // arithmetic shifts (floor)
+        if (Y >= 0) {
+            X += ys;
+            Y -= xs;
+            z += a;
+        } else {
+            X -= ys;
+            Y += xs;
+            z -= a;
+        }
+    }
+    if (z < 0) z = 0;
+    if (x < 0.0) z = (i128_t)((((u128_t)RV_PI_Q_HI) << 64) | RV_PI_Q_LO) - z;
+    return copysign(round_q124((u128_t)z), y);
+}
+
+__global__ void atan2_cr_kernel(const double* y, const double* x, int64_t n, double* out) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = atan2_cr(y[i], x[i]);
+}
 
 __global__ void project_indices_kernel(const double* cart, const int32_t* laser, const int32_t* laser_mapping, int64_t n,
                                        int H, int W, int variant, int32_t* rows, int32_t* cols, double* range) {
@@ -25,7 +108,7 @@ __global__ void project_indices_kernel(const double* cart, const int32_t* laser,
         const double x = cart[3 * i], y = cart[3 * i + 1], z = cart[3 * i + 2];
         const double hyp = hypot(x, y);
         const double r = hypot(hyp, z);
-        double az = atan2(y, x);
+        double az = atan2_cr(y, x);
         az += kPi;
         az *= (double)W / kTau;
         double col = variant == 0 ? (double)W - rint(az) : rint((double)W - az - 1.0);  // rint: round-half-even
@@ -89,6 +172,14 @@ int grid_for(int64_t work) {
 }
 
 }  // namespace
+
+extern "C" int rv_atan2_cr(const double* y, const double* x, int64_t n, double* out, rvStream stream) {
+    if (n == 0) return 0;
+    RV_REQUIRE(y && x && out, "rv_atan2_cr: null argument");
+    hipLaunchKernelGGL(atan2_cr_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, y, x, n, out);
+    RV_CHECK_LAUNCH("atan2_cr_kernel");
+    return 0;
+}
 
 extern "C" int rv_project_indices(const double* cart, const int32_t* laser, const int32_t* laser_mapping, int64_t n,
                                   int32_t H, int32_t W, int32_t variant, int32_t* rows, int32_t* cols, double* range,

@@ -510,7 +510,19 @@ static int tap_launch(const rvTapGeom* g, const rvTapShape* s, bool scatter, con
     RV_FAIL("tap conv: no kernel for tile %dx%d", mt, nt);
 }
 
+extern int g_tapconv4_min_blocks;
+
 extern "C" {
+
+int32_t rv_set_option(const char* key, int32_t value) {
+    if (key && strcmp(key, "tapconv4_min_blocks") == 0) {
+        const int32_t old = g_tapconv4_min_blocks;
+        if (value >= 0) g_tapconv4_min_blocks = value;
+        return old;
+    }
+    rv_set_error("rv_set_option: unknown key '%s'", key ? key : "(null)");
+    return -1;
+}
 
 int32_t rv_tap_stats_rows(const rvTapGeom* g, const rvTapShape* s, int32_t scatter) {
     int rows = 0;

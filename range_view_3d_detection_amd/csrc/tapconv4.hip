@@ -343,6 +343,11 @@ __global__ __launch_bounds__(512, 2) void tapconv4_kernel(const TapConvArgs a) {
 
 }  // namespace
 
+// Smallest grid (workgroups) the DMA kernel is chosen for: below one round of 256 CUs the register-staged kernels with
+// their smaller tiles fill the chip better.  A speed heuristic only -- rv_set_option("tapconv4_min_blocks", 1) lets the
+// parity tests run the production kernels on crops the CPU oracle can afford.
+int g_tapconv4_min_blocks = 256;
+
 // returns false when the layer is not eligible (caller falls back to tapconv3 / tapconv2 / the generic kernel)
 bool rv_tapconv4_plan(TapConvArgs* a, int* tiles, size_t* lds, int* bn) {
     if (a->step != 1) return false;
@@ -359,7 +364,7 @@ bool rv_tapconv4_plan(TapConvArgs* a, int* tiles, size_t* lds, int* bn) {
     a->total_tiles = a->m_tiles * a->h_tiles * a->N * a->phases;
     a->n_tiles = a->C_dst / BN;
     a->tiles_per_xcd = rv_ceil_div(a->total_tiles, 8);
-    if ((int64_t)a->total_tiles * a->n_tiles < 256) return false;  // too few tiles to fill the chip
+    if ((int64_t)a->total_tiles * a->n_tiles < g_tapconv4_min_blocks) return false;  // too few tiles to fill the chip
     *tiles = a->total_tiles;  // stats rows = 2 * tiles
     *bn = BN;
     *lds = (size_t)(BN == 256 ? kTabOffset : 9 * kPiece) + 256;

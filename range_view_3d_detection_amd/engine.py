@@ -80,7 +80,8 @@ _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 def side_stream(device) -> "torch.cuda.Stream":
     idx = torch.device(device).index or 0
     if idx not in _SIDE_STREAMS:
-        _SIDE_STREAMS[idx] = torch.cuda.Stream(device=device)
+        prio = os.environ.get("RV3D_SIDE_PRIORITY")
+        _SIDE_STREAMS[idx] = torch.cuda.Stream(device=device, priority=int(prio)) if prio is not None else torch.cuda.Stream(device=device)
     return _SIDE_STREAMS[idx]
 
 

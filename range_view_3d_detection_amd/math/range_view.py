@@ -36,6 +36,15 @@ def range_view_indices(cart: Tensor, laser_numbers: Tensor, laser_mapping: Tenso
     return rows, cols, rng
 
 
+def atan2_cr(y: Tensor, x: Tensor) -> Tensor:
+    """Correctly rounded fp64 ``atan2`` (the azimuth the binning uses; ``rv_atan2_cr``)."""
+    _require_cuda(y, "y")
+    y, x = y.double().contiguous(), x.double().contiguous()
+    out = torch.empty_like(y)
+    L.call("rv_atan2_cr", L.ptr(y), L.ptr(x), L.i64(y.numel()), L.ptr(out), L.stream_ptr())
+    return out
+
+
 def z_buffer(rows: Tensor, cols: Tensor, distances: Tensor, features: Tensor, height: int, width: int,
              min_distance: float = 1.0) -> Tuple[Tensor, Tensor]:
     """features (C,N) f64 -> (image (C,H,W) f32, winner (H,W) i64); reference z-buffer semantics."""

@@ -240,12 +240,8 @@ def test_projection_bit_exact(golden):
         ref_idx = g.np(f"indices_{variant}")
         rows_c, cols_c = rows.cpu().numpy(), cols.cpu().numpy()
         assert np.array_equal(rows_c, ref_idx[0])
-        # device atan2 vs glibc atan2 may differ in the last ulp: only points that sit within 1e-9 of a bin
-        # boundary (the fixture forces 200 exact half-bin azimuths) may land in the neighbouring column.
-        diff = np.nonzero(cols_c != ref_idx[1])[0]
-        az = (g.np("sph")[:, 0] + math.pi) * (W / math.tau)
-        frac = np.abs((az - np.floor(az)) - 0.5)
-        assert np.all(frac[diff] < 1e-9) and np.all(np.abs(cols_c[diff] - ref_idx[1][diff]) <= 1)
+        # integer work: bit-exact, including the fixture's 112 exact half-bin azimuths (round-half-to-even)
+        assert np.array_equal(cols_c, ref_idx[1]), int((cols_c != ref_idx[1]).sum())
         assert rel_err(rng, torch.from_numpy(g.np(f"hybrid_{variant}")[:, 2])) < 1e-15
         # z-buffer on the REFERENCE's indices: image and ownership bit-exact
         r_t, c_t = torch.from_numpy(ref_idx[0]).to(DEV), torch.from_numpy(ref_idx[1]).to(DEV)
@@ -254,6 +250,43 @@ def test_projection_bit_exact(golden):
         assert np.array_equal(image.cpu().numpy(), g.np(f"image_{variant}")), variant
         _, win_o = oproj.z_buffer(ref_idx[0], ref_idx[1], g.np(f"hybrid_{variant}")[:, 2], g.np("features"), H, W)
         assert np.array_equal(winner.cpu().numpy(), win_o)
+
+
+def test_atan2_correctly_rounded_and_bins_on_a_million_points():
+    """Device azimuth == THE correctly rounded fp64 atan2 (witness: oracle.project.atan2_cr), bit for bit, on random,
+    near-axis, tiny-ratio and extreme-exponent inputs; columns of 1.2e6 random points == the oracle's numpy binning."""
+    from oracle import project as oproj
+    from range_view_3d_detection_amd.math import range_view as rv
+
+    rng = np.random.default_rng(7)
+    n = 1_200_000
+    x, y = rng.normal(size=n) * 50, rng.normal(size=n) * 50
+    x[:2000] = rng.uniform(1, 100, 2000)
+    y[:2000] = x[:2000] * 2.0 ** rng.uniform(-60, -20, 2000) * rng.choice([-1, 1], 2000)  # tiny angles (series branch + its edge)
+    x[2000:3000] = -rng.uniform(1, 100, 1000)
+    y[2000:3000] = 2.0 ** rng.uniform(-80, -10, 1000)  # just below +pi
+    y[3000:4000] = rng.uniform(1, 100, 1000)
+    x[3000:4000] = 2.0 ** rng.uniform(-80, -10, 1000) * rng.choice([-1, 1], 1000)  # around pi/2
+    x[4000:4500] *= 2.0 ** 300
+    y[4000:4500] *= 2.0 ** 300
+    x[4500:5000] *= 2.0 ** -300
+    y[4500:5000] *= 2.0 ** -300
+    x[5000:5010] = [0.0, -0.0, 1.0, -1.0, 0.0, -0.0, 3.0, -3.0, np.inf, -np.inf]
+    y[5000:5010] = [0.0, 0.0, 0.0, 0.0, 2.0, -2.0, -0.0, -0.0, 1.0, 1.0]
+    az = rv.atan2_cr(torch.from_numpy(y).to(DEV), torch.from_numpy(x).to(DEV)).cpu().numpy()
+    ref = oproj.atan2_cr(y, x)
+    assert np.array_equal(az.view(np.int64), ref.view(np.int64)), int((az.view(np.int64) != ref.view(np.int64)).sum())
+    # binning of sensor-frame points: columns of both variants equal the oracle's (numpy) result
+    cart = np.stack([x, y, rng.normal(size=n) * 3], axis=1)
+    cart[4000:5010] = rng.normal(size=(1010, 3)) * 30
+    laser = rng.integers(0, 64, n)
+    mapping = rng.permutation(64)
+    H, W = 64, 2048
+    sph = oproj.cart_to_sph(cart)
+    for variant in ("converter", "library"):
+        r_o, c_o, _ = oproj.range_view_indices(sph, laser, mapping, H, W, variant)
+        r, c, _ = rv.range_view_indices(torch.from_numpy(cart).to(DEV), torch.from_numpy(laser).to(DEV), torch.from_numpy(mapping).to(DEV), H, W, variant)
+        assert np.array_equal(r.cpu().numpy(), r_o) and np.array_equal(c.cpu().numpy(), c_o), variant
 
 
 def test_z_buffer_fp64_vs_fp32_quirk():

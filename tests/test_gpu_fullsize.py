@@ -109,8 +109,21 @@ def test_decode_full_size_matches_oracle():
     s, c, b = decode_candidates(logits.to(DEV), reg.to(DEV), cart.to(DEV), mask.to(DEV), True, [0, 15, 30], [15, 30, math.inf], [8, 2, 1])
     assert s.shape == (B, 212_992)
     so, co, bo = odec.dense_candidates(logits, reg, cart, mask)
-    diff = c.cpu() != co
-    assert int(diff.sum()) <= 8  # argmax may differ only where two sigmoid values collide in fp32 (device expf vs CPU)
+    # Class arg-max.  sigmoid is monotone, so the arg-max of the fp32 scores is the arg-max of the logits EXCEPT where the two
+    # largest sigmoids collide (or swap) in fp32 -- and there the reference itself is not a function of the logits: torch's
+    # CPU sigmoid is a 1-ulp vectorised exp (Sleef) in the body of its loop and std::exp in the scalar tail, so the same
+    # logit pair resolves differently depending on where it sits in memory and on the host's vector width.  Bit-exactness
+    # is therefore required wherever the decision is decidable: at every candidate whose category differs from the oracle's,
+    # the score of the class the device picked must lie within 2 fp32 ulps of the score of the class the oracle picked
+    # (i.e. the two classes collide in fp32 sigmoid); anything else is an arg-max error.
+    diff = (c.cpu() != co).nonzero()
+    n_dec = 0
+    sd_, sod = s.cpu().double(), so.double()
+    for bi, ki in diff.tolist():
+        ulp = float(np.spacing(np.float32(sod[bi, ki])))
+        assert abs(float(sd_[bi, ki]) - float(sod[bi, ki])) <= 2 * ulp, (bi, ki, float(sd_[bi, ki]), float(sod[bi, ki]))
+        n_dec += 1
+    assert n_dec <= 64, n_dec  # collisions are rare: a wholesale arg-max bug would show up as thousands
     assert rel_err(s, so) < 1e-6 and rel_err(b, bo) < 1e-5
 
 

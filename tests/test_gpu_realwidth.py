@@ -1,0 +1,180 @@
+"""Composed-model parity at the REAL channel widths (the programs bench.py runs), against the pinned oracle.
+
+* rv-av2 widths  (layers [256,128,128,128,128], towers 512, 26 classes, 5 features) on a 1 x 64 x 256 crop;
+* rv-waymo widths ([128]*5, towers 256, 3 classes, 6 features) on a 1 x 64 x 336 crop (width not a multiple of 64);
+* one full-size (1 x 64 x 2048) eval forward of the rv-av2 model.
+
+On crops this small the library's speed heuristic would pick the register-staged kernels (too few tiles to fill 256 CUs), so
+the tests lower it with ``rv_set_option("tapconv4_min_blocks", 1)`` and ASSERT from the launch records that the production
+kernels -- ``tapconv4_kernel<256>``, ``tapconv4_kernel<128>`` and ``wgrad3_kernel`` -- are what ran.
+
+Tolerances (stated next to the asserts) are relative to the tensor maximum unless noted:
+forward vs the oracle with the same bf16 storage points (``Numerics.bf16``), forward vs the fp32 oracle (= the reference's
+CPU path, pinned by tests/golden), loss relative error, per-parameter gradient cosine against the fp32 oracle with the CPU
+bf16 emulation as the yardstick of what bf16 storage costs (see test_gpu_model.py::test_detector_gradients_vs_oracle).
+"""
+
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_backward import _cos
+from test_gpu_forward import DEV, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+class _Option:
+    def __init__(self, key: str, value: int) -> None:
+        self.key, self.value = key.encode(), value
+
+    def __enter__(self):
+        from range_view_3d_detection_amd import _lib as L
+
+        self.old = L.load().rv_set_option(self.key, ctypes.c_int32(self.value))
+        assert self.old >= 0
+        return self
+
+    def __exit__(self, *exc):
+        from range_view_3d_detection_amd import _lib as L
+
+        L.load().rv_set_option(self.key, ctypes.c_int32(self.old))
+
+
+def _check_forward(m):
+    for got, emu in (("logits", "emu~fp32"), ("reg", "reg emu~fp32")):
+        assert m[f"{got}~bf16"] < max(3e-2, 1.5 * m[emu] + 1e-2), m
+        assert m[f"{got}~fp32"] < 1.5 * m[emu] + 1e-2, m
+
+
+def _prepare(widths, n_feat, n_cls, W, bn_bias_shift, B=1, H=64, boxes=12):
+    from bench import build_model, synthetic_batch
+
+    torch.manual_seed(0)
+    backbone, head = build_model(widths, n_cls, n_feat)
+    gen = torch.Generator().manual_seed(1)
+    for m in list(backbone.modules()) + list(head.modules()):
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data = 0.5 + torch.rand(m.weight.shape, generator=gen)
+            m.bias.data = 0.2 * torch.randn(m.bias.shape, generator=gen) + bn_bias_shift
+            m.running_mean.data = 0.1 * torch.randn(m.running_mean.shape, generator=gen)
+            m.running_var.data = 0.5 + torch.rand(m.running_var.shape, generator=gen)
+    sd = {**{f"backbone.{k}": v.clone() for k, v in backbone.state_dict().items()}, **{f"head.{k}": v.clone() for k, v in head.state_dict().items()}}
+    batch = synthetic_batch(B, H, W, seed=3, device="cpu", n_feat=n_feat, boxes_per_sweep=boxes, n_cls=n_cls)
+    return backbone, head, sd, batch
+
+
+@pytest.mark.parametrize("widths,n_feat,n_cls,W,bn_bias_shift", [("rv-av2", 5, 26, 256, 3.0), ("rv-av2", 5, 26, 256, 0.0),
+                                                                 ("rv-waymo", 6, 3, 336, 3.0)])
+def test_real_width_train_step_vs_oracle(widths, n_feat, n_cls, W, bn_bias_shift):
+    from bench import Detector
+    from oracle import model as om
+    from oracle import targets as otgt
+    from range_view_3d_detection_amd import engine as E
+
+    backbone, head, sd, batch = _prepare(widths, n_feat, n_cls, W, bn_bias_shift)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+
+    def oracle_run(nm):
+        params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
+        _, logits, reg = om.detector_forward(batch["features"], batch["cart"], {**sd, **params}, nm=nm)
+        tg = otgt.compute_targets(batch["cart"], batch["annotations"], n_cls)
+        loss = otgt.detection_loss(logits, reg, batch["cart"], batch["mask"], tg, n_cls)["loss"]
+        loss.backward()
+        return logits.detach(), reg.detach(), float(loss.detach()), {k: p.grad for k, p in params.items()}, tg
+
+    lg32, rg32, loss32, g32, tg = oracle_run(om.Numerics(train=True))
+    lg16, rg16, loss16, g16, _ = oracle_run(om.Numerics.bf16(train=True))
+
+    model = Detector(backbone, head).to(DEV).train()
+    data = {k: (v.to(DEV) if k != "annotations" else v) for k, v in batch.items()}
+    with _Option("tapconv4_min_blocks", 1):
+        E.PROFILE = E.KernelProfile()
+        try:
+            feats = model.backbone(data)
+            outputs, losses = model.head(feats, data, return_loss=True)
+            losses["loss"].backward()
+            torch.cuda.synchronize()
+            ran = set(name for name, *_ in E.PROFILE.records)
+        finally:
+            E.PROFILE = None
+    # ---- the production kernels are what ran ----
+    need = {"tapconv4_kernel<256>", "tapconv4_kernel<128>", "wgrad3_kernel(+reduce)"}
+    assert need <= ran, (need - ran, sorted(ran))
+
+    logits, reg = outputs[1][0]["logits"].float().cpu(), outputs[1][0]["regressands"].float().cpu()
+    loss = float(losses["loss"].detach())
+    m = {"logits~bf16": rel_err(logits, lg16), "logits~fp32": rel_err(logits, lg32), "emu~fp32": rel_err(lg16, lg32),
+         "reg~bf16": rel_err(reg, rg16), "reg~fp32": rel_err(reg, rg32), "reg emu~fp32": rel_err(rg16, rg32)}
+    print(f"[{widths} shift {bn_bias_shift}] " + "  ".join(f"{k} {v:.3e}" for k, v in m.items()) +
+          f"  loss {loss:.6f} / bf16-emu {loss16:.6f} / fp32 {loss32:.6f}")
+    # targets are integer work: exact
+    for k in ("classification_labels", "panoptics", "points_per_obj"):
+        assert torch.equal(data[1][0][k].cpu(), tg[k]), k
+    # forward, relative to the tensor maximum: what bf16 storage costs the CPU emulation of the same model against fp32
+    # (emu~fp32) is the yardstick -- two bf16 realisations of the model (different summation order inside the fp32
+    # accumulators, ReLU gates within one bf16 ulp of zero) differ from each other by about as much as each differs from
+    # fp32.  Bounds: vs the bf16 emulation max(3e-2, 1.5 x yardstick + 1e-2); vs fp32 1.5 x yardstick + 1e-2.
+    _check_forward(m)
+    assert _cos(logits, lg32) > 0.999 and _cos(reg, rg32) > 0.999, (_cos(logits, lg32), _cos(reg, rg32))
+    # loss: 1e-2 relative to the fp32 oracle (and no further from it than 2x the bf16 emulation + 2e-3)
+    assert abs(loss - loss32) / abs(loss32) < 1e-2, (loss, loss32, loss16)
+    assert abs(loss - loss32) <= 2.0 * abs(loss16 - loss32) + 2e-3 * abs(loss32), (loss, loss32, loss16)
+
+    cos32, cos_emu, names = [], [], []
+    for k, p in model.named_parameters():
+        ref = g32[k]
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+        if float(ref.norm()) < 1e-9:
+            continue
+        names.append(k)
+        cos32.append(_cos(p.grad.cpu(), ref))
+        cos_emu.append(_cos(g16[k], ref))
+    cos32, cos_emu = np.array(cos32), np.array(cos_emu)
+    med32, med_emu = float(np.median(cos32)), float(np.median(cos_emu))
+    q32, q_emu = float(np.quantile(cos32, 0.05)), float(np.quantile(cos_emu, 0.05))
+    print(f"    {len(cos32)} parameters; gradient cosine vs fp32 oracle: HIP median {med32:.4f} q05 {q32:.4f} min {cos32.min():.4f};  "
+          f"CPU bf16 emulation median {med_emu:.4f} q05 {q_emu:.4f} min {cos_emu.min():.4f}")
+    for i in np.argsort(cos32)[:4]:
+        print(f"    worst: {names[i]:60s} HIP {cos32[i]:.4f}  emulation {cos_emu[i]:.4f}  |g| {float(g32[names[i]].norm()):.2e}")
+    # gradients: at least as close to the fp32 oracle as the CPU bf16 emulation (median - 0.02, 5 % quantile - 0.05);
+    # in the well-conditioned regime (gates firmly open) additionally median > 0.99, 5 % quantile > 0.95
+    assert med32 > med_emu - 0.02 and q32 > q_emu - 0.05, (med32, med_emu, q32, q_emu)
+    if bn_bias_shift >= 3.0:
+        assert med32 > 0.99 and q32 > 0.95, (med32, q32)
+
+
+def test_full_size_eval_forward_vs_oracle():
+    """rv-av2 model, eval mode (running statistics), ONE full 64 x 2048 sweep: logits / regressands vs the oracle."""
+    from oracle import model as om
+
+    backbone, head, sd, batch = _prepare("rv-av2", 5, 26, 2048, 0.5)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    with torch.no_grad():
+        _, lg16, rg16 = om.detector_forward(batch["features"], batch["cart"], sd, nm=om.Numerics.bf16(train=False))
+        _, lg32, rg32 = om.detector_forward(batch["features"], batch["cart"], sd, nm=om.Numerics(train=False))
+    backbone, head = backbone.to(DEV).eval(), head.to(DEV).eval()
+    data = {k: (v.to(DEV) if k != "annotations" else v) for k, v in batch.items()}
+    from range_view_3d_detection_amd import engine as E
+
+    E.PROFILE = E.KernelProfile()
+    try:
+        with torch.no_grad():
+            feats = backbone(data)
+            outputs, _ = head(feats, data, return_loss=False)
+        torch.cuda.synchronize()
+        ran = set(name for name, *_ in E.PROFILE.records)
+    finally:
+        E.PROFILE = None
+    assert {"tapconv4_kernel<256>", "tapconv4_kernel<128>"} <= ran, sorted(ran)
+    logits, reg = outputs[1][0]["logits"].float().cpu(), outputs[1][0]["regressands"].float().cpu()
+    m = {"logits~bf16": rel_err(logits, lg16), "logits~fp32": rel_err(logits, lg32), "emu~fp32": rel_err(lg16, lg32),
+         "reg~bf16": rel_err(reg, rg16), "reg~fp32": rel_err(reg, rg32), "reg emu~fp32": rel_err(rg16, rg32)}
+    print("[rv-av2 eval 1x64x2048] " + "  ".join(f"{k} {v:.3e}" for k, v in m.items()))
+    # same bounds as the training-mode crop test
+    _check_forward(m)
+    assert _cos(logits, lg32) > 0.999 and _cos(reg, rg32) > 0.999

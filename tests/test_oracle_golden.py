@@ -160,6 +160,25 @@ def test_projection_bit_exact(golden):
     close(torch.from_numpy(oproj.sph_to_cart(g.np("sph"))), g["np_sph_to_cart"], 1e-12, "np sph->cart")
 
 
+def test_correctly_rounded_azimuth_gives_the_reference_columns(golden):
+    """The device bins with THE correctly rounded atan2 (witness ``oproj.atan2_cr``); numpy's SIMD arctan2 differs from it
+    in the last bit on ~1 % of the fixture points, none of which changes a column -- the 112 exact half-bin ties included."""
+    g = golden("projection")
+    cart, sph = g.np("cart"), g.np("sph").copy()
+    az = oproj.atan2_cr(cart[:, 1], cart[:, 0])
+    assert np.max(np.abs(az - sph[:, 0])) <= np.spacing(np.pi)  # within one ulp of the reference's azimuth
+    sph[:, 0] = az
+    H, W = g.np("image_converter").shape[1:]
+    t = (az + np.pi) * (W / math.tau)
+    assert int((t - np.floor(t) == 0.5).sum()) >= 100  # the fixture really contains exact ties
+    for variant in ("converter", "library"):
+        _, cols, _ = oproj.range_view_indices(sph, g.np("laser_numbers"), g.np("row_mapping_64"), H, W, variant)
+        assert np.array_equal(cols, g.np(f"indices_{variant}")[1]), variant
+    # the decimal fallback alone (no long double) agrees with the fast path
+    for i in (0, 17, 2000, 2100, 5999):
+        assert oproj._atan2_exact_rn(float(cart[i, 1]), float(cart[i, 0])) == az[i]
+
+
 def test_w_padding_rule(golden):
     g = golden("projection")
     for ds, w_out in (("av2", 1808), ("waymo", 2656)):
