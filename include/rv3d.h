@@ -104,7 +104,8 @@ int rv_tap_launch_info(const rvTapGeom* g, const rvTapShape* s, int32_t scatter,
 /* Process-wide kernel-selection knob (speed heuristics only, never results).  Returns the previous value, -1 for an
  * unknown key.  Keys: "tapconv4_min_blocks" -- smallest grid the LDS-DMA tap-conv (generation 4) is chosen for
  * (default 256 = one round of CUs); the parity tests set 1 so that crops the CPU oracle can afford run the same
- * kernels as the full-size sweeps. */
+ * kernels as the full-size sweeps; "tapconv5_enable" (default 1) -- 0 keeps multi-tap layers on generation 4 (the tests
+ * of that kernel). */
 int32_t rv_set_option(const char* key, int32_t value);
 /* Every partial-statistics buffer handed to rv_bn_finalize / rv_bn_bwd_finalize must have room
  * for this many extra rows after its `rows` partial rows (second-stage reduction scratch). */

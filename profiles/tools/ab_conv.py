@@ -20,7 +20,9 @@ def run(layer, x, iters=10):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / iters * 1e3
 variants = sys.argv[1].split(',')   # e.g. "RV3D_TC4_VARIANT=0,RV3D_TC4_VARIANT=1,RV3D_NO_TAPCONV4=1"
-for (cin, cout, W) in ((512, 512, 2048), (256, 256, 2048), (128, 128, 1024), (128, 128, 512), (256, 128, 2048)):
+shapes = ((512, 512, 2048), (256, 256, 2048), (128, 128, 1024), (128, 128, 512), (256, 128, 2048))
+if len(sys.argv) > 2: shapes = [shapes[int(i)] for i in sys.argv[2].split(',')]   # optional: indices of the shapes to run
+for (cin, cout, W) in shapes:
     layer, x = setup(cin, cout, 3, 4, 64, W)
     res = {v: [] for v in variants}
     for rnd in range(5):

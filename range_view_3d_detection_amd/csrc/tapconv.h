@@ -52,3 +52,8 @@ int rv_tapconv3_launch(const TapConvArgs& a, int grid_x, int grid_y, size_t lds,
 // fourth-generation kernel (tapconv4.hip): 256 x 256 tiles, LDS-DMA staging, counted waits; stats rows = 2 * tiles
 bool rv_tapconv4_plan(TapConvArgs* a, int* tiles, size_t* lds, int* bn);
 int rv_tapconv4_launch(const TapConvArgs& a, size_t lds, int bn, hipStream_t stream);
+
+// fifth-generation kernel (tapconv5.hip): 256 x 256 tiles with the input halo of a channel chunk resident in LDS for all
+// taps (multi-tap layers); stats rows = 2 * tiles
+bool rv_tapconv5_plan(TapConvArgs* a, int* tiles, size_t* lds);
+int rv_tapconv5_launch(const TapConvArgs& a, size_t lds, hipStream_t stream);

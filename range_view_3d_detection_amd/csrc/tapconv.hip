@@ -385,6 +385,8 @@ int rv_build_tap_table(const rvTapGeom* g, bool scatter, TapTable* tt, int* phas
     return 0;
 }
 
+static int g_tapconv5_enable = 1;  // rv_set_option("tapconv5_enable", 0): multi-tap layers stay on tapconv4 (tests of that kernel)
+
 static int tap_launch(const rvTapGeom* g, const rvTapShape* s, bool scatter, const void* src, const float* in_scale,
                       const float* in_shift, const void* w, const float* bias, void* dst, float* stats,
                       rvStream stream, bool dry_run, int* stats_rows, int* info = nullptr) {
@@ -421,7 +423,24 @@ static int tap_launch(const rvTapGeom* g, const rvTapShape* s, bool scatter, con
     a.bias = bias;
     a.stats = stats;
 
-    // fastest path: 256 x 256 tiles streamed by LDS-DMA, counted waits (tapconv4.hip); plain bf16 inputs only
+    // multi-tap layers with 256-channel output tiles: input halo resident in LDS across the taps (tapconv5.hip)
+    if (g_tapconv5_enable && getenv("RV3D_NO_TAPCONV5") == nullptr) {
+        int tiles;
+        size_t lds5;
+        TapConvArgs a5 = a;
+        if (rv_tapconv5_plan(&a5, &tiles, &lds5)) {
+            if (stats_rows) *stats_rows = tiles * 2;
+            if (info) {
+                info[0] = 5;
+                info[1] = 256;
+                info[2] = tiles;
+                info[3] = a5.n_tiles;
+            }
+            if (dry_run) return 0;
+            return rv_tapconv5_launch(a5, lds5, (hipStream_t)stream);
+        }
+    }
+    // 256 x 256 (or x 128) tiles streamed by LDS-DMA, counted waits (tapconv4.hip); plain bf16 inputs only
     if (getenv("RV3D_NO_TAPCONV4") == nullptr) {
         int tiles, bn;
         size_t lds4;
@@ -518,6 +537,11 @@ int32_t rv_set_option(const char* key, int32_t value) {
     if (key && strcmp(key, "tapconv4_min_blocks") == 0) {
         const int32_t old = g_tapconv4_min_blocks;
         if (value >= 0) g_tapconv4_min_blocks = value;
+        return old;
+    }
+    if (key && strcmp(key, "tapconv5_enable") == 0) {
+        const int32_t old = g_tapconv5_enable;
+        if (value >= 0) g_tapconv5_enable = value ? 1 : 0;
         return old;
     }
     rv_set_error("rv_set_option: unknown key '%s'", key ? key : "(null)");

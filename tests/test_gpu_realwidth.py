@@ -51,6 +51,14 @@ def _check_forward(m):
         assert m[f"{got}~fp32"] < 1.5 * m[emu] + 1e-2, m
 
 
+def _check_direction(logits, lg16, lg32, reg, rg16, rg32):
+    """Cosine against the fp32 oracle: > 0.99, and no worse than the CPU bf16 emulation's by more than 2e-3."""
+    for name, got, emu, ref in (("logits", logits, lg16, lg32), ("regressands", reg, rg16, rg32)):
+        c, c_emu = _cos(got, ref), _cos(emu, ref)
+        print(f"    {name}: cosine vs fp32 oracle {c:.5f} (CPU bf16 emulation {c_emu:.5f})")
+        assert c > 0.99 and c > c_emu - 2e-3, (name, c, c_emu)
+
+
 def _prepare(widths, n_feat, n_cls, W, bn_bias_shift, B=1, H=64, boxes=12):
     from bench import build_model, synthetic_batch
 
@@ -103,7 +111,8 @@ def test_real_width_train_step_vs_oracle(widths, n_feat, n_cls, W, bn_bias_shift
         finally:
             E.PROFILE = None
     # ---- the production kernels are what ran ----
-    need = {"tapconv4_kernel<256>", "tapconv4_kernel<128>", "wgrad3_kernel(+reduce)"}
+    # (rv-waymo has no 256-channel pointwise conv: its only 256-channel layers are the 3x3 towers, i.e. tapconv5)
+    need = {"tapconv5_kernel<256>", "tapconv4_kernel<128>", "wgrad3_kernel(+reduce)"} | ({"tapconv4_kernel<256>"} if widths == "rv-av2" else set())
     assert need <= ran, (need - ran, sorted(ran))
 
     logits, reg = outputs[1][0]["logits"].float().cpu(), outputs[1][0]["regressands"].float().cpu()
@@ -120,7 +129,7 @@ def test_real_width_train_step_vs_oracle(widths, n_feat, n_cls, W, bn_bias_shift
     # accumulators, ReLU gates within one bf16 ulp of zero) differ from each other by about as much as each differs from
     # fp32.  Bounds: vs the bf16 emulation max(3e-2, 1.5 x yardstick + 1e-2); vs fp32 1.5 x yardstick + 1e-2.
     _check_forward(m)
-    assert _cos(logits, lg32) > 0.999 and _cos(reg, rg32) > 0.999, (_cos(logits, lg32), _cos(reg, rg32))
+    _check_direction(logits, lg16, lg32, reg, rg16, rg32)
     # loss: 1e-2 relative to the fp32 oracle (and no further from it than 2x the bf16 emulation + 2e-3)
     assert abs(loss - loss32) / abs(loss32) < 1e-2, (loss, loss32, loss16)
     assert abs(loss - loss32) <= 2.0 * abs(loss16 - loss32) + 2e-3 * abs(loss32), (loss, loss32, loss16)
@@ -170,11 +179,11 @@ def test_full_size_eval_forward_vs_oracle():
         ran = set(name for name, *_ in E.PROFILE.records)
     finally:
         E.PROFILE = None
-    assert {"tapconv4_kernel<256>", "tapconv4_kernel<128>"} <= ran, sorted(ran)
+    assert {"tapconv5_kernel<256>", "tapconv4_kernel<256>", "tapconv4_kernel<128>"} <= ran, sorted(ran)
     logits, reg = outputs[1][0]["logits"].float().cpu(), outputs[1][0]["regressands"].float().cpu()
     m = {"logits~bf16": rel_err(logits, lg16), "logits~fp32": rel_err(logits, lg32), "emu~fp32": rel_err(lg16, lg32),
          "reg~bf16": rel_err(reg, rg16), "reg~fp32": rel_err(reg, rg32), "reg emu~fp32": rel_err(rg16, rg32)}
     print("[rv-av2 eval 1x64x2048] " + "  ".join(f"{k} {v:.3e}" for k, v in m.items()))
     # same bounds as the training-mode crop test
     _check_forward(m)
-    assert _cos(logits, lg32) > 0.999 and _cos(reg, rg32) > 0.999
+    _check_direction(logits, lg16, lg32, reg, rg16, rg32)

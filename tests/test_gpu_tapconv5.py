@@ -1,9 +1,10 @@
-"""tapconv4 (256 x 256 tiles, LDS-DMA staging, counted waits): exact checks with integer data.
+"""tapconv5 (256 x 256 tiles, input halo of a channel chunk resident in LDS across the taps): exact checks with integer data.
 
-With small-integer activations and weights every product and every partial sum is an integer below 2^24, so the fp32
-accumulators hold the exact result whatever the summation order; the kernel's bf16 output must therefore equal the
-CPU convolution rounded once to bf16, bit for bit.  Every case asserts (through ``rv_tap_launch_info``) that it is this
-kernel that runs, not one of the register-staged ones.
+Same method as test_gpu_tapconv4.py: small-integer activations and weights make every partial sum an integer below 2^24, so
+the bf16 output must equal the CPU convolution rounded once to bf16, bit for bit, whatever the summation order.  Every case
+asserts (``rv_tap_launch_info``) that generation 5 runs.  Shapes cover ragged tile rows (H % 8 != 0) and columns
+(W % 32 != 0), one and several channel chunks (halo double-buffering), two channel tiles, bias, batch statistics, the
+conv-transpose phases (2 x 3 taps per phase, short chunks) and the accumulate epilogue.
 """
 
 from __future__ import annotations
@@ -15,26 +16,22 @@ import torch
 import torch.nn.functional as F
 
 from test_gpu_forward import DEV
+from test_gpu_tapconv4 import _ints
 
 pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(autouse=True)
-def _generation4_only():
-    """Multi-tap layers with 256-channel tiles go to tapconv5 by default; these tests pin generation 4."""
+def _small_grids_allowed():
+    """The library keeps grids below one round of CUs on the register-staged kernels (speed heuristic); lift that here."""
     from range_view_3d_detection_amd import _lib as L
 
-    old = L.load().rv_set_option(b"tapconv5_enable", ctypes.c_int32(0))
+    old = L.load().rv_set_option(b"tapconv4_min_blocks", ctypes.c_int32(1))
     yield
-    L.load().rv_set_option(b"tapconv5_enable", ctypes.c_int32(old))
+    L.load().rv_set_option(b"tapconv4_min_blocks", ctypes.c_int32(old))
 
 
-def _ints(shape, g, lo=-3, hi=4):
-    return torch.randint(lo, hi, shape, generator=g).float()
-
-
-def _run(module, x, stats=False, expect_kernel=4):
-    """bf16-output tap-conv launch through the engine; returns (NCHW float output, ConvOp)."""
+def _run(module, x, stats=False):
     from range_view_3d_detection_amd import _lib as L
     from range_view_3d_detection_amd import engine as E
 
@@ -43,32 +40,23 @@ def _run(module, x, stats=False, expect_kernel=4):
     op = E.ConvOp(t, layer, E.Act.from_nchw(x), stats=stats)
     info = (ctypes.c_int32 * 4)()
     assert L.load().rv_tap_launch_info(ctypes.byref(layer.geom), ctypes.byref(op.shape), 1 if layer.fwd_form == "scatter" else 0, info) == 0
-    assert info[0] == expect_kernel, list(info)
+    assert info[0] == 5, list(info)
     return op.out.data[..., : layer.c_out].permute(0, 3, 1, 2).float(), op
 
 
-@pytest.mark.parametrize("cin,cout,N,H,W,bias", [(64, 256, 4, 30, 520, False),   # ragged rows and columns, one channel tile
-                                                 (128, 512, 2, 64, 256, True),   # two channel tiles, two K chunks, bias
-                                                 (192, 256, 4, 17, 1030, False),  # three K chunks, one-row last tile
-                                                 (64, 128, 4, 30, 520, False),    # 128-channel variant (three-piece K tiles)
-                                                 (128, 384, 3, 32, 300, True)])   # 128-channel variant, three channel tiles, bias
+@pytest.mark.parametrize("cin,cout,N,H,W,bias", [(64, 256, 4, 30, 520, False),    # ragged rows / columns, ONE chunk (no halo refill)
+                                                 (128, 512, 2, 64, 256, True),    # two channel tiles, two chunks, bias
+                                                 (192, 256, 4, 17, 1030, False),  # three chunks, one-row last tile row
+                                                 (512, 256, 1, 64, 288, False),   # eight chunks
+                                                 (64, 256, 8, 8, 32, False)])     # a single tile per image
 def test_gather_3x3_exact(cin, cout, N, H, W, bias):
-    _gather_exact(cin, cout, 3, N, H, W, bias)
-
-
-@pytest.mark.parametrize("cin,cout,N,H,W", [(256, 256, 4, 32, 520), (64, 512, 2, 64, 300), (576, 256, 2, 33, 1000), (128, 128, 4, 32, 520)])
-def test_gather_1x1_exact(cin, cout, N, H, W):
-    _gather_exact(cin, cout, 1, N, H, W, False)
-
-
-def _gather_exact(cin, cout, k, N, H, W, bias):
     g = torch.Generator().manual_seed(cin + W)
-    m = torch.nn.Conv2d(cin, cout, k, padding=k // 2, bias=bias)
+    m = torch.nn.Conv2d(cin, cout, 3, padding=1, bias=bias)
     m.weight.data = _ints(m.weight.shape, g, -2, 3)
     if bias:
         m.bias.data = _ints(m.bias.shape, g, -8, 9)
     x = _ints((N, cin, H, W), g)
-    ref = F.conv2d(x, m.weight.data, m.bias.data if bias else None, padding=k // 2)
+    ref = F.conv2d(x, m.weight.data, m.bias.data if bias else None, padding=1)
     out, op = _run(m.to(DEV), x.to(DEV), stats=not bias)
     assert torch.equal(out.cpu(), ref.bfloat16().float())
     if not bias:
@@ -77,27 +65,39 @@ def _gather_exact(cin, cout, k, N, H, W, bias):
         assert torch.allclose(rows[1, :cout], (ref.double() ** 2).sum(dim=(0, 2, 3)), rtol=1e-5)
 
 
-@pytest.mark.parametrize("kernel,stride,padding,N,H,W,cout", [((3, 4), (1, 2), (1, 1), 4, 16, 512, 256), ((3, 8), (1, 4), (1, 2), 4, 16, 256, 256),
-                                                              ((3, 4), (1, 2), (1, 1), 3, 21, 600, 256), ((3, 8), (1, 4), (1, 2), 4, 16, 300, 128)])
-def test_scatter_conv_transpose_exact(kernel, stride, padding, N, H, W, cout):
+@pytest.mark.parametrize("kh,kw", [(3, 1), (1, 3), (3, 2)])
+def test_gather_other_kernels_exact(kh, kw):
+    """Column-only / row-only / even-width kernels through Conv2dSame's asymmetric padding rule."""
+    from range_view_3d_detection_amd.nn.modules.conv import Conv2dSame
+
+    g = torch.Generator().manual_seed(kh * 10 + kw)
+    m = Conv2dSame(128, 256, (kh, kw), bias=False)
+    m.conv.weight.data = _ints(m.conv.weight.shape, g, -2, 3)
+    x = _ints((2, 128, 24, 200), g)
+    th, tw = kh - 1, kw - 1
+    ref = F.conv2d(F.pad(x, [tw // 2, tw - tw // 2, th // 2, th - th // 2]), m.conv.weight.data)
+    out, _ = _run(m.conv.to(DEV), x.to(DEV))
+    assert torch.equal(out.cpu(), ref.bfloat16().float())
+
+
+@pytest.mark.parametrize("kernel,stride,padding,N,H,W", [((3, 4), (1, 2), (1, 1), 4, 16, 512), ((3, 8), (1, 4), (1, 2), 4, 16, 256),
+                                                         ((3, 4), (1, 2), (1, 1), 3, 21, 600)])
+def test_scatter_conv_transpose_exact(kernel, stride, padding, N, H, W):
     g = torch.Generator().manual_seed(W)
-    m = torch.nn.ConvTranspose2d(64, cout, kernel_size=kernel, stride=stride, padding=padding, bias=False)
+    m = torch.nn.ConvTranspose2d(128, 256, kernel_size=kernel, stride=stride, padding=padding, bias=False)
     m.weight.data = _ints(m.weight.shape, g, -2, 3)
-    x = _ints((N, 64, H, W), g)
+    x = _ints((N, 128, H, W), g)
     ref = F.conv_transpose2d(x, m.weight.data, stride=stride, padding=padding)
     out, _ = _run(m.to(DEV), x.to(DEV))
     assert torch.equal(out.cpu(), ref.bfloat16().float())
 
 
-@pytest.mark.parametrize("cin", [256, 128])
-def test_input_gradient_and_accumulate_exact(cin):
-    """Backward-data of a 3x3 conv is the scatter form with one phase (plain bf16 gradient in => this kernel), once into a
-    fresh buffer and once accumulating into an existing gradient (RV_OUT_ACCUM: bf16(bf16(conv) + old))."""
+def test_input_gradient_and_accumulate_exact():
     from range_view_3d_detection_amd import _lib as L
     from range_view_3d_detection_amd import engine as E
 
     g = torch.Generator().manual_seed(5)
-    N, H, W, cout = 4, 32, 512, 64
+    N, H, W, cin, cout = 4, 32, 512, 256, 128
     m = torch.nn.Conv2d(cin, cout, 3, padding=1, bias=False)
     m.weight.data = _ints(m.weight.shape, g, -2, 3)
     dy = _ints((N, cout, H, W), g)
@@ -109,7 +109,7 @@ def test_input_gradient_and_accumulate_exact(cin):
         dst = E.Act.from_nchw(old.to(DEV)) if accumulate else E.Act.empty(N, H, W, cin, DEV)
         shape = L.TapShape(N, H, W, W, gact.ld, dst.ld, L.OUT_ACCUM if accumulate else 0)
         info = (ctypes.c_int32 * 4)()
-        assert L.load().rv_tap_launch_info(ctypes.byref(layer.geom), ctypes.byref(shape), 1, info) == 0 and info[0] == 4, list(info)
+        assert L.load().rv_tap_launch_info(ctypes.byref(layer.geom), ctypes.byref(shape), 1, info) == 0 and info[0] == 5, list(info)
         L.call("rv_tap_scatter", ctypes.byref(layer.geom), ctypes.byref(shape), gact.ptr(), None, None, L.ptr(layer.packed("scatter")), None,
                dst.ptr(), None, L.stream_ptr())
         got = dst.data[..., :cin].permute(0, 3, 1, 2).float().cpu()
@@ -120,9 +120,8 @@ def test_input_gradient_and_accumulate_exact(cin):
 
 
 def test_repeatable_on_random_data():
-    """Race screen: the kernel is deterministic by construction (fixed summation order), so repeated launches on random
-    data must agree bit for bit; a staged piece read before its DMA landed, or overwritten while still being read, shows
-    up as a difference between runs."""
+    """Race screen (see test_gpu_tapconv4.py): fixed summation order => repeated launches on random data agree bit for bit;
+    a halo or weight piece read before its DMA landed, or overwritten while still being read, shows up as a difference."""
     g = torch.Generator().manual_seed(9)
     m = torch.nn.Conv2d(512, 512, 3, padding=1, bias=False)
     m.weight.data = torch.randn(m.weight.shape, generator=g) * 0.05
