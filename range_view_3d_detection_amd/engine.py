@@ -70,10 +70,13 @@ class KernelProfile:
 
 PROFILE: Optional[KernelProfile] = None
 
-# Weight gradients run on a second HIP stream: wgrad(L) is independent of the main backward chain
-# (dgrad(L) -> BatchNorm backward(L-1) -> dgrad(L-1) ...), and the MFMA-bound wgrad kernels overlap with the
-# HBM-bound BatchNorm-backward / element-wise passes on the main stream instead of queueing behind them.
-OVERLAP_WGRAD = os.environ.get("RV3D_NO_OVERLAP") is None
+# Weight gradients can run on a second HIP stream (RV3D_OVERLAP=free): wgrad(L) is independent of the main backward chain
+# (dgrad(L) -> BatchNorm backward(L-1) -> dgrad(L-1) ...).  Round-2 A/B on one device (profiles/r02_overlap_ab.md): the free
+# overlap is worth +3 % step throughput, but the two MFMA-bound kernel families then split the CUs (each kernel's own
+# launch-to-completion time grows by 25-40 %); restricting the overlap to the HBM-bound BatchNorm-backward passes, or giving
+# the main chain a high-priority stream, is slower than one stream.  Default: one stream -- every kernel runs alone at its
+# isolated speed, and the per-kernel figures bench.py reports are the kernels' own.
+OVERLAP_WGRAD = os.environ.get("RV3D_OVERLAP", "") == "free" and os.environ.get("RV3D_NO_OVERLAP") is None
 _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 
 
