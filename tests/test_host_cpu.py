@@ -43,8 +43,14 @@ def test_host_side_geometry(lib):
     s = lib.TapShape(4, 64, 2048, 2048, 256, 256, lib.OUT_STATS)
     info = (ctypes.c_int32 * 4)()
     assert h.rv_tap_launch_info(ctypes.byref(g), ctypes.byref(s), 0, info) == 0
-    assert list(info) == [4, 256, 32 * 16 * 4, 1]  # tapconv4<256>: (4 rows x 64 cols) pixel tiles x one 256-channel tile
-    assert h.rv_tap_stats_rows(ctypes.byref(g), ctypes.byref(s), 0) == 2 * 32 * 16 * 4
+    assert list(info) == [5, 256, 64 * 8 * 4, 1]  # tapconv5<256>: (8 rows x 32 cols) pixel tiles x one 256-channel tile
+    assert h.rv_tap_stats_rows(ctypes.byref(g), ctypes.byref(s), 0) == 2 * 64 * 8 * 4
+    # the same layer with generation 5 switched off, and a pointwise layer: tapconv4<256>, (4 rows x 64 cols) pixel tiles
+    assert h.rv_set_option(b"tapconv5_enable", 0) == 1
+    assert h.rv_tap_launch_info(ctypes.byref(g), ctypes.byref(s), 0, info) == 0 and list(info) == [4, 256, 32 * 16 * 4, 1]
+    assert h.rv_set_option(b"tapconv5_enable", 1) == 0 and h.rv_set_option(b"no such key", 1) == -1
+    g1 = lib.TapGeom(1, 1, 1, 0, 0, 256, 256)
+    assert h.rv_tap_launch_info(ctypes.byref(g1), ctypes.byref(s), 0, info) == 0 and list(info) == [4, 256, 32 * 16 * 4, 1]
     # a folded BatchNorm on the way in needs the register-staged kernel
     s_aff = lib.TapShape(4, 64, 2048, 2048, 256, 256, lib.OUT_STATS | lib.IN_AFFINE | lib.IN_RELU)
     assert h.rv_tap_launch_info(ctypes.byref(g), ctypes.byref(s_aff), 0, info) == 0
@@ -58,7 +64,7 @@ def test_host_side_geometry(lib):
     # transposed conv (3,8)/s4: four phases
     g3 = lib.TapGeom(3, 8, 4, 1, 2, 128, 256)
     s3 = lib.TapShape(4, 64, 512, 2048, 128, 256, 0)
-    assert h.rv_tap_launch_info(ctypes.byref(g3), ctypes.byref(s3), 1, info) == 0 and info[2] == 4 * 8 * 16 * 4
+    assert h.rv_tap_launch_info(ctypes.byref(g3), ctypes.byref(s3), 1, info) == 0 and list(info)[:3] == [5, 256, 4 * 16 * 8 * 4]
     rates = (ctypes.c_int32 * 3)(8, 2, 1)
     assert h.rv_decode_num_candidates(64, 2048, 3, rates) == 64 * (256 + 1024 + 2048)  # 212 992
     assert h.rv_decode_num_candidates(64, 2048, 0, rates) == 64 * 2048
