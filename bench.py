@@ -220,12 +220,15 @@ def main() -> None:
     torch.manual_seed(0)
     backbone, head = build_model(args.widths, args.classes, args.features)
     model = Detector(backbone, head).to(dev).train()
-    E.SYNC_BN = world > 1 and not args.no_sync_bn
+    E.SYNC_BN = world > 1 and not args.no_sync_bn  # explicit: sync every BatchNorm (what Lightning's sync_batchnorm: true does) / local
     step_model = model
     if world > 1:
         step_model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], gradient_as_bucket_view=True, static_graph=True)
     params = [p for p in model.parameters()]
-    opt = torch.optim.AdamW(params, lr=1e-3)
+    # the reference's recipe (nn/meta/arch.py:48-75): AdamW(1e-3) + OneCycleLR(max_lr = 0.00075 * sqrt(devices * batch)), per step
+    from range_view_3d_detection_amd.nn.meta.arch import configure_optimizers
+
+    opt, sched = configure_optimizers(params, num_devices=world, batch_size=args.batch, total_steps=args.warmup + args.steps + 8)
     batch = synthetic_batch(args.batch, args.height, args.width, seed=1234 + rank, device=dev, n_feat=args.features, n_cls=args.classes)
 
     def step():
@@ -234,6 +237,7 @@ def main() -> None:
         loss.backward()
         torch.nn.utils.clip_grad_norm_(params, 35.0)
         opt.step()
+        sched.step()
         return loss
 
     for _ in range(args.warmup):
@@ -243,6 +247,7 @@ def main() -> None:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     E.PROFILE = E.KernelProfile()  # events around each tap-conv / wgrad launch inside the timed region
+    E.COLLECTIVES.reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -252,6 +257,7 @@ def main() -> None:
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     prof = E.PROFILE
+    sync_calls, sync_bytes = E.COLLECTIVES.calls / args.steps, E.COLLECTIVES.bytes / args.steps
     # the same per-kernel events once more, outside the timed region, with the weight-gradient side stream off: with
     # it on, kernels of the two streams share the CUs and each one's event-to-event time includes its neighbour's
     iso = E.KernelProfile()
@@ -278,6 +284,9 @@ def main() -> None:
                                    + (" (BASELINE configs[2])" if (args.widths, args.width, args.height, args.batch) == ("rv-av2", 2048, 64, 4) else ""),
                        "global_batch": args.batch * world, "sweep": [args.height, args.width, args.features], "parallelism": f"dp{world}",
                        "sync_bn": bool(E.SYNC_BN), "loss": float(loss.detach().item()),
+                       "collectives": {"per_step": {"sync_bn_all_reduce": {"calls": sync_calls, "bytes": sync_bytes},
+                                                    "gradient_all_reduce_bytes": 4 * sum(p.numel() for p in params) if world > 1 else 0},
+                                       "note": "SyncBN: one all-reduce of (2C+1) fp32 per BatchNorm layer and direction; gradients: DDP buckets"},
                        "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 2)},
             "roofline": roofline(prof, iso),
             "kernels": prof.summary(),

@@ -147,6 +147,11 @@ int rv_tap_wgrad(const rvTapGeom* g, const rvTapShape* s, const void* U, int32_t
 /* partial[rows][2][c] (sum, sum of squares) -> batch mean / biased var -> folded affine
  * scale = gamma*invstd, shift = beta - mean*scale; saves mean/invstd for backward and
  * updates running_mean / running_var (unbiased) in place when they are non-NULL. */
+/* Column sums of `rows` partial rows ([rows][cols] fp32, accumulated in fp64) -> out[cols]; `partial` must have the
+ * scratch rows of the convention above behind it.  SyncBN: totals written straight into the all-reduce buffer. */
+int rv_reduce_rows(const float* partial, int32_t rows, int32_t cols, float* out, rvStream stream);
+/* count < 0 (SyncBN, rows == 1): the element count is read from the device, partial[2*c] (fp32), where it travelled with
+ * the all-reduced totals -- ranks may hold different numbers of pixels.  Same convention in rv_bn_bwd_finalize. */
 int rv_bn_finalize(const float* partial, int32_t rows, int32_t c, int64_t count, const float* gamma,
                    const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                    float* scale, float* shift, float* mean, float* invstd, rvStream stream);

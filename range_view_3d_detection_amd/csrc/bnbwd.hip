@@ -165,7 +165,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* red,
 // single-launch variant of col_reduce + finalize (see bn_reduce_finalize_kernel in misc.hip)
 __global__ __launch_bounds__(256) void bn_bwd_reduce_finalize_kernel(const float* partial, int rows, int c, double inv_count, const float* gamma,
                                                                       const float* invstd, float* dgamma, float* dbeta, int accumulate,
-                                                                      float* coef) {
+                                                                      float* coef, const float* count_dev) {
+    if (count_dev) inv_count = 1.0 / (double)count_dev[0];  // SyncBN: global count as a device scalar
     __shared__ double red[2][16][17];
     const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
     const int ch = blockIdx.x * 16 + cx;
@@ -565,9 +566,11 @@ extern "C" int rv_bn_bwd_finalize(const float* partial, int32_t rows, int32_t c,
                                   const float* invstd, float* dgamma, float* dbeta, int32_t accumulate, float* coef,
                                   rvStream stream) {
     RV_REQUIRE(partial && gamma && invstd && coef, "rv_bn_bwd_finalize: null argument");
+    RV_REQUIRE(count > 0 || (count < 0 && rows == 1), "rv_bn_bwd_finalize: a device-side count (count < 0) needs the single row of all-reduced totals");
+    const float* count_dev = count < 0 ? partial + 2 * c : nullptr;
     if (rows <= 1024 && getenv("RV3D_NO_FUSED_FINALIZE") == nullptr) {
         hipLaunchKernelGGL(bn_bwd_reduce_finalize_kernel, dim3(rv_ceil_div(c, 16)), dim3(256), 0, (hipStream_t)stream, partial, rows, c,
-                           1.0 / (double)count, gamma, invstd, dgamma, dbeta, accumulate, coef);
+                           1.0 / (double)count, gamma, invstd, dgamma, dbeta, accumulate, coef, count_dev);
         RV_CHECK_LAUNCH("bn_bwd_reduce_finalize_kernel");
         return 0;
     }

@@ -187,7 +187,12 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* red, int
 __global__ __launch_bounds__(256) void bn_reduce_finalize_kernel(const float* partial, int rows, int c, double inv_count, double unbias,
                                                                   const float* gamma, const float* beta, float eps, float momentum,
                                                                   float* running_mean, float* running_var, float* scale, float* shift,
-                                                                  float* mean_out, float* invstd_out) {
+                                                                  float* mean_out, float* invstd_out, const float* count_dev) {
+    if (count_dev) {  // SyncBN: the global element count travelled with the all-reduced totals (a device scalar)
+        const double n = (double)count_dev[0];
+        inv_count = 1.0 / n;
+        unbias = n > 1.0 ? n / (n - 1.0) : 1.0;
+    }
     __shared__ double red[2][16][17];
     const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
     const int ch = blockIdx.x * 16 + cx;
@@ -256,17 +261,39 @@ int rv_col_reduce(const float* partial, int rows, int cols, double* scratch, int
     return 0;
 }
 
+// fp32 totals of `rows` partial rows ([rows][cols], fp64 accumulation) -> out[cols]; scratch = the rows behind `rows`
+__global__ void sum_groups_f32_kernel(const double* red, int groups, int cols, float* out) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= cols) return;
+    double s = 0.0;
+    for (int g = 0; g < groups; ++g) s += red[(int64_t)g * cols + col];
+    out[col] = (float)s;
+}
+
+extern "C" int rv_reduce_rows(const float* partial, int32_t rows, int32_t cols, float* out, rvStream stream) {
+    RV_REQUIRE(partial && out && rows > 0 && cols > 0, "rv_reduce_rows: bad argument");
+    double* scratch = (double*)(partial + (int64_t)rows * cols);
+    int groups;
+    if (rv_col_reduce(partial, rows, cols, scratch, &groups, (hipStream_t)stream)) return 1;
+    hipLaunchKernelGGL(sum_groups_f32_kernel, dim3(rv_ceil_div(cols, 256)), dim3(256), 0, (hipStream_t)stream, scratch, groups, cols, out);
+    RV_CHECK_LAUNCH("sum_groups_f32_kernel");
+    return 0;
+}
+
 extern "C" int rv_bn_finalize(const float* partial, int32_t rows, int32_t c, int64_t count, const float* gamma,
                               const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                               float* scale, float* shift, float* mean, float* invstd, rvStream stream) {
     RV_REQUIRE(partial && gamma && beta && scale && shift, "rv_bn_finalize: null argument");
-    RV_REQUIRE(rows > 0 && c > 0 && count > 0, "rv_bn_finalize: empty reduction");
+    RV_REQUIRE(rows > 0 && c > 0 && count != 0, "rv_bn_finalize: empty reduction");
+    RV_REQUIRE(count > 0 || rows == 1, "rv_bn_finalize: a device-side count (count < 0) needs the single row of all-reduced totals");
+    const float* count_dev = count < 0 ? partial + 2 * c : nullptr;  // the slot right behind the (2, c) totals
     const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
     // few partial rows: one launch reduces and finalises; many (4096 rows behind a 512-channel tapconv4 launch): the
     // 64-group column reduction spreads them over the chip first (29 us vs 14 us measured for the single launch)
     if (rows <= 1024 && getenv("RV3D_NO_FUSED_FINALIZE") == nullptr) {
         hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3(rv_ceil_div(c, 16)), dim3(256), 0, (hipStream_t)stream, partial, rows, c,
-                           1.0 / (double)count, unbias, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, invstd);
+                           1.0 / (double)count, unbias, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, invstd,
+                           count_dev);
         RV_CHECK_LAUNCH("bn_reduce_finalize_kernel");
         return 0;
     }

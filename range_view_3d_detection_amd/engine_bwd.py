@@ -68,8 +68,8 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
     # ---- input gradient: the opposite tap form -------------------------------------------------
     if op.need_input_grad:
         if isinstance(op.x, Lazy):
-            dst, accumulate = src.like(), False
-            t.lazy_in[id(op.x)] = (dst, None)
+            dst, accumulate = t.lazy_grad_target(op.x)
+            dst._rv_owned = True
         else:
             dst, accumulate = t.grad_buffer(op.x)
         shape = L.TapShape(sp.N, sp.H, sp.Wu, sp.Wv, dout.ld, dst.ld, L.OUT_ACCUM if accumulate else 0)
@@ -121,7 +121,7 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
 
 
 def _smallk_grads(t: Tape, pixels: int, cp: int, dout: Act, mask: Optional[Act], y: Act, scale, shift, mean, invstd, flags: int, v: Act,
-                  lay, gamma_p, stat_mean, stat_invstd, count: int):
+                  lay, gamma_p, stat_mean, stat_invstd, count: int, sync: bool):
     """(dgamma, dbeta, dW) of a small-K conv + BatchNorm from one pass (``rv_bn_bwd_smallk``); under SyncBN the two-phase
     form with the all-reduce of (sum g, sum g*xhat) in between."""
     cin = lay.c_in
@@ -134,12 +134,13 @@ def _smallk_grads(t: Tape, pixels: int, cp: int, dout: Act, mask: Optional[Act],
     head = (L.i64(pixels), L.i32(cp), dout.ptr(), L.i32(dout.ld), mask.ptr() if mask is not None else None,
             L.i32(mask.ld if mask is not None else 0), y.ptr(), L.i32(y.ld), L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd),
             L.i32(flags), v.ptr(), L.i32(v.ld), L.i32(cin))
-    if E._world() > 1:
+    if sync:
         cin_pad = 4 if cin <= 4 else 8
         sums = torch.empty((2 + cin_pad) * cp, dtype=torch.float64, device=dev)
         moms = torch.empty(cin_pad + cin_pad * cin_pad, dtype=torch.float64, device=dev)
         L.call("rv_bn_bwd_smallk_sums", *head, L.ptr(sums), L.ptr(moms), L.ptr(ws), L.stream_ptr())
         g01 = sums[: 2 * cp].clone()
+        E.COLLECTIVES.add(g01)
         torch.distributed.all_reduce(g01)  # SyncBN: global (sum g, sum g*xhat); the other sums stay this rank's
         L.call("rv_bn_bwd_smallk_from_sums", L.i32(cp), L.i32(cin), L.ptr(sums), L.ptr(moms), L.ptr(g01), L.ptr(wp), L.i32(E.pad32(cin)),
                L.ptr(gamma_p), L.ptr(stat_mean), L.ptr(stat_invstd), L.i64(count), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dw), L.stream_ptr())
@@ -171,7 +172,7 @@ def bn_backward(op: "E.BnOp", t: Tape) -> None:
         # 1x1 conv with a handful of input channels and no input gradient (stem): BatchNorm backward and the conv's
         # weight gradient from one pass over (dOut, y, input) -- neither dy nor a separate wgrad pass (rv_bn_bwd_smallk)
         dgamma, dbeta, dw = _smallk_grads(t, pixels, cp, dout, mask, raw, st.scale, st.shift, st.mean, st.invstd, flags, conv.x, lay,
-                                          op.gamma_p, st.mean, st.invstd, st.count)
+                                          op.gamma_p, st.mean, st.invstd, st.count, op.sync_world > 1)
         c, cin = st.module.num_features, lay.c_in
         t.add_param_grad(st.module.weight, dgamma[:c])
         t.add_param_grad(st.module.bias, dbeta[:c])
@@ -186,14 +187,13 @@ def bn_backward(op: "E.BnOp", t: Tape) -> None:
     dgamma = torch.empty(cp, dtype=torch.float32, device=t.device)
     dbeta = torch.empty(cp, dtype=torch.float32, device=t.device)
     coef = torch.empty((3, cp), dtype=torch.float32, device=t.device)
-    if E._world() > 1:
-        # SyncBN backward: the normalisation coefficients need the GLOBAL (sum g, sum g*xhat) -> RCCL all-reduce;
-        # dgamma / dbeta stay LOCAL sums (DDP averages parameter gradients over ranks, as under torch SyncBatchNorm).
-        tot = partial[:rows].sum(dim=0)
-        dbeta.copy_(tot[0])
-        dgamma.copy_(tot[1])
-        partial = E.allreduce_partial_rows(partial, rows)
-        L.call("rv_bn_bwd_finalize", L.ptr(partial), L.i32(1), L.i32(cp), L.i64(st.count), L.ptr(op.gamma_p), L.ptr(st.invstd),
+    if op.sync_world > 1:
+        # SyncBN backward: the normalisation coefficients need the GLOBAL (sum g, sum g*xhat) and count -> one RCCL
+        # all-reduce; dgamma / dbeta stay LOCAL sums (DDP averages parameter gradients over ranks, as under torch SyncBatchNorm).
+        glob = E.allreduce_partial_rows(partial, rows, pixels)  # (its rv_reduce_rows leaves `partial` untouched)
+        L.call("rv_bn_bwd_finalize", L.ptr(partial), L.i32(rows), L.i32(cp), L.i64(pixels), L.ptr(op.gamma_p), L.ptr(st.invstd),
+               L.ptr(dgamma), L.ptr(dbeta), L.i32(0), L.ptr(coef), L.stream_ptr())  # local dgamma / dbeta (coef overwritten below)
+        L.call("rv_bn_bwd_finalize", L.ptr(glob), L.i32(1), L.i32(cp), L.i64(-1), L.ptr(op.gamma_p), L.ptr(st.invstd),
                None, None, L.i32(0), L.ptr(coef), L.stream_ptr())
     else:
         L.call("rv_bn_bwd_finalize", L.ptr(partial), L.i32(rows), L.i32(cp), L.i64(st.count), L.ptr(op.gamma_p), L.ptr(st.invstd),
@@ -227,7 +227,7 @@ def combine_backward(op: "E.CombineOp", t: Tape) -> None:
             g, have_x = t.grad_buffer(plains[0])
             res = (g, have_x)
             t.mark_written(plains[0])
-        t.lazy_in[id(x)] = (gout, mask, res)
+        t.add_lazy_grad(x, gout, mask, res)
     if fuse_res:
         return
     for x in plains:
@@ -249,7 +249,8 @@ def modulate_backward(op: "E.MetaModulateOp", t: Tape) -> None:
     L.call("rv_meta_modulate_bwd", g.ptr(), pos.raw.ptr(), L.ptr(pos.bn.scale), L.ptr(pos.bn.shift), feat.ptr(), L.i32(feat.ld),
            L.i32(feat.N), L.i32(feat.H), L.i32(feat.W), L.i32(feat.cp), dpos.ptr(), gf.ptr(), L.i32(gf.ld), L.stream_ptr())
     t.mark_written(feat)
-    t.lazy_in[id(pos)] = (dpos, None)
+    dpos._rv_owned = True
+    t.add_lazy_grad(pos, dpos, None)
 
 
 def smallk_backward(op: "E.SmallKOp", t: Tape) -> None:
@@ -266,7 +267,7 @@ def smallk_backward(op: "E.SmallKOp", t: Tape) -> None:
     safe_gamma = torch.where(op.gamma_p.abs() < 1e-20, torch.full_like(op.gamma_p, 1e-20), op.gamma_p)
     inv_gamma = 1.0 / safe_gamma
     dgamma, dbeta, dw = _smallk_grads(t, pixels, cp, dout, None, h, ones, zeros, op.beta_p, inv_gamma, L.BNB_RELU_Z, v, lay, op.gamma_p,
-                                      op.mean, op.invstd, op.count)
+                                      op.mean, op.invstd, op.count, op.sync_world > 1)
     c = bn.num_features
     t.add_param_grad(bn.weight, dgamma[:c])
     t.add_param_grad(bn.bias, dbeta[:c])

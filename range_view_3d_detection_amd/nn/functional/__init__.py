@@ -1,8 +1,8 @@
 """Functional interface -- mirrors ``torchbox3d/nn/functional/__init__.py:8-27``.
 
-``varifocal_loss`` is evaluated by the fused detection-loss kernel on the training path
-(``csrc/loss.hip``); this stand-alone form exists for API parity and runs the same kernel on a
-single-class, background-free problem so that it also works on arbitrary shapes.
+On the training path the varifocal term is evaluated INSIDE the fused detection-loss kernel (``csrc/loss.hip``,
+``nn/heads/detection_head.py``); this stand-alone ``varifocal_loss`` exists for API parity only and is plain torch ops on
+the caller's device (arbitrary shapes) -- it does not call the HIP library and is not on the hot path.
 """
 
 from __future__ import annotations

@@ -1,0 +1,34 @@
+"""Training-recipe glue -- mirrors ``torchbox3d/nn/meta/arch.py:48-75`` (``MetaDetector.configure_optimizers``).
+
+The reference builds, through Hydra, ``torch.optim.AdamW(lr=1e-3)`` (``conf/model/range_view.yaml:52-55``) and a
+``OneCycleLR`` stepped once per optimisation step (``"interval": "step"``) whose ``max_lr`` is scaled by
+``sqrt(num_devices * batch_size)`` when ``use_linear_lr_scaling`` is set (``conf/model/baseline.yaml:25-28``:
+``max_lr = 0.00075``, ``batch_size = 4`` per device) and whose ``total_steps`` is the trainer's
+``estimated_stepping_batches``.  Lightning calls ``scheduler.step()`` after every ``optimizer.step()``; a plain training
+loop (``bench.py``) does the same with the pair returned here.  Host-side only: no kernels involved.
+"""
+
+from __future__ import annotations
+
+import math
+from typing import Iterable, Tuple
+
+import torch
+
+
+def one_cycle_max_lr(max_lr: float, num_devices: int, batch_size: int, use_linear_lr_scaling: bool = True) -> float:
+    """``max_lr * sqrt(num_devices * batch_size)`` (``arch.py:63-66``); ``batch_size`` is per device."""
+    return max_lr * math.sqrt(num_devices * batch_size) if use_linear_lr_scaling else max_lr
+
+
+def configure_optimizers(params: Iterable[torch.nn.Parameter], num_devices: int, batch_size: int, total_steps: int,
+                         lr: float = 1e-3, max_lr: float = 0.00075, use_linear_lr_scaling: bool = True,
+                         debug: bool = False) -> Tuple[torch.optim.Optimizer, "torch.optim.lr_scheduler.LRScheduler | None"]:
+    """(AdamW, OneCycleLR stepped per optimisation step) as ``MetaDetector.configure_optimizers`` returns them; in ``debug``
+    mode the reference attaches no scheduler (``arch.py:59``)."""
+    optimizer = torch.optim.AdamW(list(params), lr=lr)
+    if debug:
+        return optimizer, None
+    scheduler = torch.optim.lr_scheduler.OneCycleLR(optimizer, max_lr=one_cycle_max_lr(max_lr, num_devices, batch_size, use_linear_lr_scaling),
+                                                    total_steps=int(total_steps))
+    return optimizer, scheduler

@@ -57,8 +57,11 @@ def meta_kernel_program(t: Tape, m: nn.Module, features: Act, cart: Tensor, out:
     f = basic_block_program(t, m.projection, features, need_input_grad=False)
     rel = E.MetaRelativeOp(t, cart).out
     pos: Operand = rel
+    n_pos = len(m.positional_kernel)
     for i, blk in enumerate(m.positional_kernel):
-        pos = E.conv_bn(t, E.tap_layer(blk[0]), pos, blk[1], relu=True, need_input_grad=(i > 0))
+        # the LAST positional layer feeds MetaModulateOp, which folds its BatchNorm+ReLU itself and needs the Lazy form
+        # (num_layers == 1: that is the 3 -> C layer, which would otherwise take the small-K fast path)
+        pos = E.conv_bn(t, E.tap_layer(blk[0]), pos, blk[1], relu=True, need_input_grad=(i > 0), smallk=(i + 1 < n_pos))
     geo: Operand = E.MetaModulateOp(t, pos, f).out
     c = m.out_channels
     for i, blk in enumerate(m.fusion_kernel):

@@ -245,3 +245,89 @@ def test_small_k_fused_paths_match_unfused_and_oracle():
         ref = params[k].grad
         assert _cos(a[k], ref) > 0.985 and _cos(a[k], b[k]) > 0.99, (k, _cos(a[k], ref), _cos(a[k], b[k]))
         assert rel_err(a[k], ref) < max(2.0 * rel_err(b[k], ref), 2e-2), (k, rel_err(a[k], ref), rel_err(b[k], ref))
+
+
+@pytest.mark.parametrize("project", [False, True])
+def test_basic_block_fed_a_lazy_input_accumulates_both_consumers(project):
+    """A Lazy (unmaterialised relu(bn(conv))) feeding a BasicBlock has TWO consumers -- the block's first conv and either
+    its projection conv or the identity branch -- whose gradients must add up (round-1 advisory: the second writer used to
+    overwrite the first).  Checked against fp32 autograd of the oracle; BatchNorm biases shifted so that the ReLU gates are
+    firmly open (see test_block_backward for why), tolerance = the block tests' (3e-2 of max + rounding floor)."""
+    from oracle import model as om
+    from range_view_3d_detection_amd import engine as E
+    from range_view_3d_detection_amd import program
+    from range_view_3d_detection_amd.nn.blocks import BasicBlock
+    from range_view_3d_detection_amd.nn.stems import conv_norm_act
+
+    gen = torch.Generator().manual_seed(11 + project)
+    cin, c = 32, 64
+    pre = conv_norm_act(cin, c, 1)  # conv -> BN -> ReLU: the Lazy producer
+    blk = BasicBlock(c, c if not project else 96, kernel_size=3, project=project)
+    holder = torch.nn.ModuleDict({"pre": pre, "blk": blk})
+    for mod in holder.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.weight.data = 0.5 + torch.rand(mod.weight.shape, generator=gen)
+            mod.bias.data = 0.2 * torch.randn(mod.bias.shape, generator=gen) + 3.0
+        if isinstance(mod, torch.nn.Conv2d):
+            mod.weight.data = bf16r(torch.randn(mod.weight.shape, generator=gen) * (2.0 / (mod.weight[0].numel())) ** 0.5)
+    sd = {k: v.detach().clone() for k, v in holder.state_dict().items()}
+    x = bf16r(torch.randn(2, cin, 8, 64, generator=gen))
+    # oracle (fp32 autograd)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k}
+    full = {**sd, **params}
+    xo = x.clone().requires_grad_(True)
+    nm = om.Numerics(train=True)
+    h = torch.relu(om.batch_norm(om.conv2d_same(xo, full["pre.0.weight"], nm=nm), full, "pre.1", nm=nm))
+    out_o = om.basic_block(h, full, "blk", project=project, nm=nm)
+    probe = bf16r(torch.randn(out_o.shape, generator=gen))
+    (out_o * probe).sum().backward()
+
+    holder = holder.to(DEV).train()
+
+    def build(t, xin):
+        a = E.Act.from_nchw(xin)
+        lazy = E.conv_bn(t, E.tap_layer(holder["pre"][0]), a, holder["pre"][1], relu=True)
+        assert isinstance(lazy, E.Lazy)
+        return [a], [program.basic_block_program(t, holder["blk"], lazy)]
+
+    xd = x.to(DEV).requires_grad_(True)
+    out = program.run(build, holder, [xd])[0]
+    assert rel_err(out.float(), out_o.detach()) < 3e-2
+    (out.float() * probe.to(DEV)).sum().backward()
+    n_px = probe.numel() // probe.shape[1]
+    pairs = [("gin", xd.grad.float(), xo.grad)] + [(k, p.grad, params[k].grad) for k, p in holder.named_parameters()]
+    for k, got, orc in pairs:
+        # (two convs deep: 5e-2 of max + the rounding floor of test_block_backward; direction within 1e-3)
+        tol = 5e-2 * float(orc.abs().max()) + 4e-4 * n_px * float(probe.abs().max())
+        err = float((got.detach().double().cpu() - orc.double()).abs().max())
+        assert err < tol and _cos(got, orc) > 0.999, (k, err, tol, _cos(got, orc))
+
+
+def test_meta_kernel_single_positional_layer():
+    """``MetaKernel(num_layers=1)`` (a legal reference constructor argument): the only positional layer is the 3 -> C one, which
+    must stay on the generic conv path because MetaModulateOp folds its BatchNorm (round-1 advisory: AttributeError)."""
+    from oracle import model as om
+    from range_view_3d_detection_amd.nn.stems import MetaKernel
+
+    gen = torch.Generator().manual_seed(3)
+    m = MetaKernel(5, 32, 3, num_layers=1)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.weight.data = 0.5 + torch.rand(mod.weight.shape, generator=gen)
+            mod.bias.data = 0.3 * torch.randn(mod.bias.shape, generator=gen) + 2.0
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    feats = torch.randn(2, 5, 8, 64, generator=gen)
+    cart = torch.randn(2, 3, 8, 64, generator=gen) * 5
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k}
+    out_o = om.meta_kernel(feats, cart, {"m." + k: v for k, v in {**sd, **params}.items()}, "m", num_layers=1, nm=om.Numerics(train=True))
+    probe = torch.randn(out_o.shape, generator=gen)
+    (out_o * probe).sum().backward()
+    m = m.to(DEV).train()
+    out = m(feats.to(DEV), cart.to(DEV)).float()
+    assert rel_err(out, out_o.detach()) < 3e-2
+    (out * probe.to(DEV)).sum().backward()
+    for k, p in m.named_parameters():
+        assert p.grad is not None and _cos(p.grad, params[k].grad) > 0.98, (k, _cos(p.grad, params[k].grad))
+    m.eval()
+    with torch.no_grad():
+        assert torch.isfinite(m(feats.to(DEV), cart.to(DEV)).float()).all()

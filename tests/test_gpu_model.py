@@ -272,6 +272,51 @@ def test_weighted_nms_matches_oracle_bit_exact(n, spread):
     assert (cnt > 0).all() and int(cnt.sum()) <= n  # nms.py:173-174 post-conditions; clusters are disjoint
 
 
+def test_wnms_gpu_ffi_shim_under_the_reference_wrapper_logic():
+    """``compat/weighted_nms_ext.wnms_gpu`` under the reference's own wrapper logic (``math/ops/nms.py:126-177`` restated line
+    for line: sort, caller-allocated zero ``output`` / device ``count`` / HOST ``keep``, the two post-condition asserts)."""
+    import sys
+
+    from oracle import nms as onms
+    from range_view_3d_detection_amd import compat
+    from range_view_3d_detection_amd.math.ops import nms as hnms
+
+    sys.path.insert(0, list(compat.__path__)[0])
+    try:
+        import weighted_nms_ext
+    finally:
+        sys.path.pop(0)
+
+    def reference_shaped_weighted_nms(boxes, data2merge, scores, nms_threshold, merge_thresh):
+        sorted_scores, order = scores.sort(0, descending=True)
+        boxes = boxes[order].contiguous().float()
+        data2merge = data2merge[order].contiguous().float()
+        data2merge_score = torch.cat([data2merge, sorted_scores[:, None]], 1).contiguous().float()
+        output = torch.zeros_like(data2merge_score)
+        count = torch.zeros(boxes.size(0), dtype=torch.long, device=boxes.device)
+        assert data2merge_score.dim() == 2
+        keep = torch.zeros(boxes.size(0), dtype=torch.long)  # host
+        num_out = weighted_nms_ext.wnms_gpu(boxes, data2merge_score, output, keep, count, nms_threshold, merge_thresh, boxes.device.index)
+        keep = order[keep[:num_out].cuda(boxes.device)].contiguous()
+        assert output[num_out:, :].sum() == 0
+        assert (count[:num_out] > 0).all()
+        return keep, output[:num_out, :], count[:num_out]
+
+    for n, spread in ((1, 10.0), (700, 30.0), (3000, 60.0)):
+        cub, scores = _random_boxes(n, n + 1, spread)
+        half = cub[:, 3:5] / 2
+        rect = torch.cat([cub[:, :2] - half, cub[:, :2] + half, cub[:, 6:7]], dim=-1)
+        data = torch.cat([cub[:, :6], cub[:, 6:7].sin(), cub[:, 6:7].cos()], dim=1)
+        keep, out, cnt = reference_shaped_weighted_nms(rect.to(DEV), data.to(DEV), scores.to(DEV), 0.3, 0.5)
+        keep_o, out_o, cnt_o = onms.weighted_nms(rect, data, scores, 0.3, 0.5)
+        assert torch.equal(keep.cpu(), keep_o) and torch.equal(cnt.cpu(), cnt_o) and torch.equal(out.cpu(), out_o)
+        k2, o2, c2 = hnms.weighted_nms(rect.to(DEV), data.to(DEV), scores.to(DEV), 0.3, 0.5)
+        assert torch.equal(keep, k2) and torch.equal(out, o2) and torch.equal(cnt, c2)
+    # contract violations raise instead of falling back
+    with pytest.raises(RuntimeError):
+        weighted_nms_ext.wnms_gpu(rect, data, data, torch.zeros(1, dtype=torch.long), torch.zeros(1, dtype=torch.long), 0.3, 0.5, 0)
+
+
 def test_rotated_iou_matches_oracle():
     from oracle import nms as onms
     from range_view_3d_detection_amd import _lib as L

@@ -145,15 +145,33 @@ b = bench.synthetic_batch(2, 8, 32, seed=1234 + rank, device="cpu", boxes_per_sw
 digest = torch.tensor([float(b["features"].double().sum())], dtype=torch.float64)
 gathered = [torch.zeros_like(digest) for _ in range(world)]
 dist.all_gather(gathered, digest)
-# (2) SyncBN statistics: local partial rows -> global totals, identical on every rank
+# (2) SyncBN statistics: local partial rows (+ this rank's element count: UNEVEN on purpose) -> global totals and count in
+#     ONE collective, identical on every rank
 g = torch.Generator().manual_seed(rank)
 partial = torch.randn(5 + 128, 2, 32, generator=g)
-tot = E.allreduce_partial_rows(partial, 5)[0]
+E.COLLECTIVES.reset()
+glob = E.allreduce_partial_rows(partial, 5, 1000 + 7 * rank)
+tot = glob[0]
+count_ok = float(glob.view(-1)[64]) == sum(1000 + 7 * r for r in range(world)) and E.COLLECTIVES.calls == 1 and E.COLLECTIVES.bytes == 65 * 4
 ref = torch.stack([torch.randn(5 + 128, 2, 32, generator=torch.Generator().manual_seed(r))[:5].sum(0) for r in range(world)]).sum(0)
+# (2b) which BatchNorm holders are synchronised (engine.SYNC_BN = None: decided per layer)
+bn, sbn = torch.nn.BatchNorm2d(4), torch.nn.SyncBatchNorm(4)
+rules = [E.bn_sync_world(sbn, True) == world, E.bn_sync_world(sbn, False) == 1]
+try:
+    E.bn_sync_world(bn, True)
+    rules.append(False)
+except RuntimeError as e:
+    rules.append("sync_batchnorm" in str(e))
+E.SYNC_BN = True
+rules.append(E.bn_sync_world(bn, True) == world)
+E.SYNC_BN = False
+rules.append(E.bn_sync_world(sbn, True) == 1 and E.bn_sync_world(bn, True) == 1)
+E.SYNC_BN = None
 # (3) step time = MAX over ranks (bench.py contract)
 t = torch.tensor([1.0 + rank], dtype=torch.float64)
 dist.all_reduce(t, op=dist.ReduceOp.MAX)
-out = {"rank": rank, "digests": [float(x) for x in gathered], "stats_err": float((tot - ref).abs().max()), "tmax": float(t)}
+out = {"rank": rank, "digests": [float(x) for x in gathered], "stats_err": float((tot - ref).abs().max()), "tmax": float(t),
+       "count_ok": bool(count_ok), "rules": rules}
 print("RESULT " + json.dumps(out), flush=True)
 dist.destroy_process_group()
 """
@@ -174,6 +192,7 @@ def test_two_process_gloo_sharding_and_syncbn_reduction(tmp_path, lib):
         res.append(json.loads([ln for ln in o.splitlines() if ln.startswith("RESULT ")][0][7:]))
     assert res[0]["digests"] == res[1]["digests"] and res[0]["digests"][0] != res[0]["digests"][1]
     assert all(r["stats_err"] < 1e-4 and r["tmax"] == 2.0 for r in res)
+    assert all(r["count_ok"] and all(r["rules"]) for r in res), res
 
 
 def test_detections_table_and_feather_files(tmp_path):
@@ -202,3 +221,43 @@ def test_detections_table_and_feather_files(tmp_path):
     assert [p.split("predictions/")[1] for p in paths] == ["run0/logA/315969904359876000.feather", "run0/logB/315969904459876000.feather"]
     a = feather.read_table(paths[0])
     assert a.schema == t.schema and a.num_rows == 3 and a.column("score").to_pylist() == [t.column("score")[i].as_py() for i in (0, 1, 5)]
+
+
+def test_wnms_gpu_shim_importable_and_refuses_cpu_tensors():
+    """The reference's ``import weighted_nms_ext`` resolves to compat/weighted_nms_ext.py; there is no CPU fallback."""
+    import sys
+
+    import torch
+
+    from range_view_3d_detection_amd import compat
+
+    sys.path.insert(0, list(compat.__path__)[0])
+    try:
+        import weighted_nms_ext
+    finally:
+        sys.path.pop(0)
+    b = torch.zeros(4, 5)
+    d = torch.zeros(4, 9)
+    with pytest.raises(RuntimeError, match="GPU"):
+        weighted_nms_ext.wnms_gpu(b, d, torch.zeros_like(d), torch.zeros(4, dtype=torch.long), torch.zeros(4, dtype=torch.long), 0.3, 0.5, 0)
+
+
+def test_training_recipe_glue():
+    """AdamW(1e-3) + OneCycleLR(max_lr = 0.00075 * sqrt(devices * batch)) stepped per optimisation step (nn/meta/arch.py:48-75)."""
+    import math
+
+    import torch
+
+    from range_view_3d_detection_amd.nn.meta.arch import configure_optimizers, one_cycle_max_lr
+
+    p = [torch.nn.Parameter(torch.zeros(3))]
+    opt, sched = configure_optimizers(p, num_devices=8, batch_size=4, total_steps=50)
+    assert isinstance(opt, torch.optim.AdamW) and isinstance(sched, torch.optim.lr_scheduler.OneCycleLR)
+    assert abs(one_cycle_max_lr(0.00075, 8, 4) - 0.00075 * math.sqrt(32)) < 1e-12 and one_cycle_max_lr(1e-3, 8, 4, False) == 1e-3
+    lrs = []
+    for _ in range(50):
+        opt.step()
+        lrs.append(opt.param_groups[0]["lr"])
+        sched.step() if len(lrs) < 50 else None
+    assert abs(max(lrs) - 0.00075 * math.sqrt(32)) < 1e-6 and lrs[0] < lrs[10] and lrs[-1] < lrs[20]
+    assert configure_optimizers(p, 1, 4, 10, debug=True)[1] is None
