@@ -331,6 +331,14 @@ int rv_z_buffer(const int32_t* rows, const int32_t* cols, const double* range, c
  * [azimuth, inclination, radius] <-> [x, y, z]; is_f64 selects double (numpy twins) or float (torch versions). */
 int rv_cart_to_sph(const void* cart, int64_t n, int32_t is_f64, void* sph, rvStream stream);
 int rv_sph_to_cart(const void* sph, int64_t n, int32_t is_f64, void* cart, rvStream stream);
+/* Loader augmentations on device (prototype/loader.py:825-990: flip_azimuth, random_rotation, random_global_scale,
+ * random_global_translation, and chains of them).  in / out: (B, C, H, W) fp32, distinct buffers.  params: B x 32 doubles
+ * on the DEVICE: {a, b} column map w_src = (a*w + b) mod W with a = +-1; A[9], t[3] affine map of the channels ix / iy / iz
+ * (xyz' = A xyz + t, fp64, rounded once); Ar[9], tr[3], use_range: the channel `irange` becomes ||Ar xyz + tr|| when
+ * use_range != 0 (the reference recomputes the range only in random_global_scale); 5 pad doubles.  ix = iy = iz = -1: only the
+ * column map is applied (mask, extra feature maps).  Every other channel is copied through the column map bit for bit. */
+int rv_augment(const float* in, float* out, int32_t B, int32_t C, int32_t H, int32_t W, int32_t ix, int32_t iy, int32_t iz,
+               int32_t irange, const double* params, rvStream stream);
 /* subsample_range_view's W padding at x_stride 1 (prototype/loader.py:792-815): out (C,H,W+2*pad) = pad(image * mask);
  * mask (H,W) may be NULL; circular != 0 wraps around in azimuth, else zeros.  AV2 pad 4 (1800 -> 1808), Waymo 3. */
 int rv_pad_range_view(const float* image, const float* mask, int32_t C, int32_t H, int32_t W, int32_t pad,

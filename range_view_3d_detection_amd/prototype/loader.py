@@ -33,3 +33,152 @@ def subsample_range_view(range_view: Tensor, mask: Tensor, cart: Tensor, dataset
     m = _pad(mask.float(), None, pad, circ)[:, :, ::x_stride]
     c = _pad(cart, None, pad, circ)[:, :, ::x_stride]
     return rv, m, c
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Augmentations (``prototype/loader.py:514-549, 825-990``) on device tensors
+# ---------------------------------------------------------------------------------------------------------------------
+# The reference augments ONE sweep at a time inside ``Dataset.__getitem__`` (a polars table on a DataLoader worker), drawing
+# from Python's ``random`` in the order of ``augmentations_config``.  Here a whole batch that already sits in HBM is
+# augmented by ``rv_augment`` (csrc/augment.hip); the random draws are made on the host, sweep by sweep, in the SAME order
+# with the same ``random`` calls, so that a seeded run picks the same parameters as the reference would.
+import math  # noqa: E402
+import random as _random  # noqa: E402
+from typing import Any, Dict, List, Mapping, Optional, Sequence  # noqa: E402
+
+COLS = ("tx_m", "ty_m", "tz_m", "length_m", "width_m", "height_m", "qw", "qx", "qy", "qz", "task_id", "offset", "batch_index")
+
+
+class SweepTransform:
+    """Composite of a chain of augmentations for one sweep: column map w_src = (a*w + b) mod W, xyz' = A xyz + t, and the
+    map (Ar, tr) whose norm becomes the ``range`` channel (only after a random_global_scale)."""
+
+    def __init__(self, width: int) -> None:
+        self.W = width
+        self.a, self.b = 1, 0
+        self.A = torch.eye(3, dtype=torch.float64)
+        self.t = torch.zeros(3, dtype=torch.float64)
+        self.Ar, self.tr, self.use_range = torch.eye(3, dtype=torch.float64), torch.zeros(3, dtype=torch.float64), False
+        self.ops: List[Any] = []
+
+    def _then_cols(self, a2: int, b2: int) -> None:
+        # new_out[w] = old_out[(a2*w + b2) mod W] = in[(a*(a2*w + b2) + b) mod W]
+        self.a, self.b = self.a * a2, (self.a * b2 + self.b) % self.W
+
+    def _then_affine(self, M: Tensor, d: Tensor) -> None:
+        self.A, self.t = M @ self.A, M @ self.t + d
+
+    def flip(self) -> None:  # loader.py:948-990
+        self._then_cols(-1, self.W - 1)
+        self._then_affine(torch.diag(torch.tensor([1.0, -1.0, 1.0], dtype=torch.float64)), torch.zeros(3, dtype=torch.float64))
+        self.ops.append(("flip",))
+
+    def rotate(self, theta: float) -> None:  # loader.py:825-882: roll by floor(theta / tau * W), xyz by rot.T = Rz(-theta)
+        shift = math.floor(theta / math.tau * self.W)
+        self._then_cols(1, -shift)
+        c, s = math.cos(theta), math.sin(theta)
+        self._then_affine(torch.tensor([[c, s, 0.0], [-s, c, 0.0], [0.0, 0.0, 1.0]], dtype=torch.float64), torch.zeros(3, dtype=torch.float64))
+        self.ops.append(("rotate", theta))
+
+    def scale(self, s: float) -> None:  # loader.py:885-915: range := ||xyz|| at this point of the chain
+        self._then_affine(s * torch.eye(3, dtype=torch.float64), torch.zeros(3, dtype=torch.float64))
+        self.Ar, self.tr, self.use_range = self.A.clone(), self.t.clone(), True
+        self.ops.append(("scale", s))
+
+    def translate(self, t: Sequence[float]) -> None:  # loader.py:918-945 (the range column is left as it is)
+        self._then_affine(torch.eye(3, dtype=torch.float64), torch.tensor(list(t), dtype=torch.float64))
+        self.ops.append(("translate", tuple(t)))
+
+    def packed(self) -> Tensor:
+        return torch.cat([torch.tensor([float(self.a), float(self.b)], dtype=torch.float64), self.A.flatten(), self.t, self.Ar.flatten(), self.tr,
+                          torch.tensor([1.0 if self.use_range else 0.0] + [0.0] * 5, dtype=torch.float64)])
+
+    # ---- annotations (host, fp64; a handful of rows) ----
+    def apply_to_annotations(self, ann: Tensor) -> Tensor:
+        """(M, >= 10) rows in ``COLS`` order [tx ty tz l w h qw qx qy qz ...] -> transformed copy."""
+        ann = ann.clone().double()
+        if ann.shape[0] == 0:
+            return ann
+        for op in self.ops:
+            if op[0] == "flip":
+                ann[:, 1] = -ann[:, 1]
+                w, x, y, z = ann[:, 6], ann[:, 7], ann[:, 8], ann[:, 9]
+                yaw = -torch.atan2(2 * (w * z + x * y), 1 - 2 * (y * y + z * z))  # the reference keeps the (negated) yaw only
+                ann[:, 6], ann[:, 7], ann[:, 8], ann[:, 9] = torch.cos(yaw / 2), 0.0, 0.0, torch.sin(yaw / 2)
+            elif op[0] == "rotate":
+                c, s = math.cos(op[1]), math.sin(op[1])
+                tx, ty = ann[:, 0].clone(), ann[:, 1].clone()
+                ann[:, 0], ann[:, 1] = c * tx + s * ty, -s * tx + c * ty
+                cw, cz = math.cos(-op[1] / 2), math.sin(-op[1] / 2)  # q' = q * q_z(-theta)  (mat = R_q @ rot.T)
+                w, x, y, z = ann[:, 6].clone(), ann[:, 7].clone(), ann[:, 8].clone(), ann[:, 9].clone()
+                ann[:, 6], ann[:, 7], ann[:, 8], ann[:, 9] = w * cw - z * cz, x * cw + y * cz, y * cw - x * cz, w * cz + z * cw
+            elif op[0] == "scale":
+                ann[:, :6] = op[1] * ann[:, :6]
+            elif op[0] == "translate":
+                ann[:, :3] = ann[:, :3] + torch.tensor(op[1], dtype=torch.float64)
+        return ann
+
+
+def draw_sweep_transform(width: int, augmentations_config: Mapping[str, Mapping[str, float]], rng=_random) -> SweepTransform:
+    """The draws of ``Dataset.apply_augmentations`` (``loader.py:514-549``) for ONE sweep, in config order, with the
+    reference's own ``random`` calls (flip: ``random() > p`` skips; rotation: ``random() > p`` skips, then ``uniform``;
+    scale: ``uniform``; translation: three ``normalvariate``)."""
+    tr = SweepTransform(width)
+    for k, v in augmentations_config.items():
+        if k == "flip_azimuth":
+            if rng.random() > v["p"]:
+                continue
+            tr.flip()
+        elif k == "random_rotation":
+            if rng.random() > v["p"]:
+                continue
+            tr.rotate(rng.uniform(v["low"], v["high"]))
+        elif k == "random_global_scale":
+            tr.scale(rng.uniform(v["low"], v["high"]))
+        elif k == "random_global_translation":
+            tr.translate([rng.normalvariate(0, v["std_x"]), rng.normalvariate(0, v["std_y"]), rng.normalvariate(0, v["std_z"])])
+        elif k == "point_dropout":
+            raise NotImplementedError("point_dropout draws H*W numbers from numpy's global generator per sweep; no shipped rv-* recipe enables it")
+        else:
+            raise KeyError(f"unknown augmentation {k!r}")
+    return tr
+
+
+def apply_sweep_transforms(x: Tensor, transforms: Sequence[SweepTransform], xyz_channels: Optional[Sequence[int]] = None,
+                           range_channel: int = -1) -> Tensor:
+    """(B, C, H, W) tensor -> augmented copy (``rv_augment``).  ``xyz_channels`` = positions of x, y, z among the channels
+    (None: apply the column map only -- the mask); bool tensors go through as fp32 0 / 1."""
+    _require_cuda(x, "tensor")
+    was_bool = x.dtype == torch.bool
+    src = x.float().contiguous()
+    b, c, h, w = src.shape
+    assert len(transforms) == b and all(t.W == w for t in transforms)
+    params = torch.stack([t.packed() for t in transforms]).to(src.device)
+    out = torch.empty_like(src)
+    ix, iy, iz = (-1, -1, -1) if xyz_channels is None else xyz_channels
+    L.call("rv_augment", L.ptr(src), L.ptr(out), L.i32(b), L.i32(c), L.i32(h), L.i32(w), L.i32(ix), L.i32(iy), L.i32(iz), L.i32(range_channel),
+           L.ptr(params), L.stream_ptr())
+    return out > 0.5 if was_bool else out
+
+
+def augment_batch(batch: Dict[str, Any], feature_column_names: Sequence[str], augmentations_config: Mapping[str, Mapping[str, float]],
+                  rng=_random) -> Dict[str, Any]:
+    """Batch-dict contract of the reference's loader (``loader.py:568-705, 245-248``): ``features`` (B, F, H, W) fp32 with the
+    channels named by ``feature_column_names`` (``conf/model/range_view.yaml:141-146``: x, y, z and range among them),
+    ``cart`` (B, 3, H, W) fp32, ``mask`` (B, 1, H, W) bool (= range > 0), ``annotations`` (M, 13) fp64 rows in ``COLS`` order,
+    sorted by sweep (``batch_index`` last).  Returns a new dict with all four augmented consistently, sweep by sweep."""
+    names = list(feature_column_names)
+    feats, cart, mask = batch["features"], batch["cart"], batch["mask"]
+    trs = [draw_sweep_transform(feats.shape[-1], augmentations_config, rng) for _ in range(feats.shape[0])]
+    xyz = [names.index(n) for n in ("x", "y", "z")] if all(n in names for n in ("x", "y", "z")) else None
+    out = dict(batch)
+    out["features"] = apply_sweep_transforms(feats, trs, xyz, names.index("range") if "range" in names and xyz is not None else -1)
+    out["cart"] = apply_sweep_transforms(cart, trs, (0, 1, 2))
+    out["mask"] = apply_sweep_transforms(mask, trs)
+    ann = batch.get("annotations")
+    if ann is not None and ann.shape[0] > 0:
+        ann = torch.as_tensor(ann).double()
+        parts = [trs[b].apply_to_annotations(ann[ann[:, -1] == b]) for b in range(feats.shape[0])]
+        out["annotations"] = torch.cat(parts) if parts else ann
+    out["transforms"] = trs
+    return out

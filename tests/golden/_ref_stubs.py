@@ -15,7 +15,8 @@ hot path touches; behaviour that matters numerically is restated faithfully:
 * ``kornia.geometry.conversions`` -- yaw-only quaternion helpers.
 * ``omegaconf.DictConfig/ListConfig`` -- hashable attr-dict / list.
 * ``hydra.utils.instantiate`` -- non-recursive ``_target_`` instantiation.
-* ``polars`` -- dtype names + a tiny frame with ``select(cols).to_numpy()``.
+* ``polars`` -- dtype names + a small columnar frame (``select`` / ``with_columns`` / ``to_numpy`` / ``from_numpy`` /
+  ``pl.col`` scalar arithmetic with polars' dtype rules): what the loader's augmentations use.
 * ``numba.njit`` -- identity decorator (the z-buffer loop runs as plain Python).
 """
 
@@ -191,23 +192,83 @@ class QuaternionCoeffOrder(enum.Enum):
 # --------------------------------------------------------------------------------------
 # polars (just enough for utils/polars.py and the dtype names in math/ops/coding.py)
 # --------------------------------------------------------------------------------------
+class _PlExpr:
+    """``pl.col(name)`` and the scalar arithmetic the loader uses on it.  Polars keeps the COLUMN's dtype when the other operand
+    is a Python scalar (``scale * pl.col("x")`` on a Float32 column stays Float32) -- reproduced with a same-dtype numpy scalar."""
+
+    def __init__(self, fn) -> None:
+        self.fn = fn
+
+    def _bin(self, other, op):
+        def run(frame):
+            a = self.fn(frame)
+            b = other.fn(frame) if isinstance(other, _PlExpr) else np.asarray(other, dtype=a.dtype)
+            return op(a, b)
+
+        return _PlExpr(run)
+
+    def __mul__(self, o):
+        return self._bin(o, lambda a, b: a * b)
+
+    __rmul__ = __mul__
+
+    def __add__(self, o):
+        return self._bin(o, lambda a, b: a + b)
+
+    __radd__ = __add__
+
+
 class _PlFrame:
+    """Columnar frame: name -> 1-D numpy array (dtype kept per column, as polars does).  Eager and "lazy" are the same object."""
+
     def __init__(self, data: Dict[str, Sequence[Any]], **_: Any) -> None:
         self._data = {k: np.asarray(v) for k, v in data.items()}
 
-    def select(self, columns: Sequence[str]) -> "_PlFrame":
+    def select(self, columns) -> "_PlFrame":
+        if isinstance(columns, str):
+            columns = [columns]
         return _PlFrame({c: self._data[c] for c in columns})
 
-    def to_numpy(self) -> np.ndarray:
+    def to_numpy(self, writable: bool = False) -> np.ndarray:
         cols = list(self._data.values())
         if not cols:
             return np.zeros((0, 0))
-        return np.stack([np.asarray(c, dtype=np.float64) for c in cols], axis=1)
+        dt = np.result_type(*[c.dtype for c in cols])
+        if not np.issubdtype(dt, np.floating):
+            dt = np.float64
+        return np.stack([np.asarray(c, dtype=dt) for c in cols], axis=1)  # mixed Float32 / Float64 columns upcast
+
+    def with_columns(self, *exprs: Any, **named: Any) -> "_PlFrame":
+        out = dict(self._data)
+        for k, v in named.items():
+            out[k] = v.fn(self._data) if isinstance(v, _PlExpr) else np.asarray(v)
+        return _PlFrame(out)
+
+    def collect(self) -> "_PlFrame":
+        return self
+
+    def lazy(self) -> "_PlFrame":
+        return self
+
+    @property
+    def schema(self) -> Dict[str, Any]:
+        return {k: v.dtype for k, v in self._data.items()}
+
+    @property
+    def columns(self):
+        return list(self._data)
 
     @property
     def shape(self):
         n = len(next(iter(self._data.values()))) if self._data else 0
         return (n, len(self._data))
+
+    def __getitem__(self, name: str) -> np.ndarray:
+        return self._data[name]
+
+
+def _pl_from_numpy(data: np.ndarray, schema: Dict[str, Any]) -> _PlFrame:
+    return _PlFrame({name: np.asarray(data[:, i], dtype=dt) for i, (name, dt) in enumerate(schema.items())})
 
 
 def install() -> None:
@@ -252,7 +313,9 @@ def install() -> None:
     for name in ("Float32", "Float64", "UInt8", "UInt16", "UInt32", "Int32", "Int64", "Utf8", "Boolean"):
         setattr(pl, name, name)
     pl.DataFrame = _PlFrame
-    pl.col = lambda *a, **k: None
+    pl.LazyFrame = _PlFrame
+    pl.col = lambda name: _PlExpr(lambda frame: frame[name])
+    pl.from_numpy = _pl_from_numpy
 
     class _PlConfig:
         @staticmethod

@@ -352,8 +352,95 @@ def gen_projection() -> None:
     save("projection", **out)
 
 
+def gen_augment() -> None:
+    """Loader augmentations (prototype/loader.py:825-990) run by the reference itself on a synthetic 8 x 64 sweep table
+    (Float32 columns, as the converter writes them) and a 6-box annotation table (Float64): one fixture per augmentation,
+    plus the chain of the shipped recipe (conf/model/baseline.yaml:12-21: flip_azimuth, random_rotation, random_global_scale)
+    followed by random_global_translation.  The random draws are reproduced by re-seeding ``random`` and drawing in the
+    order the reference does, so the fixtures also hold the parameters."""
+    import random
+
+    import polars as pl  # stub
+    from torchbox3d.prototype import loader as ref_loader
+
+    H, W = 8, 64
+    rng = np.random.default_rng(21)
+    inc = np.linspace(0.2, -0.4, H)[:, None]
+    az = np.linspace(math.pi, -math.pi, W)[None, :]
+    r = (20.0 + 15.0 * np.sin(3 * az) + 10.0 * np.cos(7 * inc) + rng.random((H, W))).astype(np.float32)
+    keep = rng.random((H, W)) >= 0.1
+    r = r * keep
+    cols = {
+        "x": (r * np.cos(inc) * np.cos(az)).astype(np.float32), "y": (r * np.cos(inc) * np.sin(az)).astype(np.float32),
+        "z": (r * np.sin(inc) * np.ones_like(az)).astype(np.float32), "intensity": (rng.random((H, W)) * keep).astype(np.float32),
+        "laser_number": (np.arange(H)[:, None] * np.ones((1, W)) * keep).astype(np.float32), "range": r.astype(np.float32),
+    }
+    names = list(cols)
+    sweep0 = pl.DataFrame({k: v.reshape(-1) for k, v in cols.items()})
+    yaw = rng.uniform(-math.pi, math.pi, 6)
+    ann = {"tx_m": rng.normal(0, 20, 6), "ty_m": rng.normal(0, 20, 6), "tz_m": rng.normal(0, 1, 6), "length_m": rng.uniform(1, 6, 6),
+           "width_m": rng.uniform(1, 3, 6), "height_m": rng.uniform(1, 3, 6), "qw": np.cos(yaw / 2), "qx": np.zeros(6), "qy": np.zeros(6),
+           "qz": np.sin(yaw / 2)}
+    ann_names = list(ann)
+    ann0 = pl.DataFrame(ann)
+    cfg = DictConfig({"height": H, "width": W})
+
+    def table(frame, nm, n):
+        return np.stack([np.asarray(frame[k], dtype=np.float64) for k in nm]).reshape(len(nm), *n)
+
+    out = {"sweep/in": table(sweep0, names, (H, W)), "ann/in": table(ann0, ann_names, (6,)), "column_names": np.array(names),
+           "ann_column_names": np.array(ann_names)}
+
+    def record(tag, sweep, annot, **params):
+        out[f"{tag}/sweep"] = table(sweep.collect(), names, (H, W))
+        out[f"{tag}/ann"] = table(annot.collect(), ann_names, (6,))
+        out[f"{tag}/sweep_is_f64"] = np.array([sweep.collect()[k].dtype == np.float64 for k in names])
+        for k, v in params.items():
+            out[f"{tag}/{k}"] = np.asarray(v, dtype=np.float64)
+
+    # --- each augmentation alone ---
+    random.seed(1)
+    s, a = ref_loader.flip_azimuth(sweep0.lazy(), ann0.lazy(), cfg, p=1.0)
+    record("flip", s, a)
+    random.seed(2)
+    s, a = ref_loader.random_rotation(sweep0.lazy(), ann0.lazy(), cfg, low=-0.78539816, high=0.78539816, p=1.0)
+    random.seed(2)
+    random.random()
+    record("rotation", s, a, theta=random.uniform(-0.78539816, 0.78539816))
+    random.seed(3)
+    s, a = ref_loader.random_global_scale(sweep0.lazy(), ann0.lazy(), low=0.95, high=1.05)
+    random.seed(3)
+    record("scale", s, a, scale=random.uniform(0.95, 1.05))
+    random.seed(4)
+    s, a = ref_loader.random_global_translation(sweep0.lazy(), ann0.lazy(), std_x=0.5, std_y=0.5, std_z=0.2)
+    random.seed(4)
+    record("translation", s, a, t=[random.normalvariate(0, 0.5), random.normalvariate(0, 0.5), random.normalvariate(0, 0.2)])
+    # --- a negative rotation (roll to the left) and a not-applied flip (p = 0) ---
+    random.seed(5)
+    s, a = ref_loader.random_rotation(sweep0.lazy(), ann0.lazy(), cfg, low=-3.0, high=-2.0, p=1.0)
+    random.seed(5)
+    random.random()
+    record("rotation_neg", s, a, theta=random.uniform(-3.0, -2.0))
+    # --- the shipped chain (+ translation) ---
+    random.seed(6)
+    s, a = ref_loader.flip_azimuth(sweep0.lazy(), ann0.lazy(), cfg, p=1.0)
+    s, a = ref_loader.random_rotation(s, a, cfg, low=-0.78539816, high=0.78539816, p=1.0)
+    s, a = ref_loader.random_global_scale(s, a, low=0.95, high=1.05)
+    s, a = ref_loader.random_global_translation(s, a, std_x=0.5, std_y=0.5, std_z=0.2)
+    random.seed(6)
+    random.random()
+    random.random()
+    theta = random.uniform(-0.78539816, 0.78539816)
+    scale = random.uniform(0.95, 1.05)
+    record("chain", s, a, theta=theta, scale=scale, t=[random.normalvariate(0, 0.5), random.normalvariate(0, 0.5), random.normalvariate(0, 0.2)])
+    save("augment", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "augment":  # (the other fixtures are unchanged since round 1)
+        gen_augment()
+        sys.exit(0)
     gen_conv_blocks()
     gen_meta_kernel()
     gen_decode()

@@ -315,3 +315,78 @@ def test_z_buffer_fp64_vs_fp32_quirk():
     img, win = rv.z_buffer(torch.from_numpy(rows).to(DEV), torch.from_numpy(cols).to(DEV), torch.from_numpy(d).to(DEV),
                            torch.from_numpy(feats).to(DEV), 4, 16)
     assert np.array_equal(win.cpu().numpy(), win_o) and np.array_equal(img.cpu().numpy(), img_o)
+
+
+def test_device_augmentations_match_the_reference(golden):
+    """Loader augmentations on device (prototype/loader.py of this package -> rv_augment) against fixtures produced by the
+    reference's own functions: pixel placement (every non-geometry channel) bit-exact, geometry 1e-6 of the channel
+    maximum, boxes 1e-9; and the seeded ``random`` draws pick the same parameters as the reference."""
+    import random
+
+    from oracle import augment as oaug
+    from range_view_3d_detection_amd.prototype import loader as ld
+
+    g = golden("augment")
+    names = [str(n) for n in g.np("column_names")]
+    s0 = torch.from_numpy(g.np("sweep/in")).float()
+    a0 = torch.from_numpy(g.np("ann/in")).T.contiguous()  # (M, 10)
+    ann = torch.cat([a0, torch.zeros(a0.shape[0], 3, dtype=torch.float64)], dim=1)  # + task_id, offset, batch_index
+    H, W = s0.shape[1:]
+    cart0 = s0[[names.index(n) for n in ("x", "y", "z")]]
+    batch = {"features": s0[None].to(DEV), "cart": cart0[None].to(DEV), "mask": (s0[names.index("range")] > 0)[None, None].to(DEV),
+             "annotations": ann}
+
+    def check(out, tag):
+        ref_s, ref_a = g.np(f"{tag}/sweep"), g.np(f"{tag}/ann")
+        got = out["features"][0].cpu().numpy()
+        for i, n in enumerate(names):
+            if n not in ("x", "y", "z", "range"):
+                assert np.array_equal(got[i], ref_s[i].astype(np.float32)), (tag, n)
+            assert np.max(np.abs(got[i] - ref_s[i])) <= 1e-6 * max(1.0, np.max(np.abs(ref_s[i]))), (tag, n)
+        gc = out["cart"][0].cpu().numpy()
+        for j, n in enumerate(("x", "y", "z")):
+            assert np.max(np.abs(gc[j] - ref_s[names.index(n)])) <= 1e-6 * max(1.0, np.max(np.abs(ref_s[names.index(n)]))), (tag, n)
+        # the mask travels with the pixels (column map only)
+        tr = out["transforms"][0]
+        ws = (tr.a * np.arange(W) + tr.b) % W
+        assert np.array_equal(out["mask"][0, 0].cpu().numpy(), (g.np("sweep/in")[names.index("range")] > 0)[:, ws]), tag
+        ga = out["annotations"].numpy()[:, :10].T
+        assert np.max(np.abs(ga[:6] - ref_a[:6])) <= 1e-9 * max(1.0, np.max(np.abs(ref_a[:6]))), tag
+        dyaw = oaug.yaw_of(ga[6:10]) - oaug.yaw_of(ref_a[6:10])
+        assert np.max(np.abs(np.arctan2(np.sin(dyaw), np.cos(dyaw)))) < 1e-9, tag
+
+    rot_cfg = {"low": -0.78539816, "high": 0.78539816, "p": 1.0}
+    random.seed(1)
+    check(ld.augment_batch(batch, names, {"flip_azimuth": {"p": 1.0}}), "flip")
+    random.seed(2)
+    out = ld.augment_batch(batch, names, {"random_rotation": rot_cfg})
+    assert out["transforms"][0].ops[0][1] == float(g.np("rotation/theta"))  # same draw as the reference
+    check(out, "rotation")
+    random.seed(5)
+    check(ld.augment_batch(batch, names, {"random_rotation": {"low": -3.0, "high": -2.0, "p": 1.0}}), "rotation_neg")
+    random.seed(3)
+    check(ld.augment_batch(batch, names, {"random_global_scale": {"low": 0.95, "high": 1.05}}), "scale")
+    random.seed(4)
+    check(ld.augment_batch(batch, names, {"random_global_translation": {"std_x": 0.5, "std_y": 0.5, "std_z": 0.2}}), "translation")
+    random.seed(6)
+    chain = {"flip_azimuth": {"p": 1.0}, "random_rotation": rot_cfg, "random_global_scale": {"low": 0.95, "high": 1.05},
+             "random_global_translation": {"std_x": 0.5, "std_y": 0.5, "std_z": 0.2}}
+    check(ld.augment_batch(batch, names, chain), "chain")
+    # a batch of two sweeps: each sweep gets its own draws; the second equals what a single-sweep call with those draws gives
+    random.seed(9)
+    two = {"features": torch.cat([batch["features"]] * 2), "cart": torch.cat([batch["cart"]] * 2), "mask": torch.cat([batch["mask"]] * 2),
+           "annotations": torch.cat([ann, torch.cat([ann[:, :-1], torch.ones(ann.shape[0], 1, dtype=torch.float64)], dim=1)])}
+    out2 = ld.augment_batch(two, names, chain)
+    t0, t1 = out2["transforms"]
+    assert t0.ops != t1.ops
+    so, ao = g.np("sweep/in"), g.np("ann/in")
+    for op in t1.ops:
+        so, ao = {"flip": lambda s, a: oaug.flip(s, names, a), "rotate": lambda s, a: oaug.rotate(s, names, a, op[1]),
+                  "scale": lambda s, a: oaug.scale(s, names, a, op[1]), "translate": lambda s, a: oaug.translate(s, names, a, op[1])}[op[0]](so, ao)
+    got = out2["features"][1].cpu().numpy()
+    for i, n in enumerate(names):
+        assert np.max(np.abs(got[i] - so[i])) <= 1e-6 * max(1.0, np.max(np.abs(so[i]))), n
+    # p = 0: nothing happens and nothing but the coin is drawn
+    random.seed(1)
+    same = ld.augment_batch(batch, names, {"flip_azimuth": {"p": 0.0}})
+    assert torch.equal(same["features"], batch["features"]) and torch.equal(same["mask"], batch["mask"])

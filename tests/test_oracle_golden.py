@@ -248,3 +248,41 @@ def test_tiny_model_eval_and_decode(golden):
     assert p.shape[0] > 10  # the fixture really has detections above min_confidence
     close(p, g["eval/dec_params"], 1e-6, "dec params")
     close(s, g["eval/dec_scores"], 1e-7, "dec scores")
+
+
+def _check_augmented(got_sweep, got_ann, g, tag, names):
+    from oracle import augment as oaug
+
+    ref_s, ref_a = g.np(f"{tag}/sweep"), g.np(f"{tag}/ann")
+    # index work (which pixel lands where) is exact: every non-geometry channel must match bit for bit
+    for i, n in enumerate(names):
+        if n not in ("x", "y", "z", "range"):
+            assert np.array_equal(got_sweep[i].astype(np.float32), ref_s[i].astype(np.float32)), (tag, n)
+    # geometry: 1e-6 of the channel maximum (the reference mixes float32 columns with float64 matrix products)
+    for i, n in enumerate(names):
+        assert np.max(np.abs(got_sweep[i] - ref_s[i])) <= 1e-6 * max(1.0, np.max(np.abs(ref_s[i]))), (tag, n)
+    assert np.max(np.abs(got_ann[:6] - ref_a[:6])) <= 1e-9 * max(1.0, np.max(np.abs(ref_a[:6]))), tag
+    dyaw = oaug.yaw_of(got_ann[6:10]) - oaug.yaw_of(ref_a[6:10])  # (q and -q are the same rotation)
+    assert np.max(np.abs(np.arctan2(np.sin(dyaw), np.cos(dyaw)))) < 1e-9, tag
+
+
+def test_augmentations_match_the_reference(golden):
+    from oracle import augment as oaug
+
+    g = golden("augment")
+    names = [str(n) for n in g.np("column_names")]
+    s0, a0 = g.np("sweep/in"), g.np("ann/in")
+    _check_augmented(*oaug.flip(s0, names, a0), g, "flip", names)
+    _check_augmented(*oaug.rotate(s0, names, a0, float(g.np("rotation/theta"))), g, "rotation", names)
+    _check_augmented(*oaug.rotate(s0, names, a0, float(g.np("rotation_neg/theta"))), g, "rotation_neg", names)
+    _check_augmented(*oaug.scale(s0, names, a0, float(g.np("scale/scale"))), g, "scale", names)
+    _check_augmented(*oaug.translate(s0, names, a0, g.np("translation/t")), g, "translation", names)
+    s, a = oaug.flip(s0, names, a0)
+    s, a = oaug.rotate(s, names, a, float(g.np("chain/theta")))
+    s, a = oaug.scale(s, names, a, float(g.np("chain/scale")))
+    s, a = oaug.translate(s, names, a, g.np("chain/t"))
+    _check_augmented(s, a, g, "chain", names)
+    # the roll really moves columns: shift = floor(theta / tau * W), negative theta rolls left
+    W = s0.shape[-1]
+    sh = math.floor(float(g.np("rotation_neg/theta")) / math.tau * W)
+    assert sh < 0 and np.array_equal(g.np("rotation_neg/sweep")[3], np.roll(s0[3], sh, axis=-1))
