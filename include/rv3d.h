@@ -310,6 +310,22 @@ int rv_rotated_iou(const float* a, int64_t n, const float* b, int64_t m, float* 
 /* ---------------------------------------------------------------------------------------
  * Range-image projection (converters/av2/utils.py:108-208 == math/numpy/conversions.py:9-128).
  * ------------------------------------------------------------------------------------- */
+/* Raw sweep -> the points the projection bins (converters/av2/utils.py:211-295, :32-55).  All device pointers.
+ * rv_unmotion_compensate: xyz (n,3) fp64 ego-frame points of the sweep stamped `sweep_timestamp_ns` with per-point
+ *   `offset_ns`; the pose track (sorted timestamps, wxyz quaternions, translations; `target_pose` = index of the pose at the
+ *   sweep timestamp).  kept[i] = 0 for points outside (first, last) pose time (the reference drops them; their xyz_p is 0);
+ *   xyz_p = the point in the ego frame AT ITS OWN capture time (scipy-Slerp rotation, the reference's translation weights).
+ * rv_correct_laser_numbers: laser ids -> image rows through LASER_MAPPING (only for `affected` logs) and the row table
+ *   (ROW_MAPPING_64 / _32 of datasets/argoverse/constants.py, passed in as data); ids outside the table give -1.
+ * rv_se3_inverse_apply: out = R(q)^T (xyz - t): ego -> sensor with the sensor's extrinsics (egovehicle_SE3_sensor); points with
+ *   kept[i] == 0 (kept may be NULL) come out as the origin: range 0, which rv_z_buffer skips -- the point order is preserved. */
+int rv_unmotion_compensate(const double* xyz, const int32_t* offset_ns, int64_t n, int64_t sweep_timestamp_ns,
+                           const int64_t* pose_timestamps_ns, const double* pose_q_wxyz, const double* pose_t, int32_t n_poses,
+                           int32_t target_pose, double* xyz_p, uint8_t* kept, rvStream stream);
+int rv_correct_laser_numbers(const int32_t* laser, int64_t n, int32_t affected, const int32_t* laser_mapping_32,
+                             const int32_t* row_mapping, int32_t n_rows, int32_t* out, rvStream stream);
+int rv_se3_inverse_apply(const double* xyz, int64_t n, const double* q_wxyz, const double* t, const uint8_t* kept, double* out,
+                         rvStream stream);
 /* Correctly rounded (round-to-nearest-even) fp64 atan2, elementwise -- the azimuth rv_project_indices bins with
  * (np.arctan2 at converters/av2/utils.py:172; see csrc/project.hip for why the device value must be THE rounded one). */
 int rv_atan2_cr(const double* y, const double* x, int64_t n, double* out, rvStream stream);

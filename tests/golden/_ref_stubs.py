@@ -193,16 +193,23 @@ class QuaternionCoeffOrder(enum.Enum):
 # polars (just enough for utils/polars.py and the dtype names in math/ops/coding.py)
 # --------------------------------------------------------------------------------------
 class _PlExpr:
-    """``pl.col(name)`` and the scalar arithmetic the loader uses on it.  Polars keeps the COLUMN's dtype when the other operand
-    is a Python scalar (``scale * pl.col("x")`` on a Float32 column stays Float32) -- reproduced with a same-dtype numpy scalar."""
+    """``pl.col(...)`` / ``pl.lit(...)`` and the arithmetic / comparisons the loader and the converter use on them.  Polars keeps
+    the COLUMN's dtype when the other operand is a Python scalar (``scale * pl.col("x")`` on a Float32 column stays Float32)
+    -- reproduced with a same-dtype numpy scalar."""
 
-    def __init__(self, fn) -> None:
+    def __init__(self, fn, names=None) -> None:
         self.fn = fn
+        self.names = names  # column selector (``pl.col("a", "b")`` / ``pl.col(["a", "b"])``) when not None
 
-    def _bin(self, other, op):
+    def _bin(self, other, op, keep_dtype=True):
         def run(frame):
             a = self.fn(frame)
-            b = other.fn(frame) if isinstance(other, _PlExpr) else np.asarray(other, dtype=a.dtype)
+            if isinstance(other, _PlExpr):
+                b = other.fn(frame)
+            elif isinstance(other, _PlSeries):
+                b = other.values
+            else:
+                b = np.asarray(other, dtype=a.dtype) if keep_dtype and np.issubdtype(np.asarray(a).dtype, np.floating) else other
             return op(a, b)
 
         return _PlExpr(run)
@@ -217,32 +224,117 @@ class _PlExpr:
 
     __radd__ = __add__
 
+    def __eq__(self, o):  # noqa: D105
+        return self._bin(o, lambda a, b: a == b, keep_dtype=False)
+
+    def eq(self, o):
+        return self == o
+
+    def __gt__(self, o):
+        return self._bin(o, lambda a, b: a > b, keep_dtype=False)
+
+    def __lt__(self, o):
+        return self._bin(o, lambda a, b: a < b, keep_dtype=False)
+
+    def __and__(self, o):
+        return self._bin(o, lambda a, b: a & b, keep_dtype=False)
+
+    __hash__ = None
+
+
+class _PlSeries:
+    def __init__(self, name: str, values) -> None:
+        self.name, self.values = name, np.asarray(values)
+
+    def min(self):
+        return self.values.min()
+
+    def max(self):
+        return self.values.max()
+
+    def to_numpy(self, writable: bool = False):
+        return self.values.copy()
+
+    def cast(self, dtype):
+        return _PlSeries(self.name, self.values.astype({"Int64": np.int64, "Float32": np.float32, "Float64": np.float64}.get(dtype, dtype)))
+
+    def search_sorted(self, other, side: str = "left"):
+        other = other.values if isinstance(other, _PlSeries) else np.asarray(other)
+        return np.searchsorted(self.values, other, side=side)
+
+    def __add__(self, o):
+        return _PlSeries(self.name, self.values + (o.values if isinstance(o, _PlSeries) else o))
+
+    __radd__ = __add__
+
+    def __len__(self):
+        return len(self.values)
+
+    def __array__(self, dtype=None, copy=None):
+        return self.values if dtype is None else self.values.astype(dtype)
+
+    @property
+    def dtype(self):
+        return self.values.dtype
+
+
+def _names_of(columns):
+    if isinstance(columns, _PlExpr):
+        assert columns.names is not None
+        return list(columns.names)
+    if isinstance(columns, str):
+        return [columns]
+    out = []
+    for c in columns:
+        out += _names_of(c) if isinstance(c, (_PlExpr, list, tuple)) else [c]
+    return out
+
 
 class _PlFrame:
     """Columnar frame: name -> 1-D numpy array (dtype kept per column, as polars does).  Eager and "lazy" are the same object."""
 
-    def __init__(self, data: Dict[str, Sequence[Any]], **_: Any) -> None:
-        self._data = {k: np.asarray(v) for k, v in data.items()}
+    def __init__(self, data: Dict[str, Sequence[Any]], schema=None, **_: Any) -> None:
+        npdt = {"Float32": np.float32, "Float64": np.float64, "UInt8": np.uint8, "Boolean": np.bool_, "Int64": np.int64, "Int32": np.int32}
+        self._data = {}
+        for k, v in data.items():
+            v = v.values if isinstance(v, _PlSeries) else np.asarray(v)
+            if schema is not None and k in schema:
+                v = v.astype(npdt.get(schema[k], schema[k]))
+            self._data[k] = v
 
-    def select(self, columns) -> "_PlFrame":
-        if isinstance(columns, str):
-            columns = [columns]
-        return _PlFrame({c: self._data[c] for c in columns})
+    def select(self, *columns) -> "_PlFrame":
+        names = _names_of(columns[0] if len(columns) == 1 else list(columns))
+        return _PlFrame({c: self._data[c] for c in names})
 
     def to_numpy(self, writable: bool = False) -> np.ndarray:
         cols = list(self._data.values())
         if not cols:
             return np.zeros((0, 0))
+        if all(c.dtype.kind in "US" for c in cols):
+            return np.stack(cols, axis=1)
         dt = np.result_type(*[c.dtype for c in cols])
         if not np.issubdtype(dt, np.floating):
-            dt = np.float64
+            dt = np.float64 if dt.kind not in "iu" else dt
         return np.stack([np.asarray(c, dtype=dt) for c in cols], axis=1)  # mixed Float32 / Float64 columns upcast
 
     def with_columns(self, *exprs: Any, **named: Any) -> "_PlFrame":
         out = dict(self._data)
+        for e in exprs:
+            if isinstance(e, _PlSeries):
+                out[e.name] = e.values
         for k, v in named.items():
-            out[k] = v.fn(self._data) if isinstance(v, _PlExpr) else np.asarray(v)
+            if isinstance(v, _PlExpr):
+                v = v.fn(self._data)
+            elif isinstance(v, _PlSeries):
+                v = v.values
+            v = np.asarray(v)
+            n = self.shape[0]
+            out[k] = np.broadcast_to(v, (n,)).copy() if v.ndim == 0 else v
         return _PlFrame(out)
+
+    def filter(self, mask) -> "_PlFrame":
+        m = mask.fn(self._data) if isinstance(mask, _PlExpr) else np.asarray(mask)
+        return _PlFrame({k: v[m] for k, v in self._data.items()})
 
     def collect(self) -> "_PlFrame":
         return self
@@ -263,8 +355,20 @@ class _PlFrame:
         n = len(next(iter(self._data.values()))) if self._data else 0
         return (n, len(self._data))
 
-    def __getitem__(self, name: str) -> np.ndarray:
-        return self._data[name]
+    def __getitem__(self, key):
+        if isinstance(key, str):
+            return _PlSeries(key, self._data[key])
+        idx = np.asarray(key)
+        return _PlFrame({k: v[idx] for k, v in self._data.items()})  # rows by integer array
+
+
+def _pl_col(*names):
+    if len(names) == 1 and isinstance(names[0], (list, tuple)):
+        names = tuple(names[0])
+    if len(names) == 1:
+        n = names[0]
+        return _PlExpr(lambda frame: np.asarray(frame[n]), names=[n])
+    return _PlExpr(None, names=list(names))
 
 
 def _pl_from_numpy(data: np.ndarray, schema: Dict[str, Any]) -> _PlFrame:
@@ -314,7 +418,9 @@ def install() -> None:
         setattr(pl, name, name)
     pl.DataFrame = _PlFrame
     pl.LazyFrame = _PlFrame
-    pl.col = lambda name: _PlExpr(lambda frame: frame[name])
+    pl.col = _pl_col
+    pl.lit = lambda v: _PlExpr(lambda frame: np.asarray(v))
+    pl.Series = _PlSeries
     pl.from_numpy = _pl_from_numpy
 
     class _PlConfig:
@@ -359,7 +465,18 @@ def install() -> None:
     _module("av2")
     _module("av2.geometry")
     se3 = _module("av2.geometry.se3")
-    se3.SE3 = object
+
+    class SE3:  # av2.geometry.se3.SE3 as the converter uses it: inverse() and transform_point_cloud() (row-vector points)
+        def __init__(self, rotation, translation) -> None:
+            self.rotation, self.translation = np.asarray(rotation, dtype=np.float64), np.asarray(translation, dtype=np.float64)
+
+        def inverse(self):
+            return SE3(self.rotation.T, self.rotation.T.dot(-self.translation))
+
+        def transform_point_cloud(self, pts):
+            return np.asarray(pts) @ self.rotation.T + self.translation
+
+    se3.SE3 = SE3
     _module("av2.datasets")
     _module("av2.datasets.sensor")
     av2c = _module("av2.datasets.sensor.constants")

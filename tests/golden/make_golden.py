@@ -436,8 +436,73 @@ def gen_augment() -> None:
     save("augment", **out)
 
 
+def gen_raw_sweep() -> None:
+    """The converter's path from a RAW AV2 sweep to the range image (converters/av2/export.py:70-133 driving
+    converters/av2/utils.py): unmotion_compensate (:231-295), correct_laser_numbers (:211-228), build_range_view (:32-105:
+    ego -> sensor SE3, spherical binning, z-buffer), run by the reference itself on a synthetic sweep, a synthetic pose
+    track and synthetic extrinsics.  The dataset tables the reference indexes (LASER_MAPPING, ROW_MAPPING_64 / _32) are
+    stored as data: the device path takes them as arguments."""
+    import polars as pl  # stub
+    from scipy.spatial.transform import Rotation, Slerp
+    from torchbox3d.datasets.argoverse.constants import LASER_MAPPING, LOG_IDS, ROW_MAPPING_32, ROW_MAPPING_64
+
+    rng = np.random.default_rng(33)
+    P, N, H, W = 14, 4000, 64, 512
+    ts = (315969904359876000 + np.cumsum(rng.integers(95_000_000, 105_000_000, P))).astype(np.int64)
+    yaw = 0.3 + 0.02 * np.arange(P) + 0.003 * rng.normal(size=P)
+    rp = 0.01 * rng.normal(size=(P, 2))
+    rots = Rotation.from_euler("xyz", np.stack([rp[:, 0], rp[:, 1], yaw], axis=1))
+    q_xyzw = rots.as_quat()
+    trans = np.stack([1000 + 1.2 * np.arange(P) + 0.01 * rng.normal(size=P), 500 + 0.3 * np.arange(P), 10 + 0.01 * rng.normal(size=P)], axis=1)
+    poses = pl.DataFrame({"timestamp_ns": ts, "qw": q_xyzw[:, 3], "qx": q_xyzw[:, 0], "qy": q_xyzw[:, 1], "qz": q_xyzw[:, 2],
+                          "tx_m": trans[:, 0], "ty_m": trans[:, 1], "tz_m": trans[:, 2]})
+    slerp = Slerp(ts, Rotation.from_quat(poses.select(ref_conv.QUATERNION_WXYZ).to_numpy()))
+    target = int(ts[6])
+    offset_ns = rng.integers(-20_000_000, 95_000_000, N).astype(np.int32)
+    offset_ns[:5] = [int(ts[0] - target) - 7, int(ts[-1] - target) + 7, int(ts[0] - target), int(ts[-1] - target), int(ts[7] - target)]  # outside / on the ends / on a pose
+    r = rng.uniform(0.5, 80.0, N)
+    az, inc = rng.uniform(-math.pi, math.pi, N), rng.uniform(-0.4, 0.25, N)
+    xyz = np.stack([r * np.cos(inc) * np.cos(az) + 1.35, r * np.cos(inc) * np.sin(az), r * np.sin(inc) + 1.64], axis=1).astype(np.float32).astype(np.float64)
+    laser = rng.integers(0, 64, N).astype(np.uint8)
+    lidar = pl.DataFrame({"x": xyz[:, 0], "y": xyz[:, 1], "z": xyz[:, 2], "intensity": rng.integers(0, 256, N).astype(np.uint8),
+                          "laser_number": laser, "offset_ns": offset_ns, "is_within_roi": rng.random(N) > 0.3})
+    out = {"poses/timestamp_ns": ts, "poses/q_wxyz": np.stack([q_xyzw[:, 3], q_xyzw[:, 0], q_xyzw[:, 1], q_xyzw[:, 2]], axis=1), "poses/t": trans,
+           "sweep/timestamp_ns": np.int64(target), "sweep/xyz": xyz, "sweep/offset_ns": offset_ns, "sweep/laser_number": laser,
+           "sweep/intensity": np.asarray(lidar["intensity"]), "sweep/is_within_roi": np.asarray(lidar["is_within_roi"]),
+           "tables/LASER_MAPPING": np.asarray(LASER_MAPPING), "tables/ROW_MAPPING_64": np.asarray(ROW_MAPPING_64),
+           "tables/ROW_MAPPING_32": np.asarray(ROW_MAPPING_32)}
+    # ---- unmotion_compensate ----
+    um = ref_conv.unmotion_compensate(lidar, poses, target, slerp)
+    out["unmotion/kept"] = np.isin(np.arange(N), np.nonzero((target + offset_ns.astype(np.int64) > ts[0]) & (target + offset_ns.astype(np.int64) < ts[-1]))[0])
+    out["unmotion/xyz_p"] = np.stack([np.asarray(um["x_p"]), np.asarray(um["y_p"]), np.asarray(um["z_p"])], axis=1)
+    assert out["unmotion/xyz_p"].shape[0] == int(out["unmotion/kept"].sum())
+    # ---- correct_laser_numbers: a log with the laser-ordering defect and one without, both image heights ----
+    lz = np.asarray(um["laser_number"]).astype(np.int64)
+    out["laser/in"] = lz
+    out["laser/h64_affected"] = ref_conv.correct_laser_numbers(lz.copy(), LOG_IDS[0], 64)
+    out["laser/h64_plain"] = ref_conv.correct_laser_numbers(lz.copy(), "not-a-listed-log", 64)
+    out["laser/h32_affected"] = ref_conv.correct_laser_numbers(lz.copy() % 32, LOG_IDS[0], 32)
+    # ---- build_range_view (ego -> up_lidar frame, binning, z-buffer) ----
+    ext_rot = Rotation.from_euler("xyz", [[0.002, -0.003, 0.01], [3.1, 0.0, 0.0]])
+    eq = ext_rot.as_quat()
+    extrinsics = pl.DataFrame({"sensor_name": np.array(["up_lidar", "down_lidar"]), "qw": eq[:, 3], "qx": eq[:, 0], "qy": eq[:, 1], "qz": eq[:, 2],
+                               "tx_m": np.array([1.35, 1.355]), "ty_m": np.array([0.01, -0.01]), "tz_m": np.array([1.64, 1.515])})
+    um = um.with_columns(pl.Series("laser_number", out["laser/h64_affected"]))
+    feats = um.select(("x", "y", "z", "intensity", "laser_number", "is_within_roi")).to_numpy()
+    rv = ref_conv.build_range_view(um, extrinsics=extrinsics, features=feats, sensor_name="up_lidar", height=H, width=W)
+    out["extrinsics/q_wxyz"] = np.array([eq[0, 3], eq[0, 0], eq[0, 1], eq[0, 2]])
+    out["extrinsics/t"] = np.array([1.35, 0.01, 1.64])
+    names = ["x", "y", "z", "intensity", "laser_number", "is_within_roi", "timedelta_ns", "range"]
+    out["range_view/column_names"] = np.array(names)
+    out["range_view/image"] = np.stack([np.asarray(rv[k]).astype(np.float64) for k in names]).reshape(len(names), H, W)
+    save("raw_sweep", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "raw_sweep":
+        gen_raw_sweep()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "augment":  # (the other fixtures are unchanged since round 1)
         gen_augment()
         sys.exit(0)

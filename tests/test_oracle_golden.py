@@ -286,3 +286,26 @@ def test_augmentations_match_the_reference(golden):
     W = s0.shape[-1]
     sh = math.floor(float(g.np("rotation_neg/theta")) / math.tau * W)
     assert sh < 0 and np.array_equal(g.np("rotation_neg/sweep")[3], np.roll(s0[3], sh, axis=-1))
+
+
+def test_raw_sweep_path_matches_the_reference(golden):
+    from oracle import rawsweep as oraw
+
+    g = golden("raw_sweep")
+    kept, xyz_p = oraw.unmotion_compensate(g.np("sweep/xyz"), g.np("sweep/offset_ns"), int(g.np("sweep/timestamp_ns")), g.np("poses/timestamp_ns"),
+                                           g.np("poses/q_wxyz"), g.np("poses/t"))
+    assert np.array_equal(kept, g.np("unmotion/kept")) and 0 < kept.sum() < kept.size
+    ref = g.np("unmotion/xyz_p")
+    assert np.max(np.abs(xyz_p - ref)) < 1e-9 * np.max(np.abs(ref))  # fp64 rigid transforms (scipy Slerp vs quaternion slerp)
+    lz = g.np("laser/in")
+    for tag, affected, rows in (("h64_affected", True, "ROW_MAPPING_64"), ("h64_plain", False, "ROW_MAPPING_64")):
+        assert np.array_equal(oraw.correct_laser_numbers(lz, affected, g.np("tables/LASER_MAPPING"), g.np(f"tables/{rows}")), g.np(f"laser/{tag}")), tag
+    assert np.array_equal(oraw.correct_laser_numbers(lz % 32, True, g.np("tables/LASER_MAPPING"), g.np("tables/ROW_MAPPING_32")), g.np("laser/h32_affected"))
+    feats = np.stack([g.np("sweep/xyz")[kept][:, 0], g.np("sweep/xyz")[kept][:, 1], g.np("sweep/xyz")[kept][:, 2], g.np("sweep/intensity")[kept].astype(np.float64),
+                      g.np("laser/h64_affected").astype(np.float64), g.np("sweep/is_within_roi")[kept].astype(np.float64)], axis=1)
+    img = oraw.build_range_view(ref, feats, g.np("laser/h64_affected"), g.np("sweep/offset_ns")[kept], g.np("extrinsics/q_wxyz"), g.np("extrinsics/t"), 64, 512)
+    want = g.np("range_view/image")
+    # the reference casts intensity / laser_number to UInt8 and is_within_roi to Boolean when it builds the table
+    got = img.astype(np.float64)
+    got[3], got[4], got[5] = got[3].astype(np.uint8), got[4].astype(np.uint8), got[5] != 0
+    assert np.array_equal(got, want), int((got != want).sum())
