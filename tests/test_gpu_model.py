@@ -367,3 +367,40 @@ def test_fused_multiclass_nms_equals_per_class_loop():
     assert fused[0].shape == loop[0].shape and fused[0].shape[0] > 26 * 20
     for a, b in zip(fused, loop):
         assert torch.equal(a, b)
+
+
+def test_detections_wire_format_from_device_decode(golden, tmp_path):
+    """SURVEY §8f rank 2 end to end on the device path: eval forward -> RangeDecoder.decode (weighted NMS) -> build_dataframe
+    -> one feather file per (log_id, timestamp_ns) -> read back.  The table holds exactly the decoder's rows (fp32 columns bit
+    for bit), categories resolved through the task frame, rows of sweeps without a uuid dropped by the inner join.  (Parity
+    with the reference's polars implementation stays unpinned: polars is not in the image; the schema / join rules are
+    restated from math/ops/coding.py:11-76 and checked on CPU in test_host_cpu.py.)"""
+    import pyarrow.feather as feather
+
+    from range_view_3d_detection_amd.math.ops.coding import DETECTION_COLUMNS, build_dataframe, write_detections
+    from range_view_3d_detection_amd.nn.decoders.range_decoder import RangeDecoder
+
+    g = golden("tiny_model")
+    backbone, head = load_tiny(g)
+    backbone.eval()
+    head.eval()
+    data = {"features": g["features"].to(DEV), "cart": g["cart"].to(DEV), "mask": g["mask"].to(DEV)}
+    with torch.no_grad():
+        outputs, _ = head(backbone(data), data, return_loss=False)
+    dec = RangeDecoder(True, True, [0, 15, 30], [15, 30, math.inf], [8, 2, 1])
+    post = {"num_pre_nms": 50000, "num_post_nms": 1000, "nms_threshold": 0.3, "min_confidence": 0.1, "nms_mode": "WEIGHTED"}
+    params, scores, cats, bidx = dec.decode(outputs, post, {0: ["c"] * NCLS}, use_nms=True)
+    assert params.is_cuda and params.shape[0] > 0
+    names = ["REGULAR_VEHICLE", "PEDESTRIAN", "BUS", "BICYCLE", "TRUCK"]
+    uuids = {"batch_index": [0], "log_id": ["log-a"], "timestamp_ns": [315969904359876000]}  # sweep 1 has no uuid: dropped
+    table = build_dataframe(params, scores, cats, bidx, uuids, names)
+    keep = (bidx.int() == 0).cpu()
+    assert table.num_rows == int(keep.sum()) and 0 < table.num_rows < params.shape[0]
+    for j, col in enumerate(DETECTION_COLUMNS):
+        assert np.array_equal(np.asarray(table.column(col)), params[:, j].float().cpu().numpy()[keep.numpy()]), col
+    assert np.array_equal(np.asarray(table.column("score")), scores.float().cpu().numpy()[keep.numpy()])
+    assert table.column("category").to_pylist() == [names[int(c)] for c in cats.int().cpu()[keep].tolist()]
+    paths = write_detections(table, str(tmp_path), "run0")
+    assert len(paths) == 1 and paths[0].endswith("predictions/run0/log-a/315969904359876000.feather")
+    back = feather.read_table(paths[0])
+    assert back.equals(table)
