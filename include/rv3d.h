@@ -305,6 +305,18 @@ int rv_wnms_classes(const float* boxes, const float* data, const int32_t* cats, 
                     float merge_thresh, float* output, int64_t* keep, int64_t* count, void* workspace,
                     int64_t* host_num_out, rvStream stream);
 /* pairwise rotated BEV IoU (n x m), exposed for tests */
+/* The whole post-decode path of a BATCH of sweeps, device-resident from end to end (csrc/nms2.hip): confidence filter +
+ * compaction, (class, score) ordering, class-segmented weighted NMS (one scan workgroup per class), per-class top-k by
+ * merged score, final compaction in the reference's output order (math/ops/nms.py:64-123, 181-266: sweeps in order, classes
+ * ascending, merged score descending).  scores (B,K) f32, cats (B,K) i64 in [0, n_classes), cuboids (B,K,7) f32
+ * [x,y,z,l,w,h,yaw]; `cap` = candidate capacity per sweep (multiple of 64, <= 32768; workspace:
+ * rv_nms_sweeps_workspace_bytes).  Outputs (device): out_boxes (B,cap,7), out_scores (B,cap), out_cats (B,cap),
+ * out_counts (B,2) = {rows written, or -1 when the sweep had more than `cap` candidates; candidates >= min_confidence}.
+ * Asynchronous: the caller reads out_counts back once for the whole batch. */
+int64_t rv_nms_sweeps_workspace_bytes(int32_t B, int32_t cap);
+int rv_nms_sweeps(const float* scores, const int64_t* cats, const float* cuboids, int32_t B, int64_t K, int32_t n_classes,
+                  float min_confidence, float nms_thresh, float merge_thresh, int32_t num_post_nms, int32_t cap,
+                  float* out_boxes, float* out_scores, int32_t* out_cats, int32_t* out_counts, void* workspace, rvStream stream);
 int rv_rotated_iou(const float* a, int64_t n, const float* b, int64_t m, float* out, rvStream stream);
 
 /* ---------------------------------------------------------------------------------------

@@ -1,0 +1,384 @@
+// nms2.hip -- the whole post-decode path of a batch of sweeps on device, without a host round trip in the middle:
+// confidence filter + compaction, segmented (class, score) sort, class-segmented weighted NMS, per-class top-k, final
+// compaction.  Replaces, for the common case, the reference's per-sweep / per-class Python loop
+// (math/ops/nms.py:64-123, 181-266: boolean masks, `unique`, `topk`, one `wnms_gpu` call and one device->host copy per
+// class) and round 1's one-launch-per-sweep variant (ATen sorts + a serial scan over ALL boxes + a host sync per sweep).
+//
+// Stages (one launch each for the WHOLE batch; every kernel reads its sweep's candidate count from device memory):
+//   1. compact     candidates with score >= min_confidence -> slot list (wave ballot + one atomic per wave);
+//   2. rank        position of every candidate in (class ascending, score descending, candidate index ascending) order by
+//                  COUNTING (rank = number of candidates with a smaller key: n^2 comparisons through LDS tiles --
+//                  n is a few thousand, the IoU stage is n^2 anyway) -- a sort without a sort library and without a sync;
+//   3. gather      boxes in that order as NMS rectangles [x1,y1,x2,y2,ry], merge rows [x,y,z,l,w,h,sin,cos,score];
+//                  class segment offsets;
+//   4. iou masks   rotated-BEV-IoU bit masks, only for 64x64 blocks whose class ranges meet (classes are contiguous now);
+//   5. scan        the sequential suppression scan -- ONE WORKGROUP PER CLASS (classes do not interact), each over its
+//                  own segment: the serial chain is the boxes of one class, not of the sweep;
+//   6. keep        prefix-sum compaction of the kept flags;
+//   7. merge       one wave per kept box (cluster = merge candidates still alive when the box was visited);
+//   8. post        per class: rank by merged score (counting again), drop ranks >= num_post_nms, write the rows in the
+//                  reference's output order (classes ascending, merged score descending) and the final count.
+// Results are the rows of the per-class loop, bit for bit (same IoU arithmetic, same merge summation order: within a class
+// the score order is the same as in a sweep-wide score order).  The host reads back ONE small array (counts of all
+// sweeps) at the end.  Candidate capacity per sweep (`cap`) bounds the workspace (two n x n/64 bit masks); a sweep with more
+// candidates reports it through the counts and the caller takes the reference-shaped loop for it.
+#include "common.h"
+#include "nms_geom.h"
+
+namespace {
+
+constexpr int kMaxClasses = 64;
+
+struct SweepPtrs {  // workspace layout of one sweep (all device pointers)
+    int32_t* n;           // [2]: candidates >= min_conf (may exceed cap), kept boxes
+    int32_t* cand;        // [cap] slot list (indices into the K candidates)
+    int32_t* order;       // [cap] sorted position -> slot-list position
+    int32_t* cats;        // [cap] class of the sorted boxes
+    int32_t* seg;         // [kMaxClasses + 1] class segment offsets
+    float* rect;          // [cap][5]
+    float* data;          // [cap][9]
+    float* sc;            // [cap][2] fp32(sin(ry)), fp32(cos(ry)) for the IoU
+    unsigned long long* nms_mask;    // [cap][cb]
+    unsigned long long* merge_mask;  // [cap][cb]
+    uint8_t* kept;        // [cap]
+    int32_t* keep;        // [cap] kept boxes, ascending sorted position
+    float* merged;        // [cap][9]
+};
+
+struct Args {
+    const float* scores;    // [B][K]
+    const int64_t* cats;    // [B][K]
+    const float* cuboids;   // [B][K][7]
+    uint8_t* ws;
+    int64_t ws_stride;      // bytes per sweep
+    int64_t K;
+    int32_t B, cap, cb, n_classes, num_post;
+    float min_conf, nms_t, merge_t;
+    float* out_boxes;       // [B][cap][7]
+    float* out_scores;      // [B][cap]
+    int32_t* out_cats;      // [B][cap]
+    int32_t* out_counts;    // [B][2]: final rows, candidates >= min_conf
+};
+
+__host__ __device__ inline int64_t al256(int64_t v) { return (v + 255) & ~255ll; }
+
+__host__ __device__ inline SweepPtrs carve(uint8_t* base, int cap, int cb) {
+    SweepPtrs p;
+    int64_t o = 0;
+    p.n = (int32_t*)(base + o); o += 256;
+    p.cand = (int32_t*)(base + o); o += al256((int64_t)cap * 4);
+    p.order = (int32_t*)(base + o); o += al256((int64_t)cap * 4);
+    p.cats = (int32_t*)(base + o); o += al256((int64_t)cap * 4);
+    p.seg = (int32_t*)(base + o); o += al256((kMaxClasses + 1) * 4);
+    p.rect = (float*)(base + o); o += al256((int64_t)cap * 5 * 4);
+    p.data = (float*)(base + o); o += al256((int64_t)cap * 9 * 4);
+    p.sc = (float*)(base + o); o += al256((int64_t)cap * 2 * 4);
+    p.nms_mask = (unsigned long long*)(base + o); o += al256((int64_t)cap * cb * 8);
+    p.merge_mask = (unsigned long long*)(base + o); o += al256((int64_t)cap * cb * 8);
+    p.kept = (uint8_t*)(base + o); o += al256(cap);
+    p.keep = (int32_t*)(base + o); o += al256((int64_t)cap * 4);
+    p.merged = (float*)(base + o); o += al256((int64_t)cap * 9 * 4);
+    return p;
+}
+inline int64_t sweep_bytes(int cap, int cb) {
+    return 256 + 4 * al256((int64_t)cap * 4) + al256((kMaxClasses + 1) * 4) + al256((int64_t)cap * 20) + 2 * al256((int64_t)cap * 36) +
+           al256((int64_t)cap * 8) + 2 * al256((int64_t)cap * cb * 8) + al256(cap);
+}
+
+__device__ __forceinline__ SweepPtrs sweep(const Args& a, int b) { return carve(a.ws + (int64_t)b * a.ws_stride, a.cap, a.cb); }
+__device__ __forceinline__ int n_of(const SweepPtrs& p, int cap) { const int n = p.n[0]; return n < cap ? n : cap; }
+
+__global__ void k_zero(const Args a) {
+    const SweepPtrs p = sweep(a, blockIdx.x);
+    if (threadIdx.x < 2) p.n[threadIdx.x] = 0;
+}
+
+// 1. compaction: blockIdx.y = sweep
+__global__ __launch_bounds__(256) void k_compact(const Args a) {
+    const int b = blockIdx.y;
+    const SweepPtrs p = sweep(a, b);
+    const float* s = a.scores + (int64_t)b * a.K;
+    const int lane = threadIdx.x & 63;
+    for (int64_t base = (int64_t)blockIdx.x * 256; base < a.K; base += (int64_t)gridDim.x * 256) {
+        const int64_t i = base + threadIdx.x;
+        const bool pick = i < a.K && s[i] >= a.min_conf;
+        const unsigned long long m = __ballot(pick);
+        int pos0 = 0;
+        if (lane == 0 && m) pos0 = atomicAdd(p.n, __popcll(m));
+        pos0 = __shfl(pos0, 0, 64);
+        if (pick) {
+            const int pos = pos0 + __popcll(m & ((1ull << lane) - 1ull));
+            if (pos < a.cap) p.cand[pos] = (int32_t)i;
+        }
+    }
+}
+
+// 2. rank by counting.  key(i) < key(j)  <=>  (cat_i, -score_i, slot_i) lexicographically smaller
+__global__ __launch_bounds__(256) void k_rank(const Args a) {
+    const int b = blockIdx.y;
+    const SweepPtrs p = sweep(a, b);
+    const int n = n_of(p, a.cap);
+    if ((int)(blockIdx.x * 256) >= n) return;
+    const float* s = a.scores + (int64_t)b * a.K;
+    const int64_t* c = a.cats + (int64_t)b * a.K;
+    __shared__ float ts[256];
+    __shared__ int32_t tc[256], ti[256];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float si = 0.f;
+    int ci = 0, ii = 0;
+    if (i < n) {
+        ii = p.cand[i];
+        si = s[ii];
+        ci = (int)c[ii];
+    }
+    int rank = 0;
+    for (int j0 = 0; j0 < n; j0 += 256) {
+        const int j = j0 + threadIdx.x;
+        if (j < n) {
+            const int jj = p.cand[j];
+            ts[threadIdx.x] = s[jj];
+            tc[threadIdx.x] = (int)c[jj];
+            ti[threadIdx.x] = jj;
+        }
+        __syncthreads();
+        const int m = n - j0 < 256 ? n - j0 : 256;
+        for (int k = 0; k < m; ++k) {
+            const int cj = tc[k];
+            const float sj = ts[k];
+            rank += (cj < ci) || (cj == ci && (sj > si || (sj == si && ti[k] < ii)));
+        }
+        __syncthreads();
+    }
+    if (i < n) p.order[rank] = i;
+}
+
+// 3. gather in sorted order + class segments
+__global__ __launch_bounds__(256) void k_gather(const Args a) {
+    const int b = blockIdx.y;
+    const SweepPtrs p = sweep(a, b);
+    const int n = n_of(p, a.cap);
+    const float* s = a.scores + (int64_t)b * a.K;
+    const int64_t* c = a.cats + (int64_t)b * a.K;
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r < n) {
+        const int64_t src = p.cand[p.order[r]];
+        const float* q = a.cuboids + ((int64_t)b * a.K + src) * 7;
+        const float x = q[0], y = q[1], l = q[3], w = q[4], yaw = q[6];
+        const float hl = l / 2, hw = w / 2;
+        float* rc = p.rect + (int64_t)r * 5;
+        rc[0] = x - hl; rc[1] = y - hw; rc[2] = x + hl; rc[3] = y + hw; rc[4] = yaw;
+        float* d = p.data + (int64_t)r * 9;
+        d[0] = x; d[1] = y; d[2] = q[2]; d[3] = l; d[4] = w; d[5] = q[5];
+        d[6] = sinf(yaw); d[7] = cosf(yaw); d[8] = s[src];
+        p.sc[2 * r] = (float)sin((double)yaw);
+        p.sc[2 * r + 1] = (float)cos((double)yaw);
+        p.cats[r] = (int32_t)c[src];
+        p.kept[r] = 0;
+    }
+    if (blockIdx.x == 0 && threadIdx.x <= kMaxClasses) {  // seg[c] = number of candidates with class < c
+        int cnt = 0;
+        for (int j = 0; j < n; ++j) cnt += (int)c[p.cand[j]] < (int)threadIdx.x;
+        p.seg[threadIdx.x] = cnt;
+    }
+}
+
+// 4. IoU bit masks: grid (col block, row block, sweep); upper triangle, blocks whose class ranges meet
+__global__ __launch_bounds__(64) void k_iou(const Args a) {
+    const int col = blockIdx.x, row = blockIdx.y;
+    if (col < row) return;
+    const SweepPtrs p = sweep(a, blockIdx.z);
+    const int n = n_of(p, a.cap);
+    const int64_t j0 = (int64_t)col * 64, i0 = (int64_t)row * 64;
+    if (j0 >= n || i0 >= n) return;
+    const int row_last = (int)(i0 + 63 < n ? i0 + 63 : n - 1);
+    if (p.cats[row_last] < p.cats[j0]) return;  // sorted by class: every box of the column block is of a later class
+    __shared__ float cbox[64][7];
+    __shared__ int32_t ccat[64];
+    const int t = threadIdx.x;
+    if (j0 + t < n) {
+        ccat[t] = p.cats[j0 + t];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) cbox[t][k] = p.rect[(j0 + t) * 5 + k];
+        cbox[t][5] = p.sc[2 * (j0 + t)];
+        cbox[t][6] = p.sc[2 * (j0 + t) + 1];
+    }
+    __syncthreads();
+    const int64_t i = i0 + t;
+    if (i >= n) return;
+    float bx[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) bx[k] = p.rect[i * 5 + k];
+    const float sa = p.sc[2 * i], ca = p.sc[2 * i + 1];
+    const int32_t cat_i = p.cats[i];
+    unsigned long long bits_n = 0ull, bits_m = 0ull;
+    const int jn = (int)((n - j0) < 64 ? (n - j0) : 64);
+    for (int j = 0; j < jn; ++j) {
+        if (j0 + j <= i || ccat[j] != cat_i) continue;
+        const float iou = rotated_iou(bx, sa, ca, cbox[j], cbox[j][5], cbox[j][6]);
+        if (iou > a.nms_t) bits_n |= 1ull << j;
+        if (iou > a.merge_t) bits_m |= 1ull << j;
+    }
+    p.nms_mask[i * a.cb + col] = bits_n;
+    p.merge_mask[i * a.cb + col] = bits_m;
+}
+
+// 5. suppression scan: grid (class, sweep).  Words of the masks outside [first, last] word of the segment are never read
+// (k_iou may not have written them).
+__global__ __launch_bounds__(256) void k_scan(const Args a) {
+    const SweepPtrs p = sweep(a, blockIdx.y);
+    const int s0 = p.seg[blockIdx.x], s1 = p.seg[blockIdx.x + 1];
+    if (s0 >= s1) return;
+    extern __shared__ unsigned long long remv[];  // words w0 .. w1
+    const int w0 = s0 >> 6, w1 = (s1 - 1) >> 6;
+    for (int w = threadIdx.x; w <= w1 - w0; w += blockDim.x) remv[w] = 0ull;
+    __syncthreads();
+    for (int i = s0; i < s1; ++i) {
+        const int wi = i >> 6;
+        if (remv[wi - w0] & (1ull << (i & 63))) continue;  // uniform: every thread reads the same word
+        if (threadIdx.x == 0) p.kept[i] = 1;
+        __syncthreads();  // all threads have evaluated the branch on the old remv
+        for (int w = wi + threadIdx.x; w <= w1; w += blockDim.x) {
+            // a word at the segment's edge may hold bits of the neighbouring class: k_iou never sets those (class check)
+            const unsigned long long alive = ~remv[w - w0];
+            p.merge_mask[(int64_t)i * a.cb + w] &= alive;  // cluster = merge candidates not suppressed before i was visited
+            remv[w - w0] |= p.nms_mask[(int64_t)i * a.cb + w];
+        }
+        __syncthreads();
+    }
+}
+
+// 6. compaction of the kept flags (ascending position): one workgroup per sweep
+__global__ __launch_bounds__(1024) void k_keep(const Args a) {
+    const SweepPtrs p = sweep(a, blockIdx.x);
+    const int n = n_of(p, a.cap);
+    __shared__ int part[1024];
+    const int per = (n + 1023) / 1024;
+    const int i0 = threadIdx.x * per, i1 = i0 + per < n ? i0 + per : n;
+    int cnt = 0;
+    for (int i = i0; i < i1; ++i) cnt += p.kept[i];
+    part[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {  // inclusive scan
+        const int v = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int pos = part[threadIdx.x] - cnt;
+    for (int i = i0; i < i1; ++i)
+        if (p.kept[i]) p.keep[pos++] = i;
+    if (threadIdx.x == 1023) p.n[1] = part[1023];
+}
+
+// 7. cluster merge: one wave per kept box; lane = data column; members in ascending position (fixed summation order)
+__global__ __launch_bounds__(64) void k_merge(const Args a) {
+    const SweepPtrs p = sweep(a, blockIdx.y);
+    const int o = blockIdx.x;
+    if (o >= p.n[1]) return;
+    const int i = p.keep[o];
+    const int w1 = (p.seg[p.cats[i] + 1] - 1) >> 6;  // last mask word of the box's class segment
+    const int c = threadIdx.x;
+    const bool active = c < 9;
+    const float wi = p.data[(int64_t)i * 9 + 8];
+    float acc = active ? wi * p.data[(int64_t)i * 9 + c] : 0.f;
+    float wsum = wi;
+    for (int w = i >> 6; w <= w1; ++w) {
+        unsigned long long bits = p.merge_mask[(int64_t)i * a.cb + w];
+        while (bits) {
+            const int bb = __ffsll((long long)bits) - 1;
+            bits &= bits - 1;
+            const int64_t j = (int64_t)w * 64 + bb;
+            const float wj = p.data[j * 9 + 8];
+            if (active) acc += wj * p.data[j * 9 + c];
+            wsum += wj;
+        }
+    }
+    if (active) p.merged[(int64_t)o * 9 + c] = acc / wsum;
+}
+
+// 8. per-class top-k by merged score and the final order: grid (blocks over kept boxes, sweep)
+__global__ __launch_bounds__(256) void k_post(const Args a) {
+    const int b = blockIdx.y;
+    const SweepPtrs p = sweep(a, b);
+    const int k = p.n[1];
+    __shared__ int cls_cnt[kMaxClasses], cls_base[kMaxClasses + 1];
+    if (threadIdx.x < kMaxClasses) cls_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (int j = threadIdx.x; j < k; j += 256) atomicAdd(&cls_cnt[p.cats[p.keep[j]]], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int c = 0; c < kMaxClasses; ++c) {
+            cls_base[c] = acc;
+            acc += cls_cnt[c] < a.num_post ? cls_cnt[c] : a.num_post;
+        }
+        cls_base[kMaxClasses] = acc;
+        if (blockIdx.x == 0) {
+            a.out_counts[2 * b] = p.n[0] > a.cap ? -1 : acc;  // -1: more candidates than the capacity -- nothing usable was written
+            a.out_counts[2 * b + 1] = p.n[0];
+        }
+    }
+    __syncthreads();
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= k) return;
+    const int co = p.cats[p.keep[o]];
+    const float so = p.merged[(int64_t)o * 9 + 8];
+    int rank = 0;  // within the class: merged score descending, kept order ascending on ties
+    for (int j = 0; j < k; ++j) {
+        if (p.cats[p.keep[j]] != co) continue;
+        const float sj = p.merged[(int64_t)j * 9 + 8];
+        rank += sj > so || (sj == so && j < o);
+    }
+    if (rank >= a.num_post) return;
+    const int pos = cls_base[co] + rank;
+    const float* m = p.merged + (int64_t)o * 9;
+    float* ob = a.out_boxes + ((int64_t)b * a.cap + pos) * 7;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) ob[q] = m[q];
+    ob[6] = atan2f(m[6], m[7]);
+    a.out_scores[(int64_t)b * a.cap + pos] = so;
+    a.out_cats[(int64_t)b * a.cap + pos] = co;
+}
+
+}  // namespace
+
+extern "C" int64_t rv_nms_sweeps_workspace_bytes(int32_t B, int32_t cap) {
+    if (B <= 0 || cap <= 0) return 0;
+    return (int64_t)B * sweep_bytes(cap, (cap + 63) / 64);
+}
+
+extern "C" int rv_nms_sweeps(const float* scores, const int64_t* cats, const float* cuboids, int32_t B, int64_t K, int32_t n_classes,
+                             float min_confidence, float nms_thresh, float merge_thresh, int32_t num_post_nms, int32_t cap,
+                             float* out_boxes, float* out_scores, int32_t* out_cats, int32_t* out_counts, void* workspace,
+                             rvStream stream) {
+    RV_REQUIRE(scores && cats && cuboids && out_boxes && out_scores && out_cats && out_counts && workspace, "rv_nms_sweeps: null argument");
+    RV_REQUIRE(B > 0 && K > 0 && cap >= 64 && cap % 64 == 0 && cap <= 32768, "rv_nms_sweeps: bad sizes (cap: multiple of 64, <= 32768)");
+    RV_REQUIRE(n_classes >= 1 && n_classes <= kMaxClasses, "rv_nms_sweeps: 1..%d classes", kMaxClasses);
+    RV_REQUIRE(num_post_nms >= 1, "rv_nms_sweeps: num_post_nms must be positive");
+    Args a;
+    a.scores = scores; a.cats = cats; a.cuboids = cuboids;
+    a.ws = (uint8_t*)workspace;
+    a.cb = (cap + 63) / 64;
+    a.ws_stride = sweep_bytes(cap, a.cb);
+    a.K = K; a.B = B; a.cap = cap; a.n_classes = n_classes; a.num_post = num_post_nms;
+    a.min_conf = min_confidence; a.nms_t = nms_thresh; a.merge_t = merge_thresh;
+    a.out_boxes = out_boxes; a.out_scores = out_scores; a.out_cats = out_cats; a.out_counts = out_counts;
+    hipStream_t st = (hipStream_t)stream;
+    const int cblocks = (int)((K + 255) / 256 < 256 ? (K + 255) / 256 : 256);
+    hipLaunchKernelGGL(k_zero, dim3(B), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_compact, dim3(cblocks, B), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_rank, dim3((cap + 255) / 256, B), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_gather, dim3((cap + 255) / 256, B), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_iou, dim3(a.cb, a.cb, B), dim3(64), 0, st, a);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)k_scan, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL(k_scan, dim3(n_classes, B), dim3(256), (size_t)(a.cb + 1) * 8, st, a);
+    hipLaunchKernelGGL(k_keep, dim3(B), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(k_merge, dim3(cap, B), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_post, dim3((cap + 255) / 256, B), dim3(256), 0, st, a);
+    RV_CHECK_LAUNCH("rv_nms_sweeps kernels");
+    return 0;
+}

@@ -9,6 +9,7 @@ the semantics implemented are declared in ``DESIGN.md`` / ``oracle/nms.py`` -- p
 from __future__ import annotations
 
 import ctypes
+import math
 from typing import List, Tuple
 
 import torch
@@ -36,54 +37,46 @@ def weighted_nms(boxes: Tensor, data2merge: Tensor, scores: Tensor, nms_threshol
     return order[keep[:k]].contiguous(), output[:k], count[:k]
 
 
-# All classes of a sweep in ONE weighted-NMS launch (``rv_wnms_classes``) when the sweep has at most this many candidates
-# (the pair masks take n^2 / 4 bytes); above it, or when a class could exceed ``num_pre_nms``, the per-class loop runs.
-FUSED_CLASSES_MAX = 32768
+# Device-resident path (``rv_nms_sweeps``, csrc/nms2.hip): all sweeps of a batch in one set of launches, one device->host
+# read at the end.  Candidate capacity per sweep: the pair masks take cap^2 / 4 bytes; a sweep with more candidates than
+# that (or a recipe whose ``num_pre_nms`` is below the capacity: the per-class pre-NMS cut would matter) takes the
+# reference-shaped per-class loop below.
+FUSED_CLASSES_MAX = 16384
 
 
-def _weighted_multiclass_nms_fused(cuboids_i: Tensor, scores_i: Tensor, categories_i: Tensor, iou_threshold: float,
-                                   num_post_nms: int) -> Tuple[Tensor, Tensor, Tensor]:
-    """Same rows as the per-class loop below (classes do not interact; the score order within a class is the same), without
-    its ``unique`` / boolean-mask / per-class host syncs: sort by score, one class-aware launch, then per-class top-k and
-    the loop's output order (classes ascending, merged score descending within a class) by two stable sorts."""
-    dev = cuboids_i.device
-    sorted_scores, order = scores_i.sort(0, descending=True)
-    b = cuboids_i[order].float()
-    cats = categories_i[order].to(torch.int32).contiguous()
-    half = b[:, 3:5] / 2
-    rect = torch.cat([b[:, :2] - half, b[:, :2] + half, b[:, 6:7]], dim=-1).contiguous()
-    data = torch.cat([b[:, :6], b[:, 6:7].sin(), b[:, 6:7].cos(), sorted_scores[:, None].float()], dim=1).contiguous()
-    n, d = data.shape
-    output = torch.zeros_like(data)
-    keep = torch.zeros(n, dtype=torch.long, device=dev)
-    count = torch.zeros(n, dtype=torch.long, device=dev)
-    ws = torch.empty(L.load().rv_wnms_workspace_bytes(L.i64(n)), dtype=torch.uint8, device=dev)
-    num_out = ctypes.c_int64(0)
-    L.call("rv_wnms_classes", L.ptr(rect), L.ptr(data), L.ptr(cats), L.i64(n), L.i32(d), L.f32(iou_threshold), L.f32(0.5), L.ptr(output),
-           L.ptr(keep), L.ptr(count), L.ptr(ws), ctypes.byref(num_out), L.stream_ptr())
-    k = int(num_out.value)
-    merged, kc = output[:k], cats[keep[:k]]
-    box6, sn, cs, sc = merged.split([6, 1, 1, 1], dim=1)
-    boxes = torch.cat([box6, torch.atan2(sn, cs)], dim=1)
-    sc = sc.flatten()
-    o1 = torch.sort(sc, descending=True, stable=True).indices       # merged score descending ...
-    o2 = torch.sort(kc[o1], stable=True).indices                    # ... then classes ascending, keeping that order
-    sel = o1[o2]
-    boxes, sc, kc = boxes[sel], sc[sel], kc[sel]
-    if k > num_post_nms:  # only then can a class hold more than num_post_nms rows: drop ranks >= num_post_nms within a class
-        idx = torch.arange(k, device=dev)
-        start = torch.where(torch.cat([torch.ones(1, dtype=torch.bool, device=dev), kc[1:] != kc[:-1]]), idx, torch.zeros_like(idx))
-        rank = idx - torch.cummax(start, 0).values
-        m = rank < num_post_nms
-        boxes, sc, kc = boxes[m], sc[m], kc[m]
-    return boxes, sc, kc.to(sc.dtype)
+def nms_sweeps(cuboids: Tensor, scores: Tensor, categories: Tensor, n_classes: int, iou_threshold: float, min_confidence: float,
+               num_post_nms: int, cap: int) -> Tuple[Tensor, Tensor, Tensor, List[int]]:
+    """(B,K,7), (B,K), (B,K) -> padded (B,cap,7) boxes, (B,cap) scores, (B,cap) int32 classes and the per-sweep row counts
+    (-1: the sweep had more than ``cap`` candidates -- its rows are not valid)."""
+    _require_cuda(cuboids, "cuboids")
+    dev = cuboids.device
+    B, K, _ = cuboids.shape
+    cub = cuboids.detach().float().contiguous()
+    sc = scores.detach().float().contiguous()
+    ct = categories.detach().to(torch.int64).contiguous()
+    ob = torch.empty((B, cap, 7), dtype=torch.float32, device=dev)
+    os_ = torch.empty((B, cap), dtype=torch.float32, device=dev)
+    oc = torch.empty((B, cap), dtype=torch.int32, device=dev)
+    counts = torch.empty((B, 2), dtype=torch.int32, device=dev)
+    ws = torch.empty(L.load().rv_nms_sweeps_workspace_bytes(L.i32(B), L.i32(cap)), dtype=torch.uint8, device=dev)
+    L.call("rv_nms_sweeps", L.ptr(sc), L.ptr(ct), L.ptr(cub), L.i32(B), L.i64(K), L.i32(n_classes), L.f32(min_confidence), L.f32(iou_threshold),
+           L.f32(0.5), L.i32(num_post_nms), L.i32(cap), L.ptr(ob), L.ptr(os_), L.ptr(oc), L.ptr(counts), L.ptr(ws), L.stream_ptr())
+    return ob, os_, oc, counts[:, 0].tolist()  # the one device->host read of the batch
+
+
+def _capacity(k: int) -> int:
+    return max(64, min(FUSED_CLASSES_MAX, (k + 63) // 64 * 64))
 
 
 def weighted_multiclass_nms(cuboids_i: Tensor, scores_i: Tensor, categories_i: Tensor, iou_threshold: float, num_pre_nms: int,
                             num_post_nms: int) -> Tuple[Tensor, Tensor, Tensor]:
     """Per class (ascending ``unique``): top-k pre, weighted NMS with merge threshold 0.5 (``nms.py:105-106``), top-k post."""
-    if 0 < scores_i.shape[0] <= min(FUSED_CLASSES_MAX, num_pre_nms):
-        return _weighted_multiclass_nms_fused(cuboids_i, scores_i, categories_i, iou_threshold, num_post_nms)
+    n = scores_i.shape[0]
+    if 0 < n <= min(FUSED_CLASSES_MAX, num_pre_nms) and FUSED_CLASSES_MAX > 0:
+        n_cls = int(categories_i.max().item()) + 1
+        if n_cls <= 64:
+            b, s, c, cnt = nms_sweeps(cuboids_i[None], scores_i[None], categories_i[None], n_cls, iou_threshold, -math.inf, num_post_nms, _capacity(n))
+            return b[0, : cnt[0]], s[0, : cnt[0]], c[0, : cnt[0]].to(s.dtype)
     out_b: List[Tensor] = []
     out_s: List[Tensor] = []
     out_c: List[Tensor] = []
@@ -107,13 +100,29 @@ def weighted_multiclass_nms(cuboids_i: Tensor, scores_i: Tensor, categories_i: T
 
 
 def batched_multiclass_nms(cuboids: Tensor, scores: Tensor, categories: Tensor, num_pre_nms: int, num_post_nms: int,
-                           iou_threshold: float, min_confidence: float, nms_mode: str) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+                           iou_threshold: float, min_confidence: float, nms_mode: str, n_classes: int = None) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
     """Per sweep: ``score >= min_confidence`` filter, then per-class NMS (``nms.py:181-266``)."""
     nms_mode = nms_mode.upper()
     if nms_mode != "WEIGHTED":
         raise NotImplementedError("NMS mode HARD (detectron2 nms_rotated) is not selected by the rv-* configs (conf/model/baseline.yaml:52)")
     bs, ss, cs, ids = [], [], [], []
-    for i in range(cuboids.shape[0]):
+    B, K = scores.shape
+    fast = None
+    cap = _capacity(K)
+    if FUSED_CLASSES_MAX > 0 and n_classes is not None and n_classes <= 64 and cap <= num_pre_nms:
+        # device-resident path for the whole batch; sweeps that overflow its capacity fall through to the loop below
+        fast = nms_sweeps(cuboids, scores, categories, n_classes, iou_threshold, min_confidence, num_post_nms, cap)
+    for i in range(B):
+        if fast is not None and fast[3][i] >= 0:
+            k = fast[3][i]
+            if k == 0:
+                continue
+            b, s, c = fast[0][i, :k], fast[1][i, :k], fast[2][i, :k].to(scores.dtype)
+            bs.append(b)
+            ss.append(s)
+            cs.append(c)
+            ids.append(torch.full_like(s, fill_value=float(i)))
+            continue
         m = scores[i] >= min_confidence
         if not bool(m.any()):
             continue

@@ -77,7 +77,7 @@ class RangeDecoder:
                 params, scores, cats,
                 num_pre_nms=post_processing_config["num_pre_nms"], num_post_nms=post_processing_config["num_post_nms"],
                 iou_threshold=post_processing_config["nms_threshold"], min_confidence=post_processing_config["min_confidence"],
-                nms_mode=post_processing_config["nms_mode"],
+                nms_mode=post_processing_config["nms_mode"], n_classes=sum(len(g) for g in task_config.values()),
             )
         else:
             B, N, _ = params.shape
