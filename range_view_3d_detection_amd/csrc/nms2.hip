@@ -175,23 +175,24 @@ __global__ __launch_bounds__(256) void k_gather(const Args a) {
         p.cats[r] = (int32_t)c[src];
         p.kept[r] = 0;
     }
-    if (blockIdx.x == 0 && threadIdx.x <= kMaxClasses) {  // seg[c] = number of candidates with class < c
-        int cnt = 0;
-        for (int j = 0; j < n; ++j) cnt += (int)c[p.cand[j]] < (int)threadIdx.x;
-        p.seg[threadIdx.x] = cnt;
-    }
 }
 
-// 4. IoU bit masks: grid (col block, row block, sweep); upper triangle, blocks whose class ranges meet
-__global__ __launch_bounds__(64) void k_iou(const Args a) {
-    const int col = blockIdx.x, row = blockIdx.y;
-    if (col < row) return;
-    const SweepPtrs p = sweep(a, blockIdx.z);
+// class segment offsets: seg[c] = first sorted position with class >= c (binary search; one thread per class)
+__global__ void k_seg(const Args a) {
+    const SweepPtrs p = sweep(a, blockIdx.x);
     const int n = n_of(p, a.cap);
+    const int c = threadIdx.x;
+    if (c > kMaxClasses) return;
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (p.cats[mid] < c) lo = mid + 1; else hi = mid;
+    }
+    p.seg[c] = lo;
+}
+
+__device__ void k_iou_block(const Args& a, const SweepPtrs& p, int n, int row, int col) {
     const int64_t j0 = (int64_t)col * 64, i0 = (int64_t)row * 64;
-    if (j0 >= n || i0 >= n) return;
-    const int row_last = (int)(i0 + 63 < n ? i0 + 63 : n - 1);
-    if (p.cats[row_last] < p.cats[j0]) return;  // sorted by class: every box of the column block is of a later class
     __shared__ float cbox[64][7];
     __shared__ int32_t ccat[64];
     const int t = threadIdx.x;
@@ -204,44 +205,100 @@ __global__ __launch_bounds__(64) void k_iou(const Args a) {
     }
     __syncthreads();
     const int64_t i = i0 + t;
-    if (i >= n) return;
+    if (i >= n) { __syncthreads(); return; }
     float bx[5];
 #pragma unroll
     for (int k = 0; k < 5; ++k) bx[k] = p.rect[i * 5 + k];
     const float sa = p.sc[2 * i], ca = p.sc[2 * i + 1];
     const int32_t cat_i = p.cats[i];
+    // bounding circle of box i: boxes whose circles are apart cannot intersect -- their IoU is 0 in the clipping arithmetic
+    // too, so skipping them changes no bit of the masks (thresholds are positive) and skips ~all pairs of a spread-out scene
+    const float cxi = 0.5f * (bx[0] + bx[2]), cyi = 0.5f * (bx[1] + bx[3]);
+    const float ri = 0.5f * sqrtf((bx[2] - bx[0]) * (bx[2] - bx[0]) + (bx[3] - bx[1]) * (bx[3] - bx[1]));
     unsigned long long bits_n = 0ull, bits_m = 0ull;
     const int jn = (int)((n - j0) < 64 ? (n - j0) : 64);
     for (int j = 0; j < jn; ++j) {
         if (j0 + j <= i || ccat[j] != cat_i) continue;
+        const float dx = 0.5f * (cbox[j][0] + cbox[j][2]) - cxi, dy = 0.5f * (cbox[j][1] + cbox[j][3]) - cyi;
+        const float rj = 0.5f * sqrtf((cbox[j][2] - cbox[j][0]) * (cbox[j][2] - cbox[j][0]) + (cbox[j][3] - cbox[j][1]) * (cbox[j][3] - cbox[j][1]));
+        if (dx * dx + dy * dy > (ri + rj) * (ri + rj) * 1.001f + 1e-4f) continue;
         const float iou = rotated_iou(bx, sa, ca, cbox[j], cbox[j][5], cbox[j][6]);
         if (iou > a.nms_t) bits_n |= 1ull << j;
         if (iou > a.merge_t) bits_m |= 1ull << j;
     }
     p.nms_mask[i * a.cb + col] = bits_n;
     p.merge_mask[i * a.cb + col] = bits_m;
+    __syncthreads();  // (the LDS tile is reused by the next column block)
+}
+
+
+// 4. IoU bit masks: grid (kIouCols column offsets, row block, sweep).  A row block only meets the column blocks from its own
+// up to the last block of the class of its last box (classes are contiguous); workgroup (dc, row) takes columns
+// row + dc, row + dc + kIouCols, ...
+constexpr int kIouCols = 16;
+__global__ __launch_bounds__(64) void k_iou(const Args a) {
+    const int row = blockIdx.y;
+    const SweepPtrs p = sweep(a, blockIdx.z);
+    const int n = n_of(p, a.cap);
+    const int64_t i0 = (int64_t)row * 64;
+    if (i0 >= n) return;
+    const int row_last = (int)(i0 + 63 < n ? i0 + 63 : n - 1);
+    const int col_last = (p.seg[p.cats[row_last] + 1] - 1) >> 6;
+    for (int col = row + blockIdx.x; col <= col_last; col += kIouCols) k_iou_block(a, p, n, row, col);
 }
 
 // 5. suppression scan: grid (class, sweep).  Words of the masks outside [first, last] word of the segment are never read
 // (k_iou may not have written them).
+// The scan walks the segment in blocks of 64 boxes (one mask word).  Inside a block the chain "is box b still alive?" is
+// resolved by ONE wave from the 64 diagonal words held one per lane (64 register-only steps); then every thread owning a later
+// word w folds the rows of the block's kept boxes into remv[w] (and masks their merge rows with the boxes alive at their
+// visit) -- one round of global loads per 64 boxes instead of one per kept box.
 __global__ __launch_bounds__(256) void k_scan(const Args a) {
     const SweepPtrs p = sweep(a, blockIdx.y);
     const int s0 = p.seg[blockIdx.x], s1 = p.seg[blockIdx.x + 1];
     if (s0 >= s1) return;
     extern __shared__ unsigned long long remv[];  // words w0 .. w1
+    __shared__ unsigned long long kept_word;
     const int w0 = s0 >> 6, w1 = (s1 - 1) >> 6;
     for (int w = threadIdx.x; w <= w1 - w0; w += blockDim.x) remv[w] = 0ull;
     __syncthreads();
-    for (int i = s0; i < s1; ++i) {
-        const int wi = i >> 6;
-        if (remv[wi - w0] & (1ull << (i & 63))) continue;  // uniform: every thread reads the same word
-        if (threadIdx.x == 0) p.kept[i] = 1;
-        __syncthreads();  // all threads have evaluated the branch on the old remv
-        for (int w = wi + threadIdx.x; w <= w1; w += blockDim.x) {
+    for (int wi = w0; wi <= w1; ++wi) {
+        if (threadIdx.x < 64) {
+            const int b = threadIdx.x;
+            const int i = wi * 64 + b;
+            const bool in_seg = i >= s0 && i < s1;
+            const unsigned long long diag = in_seg ? p.nms_mask[(int64_t)i * a.cb + wi] : 0ull;
+            const unsigned long long seg_bits = __ballot(in_seg);
+            const uint32_t dlo = (uint32_t)diag, dhi = (uint32_t)(diag >> 32);
+            unsigned long long rem = remv[wi - w0], kept = 0ull, alive_mine = 0ull;
+            for (int q = 0; q < 64; ++q) {  // uniform loop; lane q's diagonal word through readlane
+                if (!((seg_bits >> q) & 1ull) || ((rem >> q) & 1ull)) continue;
+                kept |= 1ull << q;
+                if (b == q) alive_mine = ~rem;
+                rem |= ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)dhi, q) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)dlo, q);
+            }
+            if ((kept >> b) & 1ull) {
+                p.kept[i] = 1;
+                p.merge_mask[(int64_t)i * a.cb + wi] &= alive_mine;  // cluster = merge candidates not suppressed before i was visited
+            }
+            if (b == 0) {
+                remv[wi - w0] = rem;
+                kept_word = kept;
+            }
+        }
+        __syncthreads();
+        const unsigned long long kept = kept_word;
+        for (int w = wi + 1 + threadIdx.x; w <= w1; w += blockDim.x) {
             // a word at the segment's edge may hold bits of the neighbouring class: k_iou never sets those (class check)
-            const unsigned long long alive = ~remv[w - w0];
-            p.merge_mask[(int64_t)i * a.cb + w] &= alive;  // cluster = merge candidates not suppressed before i was visited
-            remv[w - w0] |= p.nms_mask[(int64_t)i * a.cb + w];
+            unsigned long long r = remv[w - w0], bits = kept;
+            while (bits) {
+                const int q = __ffsll((long long)bits) - 1;
+                bits &= bits - 1;
+                const int64_t i = (int64_t)wi * 64 + q;
+                p.merge_mask[i * a.cb + w] &= ~r;
+                r |= p.nms_mask[i * a.cb + w];
+            }
+            remv[w - w0] = r;
         }
         __syncthreads();
     }
@@ -319,17 +376,26 @@ __global__ __launch_bounds__(256) void k_post(const Args a) {
         }
     }
     __syncthreads();
+    if ((int)(blockIdx.x * 256) >= k) return;
     const int o = blockIdx.x * 256 + threadIdx.x;
-    if (o >= k) return;
-    const int co = p.cats[p.keep[o]];
-    const float so = p.merged[(int64_t)o * 9 + 8];
+    const bool live = o < k;
+    const int co = live ? p.cats[p.keep[o]] : -1;
+    const float so = live ? p.merged[(int64_t)o * 9 + 8] : 0.f;
+    __shared__ float ts[256];
+    __shared__ int32_t tc[256];
     int rank = 0;  // within the class: merged score descending, kept order ascending on ties
-    for (int j = 0; j < k; ++j) {
-        if (p.cats[p.keep[j]] != co) continue;
-        const float sj = p.merged[(int64_t)j * 9 + 8];
-        rank += sj > so || (sj == so && j < o);
+    for (int j0 = 0; j0 < k; j0 += 256) {
+        const int j = j0 + threadIdx.x;
+        if (j < k) {
+            tc[threadIdx.x] = p.cats[p.keep[j]];
+            ts[threadIdx.x] = p.merged[(int64_t)j * 9 + 8];
+        }
+        __syncthreads();
+        const int m = k - j0 < 256 ? k - j0 : 256;
+        for (int q = 0; q < m; ++q) rank += tc[q] == co && (ts[q] > so || (ts[q] == so && j0 + q < o));
+        __syncthreads();
     }
-    if (rank >= a.num_post) return;
+    if (!live || rank >= a.num_post) return;
     const int pos = cls_base[co] + rank;
     const float* m = p.merged + (int64_t)o * 9;
     float* ob = a.out_boxes + ((int64_t)b * a.cap + pos) * 7;
@@ -369,7 +435,8 @@ extern "C" int rv_nms_sweeps(const float* scores, const int64_t* cats, const flo
     hipLaunchKernelGGL(k_compact, dim3(cblocks, B), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_rank, dim3((cap + 255) / 256, B), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_gather, dim3((cap + 255) / 256, B), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(k_iou, dim3(a.cb, a.cb, B), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_seg, dim3(B), dim3(128), 0, st, a);
+    hipLaunchKernelGGL(k_iou, dim3(kIouCols, a.cb, B), dim3(64), 0, st, a);
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)k_scan, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
