@@ -36,6 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+PMC_TRAFFIC = "profiles/r02_pmc_traffic.json"  # HBM bytes per launch per kernel, collected over this same command this round
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 (MI355X_MICROARCH.md: ~2.5 PF dense; 2:1-sparsity figures are not used)
 HBM_PEAK_GBS = 8000.0
 
@@ -112,11 +113,24 @@ class Detector(torch.nn.Module):
         return losses["loss"]
 
 
-def cpu_baseline(seconds_budget: float = 20.0):
-    """Oracle (``oracle/`` = CPU restatement of the reference, fp32 PyTorch-CPU) fwd+loss+bwd on a bounded sample.
+def _cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
 
-    The sample is one 64 x W crop of a synthetic sweep with the full rv-av2 widths; W is chosen from a short probe
-    so that the timed part stays within ~``seconds_budget`` on whatever host cores this box grants the process.
+
+def cpu_baseline(seconds_budget: float = 45.0, full: bool = False):
+    """Oracle (``oracle/`` = CPU restatement of the reference, fp32 PyTorch-CPU) fwd+loss+bwd, B=1, rv-av2 widths
+    (1 warm-up + 2 timed iterations, thread count and CPU stated).
+
+    ``full``: the whole 64 x 2048 x 5 sweep (minutes of CPU time: ``--cpu-baseline full``).  Default: the widest 64 x W crop
+    of the same sweep whose warm-up + two timed iterations fit ``seconds_budget`` on the cores this box grants, scaled to
+    sweeps/s by W / 2048 (the path is convolutional: cost is linear in W).
     """
     from oracle import model as om
     from oracle import targets as otgt
@@ -125,42 +139,49 @@ def cpu_baseline(seconds_budget: float = 20.0):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    threads = max(1, min(cores, 32))  # beyond ~32 threads PyTorch-CPU convs of this size stop scaling
-    torch.set_num_threads(threads)
     H, W_full = 64, 2048
     backbone, head = build_model("rv-av2", AV2_CLASSES)
     sd = {**{f"backbone.{k}": v for k, v in backbone.state_dict().items()}, **{f"head.{k}": v for k, v in head.state_dict().items()}}
     params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
-    full = {**sd, **params}
+    weights = {**sd, **params}
 
     def run(W: int) -> float:
         batch = synthetic_batch(1, H, W, seed=0, device="cpu", boxes_per_sweep=2)
         t0 = time.perf_counter()
-        feats, logits, reg = om.detector_forward(batch["features"], batch["cart"], full, nm=om.Numerics(train=True))
+        feats, logits, reg = om.detector_forward(batch["features"], batch["cart"], weights, nm=om.Numerics(train=True))
         tg = otgt.compute_targets(batch["cart"], batch["annotations"], AV2_CLASSES)
         otgt.detection_loss(logits, reg, batch["cart"], batch["mask"], tg, AV2_CLASSES)["loss"].backward()
+        for v in params.values():
+            v.grad = None
         return time.perf_counter() - t0
 
-    run(16)  # warm-up (allocator, thread pool), discarded
-    probe = run(16)
-    W = 16
-    while W < 256 and probe * (2 * W / 16) * 2 < seconds_budget:  # two timed iterations must fit the budget
-        W *= 2
-    times = [run(W)]
-    if sum(times) + times[0] < seconds_budget:
-        times.append(run(W))
+    # thread count: all granted cores, unless a short probe shows the PyTorch-CPU convolutions are faster on 32
+    probes = {}
+    for th in sorted({cores, min(cores, 32)}):
+        torch.set_num_threads(th)
+        run(32)  # warm-up (allocator, thread pool), discarded
+        probes[th] = run(32)
+    threads = min(probes, key=probes.get)
+    torch.set_num_threads(threads)
+    W = W_full
+    if not full:
+        W = 32
+        while W < W_full and probes[threads] * (2 * W / 32) * 3 < seconds_budget:  # warm-up + two timed iterations within the budget
+            W *= 2
+    run(W)  # warm-up at the timed size
+    times = [run(W), run(W)]
     dt = sum(times) / len(times)
     return {
         "value": (W / W_full) / dt, "unit": "sweeps/s", "cores": threads, "kind": "port",
-        "sample": f"oracle fwd+loss+bwd, rv-av2 widths, fp32, B=1, one 64x{W}x5 crop ({W}/{W_full} of a sweep), "
-                  f"{len(times)} timed iteration(s) of {dt:.1f} s on {threads} threads ({cores} cores visible)",
+        "sample": f"oracle fwd+loss+bwd, rv-av2 widths, fp32, B=1, 64x{W}x5 ({'the full sweep' if W == W_full else f'{W}/{W_full} of a sweep'}), "
+                  f"1 warm-up + 2 timed iterations of {times[0]:.1f} / {times[1]:.1f} s on {threads} threads ({cores} cores visible, {_cpu_model()})",
     }
 
 
 def roofline(prof, iso) -> dict:
     """Dominant kernel of the timed region against the dense bf16 MFMA peak; ``traffic`` = HBM bytes per launch of that
-    kernel from the committed PMC passes over this same command (profiles/r01_pmc_traffic.json, made by
-    profiles/pmc_traffic.py: FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate passes); ``isolated`` = the same kernel's
+    kernel from the committed PMC passes over this same command (``PMC_TRAFFIC``, made by profiles/pmc_traffic.py:
+    FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate passes; null when that file has no row for the kernel); ``isolated`` = the same kernel's
     launches timed with nothing else on the GPU (side stream off, outside the timed region)."""
     iso_sum = iso.summary()
     if not iso_sum:
@@ -172,13 +193,14 @@ def roofline(prof, iso) -> dict:
     d = iso_sum[name]
     r["isolated"] = {"achieved": d["tflops"], "frac": d["tflops"] / MFMA_BF16_PEAK_TFLOPS, "avg_launch_us": d["avg_us"]}
     try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")) as f:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), PMC_TRAFFIC)) as f:
             k = json.load(f)["kernels"].get(r["kernel"].replace("(+reduce)", ""))
         if k:
             r["traffic"] = k["hbm_bytes_per_launch"]
-            r["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 gfx950 correction)"
+            r["traffic_source"] = PMC_TRAFFIC + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 gfx950 correction)"
     except OSError:
         pass
+    r.setdefault("traffic", None)
     return r
 
 
@@ -194,6 +216,7 @@ def main() -> None:
     ap.add_argument("--features", type=int, default=5, help="input channels: 5 (AV2) or 6 (Waymo)")
     ap.add_argument("--classes", type=int, default=AV2_CLASSES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", choices=["sample", "full"], default="sample", help="full: time the whole 64x2048 sweep on the host (minutes)")
     ap.add_argument("--no-sync-bn", action="store_true")
     args = ap.parse_args()
 
@@ -292,7 +315,7 @@ def main() -> None:
             "kernels": prof.summary(),
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(full=args.cpu_baseline == "full")
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

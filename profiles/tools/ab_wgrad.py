@@ -26,7 +26,9 @@ def time(run, iters=10):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / iters * 1e3
 variants = sys.argv[1].split(',')
-for (cin, cout, W) in ((512, 512, 2048), (256, 256, 2048), (128, 128, 1024)):
+SH = ((512, 512, 2048), (256, 256, 2048), (128, 128, 1024))
+if len(sys.argv) > 2: SH = [SH[int(i)] for i in sys.argv[2].split(',')]
+for (cin, cout, W) in SH:
     run, packed = setup(cin, cout, 3, 4, 64, W)
     res = {v: [] for v in variants}; outs = {}
     for rnd in range(5):

@@ -16,6 +16,9 @@
 // summed by a second kernel in a fixed order (bitwise reproducible, no atomics).
 #include <stdlib.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "common.h"
 #include "tapconv.h"
 
@@ -409,18 +412,45 @@ __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const Wgrad2Args a) {
 
 // ------------------------------------------------------------------------------------------------------------------
 // wgrad3: wgrad2's tiling (128 cu x 128 cv x up to 3 taps of one kernel row, 64-pixel chunks, 8 waves) with the operands
-// streamed global -> LDS by LDS-DMA into a ring of FOUR chunk buffers: the chunk three iterations ahead is issued before
-// each compute step, the only waits are counted (s_waitcnt vmcnt(10): two chunks stay in flight across the barrier) and
-// there is one raw barrier per chunk.  Plain bf16 operands only (the DMA bypasses the registers, so no folded
-// BatchNorm on the way in) -- which is what the engine provides on the wide layers (engine.py, MATERIALIZE_FOR_DMA).
-// The 32-byte granule swizzle sigma() is applied to the per-lane SOURCE address (the DMA writes LDS lane-linearly).
+// streamed global -> LDS by LDS-DMA into a ring of FOUR chunk slots: the chunk three ahead is issued during each chunk, the
+// only memory waits are counted (two chunks stay in flight across the barrier) and there is one raw barrier per chunk.
+// Plain bf16 operands only (the DMA bypasses the registers, so no folded BatchNorm on the way in) -- which is what the
+// engine provides on the wide layers (engine.py, MATERIALIZE_FOR_DMA).  The 32-byte granule swizzle sigma() is applied to
+// the per-lane SOURCE address (the DMA writes LDS lane-linearly).
+// What the loop is built around (profiles/r02_wgrad_ablation.md): DMA issue, fragment reads and MFMAs of the first version
+// ADDED UP instead of overlapping -- ~120 address instructions per wave and chunk, all eight waves in the same phase.  Here
+// (a) no address arithmetic is left in the loop (incremental source pointers, immediate LDS offsets), (b) the fragments of
+// tap-step u+1 are requested before the MFMAs of tap-step u, (c) the two waves of a SIMD issue their DMA half a chunk apart.
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int kW3U = 64 * 256;        // bytes: 64 pixel rows x 128 channels
-constexpr int kW3V = 68 * 256;        // 66 halo rows (+2 so that the last DMA instruction is whole)
-constexpr int kW3Buf = kW3U + kW3V;   // 33 792
-constexpr int kW3Ring = 4;
 
 __device__ __attribute__((aligned(256))) uint32_t g_wgrad_zero_page[64];
+
+// LDS image of the ring: [group of 4 pixel rows][slot][4 rows x 256 B] -- a DMA instruction still writes 1 KiB contiguous
+// (4 rows of one slot), while the slot and the K-step enter every fragment read as an IMMEDIATE offset (slot * 1 KiB,
+// K-step * 32 KiB): the per-lane read addresses are loop-invariant registers and the main loop has no address arithmetic.
+constexpr int kW3VBase = 16 * 4096;            // U: 16 groups, V: 17 groups (rows 64..67 = the tap halo)
+constexpr int kW3Lds = kW3VBase + 17 * 4096;   // 135 168 B: one workgroup per CU
+
+template <int I>
+using w3_int = std::integral_constant<int, I>;
+template <class F, int... I>
+__device__ __forceinline__ void w3_for(F&& f, std::integer_sequence<int, I...>) {
+    (f(w3_int<I>{}), ...);
+}
+
+struct W3Frag {  // the two halves of an MFMA operand as the transposed reads deliver them; joined only at the use, after the wait
+    s16x4 lo, hi;
+};
+template <int OFF_LO, int OFF_HI>
+__device__ __forceinline__ void w3_read(W3Frag& f, uint32_t a_lo, uint32_t a_hi) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.lo) : "v"(a_lo), "i"(OFF_LO));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.hi) : "v"(a_hi), "i"(OFF_HI));
+}
+__device__ __forceinline__ bf16x8 w3_join(const W3Frag& f) {
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 both = __builtin_shufflevector(f.lo, f.hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, both);
+}
 
 template <int TG>
 __device__ __forceinline__ void wgrad3_body(const Wgrad2Args& a, uint8_t* smem) {
@@ -447,37 +477,64 @@ __device__ __forceinline__ void wgrad3_body(const Wgrad2Args& a, uint8_t* smem) 
     const int wchunks = (a.Wu + 63) / 64;  // the last chunk of an image row may be partial (W = 1808, 2656 ...): zero-filled
     const int c_begin = ks * a.chunks_per_split;
     const int c_end = (c_begin + a.chunks_per_split < a.chunks) ? c_begin + a.chunks_per_split : a.chunks;
+    if (c_begin >= c_end) return;  // (the plan never makes an empty slice; its slab would be left unwritten)
 
-    // DMA map: one wave-instruction = 4 pixel rows x 16 chunks of 16 bytes; wave w owns rows 8w .. 8w+7 of both tiles
+    // ---- operand stream.  One wave-instruction = 4 pixel rows x 16 chunks of 16 bytes; wave w owns rows 8w .. 8w+7 of both
+    // tiles, wave 0 also the halo rows 64..67.  Per lane five NOMINAL source pointers (valid or not) that advance by 64 pixels
+    // per chunk; a chunk that touches an image edge (first / last of a row, a row whose tap row is outside the image) takes the
+    // slow path, which recomputes them and swaps the out-of-image lanes' pointers for the zero page.
     const int d_row = lane >> 4, d_c16 = lane & 15;
     typedef const __attribute__((address_space(1))) void glb_t;
     typedef __attribute__((address_space(3))) void lds_t;
-    const bf16_t* zero = (const bf16_t*)g_wgrad_zero_page + (d_c16 & 7) * 8;
-    auto src_chunk = [&](int k) { return ((((d_c16 >> 1) ^ sigma(k)) << 1) | (d_c16 & 1)) * 8; };  // logical channel offset
-    auto issue = [&](int c) {
-        uint8_t* buf = smem + (c & (kW3Ring - 1)) * kW3Buf;
-        c = c < c_end ? c : c_end - 1;  // past the end: re-fetch the last chunk (never read; keeps the wait counts uniform)
-        const int row = c / wchunks, w0 = (c - row * wchunks) * 64;  // row = n*H + h
-        const int h = row % a.H;
-        const bf16_t* urow = a.U + ((int64_t)row * a.Wu + w0) * a.ld_u + u0;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int k = wave * 8 + j * 4 + d_row;
-            const bf16_t* pu = (w0 + k < a.Wu) ? urow + (int64_t)k * a.ld_u + src_chunk(k) : zero;
-            __builtin_amdgcn_global_load_lds((glb_t*)pu, (lds_t*)(buf + (wave * 8 + j * 4) * 256), 16, 0, 0);
+    const uint8_t* zero = (const uint8_t*)g_wgrad_zero_page + (d_c16 & 7) * 16;
+    const int sg = d_row | ((wave & 1) << 2);  // sigma(k) of this lane's rows 8w + 4j + d_row; rows 64.. : d_row
+    const int swz_own = ((((d_c16 >> 1) ^ sg) << 1) | (d_c16 & 1)) * 16, swz_halo = ((((d_c16 >> 1) ^ d_row) << 1) | (d_c16 & 1)) * 16;
+    const bool halo_wave = wave == 0;
+    const bool halo_lane = d_row < TG - 1;  // halo rows 64 .. 64 + TG - 2 exist
+    const int64_t step_u = (int64_t)64 * a.ld_u * 2, step_v = (int64_t)64 * a.ld_v * 2;
+    const uint8_t *pu0 = zero, *pu1 = zero, *pv0 = zero, *pv1 = zero, *pv2 = zero;
+    bool fresh = true;  // the pointers hold nothing yet
+    int cur = c_begin, cur_row = c_begin / wchunks, cur_w0 = (c_begin - cur_row * wchunks) * 64, cur_h = cur_row % a.H;
+    // (by-value helper: `c ? x : y` on two pointer LVALUES is itself an lvalue, which clang lowers to a select of stack addresses)
+    auto pick = [](bool c, const uint8_t* x, const uint8_t* y) -> const uint8_t* { return c ? x : y; };
+    auto dma = [&](const uint8_t* p, int lds_byte) { __builtin_amdgcn_global_load_lds((glb_t*)p, (lds_t*)(smem + lds_byte), 16, 0, 0); };
+    auto issue = [&](int slot) {  // the chunk at the cursor -> ring slot; then the cursor moves on
+        const int dst = slot * 1024 + wave * 8192;  // rows 8w.. = groups 2w, 2w+1
+        const int dst_halo = kW3VBase + 16 * 4096 + slot * 1024;
+        const uint8_t *su0 = zero, *su1 = zero, *sv0 = zero, *sv1 = zero, *sv2 = zero;  // what this chunk's instructions read
+        if (cur < c_end) {  // (past the slice: same instruction count -- the waits are counted -- from the zero page)
+            const int hv = cur_h + dh;
+            const bool row_ok = hv >= 0 && hv < a.H;
+            const bool slow = fresh || cur_w0 == 0 || cur_w0 + 64 + dw0 + TG - 1 > a.Wu || cur_w0 + 64 > a.Wu || cur_w0 + dw0 < 0 || !row_ok;
+            if (!slow) {
+                pu0 += step_u, pu1 += step_u, pv0 += step_v, pv1 += step_v, pv2 += step_v;
+                su0 = pu0, su1 = pu1, sv0 = pv0, sv1 = pv1, sv2 = pick(halo_lane, pv2, zero);
+            } else {
+                const uint8_t* urow = (const uint8_t*)(a.U + ((int64_t)cur_row * a.Wu + cur_w0) * a.ld_u + u0);
+                const uint8_t* vrow = (const uint8_t*)(a.V + ((int64_t)(cur_row + dh) * a.Wu + cur_w0 + dw0) * a.ld_v + v0);
+                const int k0 = wave * 8 + d_row, k1 = k0 + 4, wv = cur_w0 + dw0;
+                pu0 = urow + (int64_t)k0 * a.ld_u * 2 + swz_own;
+                pu1 = urow + (int64_t)k1 * a.ld_u * 2 + swz_own;
+                pv0 = vrow + (int64_t)k0 * a.ld_v * 2 + swz_own;
+                pv1 = vrow + (int64_t)k1 * a.ld_v * 2 + swz_own;
+                pv2 = vrow + (int64_t)(64 + d_row) * a.ld_v * 2 + swz_halo;
+                su0 = pick(cur_w0 + k0 < a.Wu, pu0, zero);
+                su1 = pick(cur_w0 + k1 < a.Wu, pu1, zero);
+                sv0 = pick(row_ok && wv + k0 >= 0 && wv + k0 < a.Wu, pv0, zero);
+                sv1 = pick(row_ok && wv + k1 >= 0 && wv + k1 < a.Wu, pv1, zero);
+                sv2 = pick(row_ok && halo_lane && wv + 64 + d_row < a.Wu, pv2, zero);
+            }
+            fresh = false;
+            ++cur;
+            cur_w0 += 64;
+            if (cur_w0 >= a.Wu) {
+                cur_w0 = 0;
+                ++cur_row;
+                cur_h = cur_h + 1 == a.H ? 0 : cur_h + 1;
+            }
         }
-        const int hv = h + dh;
-        const bool row_ok = hv >= 0 && hv < a.H;
-        const bf16_t* vrow = a.V + ((int64_t)(row + dh) * a.Wu) * a.ld_v + v0;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int k0 = (j < 2) ? wave * 8 + j * 4 : 64;  // the third instruction of every wave fetches halo rows 64..67
-            const int k = k0 + d_row;
-            const int wv = w0 + k + dw0;
-            const bool ok = row_ok && k < 64 + TG - 1 && wv >= 0 && wv < a.Wu;
-            const bf16_t* p = ok ? vrow + (int64_t)wv * a.ld_v + src_chunk(k) : zero;
-            __builtin_amdgcn_global_load_lds((glb_t*)p, (lds_t*)(buf + kW3U + k0 * 256), 16, 0, 0);
-        }
+        dma(su0, dst), dma(su1, dst + 4096), dma(sv0, kW3VBase + dst), dma(sv1, kW3VBase + dst + 4096);
+        if (halo_wave) dma(sv2, dst_halo);
     };
 
     f32x4 acc[TG][4][2];
@@ -488,69 +545,99 @@ __device__ __forceinline__ void wgrad3_body(const Wgrad2Args& a, uint8_t* smem) 
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // Transposed fragment reads as inline asm: hipcc (ROCm 7.2) puts an s_waitcnt vmcnt(0) in front of the
-    // ds_read_tr16_b64 BUILTIN whenever an LDS-DMA is in flight (it cannot tell the DMA's LDS destination from the read's
-    // source), which would drain the ring every chunk.  The price: the compiler does not see these reads, so their
-    // lgkmcnt waits are placed by hand (and pinned with sched_barrier, cdna_hip_programming.md rule 18).
+    // ---- fragment read addresses (transposed reads as inline asm: hipcc puts an s_waitcnt vmcnt(0) in front of the
+    // ds_read_tr BUILTIN whenever an LDS-DMA is in flight, which would drain the ring every chunk; the price is that the compiler
+    // does not see these reads, so their lgkmcnt waits are placed by hand and pinned with sched_barrier, rule 18).
+    // Row r of a tile sits at (r >> 2) * 4096 + slot * 1024 + (r & 3) * 256; a lane reads rows r = row0 + 8g + q and r + 4.
     const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
-    typedef __attribute__((ext_vector_type(8))) short s16x8;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
-    auto frag = [&](uint32_t tile_byte, int row0, int col0) -> bf16x8 {
-        // rows row0 + 8g + q (+4), columns col0 + 4p .. +3 (before the granule swizzle)
-        const int r_lo = row0 + 8 * g + q, r_hi = r_lo + 4, gran = col0 >> 4;
-        const uint32_t a_lo = tile_byte + (uint32_t)(r_lo * 128 + ((gran ^ sigma(r_lo)) << 4) + 4 * p) * 2u;
-        const uint32_t a_hi = tile_byte + (uint32_t)(r_hi * 128 + ((gran ^ sigma(r_hi)) << 4) + 4 * p) * 2u;
-        s16x4 lo, hi;
-        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a_lo));
-        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a_hi));
-        const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        return __builtin_bit_cast(bf16x8, both);
+    uint32_t bu[4], bv[TG][2][2];
+    auto row_byte = [](int r) { return (uint32_t)((r >> 2) * 4096 + (r & 3) * 256); };
+#pragma unroll
+    for (int i = 0; i < 4; ++i)  // U rows 8g + q (+4: the next group, same sigma -> immediate +4096)
+        bu[i] = lds0 + row_byte(8 * g + q) + (uint32_t)((((wm * 4 + i) ^ sigma(8 * g + q)) << 4) + 4 * p) * 2u;
+#pragma unroll
+    for (int t = 0; t < TG; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int hi = 0; hi < 2; ++hi) {
+                const int r = t + 8 * g + q + 4 * hi;  // tap t reads the V rows shifted by t pixels
+                bv[t][j][hi] = lds0 + kW3VBase + row_byte(r) + (uint32_t)((((wn * 2 + j) ^ sigma(r)) << 4) + 4 * p) * 2u;
+            }
+
+    W3Frag fa[2][4], fb[2][2];
+    // one UNIT = one tap of one 32-pixel K-step = 8 MFMAs; units of a chunk: u = kk * TG + t
+    auto read_unit = [&](auto S_, auto U_) {  // fragments of unit U of the chunk in slot S
+        constexpr int S = decltype(S_)::value, U = decltype(U_)::value, kk = U / TG, t = U % TG;
+        constexpr int off = kk * 8 * 4096 + S * 1024;
+        if constexpr (t == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w3_read<off, off + 4096>(fa[kk & 1][i], bu[i], bu[i]);
+        }
+        w3_read<off, off>(fb[U & 1][0], bv[t][0][0], bv[t][0][1]);
+        w3_read<off, off>(fb[U & 1][1], bv[t][1][0], bv[t][1][1]);
+    };
+    auto mfma_unit = [&](auto U_) {
+        constexpr int U = decltype(U_)::value, kk = U / TG, t = U % TG;
+        const bf16x8 b0 = w3_join(fb[U & 1][0]), b1 = w3_join(fb[U & 1][1]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bf16x8 ai = w3_join(fa[kk & 1][i]);
+            acc[t][i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ai, b0, acc[t][i][0], 0, 0, 0);
+            acc[t][i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ai, b1, acc[t][i][1], 0, 0, 0);
+        }
+    };
+    // The two halves of the workgroup (waves w and w + 4 share a SIMD) issue their DMA at different points of the chunk -- half A
+    // before its first unit, half B between the two K-steps -- so that one half's address / issue work runs under the other
+    // half's MFMAs; both meet at the one barrier per chunk.
+    const bool half_b = wave >= 4;
+    auto step = [&](auto S_) {  // chunk in slot S: its unit-0 fragments were requested before the barrier that opened it
+        constexpr int S = decltype(S_)::value, NU = 2 * TG;
+        if (!half_b) issue((S + 3) & 3);  // into the slot the chunk before this one was read from (closed by the last barrier)
+        w3_for([&](auto U_) {
+            constexpr int U = decltype(U_)::value;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // unit U's fragments are in registers
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (U + 1 < NU) {
+                read_unit(S_, w3_int<U + 1>{});  // lands under unit U's MFMAs
+            } else {
+                // every fragment of this chunk has been read by this wave and the next chunk's DMA has landed: close the chunk
+                if (halo_wave)
+                    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // chunks +2 and +3 stay in flight (5 instructions each)
+                else
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // (4 each)
+                __builtin_amdgcn_s_barrier();
+                read_unit(w3_int<(S + 1) & 3>{}, w3_int<0>{});
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_unit(U_);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (U == TG - 1)
+                if (half_b) issue((S + 3) & 3);
+        }, std::make_integer_sequence<int, NU>{});
     };
 
-    auto read_frags = [&](bf16x8 (&fa)[4], bf16x8 (&fb)[TG][2], uint32_t tu_, uint32_t tv_, int kk) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = frag(tu_, kk * 32, wm * 64 + i * 16);
-#pragma unroll
-        for (int t = 0; t < TG; ++t)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) fb[t][j] = frag(tv_, kk * 32 + t, wn * 32 + j * 16);
-    };
-    if (c_begin < c_end) {
-        issue(c_begin);
-        issue(c_begin + 1);
-        issue(c_begin + 2);
+    issue(0);
+    issue(1);
+    issue(2);
+    if (halo_wave)
         asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        for (int c = c_begin; c < c_end; ++c) {
-            issue(c + 3);  // into the buffer chunk c-1 was read from; the barrier that ended that iteration orders it
-            const uint32_t tu_ = lds0 + (uint32_t)((c & (kW3Ring - 1)) * kW3Buf), tv_ = tu_ + kW3U;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 fa[4], fb[TG][2];
-                read_frags(fa, fb, tu_, tv_, kk);
-#pragma unroll
-                for (int t = 0; t < TG; ++t) {
-                    // 8 + 4*TG reads were issued in order; tap t needs all but the last 4*(TG-1-t)
-                    if (TG - 1 - t == 2)
-                        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-                    else if (TG - 1 - t == 1)
-                        asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-                    else
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[t][j], acc[t][i][j], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // chunk c+1 landed; c+2 and c+3 stay in flight
-            __builtin_amdgcn_s_barrier();
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_unit(w3_int<0>{}, w3_int<0>{});
+    for (int c = c_begin;;) {
+        step(w3_int<0>{});
+        if (++c >= c_end) break;
+        step(w3_int<1>{});
+        if (++c >= c_end) break;
+        step(w3_int<2>{});
+        if (++c >= c_end) break;
+        step(w3_int<3>{});
+        if (++c >= c_end) break;
     }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #pragma unroll
     for (int t = 0; t < TG; ++t) {
         float* slab = a.slabs + ((int64_t)ks * a.taps + tap0 + t) * a.cu_pad * a.cv_pad;
@@ -712,7 +799,7 @@ extern "C" int rv_tap_wgrad(const rvTapGeom* g, const rvTapShape* s, const void*
                 (void)hipFuncSetAttribute((const void*)wgrad3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 attr_set = true;
             }
-            hipLaunchKernelGGL(wgrad3_kernel, dim3(grid2), dim3(512), kW3Ring * kW3Buf, st2, b);
+            hipLaunchKernelGGL(wgrad3_kernel, dim3(grid2), dim3(512), kW3Lds, st2, b);
             RV_CHECK_LAUNCH("wgrad3_kernel");
         } else {
             hipLaunchKernelGGL(wgrad2_kernel, dim3(grid2), dim3(512), 0, st2, b);
