@@ -498,10 +498,9 @@ __device__ __forceinline__ void wgrad3_body(const Wgrad2Args& a, uint8_t* smem) 
     // (by-value helper: `c ? x : y` on two pointer LVALUES is itself an lvalue, which clang lowers to a select of stack addresses)
     auto pick = [](bool c, const uint8_t* x, const uint8_t* y) -> const uint8_t* { return c ? x : y; };
     auto dma = [&](const uint8_t* p, int lds_byte) { __builtin_amdgcn_global_load_lds((glb_t*)p, (lds_t*)(smem + lds_byte), 16, 0, 0); };
-    auto issue = [&](int slot) {  // the chunk at the cursor -> ring slot; then the cursor moves on
-        const int dst = slot * 1024 + wave * 8192;  // rows 8w.. = groups 2w, 2w+1
-        const int dst_halo = kW3VBase + 16 * 4096 + slot * 1024;
-        const uint8_t *su0 = zero, *su1 = zero, *sv0 = zero, *sv1 = zero, *sv2 = zero;  // what this chunk's instructions read
+    const uint8_t *su0 = zero, *su1 = zero, *sv0 = zero, *sv1 = zero, *sv2 = zero;  // what the next chunk's instructions read
+    auto prepare = [&]() {  // sources of the chunk at the cursor; then the cursor moves on
+        su0 = zero, su1 = zero, sv0 = zero, sv1 = zero, sv2 = zero;
         if (cur < c_end) {  // (past the slice: same instruction count -- the waits are counted -- from the zero page)
             const int hv = cur_h + dh;
             const bool row_ok = hv >= 0 && hv < a.H;
@@ -533,8 +532,19 @@ __device__ __forceinline__ void wgrad3_body(const Wgrad2Args& a, uint8_t* smem) 
                 cur_h = cur_h + 1 == a.H ? 0 : cur_h + 1;
             }
         }
-        dma(su0, dst), dma(su1, dst + 4096), dma(sv0, kW3VBase + dst), dma(sv1, kW3VBase + dst + 4096);
-        if (halo_wave) dma(sv2, dst_halo);
+    };
+    auto piece = [&](int k, int slot) {  // instruction k of the prepared chunk -> ring slot
+        const int dst = slot * 1024 + wave * 8192;  // rows 8w.. = groups 2w, 2w+1
+        if (k == 0) dma(su0, dst);
+        if (k == 1) dma(su1, dst + 4096);
+        if (k == 2) dma(sv0, kW3VBase + dst);
+        if (k == 3) dma(sv1, kW3VBase + dst + 4096);
+        if (k == 4 && halo_wave) dma(sv2, kW3VBase + 16 * 4096 + slot * 1024);
+    };
+    auto issue = [&](int slot) {
+        prepare();
+#pragma unroll
+        for (int k = 0; k < 5; ++k) piece(k, slot);
     };
 
     f32x4 acc[TG][4][2];
@@ -594,7 +604,9 @@ __device__ __forceinline__ void wgrad3_body(const Wgrad2Args& a, uint8_t* smem) 
     const bool half_b = wave >= 4;
     auto step = [&](auto S_) {  // chunk in slot S: its unit-0 fragments were requested before the barrier that opened it
         constexpr int S = decltype(S_)::value, NU = 2 * TG;
-        if (!half_b) issue((S + 3) & 3);  // into the slot the chunk before this one was read from (closed by the last barrier)
+        // the five (four) instructions of chunk +3 go into the slot the chunk before this one was read from (closed by the last
+        // barrier), one after each tap-step: half A after units 0.., half B one unit later, all before the last unit's wait
+        prepare();
         w3_for([&](auto U_) {
             constexpr int U = decltype(U_)::value;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // unit U's fragments are in registers
@@ -613,8 +625,14 @@ __device__ __forceinline__ void wgrad3_body(const Wgrad2Args& a, uint8_t* smem) 
             __builtin_amdgcn_sched_barrier(0);
             mfma_unit(U_);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (U == TG - 1)
-                if (half_b) issue((S + 3) & 3);
+            if constexpr (U < NU - 1) {
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    const int ua = k < NU - 2 ? k : NU - 2, ub = k + 1 < NU - 2 ? k + 1 : NU - 2;
+                    if (ua == U && !half_b) piece(k, (S + 3) & 3);
+                    if (ub == U && half_b) piece(k, (S + 3) & 3);
+                }
+            }
         }, std::make_integer_sequence<int, NU>{});
     };
 
