@@ -51,10 +51,18 @@ __global__ __launch_bounds__(64) void iou_mask_kernel(const float* boxes, const 
     for (int k = 0; k < 5; ++k) a[k] = boxes[i * 5 + k];
     const float sa = sc[2 * i], ca = sc[2 * i + 1];
     const int32_t cat_i = cats ? cats[i] : 0;
+    // bounding circle of box i: boxes whose circles are apart cannot intersect -- their IoU is 0 in the clipping arithmetic
+    // too, so skipping them changes no bit of the masks (the thresholds are positive)
+    const float cxi = 0.5f * (a[0] + a[2]), cyi = 0.5f * (a[1] + a[3]);
+    const float ri = 0.5f * sqrtf((a[2] - a[0]) * (a[2] - a[0]) + (a[3] - a[1]) * (a[3] - a[1]));
+    const bool skip_far = nms_t >= 0.f && merge_t >= 0.f;
     unsigned long long bits_n = 0ull, bits_m = 0ull;
     const int jn = (int)((n - j0) < 64 ? (n - j0) : 64);
     for (int j = 0; j < jn; ++j) {
         if (j0 + j <= i || ccat[j] != cat_i) continue;
+        const float dx = 0.5f * (cbox[j][0] + cbox[j][2]) - cxi, dy = 0.5f * (cbox[j][1] + cbox[j][3]) - cyi;
+        const float rj = 0.5f * sqrtf((cbox[j][2] - cbox[j][0]) * (cbox[j][2] - cbox[j][0]) + (cbox[j][3] - cbox[j][1]) * (cbox[j][3] - cbox[j][1]));
+        if (skip_far && dx * dx + dy * dy > (ri + rj) * (ri + rj) * 1.001f + 1e-4f) continue;
         const float iou = rotated_iou(a, sa, ca, cbox[j], cbox[j][5], cbox[j][6]);
         if (iou > nms_t) bits_n |= 1ull << j;
         if (iou > merge_t) bits_m |= 1ull << j;
@@ -63,27 +71,59 @@ __global__ __launch_bounds__(64) void iou_mask_kernel(const float* boxes, const 
     merge_mask[i * cb + col] = bits_m;
 }
 
-// one workgroup; remv (suppressed set) lives in LDS
+// One workgroup; remv (suppressed set) lives in LDS.  The scan walks the boxes in blocks of 64 (one mask word): inside a block
+// the chain "is box b still alive?" is resolved by ONE wave from the 64 diagonal words held one per lane (64 register-only
+// steps, no barrier); then every thread owning a later word w folds the rows of the block's kept boxes into remv[w] (and
+// masks their merge rows with the boxes alive at their visit) -- one round of global loads and two barriers per 64 boxes
+// instead of per kept box.  Same visiting order and the same sets as the box-by-box loop (oracle/nms.py).
 __global__ __launch_bounds__(1024) void scan_kernel(int64_t n, int cb, const unsigned long long* nms_mask,
                                                     unsigned long long* merge_mask, long long* keep, long long* num_out) {
     extern __shared__ unsigned long long remv[];
+    __shared__ unsigned long long kept_word;
     for (int w = threadIdx.x; w < cb; w += blockDim.x) remv[w] = 0ull;
     __syncthreads();
-    long long kept = 0;
-    for (int64_t i = 0; i < n; ++i) {
-        const int wi = (int)(i >> 6);
-        if (remv[wi] & (1ull << (i & 63))) continue;  // uniform: every thread reads the same word
-        if (threadIdx.x == 0) keep[kept] = i;
-        ++kept;
-        __syncthreads();  // all threads have evaluated the branch on the old remv
-        for (int w = wi + threadIdx.x; w < cb; w += blockDim.x) {
-            const unsigned long long alive = ~remv[w];
-            merge_mask[i * cb + w] &= alive;  // cluster = merge candidates not suppressed before i was visited
-            remv[w] |= nms_mask[i * cb + w];
+    long long kept_total = 0;
+    for (int wi = 0; wi < cb; ++wi) {
+        if (threadIdx.x < 64) {
+            const int b = threadIdx.x;
+            const int64_t i = (int64_t)wi * 64 + b;
+            const bool in = i < n;
+            const unsigned long long diag = in ? nms_mask[i * cb + wi] : 0ull;
+            const unsigned long long in_bits = __ballot(in);
+            const uint32_t dlo = (uint32_t)diag, dhi = (uint32_t)(diag >> 32);
+            unsigned long long rem = remv[wi], kept = 0ull, alive_mine = 0ull;
+            for (int q = 0; q < 64; ++q) {  // uniform loop; lane q's diagonal word through readlane
+                if (!((in_bits >> q) & 1ull) || ((rem >> q) & 1ull)) continue;
+                kept |= 1ull << q;
+                if (b == q) alive_mine = ~rem;
+                rem |= ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)dhi, q) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)dlo, q);
+            }
+            if ((kept >> b) & 1ull) {
+                keep[kept_total + __popcll(kept & ((1ull << b) - 1ull))] = i;
+                merge_mask[i * cb + wi] &= alive_mine;  // cluster = merge candidates not suppressed before i was visited
+            }
+            if (b == 0) {
+                remv[wi] = rem;
+                kept_word = kept;
+            }
+        }
+        __syncthreads();
+        const unsigned long long kept = kept_word;
+        kept_total += __popcll(kept);
+        for (int w = wi + 1 + threadIdx.x; w < cb; w += blockDim.x) {
+            unsigned long long r = remv[w], bits = kept;
+            while (bits) {
+                const int q = __ffsll((long long)bits) - 1;
+                bits &= bits - 1;
+                const int64_t i = (int64_t)wi * 64 + q;
+                merge_mask[i * cb + w] &= ~r;
+                r |= nms_mask[i * cb + w];
+            }
+            remv[w] = r;
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) *num_out = kept;
+    if (threadIdx.x == 0) *num_out = kept_total;
 }
 
 // one wave per kept box; lane = data column
@@ -149,7 +189,7 @@ extern "C" int rv_wnms_classes(const float* boxes, const float* data, const int3
     RV_REQUIRE(boxes && data && output && keep && count && workspace, "rv_wnms: null argument");
     RV_REQUIRE(d >= 1 && d <= 64, "rv_wnms: data width %d unsupported (1..64)", d);
     const int64_t cb64 = (n + 63) / 64;
-    RV_REQUIRE(cb64 * 8 <= 160 * 1024, "rv_wnms: too many boxes (%lld)", (long long)n);
+    RV_REQUIRE(cb64 * 8 <= 160 * 1024 - 256, "rv_wnms: too many boxes (%lld)", (long long)n);
     const int cb = (int)cb64;
     hipStream_t st = (hipStream_t)stream;
     uint8_t* ws = (uint8_t*)workspace;
@@ -162,7 +202,7 @@ extern "C" int rv_wnms_classes(const float* boxes, const float* data, const int3
                        merge_mask);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);  // + the static word
         attr = true;
     }
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(cb < 1024 ? ((cb + 63) / 64) * 64 : 1024), (size_t)cb * 8, st, n, cb,

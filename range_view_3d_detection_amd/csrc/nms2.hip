@@ -215,13 +215,14 @@ __device__ void k_iou_block(const Args& a, const SweepPtrs& p, int n, int row, i
     // too, so skipping them changes no bit of the masks (thresholds are positive) and skips ~all pairs of a spread-out scene
     const float cxi = 0.5f * (bx[0] + bx[2]), cyi = 0.5f * (bx[1] + bx[3]);
     const float ri = 0.5f * sqrtf((bx[2] - bx[0]) * (bx[2] - bx[0]) + (bx[3] - bx[1]) * (bx[3] - bx[1]));
+    const bool skip_far = a.nms_t >= 0.f && a.merge_t >= 0.f;
     unsigned long long bits_n = 0ull, bits_m = 0ull;
     const int jn = (int)((n - j0) < 64 ? (n - j0) : 64);
     for (int j = 0; j < jn; ++j) {
         if (j0 + j <= i || ccat[j] != cat_i) continue;
         const float dx = 0.5f * (cbox[j][0] + cbox[j][2]) - cxi, dy = 0.5f * (cbox[j][1] + cbox[j][3]) - cyi;
         const float rj = 0.5f * sqrtf((cbox[j][2] - cbox[j][0]) * (cbox[j][2] - cbox[j][0]) + (cbox[j][3] - cbox[j][1]) * (cbox[j][3] - cbox[j][1]));
-        if (dx * dx + dy * dy > (ri + rj) * (ri + rj) * 1.001f + 1e-4f) continue;
+        if (skip_far && dx * dx + dy * dy > (ri + rj) * (ri + rj) * 1.001f + 1e-4f) continue;
         const float iou = rotated_iou(bx, sa, ca, cbox[j], cbox[j][5], cbox[j][6]);
         if (iou > a.nms_t) bits_n |= 1ull << j;
         if (iou > a.merge_t) bits_m |= 1ull << j;
