@@ -127,6 +127,28 @@ int rv_tap_scatter(const rvTapGeom* g, const rvTapShape* s, const void* U, const
                    const float* in_shift, const void* scatter_w, const float* bias, void* V,
                    float* stats_partial, rvStream stream);
 
+/* Backward-data launch that ALSO forms the BatchNorm-backward sums of the layer whose output gradient it writes
+ * (conv -> BatchNorm(+ReLU) -> THIS conv: autograd's native_batch_norm_backward reduce over (dOut, y), fused into the
+ * epilogue of conv2d backward-data).  dx = the gradient w.r.t. the (activated) BatchNorm output, written as by
+ * rv_tap_gather / rv_tap_scatter (scatter != 0: the SCATTER form) without RV_OUT_ACCUM; from the bf16 values it stores,
+ *   g = dx * [scale*y+shift > 0 if flags & RV_BNB_RELU_Z],   partial[row][0][c] = sum g,  partial[row][1][c] = sum g * (y-mean)*invstd
+ * over the row's pixels -- the layout rv_bn_bwd_finalize takes (rv_bn_bwd_reduce then is not needed).
+ * rv_tap_bnb_rows: partial rows such a launch writes; 0 = the kernel (g, s) selects has no such epilogue (only the
+ * fifth-generation tap-conv has): use rv_tap_gather/scatter + rv_bn_bwd_reduce. */
+typedef struct rvBnbEpilogue {
+    const void* y;      /* bf16 NHWC pre-BatchNorm conv output of the destination layer, same pixels as dx */
+    int32_t ld_y;       /* its channel stride (elements) */
+    int32_t flags;      /* RV_BNB_RELU_Z */
+    const float* scale; /* folded BatchNorm: gamma*invstd, beta - mean*scale (the ReLU mask) */
+    const float* shift;
+    const float* mean;
+    const float* invstd;
+    float* partial;     /* [rows + RV_STATS_SCRATCH_ROWS][2][c_pad] fp32 */
+} rvBnbEpilogue;
+int32_t rv_tap_bnb_rows(const rvTapGeom* g, const rvTapShape* s, int32_t scatter);
+int rv_tap_data_grad_bnb(const rvTapGeom* g, const rvTapShape* s, int32_t scatter, const void* dout, const void* w, void* dx,
+                         const rvBnbEpilogue* e, rvStream stream);
+
 /* Weight gradient.  dT_packed[tap][cu_pad][cv_pad] (fp32) = sum_{n,h,wu} U * f(V) (shifted).
  * `workspace` holds split-K partial slabs; rv_tap_wgrad_workspace_bytes() sizes it.
  * V may carry the same folded BN+ReLU as in the forward (RV_IN_AFFINE|RV_IN_RELU in

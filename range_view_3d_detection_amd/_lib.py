@@ -33,6 +33,13 @@ class TapShape(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ("N", "H", "Wu", "Wv", "ld_src", "ld_dst", "flags")]
 
 
+class BnbEpilogue(ctypes.Structure):
+    """``rvBnbEpilogue`` of include/rv3d.h (rv_tap_data_grad_bnb)."""
+
+    _fields_ = [("y", ctypes.c_void_p), ("ld_y", ctypes.c_int32), ("flags", ctypes.c_int32), ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p),
+                ("mean", ctypes.c_void_p), ("invstd", ctypes.c_void_p), ("partial", ctypes.c_void_p)]
+
+
 class RvError(RuntimeError):
     pass
 

@@ -4,6 +4,7 @@
 
 constexpr int kMaxTaps = 24;   // 3x8 (ConvTranspose2d k=(3,8)) is the largest kernel on the path
 constexpr int kMaxPhases = 4;  // stride_w <= 4
+constexpr int RV_OUT_BNB = 1 << 16;  // internal launch flag: see TapConvArgs::bnb_*
 
 struct TapTable {
     int32_t ntaps[kMaxPhases];    // taps of each output phase
@@ -35,6 +36,11 @@ struct TapConvArgs {
     int32_t lds_a_elems;
     int32_t lds_tab_offset;  // byte offset of the per-tap offset table in dynamic LDS
     int32_t flags;
+    // RV_OUT_BNB (backward-data launches): BatchNorm-backward sums of the layer whose output gradient this launch writes
+    const bf16_t* bnb_y;
+    const float *bnb_scale, *bnb_shift, *bnb_mean, *bnb_invstd;
+    float* bnb_partial;  // [tiles][2][C_dst]
+    int32_t ld_bnb_y, bnb_flags;
     TapTable tt;
 };
 

@@ -389,7 +389,8 @@ static int g_tapconv5_enable = 1;  // rv_set_option("tapconv5_enable", 0): multi
 
 static int tap_launch(const rvTapGeom* g, const rvTapShape* s, bool scatter, const void* src, const float* in_scale,
                       const float* in_shift, const void* w, const float* bias, void* dst, float* stats,
-                      rvStream stream, bool dry_run, int* stats_rows, int* info = nullptr) {
+                      rvStream stream, bool dry_run, int* stats_rows, int* info = nullptr, const rvBnbEpilogue* bnb = nullptr,
+                      int* bnb_rows = nullptr) {
     TapConvArgs a;
     memset(&a, 0, sizeof(a));
     int phases, step;
@@ -422,6 +423,22 @@ static int tap_launch(const rvTapGeom* g, const rvTapShape* s, bool scatter, con
     a.in_shift = in_shift;
     a.bias = bias;
     a.stats = stats;
+    if (bnb_rows) *bnb_rows = 0;
+    if (bnb || bnb_rows) {  // backward-data launch that also forms the BatchNorm-backward sums of its destination layer
+        a.flags |= RV_OUT_BNB;
+        if (bnb) {
+            RV_REQUIRE(bnb->y && bnb->scale && bnb->shift && bnb->mean && bnb->invstd && bnb->partial, "rv_tap_data_grad_bnb: null epilogue pointer");
+            RV_REQUIRE(bnb->ld_y >= a.C_dst && bnb->ld_y % 8 == 0, "rv_tap_data_grad_bnb: bad channel stride of y (%d)", bnb->ld_y);
+            a.bnb_y = (const bf16_t*)bnb->y;
+            a.ld_bnb_y = bnb->ld_y;
+            a.bnb_flags = bnb->flags;
+            a.bnb_scale = bnb->scale;
+            a.bnb_shift = bnb->shift;
+            a.bnb_mean = bnb->mean;
+            a.bnb_invstd = bnb->invstd;
+            a.bnb_partial = bnb->partial;
+        }
+    }
 
     // multi-tap layers with 256-channel output tiles: input halo resident in LDS across the taps (tapconv5.hip)
     if (g_tapconv5_enable && getenv("RV3D_NO_TAPCONV5") == nullptr) {
@@ -430,6 +447,7 @@ static int tap_launch(const rvTapGeom* g, const rvTapShape* s, bool scatter, con
         TapConvArgs a5 = a;
         if (rv_tapconv5_plan(&a5, &tiles, &lds5)) {
             if (stats_rows) *stats_rows = tiles * 2;
+            if (bnb_rows) *bnb_rows = tiles;
             if (info) {
                 info[0] = 5;
                 info[1] = 256;
@@ -439,6 +457,10 @@ static int tap_launch(const rvTapGeom* g, const rvTapShape* s, bool scatter, con
             if (dry_run) return 0;
             return rv_tapconv5_launch(a5, lds5, (hipStream_t)stream);
         }
+    }
+    if (a.flags & RV_OUT_BNB) {  // only the fifth-generation kernel carries that epilogue
+        if (dry_run) return 0;   // (rows = 0: the caller takes the separate reduce pass)
+        RV_FAIL("rv_tap_data_grad_bnb: this launch has no fused BatchNorm-backward sums (rv_tap_bnb_rows returned 0)");
     }
     // 256 x 256 (or x 128) tiles streamed by LDS-DMA, counted waits (tapconv4.hip); plain bf16 inputs only
     if (getenv("RV3D_NO_TAPCONV4") == nullptr) {
@@ -557,6 +579,20 @@ int32_t rv_tap_stats_rows(const rvTapGeom* g, const rvTapShape* s, int32_t scatt
 int rv_tap_launch_info(const rvTapGeom* g, const rvTapShape* s, int32_t scatter, int32_t* host_info) {
     RV_REQUIRE(g && s && host_info, "rv_tap_launch_info: null argument");
     return tap_launch(g, s, scatter != 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, true, nullptr, host_info);
+}
+
+int32_t rv_tap_bnb_rows(const rvTapGeom* g, const rvTapShape* s, int32_t scatter) {
+    int rows = 0;
+    if (!g || !s) return 0;
+    if (tap_launch(g, s, scatter != 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, true, nullptr, nullptr, nullptr, &rows))
+        return -1;
+    return rows;
+}
+
+int rv_tap_data_grad_bnb(const rvTapGeom* g, const rvTapShape* s, int32_t scatter, const void* dout, const void* w, void* dx,
+                         const rvBnbEpilogue* e, rvStream stream) {
+    RV_REQUIRE(g && s && dout && w && dx && e, "rv_tap_data_grad_bnb: null argument");
+    return tap_launch(g, s, scatter != 0, dout, nullptr, nullptr, w, nullptr, dx, nullptr, stream, false, nullptr, nullptr, e);
 }
 
 int rv_tap_gather(const rvTapGeom* g, const rvTapShape* s, const void* V, const float* in_scale, const float* in_shift,

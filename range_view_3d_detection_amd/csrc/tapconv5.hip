@@ -339,22 +339,93 @@ __global__ __launch_bounds__(512, 2) void tapconv5_kernel(const TapConvArgs a) {
                 const int pc = wc * WN + j * 16 + l15;
                 epi[pm * kEpi + pc] = f2bf(acc[i][j][r]);
             }
-    __syncthreads();
     constexpr int kChunks = kBN / 8;
     const bool accum = a.flags & RV_OUT_ACCUM;
-    for (int q = tid; q < kTR * kTC * kChunks; q += 512) {
+    // RV_OUT_BNB: this launch writes dOut of a BatchNorm(+ReLU) layer -- its backward needs sum(g) and sum(g * xhat) per channel
+    // with g = dOut * [scale*y+shift > 0], xhat = (y - mean) * invstd.  A thread keeps ONE 8-channel chunk through the store loop
+    // (512 threads = 16 pixels x 32 chunks per pass), so the sums are formed here, from the bf16 values being stored, with one
+    // extra 16-byte read of y per chunk: the separate reduce pass over (dOut, y) disappears (bnbwd.hip: bn_bwd_reduce_kernel).
+    const bool bnb = a.flags & RV_OUT_BNB;
+    float bsc[8], bsh[8], bmu[8], bis[8], s0[8], s1[8];
+    if (bnb) {
+        const int c = n0 + (tid & (kChunks - 1)) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            bsc[j] = a.bnb_scale[c + j];
+            bsh[j] = a.bnb_shift[c + j];
+            bmu[j] = a.bnb_mean[c + j];
+            bis[j] = a.bnb_invstd[c + j];
+            s0[j] = 0.f;
+            s1[j] = 0.f;
+        }
+    }
+    constexpr int kPasses = kTR * kTC * kChunks / 512;  // 16
+    u32x4 yv[kPasses];
+    if (bnb) {  // (before the barrier that publishes the staged tile) all of this thread's y chunks in flight at once (the staged tile is being read meanwhile): one HBM latency, not sixteen
+#pragma unroll
+        for (int it = 0; it < kPasses; ++it) {
+            const int q = tid + it * 512, pm = q / kChunks, c8 = q - pm * kChunks;
+            const int rr = pm / kTC, mm = pm - rr * kTC;
+            const int m = m0 + mm, c = n0 + c8 * 8, hh = h0 + rr;
+            yv[it] = u32x4{0u, 0u, 0u, 0u};
+            if (m < Wm && hh < a.H) yv[it] = *(const u32x4*)(a.bnb_y + (((int64_t)(n * a.H + hh) * a.W_dst) + (a.phases * m + ph)) * a.ld_bnb_y + c);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < kPasses; ++it) {
+        const int q = tid + it * 512;
         const int pm = q / kChunks, c8 = q - pm * kChunks;
         const int rr = pm / kTC, mm = pm - rr * kTC;
         const int m = m0 + mm, c = n0 + c8 * 8, hh = h0 + rr;
         if (m >= Wm || hh >= a.H) continue;
         u32x4 v = *(const u32x4*)(epi + pm * kEpi + c8 * 8);
-        bf16_t* p = (bf16_t*)a.dst + (((int64_t)(n * a.H + hh) * a.W_dst) + (a.phases * m + ph)) * a.ld_dst + c;
+        const int64_t px = ((int64_t)(n * a.H + hh) * a.W_dst) + (a.phases * m + ph);
+        bf16_t* p = (bf16_t*)a.dst + px * a.ld_dst + c;
         if (accum) {
             const u32x4 o = *(const u32x4*)p;
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = pack_bf2(bf_lo(v[j]) + bf_lo(o[j]), bf_hi(v[j]) + bf_hi(o[j]));
         }
         *(u32x4*)p = v;
+        if (bnb) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float y0 = bf_lo(yv[it][j]), y1 = bf_hi(yv[it][j]);
+                float g0 = bf_lo(v[j]), g1 = bf_hi(v[j]);
+                if (a.bnb_flags & 1) {  // RV_BNB_RELU_Z
+                    g0 = y0 * bsc[2 * j] + bsh[2 * j] > 0.f ? g0 : 0.f;
+                    g1 = y1 * bsc[2 * j + 1] + bsh[2 * j + 1] > 0.f ? g1 : 0.f;
+                }
+                s0[2 * j] += g0;
+                s0[2 * j + 1] += g1;
+                s1[2 * j] += g0 * ((y0 - bmu[2 * j]) * bis[2 * j]);
+                s1[2 * j + 1] += g1 * ((y1 - bmu[2 * j + 1]) * bis[2 * j + 1]);
+            }
+        }
+    }
+    if (bnb) {
+        // lanes l and l + 32 of a wave hold the same chunk; then the eight waves through LDS (the staged tile is dead now)
+        __syncthreads();
+        float* red = (float*)smem;  // [8 waves][32 chunks][16]
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            s0[j] += __shfl_xor(s0[j], 32, 64);
+            s1[j] += __shfl_xor(s1[j], 32, 64);
+        }
+        if (lane < 32) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                red[(wave * 32 + lane) * 16 + j] = s0[j];
+                red[(wave * 32 + lane) * 16 + 8 + j] = s1[j];
+            }
+        }
+        __syncthreads();
+        const int chunk = tid >> 4, jj = tid & 15;  // 32 chunks x 16 values = 512 threads
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) sum += red[(w * 32 + chunk) * 16 + jj];
+        a.bnb_partial[((int64_t)tile * 2 + (jj >> 3)) * a.C_dst + n0 + chunk * 8 + (jj & 7)] = sum;
     }
 }
 
@@ -366,6 +437,7 @@ extern int g_tapconv4_min_blocks;
 bool rv_tapconv5_plan(TapConvArgs* a, int* tiles, size_t* lds) {
     if (a->step != 1) return false;
     if (a->flags & (RV_IN_AFFINE | RV_IN_RELU | RV_OUT_F32)) return false;  // the DMA path has no register prologue
+    if ((a->flags & RV_OUT_BNB) && (a->flags & RV_OUT_ACCUM)) return false;   // the sums are formed from this launch's values only
     if (a->C_src % kBK != 0 || a->C_dst % kBN != 0) return false;
     const int wm_total = a->W_dst / a->phases;
     if (wm_total < kTC || a->H < kTR) return false;

@@ -298,6 +298,8 @@ Operand = Union[Act, Lazy]
 # register-staged kernels (3x3 512 -> 512: 1330 vs 980 TFLOP/s, one box) to pay for writing the operand out once
 # (one HBM-bound pass); forward conv, and the weight gradient in backward, then both read the plain tensor.
 MATERIALIZE_FOR_DMA = os.environ.get("RV3D_NO_MATERIALIZE") is None
+# conv -> BatchNorm(+ReLU) -> conv: the second conv's backward-data launch also forms the BatchNorm-backward sums (rv_tap_data_grad_bnb)
+BNB_FUSE = os.environ.get("RV3D_NO_BNB_FUSE") is None
 
 
 def _dma_eligible(geom, n: int, h: int, wu: int, wv: int, ld_src: int, ld_dst: int, scatter: bool) -> bool:
@@ -395,6 +397,7 @@ class Tape:
         self.grads: Dict[int, Act] = {}          # id(root Act) -> gradient Act (same padded shape)
         self.written: set = set()                # ids of gradient Acts (roots) already holding a value
         self.lazy_in: Dict[int, Tuple[Act, Optional[Act]]] = {}  # id(Lazy) -> (dOut, OUT mask source)
+        self.lazy_sums: Dict[int, Tuple[Tensor, int]] = {}  # id(Lazy) -> BatchNorm-backward partial sums its ONE writer formed, rows
         self.raw_grad: Dict[int, Act] = {}       # id(raw Act) -> gradient w.r.t. the raw conv output
         self.param_grads: Dict[int, Tensor] = {}  # id(param) -> fp32 gradient
         self.params: Dict[int, nn.Parameter] = {}
@@ -437,6 +440,7 @@ class Tape:
         contributions add up -- a second writer folds the pending entry into one plain buffer first."""
         key = id(lazy)
         prev = self.lazy_in.get(key)
+        self.lazy_sums.pop(key, None)  # (a first writer re-registers its sums after its launch; a second one voids them)
         if prev is None:
             dst = lazy.raw.like()
             dst._rv_owned = True
@@ -450,6 +454,7 @@ class Tape:
         (buffer, accumulate) asks the BatchNorm-backward apply pass to also emit that masked gradient for a residual
         branch -- only possible for a single consumer, otherwise it is written here."""
         key = id(lazy)
+        self.lazy_sums.pop(key, None)
         if key not in self.lazy_in:
             self.lazy_in[key] = (dout, mask, res)
             return

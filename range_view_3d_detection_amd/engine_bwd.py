@@ -76,6 +76,17 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
         wp = layer.packed(bwd)
         call = lambda: L.call("rv_tap_" + bwd, ctypes.byref(g), ctypes.byref(shape), dout.ptr(), None, None, L.ptr(wp), None,
                               dst.ptr(), None, L.stream_ptr())
+        if E.BNB_FUSE and isinstance(op.x, Lazy) and not accumulate and op.x.bn.mean is not None:
+            # first (often only) consumer of relu(bn(y)): this launch can form that BatchNorm's backward sums on the way out
+            rows = L.load().rv_tap_bnb_rows(ctypes.byref(g), ctypes.byref(shape), L.i32(1 if bwd == "scatter" else 0))
+            if rows > 0:
+                lz, st = op.x, op.x.bn
+                partial = torch.empty((rows + L.STATS_SCRATCH_ROWS, 2, dst.cp), dtype=torch.float32, device=t.device)
+                epi = L.BnbEpilogue(lz.raw.ptr().value, lz.raw.ld, L.BNB_RELU_Z if lz.relu else 0, L.ptr(st.scale).value, L.ptr(st.shift).value,
+                                    L.ptr(st.mean).value, L.ptr(st.invstd).value, L.ptr(partial).value)
+                call = lambda: L.call("rv_tap_data_grad_bnb", ctypes.byref(g), ctypes.byref(shape), L.i32(1 if bwd == "scatter" else 0), dout.ptr(),
+                                      L.ptr(wp), dst.ptr(), ctypes.byref(epi), L.stream_ptr())
+                t.lazy_sums[id(lz)] = (partial, rows, dst)
         if E.PROFILE is not None:
             E._launch(E.tap_kernel_name(g, shape, bwd == "scatter"), E.tap_flops(g, shape), call)
         else:
@@ -178,12 +189,16 @@ def bn_backward(op: "E.BnOp", t: Tape) -> None:
         t.add_param_grad(st.module.bias, dbeta[:c])
         t.add_param_grad(lay.weight, lay.unpermute_grad(dw[: lay.c_out].reshape(lay.c_out, cin, 1, 1).contiguous()))
         return
-    rows = L.load().rv_bn_bwd_rows(L.i64(pixels))
-    partial = torch.empty((rows + L.STATS_SCRATCH_ROWS, 2, cp), dtype=torch.float32, device=t.device)
     common = (L.i64(pixels), L.i32(cp), dout.ptr(), L.i32(dout.ld), mask.ptr() if mask is not None else None,
               L.i32(mask.ld if mask is not None else 0), raw.ptr(), L.i32(raw.ld), L.ptr(st.scale), L.ptr(st.shift),
               L.ptr(st.mean), L.ptr(st.invstd))
-    L.call("rv_bn_bwd_reduce", *common, L.i32(flags), L.ptr(partial), L.stream_ptr())
+    sums = t.lazy_sums.pop(id(lazy), None)
+    if sums is not None and sums[2] is dout and mask is None and res is None:
+        partial, rows = sums[0], sums[1]  # formed by the backward-data launch that wrote dout (rv_tap_data_grad_bnb)
+    else:
+        rows = L.load().rv_bn_bwd_rows(L.i64(pixels))
+        partial = torch.empty((rows + L.STATS_SCRATCH_ROWS, 2, cp), dtype=torch.float32, device=t.device)
+        L.call("rv_bn_bwd_reduce", *common, L.i32(flags), L.ptr(partial), L.stream_ptr())
     dgamma = torch.empty(cp, dtype=torch.float32, device=t.device)
     dbeta = torch.empty(cp, dtype=torch.float32, device=t.device)
     coef = torch.empty((3, cp), dtype=torch.float32, device=t.device)

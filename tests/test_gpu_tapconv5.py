@@ -133,3 +133,49 @@ def test_repeatable_on_random_data():
     for _ in range(30):
         again, _ = _run(m, x)
         assert torch.equal(first, again)
+
+
+@pytest.mark.parametrize("cin,c,N,H,W,relu", [(64, 256, 2, 24, 200, True), (64, 512, 1, 17, 96, True), (128, 256, 2, 16, 64, False)])
+def test_data_grad_launch_forms_the_batchnorm_backward_sums(cin, c, N, H, W, relu, monkeypatch):
+    """conv -> BatchNorm(+ReLU) -> conv: the second conv's backward-data launch (``rv_tap_data_grad_bnb``) also emits
+    sum(g), sum(g*xhat) of the BatchNorm between them, so ``rv_bn_bwd_reduce`` is not launched.  Same tape run both ways:
+    the input gradient of the second conv is bit-identical (same kernel, same values), dgamma / dbeta agree to 1e-5
+    relative (fp32 sums in another order), the first conv's output gradient to bf16 rounding of those coefficients."""
+    from range_view_3d_detection_amd import _lib as L
+    from range_view_3d_detection_amd import engine as E
+    from range_view_3d_detection_amd import engine_bwd
+
+    gen = torch.Generator().manual_seed(c + W)
+    c1 = torch.nn.Conv2d(cin, c, 3, padding=1, bias=False).to(DEV)
+    bn = torch.nn.BatchNorm2d(c).to(DEV).train()
+    c2 = torch.nn.Conv2d(c, 256, 3, padding=1, bias=False).to(DEV)
+    bn.weight.data = (0.5 + torch.rand(c, generator=gen)).to(DEV)
+    bn.bias.data = (0.3 * torch.randn(c, generator=gen)).to(DEV)
+    x = torch.randn(N, cin, H, W, generator=gen).to(DEV)
+    gout = torch.randn(N, 256, H, W, generator=gen).to(DEV)
+
+    def run(fuse):
+        calls = []
+        real = L.call
+        monkeypatch.setattr(L, "call", lambda name, *a: (calls.append(name), real(name, *a))[1])
+        monkeypatch.setattr(E, "BNB_FUSE", fuse)
+        t = E.Tape(True, x.device)
+        h = E.conv_bn(t, E.tap_layer(c1), E.Act.from_nchw(x), bn, relu=relu)
+        op2 = E.ConvOp(t, E.tap_layer(c2), h, stats=False)
+        t.set_grad(op2.out, engine_bwd.grad_act_like(op2.out, gout.to(torch.bfloat16)))
+        t.backward()
+        torch.cuda.synchronize()
+        monkeypatch.setattr(L, "call", real)
+        raw = h.raw if isinstance(h, E.Lazy) else None
+        return calls, t.param_grads[id(bn.weight)].float().cpu(), t.param_grads[id(bn.bias)].float().cpu(), t.param_grads[id(c1.weight)].float().cpu()
+
+    calls_f, dg_f, db_f, dw_f = run(True)
+    calls_s, dg_s, db_s, dw_s = run(False)
+    assert "rv_tap_data_grad_bnb" in calls_f and "rv_bn_bwd_reduce" not in calls_f, calls_f
+    assert "rv_bn_bwd_reduce" in calls_s and "rv_tap_data_grad_bnb" not in calls_s
+    assert torch.allclose(dg_f, dg_s, rtol=1e-4, atol=1e-3 * float(dg_s.abs().max()))
+    assert torch.allclose(db_f, db_s, rtol=1e-4, atol=1e-3 * float(db_s.abs().max()))
+    # the first conv's weight gradient sees the BatchNorm-backward output: equal up to bf16 roundings that the coefficients' last bits flip
+    assert float((dw_f - dw_s).abs().max()) <= 2e-2 * float(dw_s.abs().max())
+    cos = float((dw_f * dw_s).sum() / (dw_f.norm() * dw_s.norm()))
+    assert cos > 0.99999, cos
