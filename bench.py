@@ -194,7 +194,9 @@ def roofline(prof, iso) -> dict:
     r["isolated"] = {"achieved": d["tflops"], "frac": d["tflops"] / MFMA_BF16_PEAK_TFLOPS, "avg_launch_us": d["avg_us"]}
     try:
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), PMC_TRAFFIC)) as f:
-            k = json.load(f)["kernels"].get(r["kernel"].replace("(+reduce)", ""))
+            rows = json.load(f)["kernels"]
+        name = r["kernel"].replace("(+reduce)", "")
+        k = rows.get(name) or rows.get(name.split("<")[0])  # (tapconv5_kernel is not a template: the profiler knows it without <256>)
         if k:
             r["traffic"] = k["hbm_bytes_per_launch"]
             r["traffic_source"] = PMC_TRAFFIC + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 gfx950 correction)"

@@ -184,3 +184,23 @@ def test_sph_cart_and_w_padding(golden):
             rv, m, _ = subsample_range_view(rv_in, m_in, rv_in[:1].expand(3, -1, -1).contiguous(), ds, 1, mode)
             assert rv.shape[-1] == w_out and w_out % 16 == 0
             assert torch.equal(rv.cpu(), p[f"pad/{ds}/{mode}/rv"]) and torch.equal(m.cpu(), p[f"pad/{ds}/{mode}/mask"])
+
+
+def test_rv_waymo_training_step_at_its_stated_size():
+    """BASELINE configs[4] on one GPU: rv-waymo widths ([128]*5, towers 256, 3 classes) on 64 x 2656 x 6 sweeps (2650 padded
+    by (3,3), prototype/loader.py) -- W % 64 != 0, so the ragged-column paths of the tap-convs and of the weight gradient
+    run at full size.  Two sweeps per step through bench.py's own step (fwd + loss + bwd + AdamW); finite loss, and the
+    kernels of the wide layers are the LDS-DMA generations."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--widths", "rv-waymo", "--width", "2656", "--features", "6",
+           "--classes", "3", "--batch", "2", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    j = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert j["config"]["sweep"] == [64, 2656, 6] and 0.0 < j["config"]["loss"] < 100.0 and j["value"] > 0
+    assert any(k.startswith("tapconv5_kernel") for k in j["kernels"]) and any(k.startswith("wgrad3_kernel") for k in j["kernels"]), list(j["kernels"])
