@@ -381,6 +381,15 @@ int rv_z_buffer(const int32_t* rows, const int32_t* cols, const double* range, c
  * [azimuth, inclination, radius] <-> [x, y, z]; is_f64 selects double (numpy twins) or float (torch versions). */
 int rv_cart_to_sph(const void* cart, int64_t n, int32_t is_f64, void* sph, rvStream stream);
 int rv_sph_to_cart(const void* sph, int64_t n, int32_t is_f64, void* cart, rvStream stream);
+/* The loader's per-sweep contract (prototype/loader.py:568-705, DataLoader.__getitem__): a range-view table with H*W rows
+ * and named fp32 columns (`table`: [n_cols][hw], one column after the other, as Arrow stores it) -> features [n_feat][hw]
+ * (= (F,H,W)), cart [3][hw], mask [hw] (range > 0).  roi_col >= 0: every column is first multiplied by that 0/1 column
+ * (`filter_roi`, loader.py:599-601).  host_feat_op[f]: 0 copy, 1 tanh (Waymo intensity, :627), 2 times 1e-9 (timedelta_ns, :633).
+ * The index arrays are HOST arrays (<= 16 features).  Replaces the polars select / to_numpy / transpose / reshape chain. */
+int rv_table_to_range_view(const float* table, int32_t n_cols, int64_t hw, int32_t n_feat, const int32_t* host_feat_col,
+                           const int32_t* host_feat_op, const int32_t* host_cart_col, int32_t range_col, int32_t roi_col,
+                           float* features, float* cart, uint8_t* mask, rvStream stream);
+
 /* Loader augmentations on device (prototype/loader.py:825-990: flip_azimuth, random_rotation, random_global_scale,
  * random_global_translation, and chains of them).  in / out: (B, C, H, W) fp32, distinct buffers.  params: B x 32 doubles
  * on the DEVICE: {a, b} column map w_src = (a*w + b) mod W with a = +-1; A[9], t[3] affine map of the channels ix / iy / iz

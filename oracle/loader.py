@@ -1,0 +1,49 @@
+"""Oracle: the loader's per-sweep contract, table -> (features, cart, mask).
+
+TEST INFRASTRUCTURE (see ``oracle/__init__.py``).  numpy restatement of ``DataLoader.__getitem__``,
+``/root/reference/src/torchbox3d/prototype/loader.py``:
+
+* ``:594-601``  the sweep table; ``filter_roi``: EVERY column times the 0/1 ``is_within_roi`` column
+* ``:625-634``  feature columns in ``feature_column_names`` order; Waymo: tanh(intensity); ``timedelta_ns`` times 1e-9
+* ``:636-652``  ``_npy_to_tch`` (``:818-822``): column f of the (H*W, F) table is image f, row-major (H, W); mask = range > 0
+* ``:690-697``  ``subsample_range_view`` (``:792-815``): features *= mask, W padded by [4,4] (av2) / [3,3] (waymo), constant or
+                circular, every ``x_stride``-th column
+
+Pinned by ``tests/golden/loader_item.npz`` (made by ``make_golden.py loader_item`` running the reference's own ``__getitem__``).
+The ``view`` feature (``:611-624``) is not restated: no shipped config selects it.
+"""
+
+from __future__ import annotations
+
+from typing import Dict, Mapping, Sequence
+
+import numpy as np
+
+_PAD = {("waymo", 1): 3, ("waymo", 4): 19, ("av2", 1): 4, ("av2", 4): 28}
+
+
+def _pad_w(x: np.ndarray, pad: int, mode: str) -> np.ndarray:
+    return np.pad(x, ((0, 0), (0, 0), (pad, pad)), mode="wrap" if mode == "circular" else "constant")
+
+
+def range_view_from_table(table: Mapping[str, np.ndarray], feature_column_names: Sequence[str], height: int, width: int, dataset_name: str,
+                          filter_roi: bool, x_stride: int = 1, padding_mode: str = "constant") -> Dict[str, np.ndarray]:
+    names = list(feature_column_names)
+    assert "view" not in names
+    roi = np.asarray(table["is_within_roi"]).astype(np.float32) if filter_roi else np.float32(1.0)
+    col = lambda n: np.asarray(table[n], dtype=np.float32) * roi  # noqa: E731
+    feats = []
+    for n in names:
+        v = col(n)
+        if n == "intensity" and dataset_name == "waymo":
+            v = np.tanh(v)
+        if n == "timedelta_ns":
+            v = (v.astype(np.float64) * 1e-9).astype(np.float32)
+        feats.append(v)
+    features = np.stack(feats).reshape(len(names), height, width)
+    cart = np.stack([col(n) for n in ("x", "y", "z")]).reshape(3, height, width)
+    mask = (col("range").reshape(1, height, width) > 0.0)
+    pad = _PAD[(dataset_name, 4 if x_stride == 4 else 1)]
+    features = features * mask
+    return {"features": _pad_w(features, pad, padding_mode)[:, :, ::x_stride], "mask": _pad_w(mask, pad, padding_mode)[:, :, ::x_stride],
+            "cart": _pad_w(cart, pad, padding_mode)[:, :, ::x_stride]}

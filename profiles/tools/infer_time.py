@@ -31,10 +31,38 @@ for B in (1, 4):
         old = hnms.FUSED_CLASSES_MAX; hnms.FUSED_CLASSES_MAX = 0
         try: return full()
         finally: hnms.FUSED_CLASSES_MAX = old
-    for name, fn in (("forward", fwd), ("forward+decode+NMS (one launch per sweep)", full), ("forward+decode+NMS (per-class loop)", full_loop)):
+    for name, fn in (("forward", fwd), ("forward+decode+NMS (device-resident batch path)", full), ("forward+decode+NMS (per-class loop)", full_loop)):
         for _ in range(3): r = fn()
         torch.cuda.synchronize(); t = time.perf_counter()
         for _ in range(10): r = fn()
         torch.cuda.synchronize(); ms = (time.perf_counter() - t) / 10 * 1e3
         extra = f" ({r[0].shape[0]} boxes out)" if name != "forward" else ""
         print(f"B={B} {name}: {ms:.1f} ms/batch, {B / ms * 1e3:.1f} sweeps/s{extra}")
+
+# B = 1 is launch-bound (~250 C-ABI launches per forward): the same forward captured once into a HIP graph and replayed
+try:
+    batch = synthetic_batch(1, 64, 2048, seed=1, device=dev)
+    def fwd1():
+        with torch.no_grad():
+            feats = backbone(batch)
+            out, _ = head(feats, batch, return_loss=False)
+        return out[1][0]["logits"], out[1][0]["regressands"]
+    for _ in range(3): fwd1()
+    torch.cuda.synchronize()
+    ref = [t.clone() for t in fwd1()]
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        fwd1()
+    torch.cuda.current_stream().wait_stream(s)
+    with torch.cuda.graph(g):
+        outs = fwd1()
+    g.replay(); torch.cuda.synchronize()
+    same = all(torch.equal(a, b) for a, b in zip(outs, ref))
+    t = time.perf_counter()
+    for _ in range(20): g.replay()
+    torch.cuda.synchronize(); ms = (time.perf_counter() - t) / 20 * 1e3
+    print(f"B=1 forward as a HIP graph replay: {ms:.2f} ms/batch, {1 / ms * 1e3:.1f} sweeps/s (outputs identical to the eager run: {same})")
+except Exception as e:  # noqa: BLE001
+    print("HIP graph capture of the eval forward failed:", type(e).__name__, str(e)[:300])

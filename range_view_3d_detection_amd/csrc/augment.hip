@@ -58,7 +58,67 @@ __global__ void augment_kernel(const float* in, float* out, int B, int C, int H,
     }
 }
 
+// ---- the loader's per-sweep contract (prototype/loader.py:568-705): table columns -> features / cart / mask ------------------
+struct TableArgs {
+    const float* table;  // [n_cols][hw] fp32, column-major like the feather table
+    int64_t hw;
+    int32_t n_feat;
+    int32_t feat_col[16], feat_op[16];  // op: 0 copy, 1 tanh (Waymo intensity), 2 x 1e-9 (timedelta_ns)
+    int32_t cart_col[3];
+    int32_t range_col, roi_col;  // roi_col < 0: no ROI filter
+    float* features;             // [n_feat][hw]
+    float* cart;                 // [3][hw]
+    uint8_t* mask;               // [hw], range > 0
+};
+
+__global__ void table_to_range_view_kernel(const TableArgs a) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < a.hw; i += (int64_t)gridDim.x * blockDim.x) {
+        // `sweep * sweep["is_within_roi"]` (loader.py:599-601) multiplies EVERY column by the 0 / 1 flag
+        const float roi = a.roi_col >= 0 ? (a.table[(int64_t)a.roi_col * a.hw + i] != 0.f ? 1.f : 0.f) : 1.f;
+        for (int f = 0; f < a.n_feat; ++f) {
+            float v = a.table[(int64_t)a.feat_col[f] * a.hw + i] * roi;
+            if (a.feat_op[f] == 1) v = tanhf(v);
+            else if (a.feat_op[f] == 2) v = (float)((double)v * 1e-9);
+            a.features[(int64_t)f * a.hw + i] = v;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a.cart[(int64_t)c * a.hw + i] = a.table[(int64_t)a.cart_col[c] * a.hw + i] * roi;
+        a.mask[i] = a.table[(int64_t)a.range_col * a.hw + i] * roi > 0.f ? 1 : 0;
+    }
+}
+
 }  // namespace
+
+extern "C" int rv_table_to_range_view(const float* table, int32_t n_cols, int64_t hw, int32_t n_feat, const int32_t* host_feat_col,
+                                      const int32_t* host_feat_op, const int32_t* host_cart_col, int32_t range_col, int32_t roi_col,
+                                      float* features, float* cart, uint8_t* mask, rvStream stream) {
+    RV_REQUIRE(table && host_feat_col && host_feat_op && host_cart_col && features && cart && mask, "rv_table_to_range_view: null argument");
+    RV_REQUIRE(n_feat >= 1 && n_feat <= 16, "rv_table_to_range_view: %d feature columns (1..16)", n_feat);
+    RV_REQUIRE(hw > 0 && n_cols > 0 && range_col >= 0 && range_col < n_cols && roi_col < n_cols, "rv_table_to_range_view: bad table shape / column index");
+    TableArgs a;
+    a.table = table;
+    a.hw = hw;
+    a.n_feat = n_feat;
+    for (int f = 0; f < n_feat; ++f) {
+        RV_REQUIRE(host_feat_col[f] >= 0 && host_feat_col[f] < n_cols && host_feat_op[f] >= 0 && host_feat_op[f] <= 2, "rv_table_to_range_view: bad feature column %d", f);
+        a.feat_col[f] = host_feat_col[f];
+        a.feat_op[f] = host_feat_op[f];
+    }
+    for (int c = 0; c < 3; ++c) {
+        RV_REQUIRE(host_cart_col[c] >= 0 && host_cart_col[c] < n_cols, "rv_table_to_range_view: bad Cartesian column %d", c);
+        a.cart_col[c] = host_cart_col[c];
+    }
+    a.range_col = range_col;
+    a.roi_col = roi_col;
+    a.features = features;
+    a.cart = cart;
+    a.mask = mask;
+    int64_t blocks = (hw + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(table_to_range_view_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    RV_CHECK_LAUNCH("table_to_range_view_kernel");
+    return 0;
+}
 
 extern "C" int rv_augment(const float* in, float* out, int32_t B, int32_t C, int32_t H, int32_t W, int32_t ix, int32_t iy,
                           int32_t iz, int32_t irange, const double* params, rvStream stream) {

@@ -1,9 +1,11 @@
-"""The one piece of ``torchbox3d/prototype/loader.py`` that shapes the hot path's input: the W padding that makes
-the range-image width divisible by 16 (``subsample_range_view``, ``loader.py:792-815``) -- on device."""
+"""What of ``torchbox3d/prototype/loader.py`` shapes the hot path's input, on device: the table -> image step of
+``DataLoader.__getitem__`` (``loader.py:568-705``: :func:`range_view_from_table`), the W padding that makes the range-image
+width divisible by 16 (``subsample_range_view``, ``loader.py:792-815``) and the augmentations (``loader.py:825-990``)."""
 
 from __future__ import annotations
 
-from typing import Tuple
+import ctypes
+from typing import Any, Dict, List, Mapping, Tuple
 
 import torch
 from torch import Tensor
@@ -33,6 +35,62 @@ def subsample_range_view(range_view: Tensor, mask: Tensor, cart: Tensor, dataset
     m = _pad(mask.float(), None, pad, circ)[:, :, ::x_stride]
     c = _pad(cart, None, pad, circ)[:, :, ::x_stride]
     return rv, m, c
+
+
+CART_COLUMNS = ("x", "y", "z")
+
+
+def read_sweep_table(path) -> Dict[str, "np.ndarray"]:
+    """Range-view feather file (``pl.scan_ipc(self.lidar_path(...))``, ``loader.py:595``) -> name -> column array (host I/O)."""
+    import pyarrow as pa
+
+    with pa.memory_map(str(path), "r") as src:
+        t = pa.ipc.open_file(src).read_all()
+    return {name: t.column(name).to_numpy(zero_copy_only=False) for name in t.column_names}
+
+
+def range_view_from_table(table: Mapping[str, Any], range_view_config: Mapping[str, Any], dataset_name: str, x_stride: int = 1,
+                          padding_mode: str = "constant", device="cuda") -> Dict[str, Tensor]:
+    """``DataLoader.__getitem__`` from the sweep table on (``loader.py:594-690``): ``table`` maps column names to H*W-row
+    arrays (numpy or tensors); returns ``features`` (F,H,W'), ``mask`` (1,H,W') bool, ``cart`` (3,H,W') on ``device`` with W'
+    the padded width.  The needed columns cross PCIe once, as ONE (n_cols, H*W) fp32 block; ROI filter, tanh(intensity)
+    (Waymo), the 1e-9 of ``timedelta_ns``, the (F,H,W) layout and the mask are one kernel (``rv_table_to_range_view``).
+    The ``view`` feature (``loader.py:611-624``) is not selected by any shipped config and is not implemented."""
+    import numpy as np
+
+    names = list(range_view_config["feature_column_names"])
+    if "view" in names:
+        raise NotImplementedError("the 'view' feature (loader.py:611-624) is not selected by any shipped rv-* config")
+    h, w = int(range_view_config["height"]), int(range_view_config["width"])
+    roi = bool(range_view_config.get("filter_roi", False))
+    need: List[str] = []
+    for n in names + list(CART_COLUMNS) + ["range"] + (["is_within_roi"] if roi else []):
+        if n not in need:
+            need.append(n)
+    cols = []
+    for n in need:
+        c = table[n]
+        c = c.detach().cpu().numpy() if isinstance(c, Tensor) else np.asarray(c)
+        if c.shape != (h * w,):
+            raise L.RvError(f"column {n!r} has shape {c.shape}, expected ({h * w},) = height * width rows")
+        cols.append(c.astype(np.float32, copy=False))
+    host = torch.from_numpy(np.stack(cols))
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise L.RvError("range_view_from_table needs a CUDA (ROCm) device: the hot path has no CPU fallback")
+    block = host.pin_memory().to(dev, non_blocking=True)
+    feat_col = (ctypes.c_int32 * len(names))(*[need.index(n) for n in names])
+    feat_op = (ctypes.c_int32 * len(names))(*[1 if (n == "intensity" and dataset_name == "waymo") else (2 if n == "timedelta_ns" else 0) for n in names])
+    cart_col = (ctypes.c_int32 * 3)(*[need.index(n) for n in CART_COLUMNS])
+    features = torch.empty((len(names), h, w), dtype=torch.float32, device=dev)
+    cart = torch.empty((3, h, w), dtype=torch.float32, device=dev)
+    mask = torch.empty((1, h, w), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        L.call("rv_table_to_range_view", L.ptr(block), L.i32(len(need)), L.i64(h * w), L.i32(len(names)), feat_col, feat_op, cart_col,
+               L.i32(need.index("range")), L.i32(need.index("is_within_roi") if roi else -1), L.ptr(features), L.ptr(cart), L.ptr(mask),
+               L.stream_ptr())
+        features, m, cart = subsample_range_view(features, mask.bool(), cart, dataset_name, x_stride, padding_mode)
+    return {"features": features, "mask": m > 0.5 if m.dtype != torch.bool else m, "cart": cart}
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -239,6 +239,20 @@ class _PlExpr:
     def __and__(self, o):
         return self._bin(o, lambda a, b: a & b, keep_dtype=False)
 
+    def gt(self, o):
+        return self > o
+
+    def is_in(self, values):
+        vals = list(values)
+        return _PlExpr(lambda frame: np.isin(self.fn(frame), vals))
+
+    def tanh(self):  # polars keeps the column's float dtype
+        return _PlExpr(lambda frame: np.tanh(self.fn(frame)))
+
+    def cast(self, dtype):
+        npdt = {"Float32": np.float32, "Float64": np.float64, "Int64": np.int64}.get(dtype, dtype)
+        return _PlExpr(lambda frame: np.asarray(self.fn(frame)).astype(npdt))
+
     __hash__ = None
 
 
@@ -336,6 +350,22 @@ class _PlFrame:
         m = mask.fn(self._data) if isinstance(mask, _PlExpr) else np.asarray(mask)
         return _PlFrame({k: v[m] for k, v in self._data.items()})
 
+    def with_row_count(self, name: str = "row_nr") -> "_PlFrame":
+        return _PlFrame({name: np.arange(self.shape[0], dtype=np.uint32), **self._data})
+
+    def row(self, index: int):
+        return tuple(v[index].item() if hasattr(v[index], "item") else v[index] for v in self._data.values())
+
+    def __mul__(self, other):
+        """``frame * series``: every column times the series, element-wise (a Boolean series acts as 0 / 1; the column keeps its
+        dtype when it is a float, as in polars' arithmetic supertype rules for Float32 x Boolean)."""
+        o = other.values if isinstance(other, _PlSeries) else np.asarray(other)
+        out = {}
+        for k, v in self._data.items():
+            w = o.astype(v.dtype) if o.dtype == np.bool_ and v.dtype.kind in "fiu" else o
+            out[k] = (v.astype(np.uint8) * w.astype(np.uint8)).astype(np.bool_) if v.dtype == np.bool_ else v * w
+        return _PlFrame(out)
+
     def collect(self) -> "_PlFrame":
         return self
 
@@ -369,6 +399,13 @@ def _pl_col(*names):
         n = names[0]
         return _PlExpr(lambda frame: np.asarray(frame[n]), names=[n])
     return _PlExpr(None, names=list(names))
+
+
+def _pl_scan_ipc(path, **_: Any) -> _PlFrame:
+    import pyarrow.feather as feather
+
+    t = feather.read_table(str(path))
+    return _PlFrame({name: t.column(name).to_numpy(zero_copy_only=False) for name in t.column_names})
 
 
 def _pl_from_numpy(data: np.ndarray, schema: Dict[str, Any]) -> _PlFrame:

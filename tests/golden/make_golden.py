@@ -436,6 +436,64 @@ def gen_augment() -> None:
     save("augment", **out)
 
 
+def gen_loader_item() -> None:
+    """The loader's per-sweep contract (prototype/loader.py:568-705, ``DataLoader.__getitem__``): a range-view feather table
+    (H*W rows x named columns) -> ``features`` (F,H,W), ``cart`` (3,H,W), ``mask`` (1,H,W), W padded by ``subsample_range_view``.
+    The reference's own ``__getitem__`` is run (unbound, on a stand-in ``self``: the constructor walks a dataset directory)
+    on two synthetic tables written as feather files: AV2 columns with ``filter_roi`` and circular padding
+    (conf/model/baseline.yaml:57, range_view.yaml:141-149), Waymo columns with tanh(intensity) and constant padding
+    (conf/experiment/base-waymo.yaml:26-33)."""
+    import tempfile
+    import types
+    from pathlib import Path
+
+    import polars as pl  # stub
+    import pyarrow as pa
+    import pyarrow.feather as feather
+    from torchbox3d.prototype import loader as ref_loader
+
+    pl.scan_ipc = _ref_stubs._pl_scan_ipc
+    H, W = 8, 64
+    out = {}
+    for tag, ds, names, roi, mode in (("av2", "av2", ["intensity", "range", "x", "y", "z"], True, "circular"),
+                                      ("waymo", "waymo", ["elongation", "intensity", "range", "x", "y", "z"], False, "constant")):
+        rng = np.random.default_rng(31 if ds == "av2" else 32)
+        inc = np.linspace(0.2, -0.4, H)[:, None]
+        az = np.linspace(math.pi, -math.pi, W)[None, :]
+        r = (20.0 + 15.0 * np.sin(3 * az) + 10.0 * np.cos(7 * inc) + rng.random((H, W))).astype(np.float32)
+        keep = rng.random((H, W)) >= 0.1
+        r = (r * keep).astype(np.float32)
+        cols = {"x": (r * np.cos(inc) * np.cos(az)).astype(np.float32), "y": (r * np.cos(inc) * np.sin(az)).astype(np.float32),
+                "z": (r * np.sin(inc) * np.ones_like(az)).astype(np.float32), "range": r,
+                "intensity": ((rng.random((H, W)) * (255.0 if ds == "av2" else 3.0)) * keep).astype(np.float32),
+                "elongation": (rng.random((H, W)) * keep).astype(np.float32),
+                "laser_number": (np.arange(H)[:, None] * np.ones((1, W)) * keep).astype(np.float32),
+                "is_within_roi": rng.random((H, W)) >= 0.25}
+        tmp = Path(tempfile.mkdtemp())
+        lidar = tmp / "sweep.feather"
+        feather.write_feather(pa.table({k: v.reshape(-1) for k, v in cols.items()}), str(lidar), compression="uncompressed")
+        annp = tmp / "annotations.feather"
+        feather.write_feather(pa.table({"timestamp_ns": np.array([7, 7], dtype=np.int64), "num_interior_pts": np.array([5, 0], dtype=np.int64),
+                                        "category": np.array(["REGULAR_VEHICLE", "BUS"])}), str(annp), compression="uncompressed")
+        me = types.SimpleNamespace(
+            metadata=pl.DataFrame({"log_id": np.array(["log0"]), "timestamp_ns": np.array([7], dtype=np.int64)}),
+            categories=["REGULAR_VEHICLE"], annotations_path=lambda log_id: annp, lidar_path=lambda log_id, ts: lidar,
+            range_view_config=DictConfig({"feature_column_names": names, "filter_roi": roi, "height": H, "width": W}),
+            split_name="val", augmentations_config=None, dataset_name=ds, enable_database=False, db_config=None, x_stride=1,
+            padding_mode=mode, targets_config=None)
+        datum = ref_loader.DataLoader.__getitem__(me, 0)
+        for k in ("intensity", "range", "x", "y", "z", "elongation", "is_within_roi"):
+            out[f"{tag}/table/{k}"] = cols[k].reshape(-1)
+        out[f"{tag}/feature_column_names"] = np.array(names)
+        out[f"{tag}/padding_mode"] = np.array(mode)
+        out[f"{tag}/filter_roi"] = np.array(roi)
+        out[f"{tag}/features"] = datum["features"].numpy()
+        out[f"{tag}/cart"] = datum["cart"].numpy()
+        out[f"{tag}/mask"] = datum["mask"].numpy()
+        print(tag, "features", tuple(datum["features"].shape), "mask", datum["mask"].dtype, float(datum["mask"].float().mean()))
+    save("loader_item", **out)
+
+
 def gen_raw_sweep() -> None:
     """The converter's path from a RAW AV2 sweep to the range image (converters/av2/export.py:70-133 driving
     converters/av2/utils.py): unmotion_compensate (:231-295), correct_laser_numbers (:211-228), build_range_view (:32-105:
@@ -502,6 +560,9 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     if len(sys.argv) > 1 and sys.argv[1] == "raw_sweep":
         gen_raw_sweep()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "loader_item":
+        gen_loader_item()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "augment":  # (the other fixtures are unchanged since round 1)
         gen_augment()

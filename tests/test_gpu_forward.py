@@ -317,6 +317,38 @@ def test_z_buffer_fp64_vs_fp32_quirk():
     assert np.array_equal(win.cpu().numpy(), win_o) and np.array_equal(img.cpu().numpy(), img_o)
 
 
+def test_device_loader_item_matches_the_reference(golden, tmp_path):
+    """``range_view_from_table`` (rv_table_to_range_view + the padding kernel) against the reference's own ``__getitem__`` output:
+    everything but tanh(intensity) bit-exact (copies, 0/1 products, mask, circular / constant padding), tanh within 2 fp32 ulps
+    (device tanhf vs numpy).  Also through a feather file written and read back (the on-disk form of the contract)."""
+    import pyarrow as pa
+
+    from range_view_3d_detection_amd.prototype import loader as ld
+    from test_oracle_golden import _loader_case
+
+    g = golden("loader_item")
+    for tag, ds in (("av2", "av2"), ("waymo", "waymo")):
+        names, table, roi, mode = _loader_case(g, tag)
+        cfg = {"feature_column_names": names, "filter_roi": roi, "height": 8, "width": 64}
+        path = tmp_path / f"{tag}.feather"
+        with pa.OSFile(str(path), "wb") as sink:
+            t = pa.table(table)
+            with pa.ipc.new_file(sink, t.schema) as w:
+                w.write_table(t)
+        for src in (table, ld.read_sweep_table(path)):
+            got = ld.range_view_from_table(src, cfg, ds, 1, mode, device=DEV)
+            assert got["mask"].dtype == torch.bool and torch.equal(got["mask"].cpu(), torch.from_numpy(g.np(f"{tag}/mask")))
+            assert torch.equal(got["cart"].cpu(), torch.from_numpy(g.np(f"{tag}/cart")))
+            ref = torch.from_numpy(g.np(f"{tag}/features"))
+            for i, n in enumerate(names):
+                if n == "intensity" and ds == "waymo":
+                    assert float((got["features"][i].cpu() - ref[i]).abs().max()) <= 2.4e-7 * float(ref[i].abs().max()), (tag, n)
+                else:
+                    assert torch.equal(got["features"][i].cpu(), ref[i]), (tag, n)
+    with pytest.raises(Exception):
+        ld.range_view_from_table(table, cfg, ds, 1, mode, device="cpu")  # no CPU fallback
+
+
 def test_device_augmentations_match_the_reference(golden):
     """Loader augmentations on device (prototype/loader.py of this package -> rv_augment) against fixtures produced by the
     reference's own functions: pixel placement (every non-geometry channel) bit-exact, geometry 1e-6 of the channel

@@ -288,6 +288,29 @@ def test_augmentations_match_the_reference(golden):
     assert sh < 0 and np.array_equal(g.np("rotation_neg/sweep")[3], np.roll(s0[3], sh, axis=-1))
 
 
+def _loader_case(g, tag):
+    names = [str(n) for n in g.np(f"{tag}/feature_column_names")]
+    table = {k: g.np(f"{tag}/table/{k}") for k in ("intensity", "range", "x", "y", "z", "elongation", "is_within_roi")}
+    return names, table, bool(g.np(f"{tag}/filter_roi")), str(g.np(f"{tag}/padding_mode"))
+
+
+def test_loader_item_matches_the_reference(golden):
+    """Table -> (features, cart, mask) of DataLoader.__getitem__ (loader.py:568-705) against the reference's own output: AV2
+    columns with the ROI filter and circular padding, Waymo columns with tanh(intensity) and constant padding.  Copies,
+    products with 0/1 and the mask are exact; tanh is numpy's on both sides here."""
+    from oracle import loader as old
+
+    g = golden("loader_item")
+    for tag, ds in (("av2", "av2"), ("waymo", "waymo")):
+        names, table, roi, mode = _loader_case(g, tag)
+        got = old.range_view_from_table(table, names, 8, 64, ds, roi, 1, mode)
+        for k in ("features", "cart", "mask"):
+            ref = g.np(f"{tag}/{k}")
+            assert got[k].shape == ref.shape and got[k].dtype == ref.dtype, (tag, k, got[k].shape, ref.shape, got[k].dtype, ref.dtype)
+            assert np.array_equal(got[k], ref), (tag, k)
+        assert got["features"].shape[-1] == {"av2": 72, "waymo": 70}[tag]
+
+
 def test_raw_sweep_path_matches_the_reference(golden):
     from oracle import rawsweep as oraw
 
