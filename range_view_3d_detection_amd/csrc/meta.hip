@@ -48,21 +48,47 @@ __device__ __forceinline__ u32x4 pack8(const float* f) {
     return v;
 }
 
+// Work order of the two 9x-grid gather kernels.  Workgroups are dealt round-robin over the 8 XCDs (one L2 each); every pixel
+// reads the feature rows h-1, h, h+1 of its 3 x 3 neighbourhood.  XCD x therefore owns a COLUMN STRIP of the image
+// (ceil(W/8) columns, all rows, row after row): the three feature rows of its strip (3 x 128 KB at W = 2048, C = 256) stay in its
+// L2 while the 2.4 GB position / output tensors stream through, instead of every L2 fetching every feature row nine times.
+struct StripItem {
+    int64_t p;      // pixel index n*H*W + h*W + w
+    int64_t n, r;   // image, h*W + w
+    int h, w, k, oc;
+    bool ok;
+};
+__device__ __forceinline__ StripItem strip_item(int64_t q, int xcd, int N, int H, int W, int c8) {
+    const int ws = (W + 7) / 8;
+    StripItem it;
+    it.oc = (int)(q % c8);
+    q /= c8;
+    it.k = (int)(q % 9);
+    q /= 9;
+    const int wl = (int)(q % ws);
+    const int64_t row = q / ws;  // n*H + h
+    it.w = xcd * ws + wl;
+    it.n = row / H;
+    it.h = (int)(row - it.n * H);
+    it.ok = row < (int64_t)N * H && it.w < W;
+    it.r = (int64_t)it.h * W + it.w;
+    it.p = it.n * H * W + it.r;
+    return it;
+}
+
 // geo[p][k*C + c] = relu(scale*pos[p*9+k][c] + shift) * feat[nbr_k(p)][c]
 __global__ __launch_bounds__(256) void meta_modulate_kernel(const bf16_t* pos, const float* scale, const float* shift,
                                                             const bf16_t* feat, int ld_feat, int N, int H, int W, int C,
                                                             bf16_t* geo) {
     const int c8 = C / 8;
     const int64_t hw = (int64_t)H * W;
-    const int64_t total = (int64_t)N * hw * 9 * c8;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int oc = (int)(i % c8);
-        const int64_t pk = i / c8;  // p*9 + k
-        const int k = (int)(pk % 9);
-        const int64_t p = pk / 9;
-        const int64_t n = p / hw;
-        const int64_t r = p - n * hw;
-        const int h = (int)(r / W), w = (int)(r - (int64_t)h * W);
+    const int xcd = blockIdx.x & 7;
+    const int64_t per_xcd = (int64_t)N * H * ((W + 7) / 8) * 9 * c8, stride = (int64_t)(gridDim.x >> 3) * blockDim.x;
+    for (int64_t q = (int64_t)(blockIdx.x >> 3) * blockDim.x + threadIdx.x; q < per_xcd; q += stride) {
+        const StripItem it = strip_item(q, xcd, N, H, W, c8);
+        if (!it.ok) continue;
+        const int oc = it.oc, k = it.k, h = it.h, w = it.w;
+        const int64_t n = it.n, pk = it.p * 9 + k;
         const int hn = h + k / 3 - 1, wn = w + k % 3 - 1;
         float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (hn >= 0 && hn < H && wn >= 0 && wn < W) {
@@ -81,15 +107,13 @@ __global__ __launch_bounds__(256) void meta_modulate_bwd_pos_kernel(const bf16_t
                                                                     int N, int H, int W, int C, bf16_t* dpos) {
     const int c8 = C / 8;
     const int64_t hw = (int64_t)H * W;
-    const int64_t total = (int64_t)N * hw * 9 * c8;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int oc = (int)(i % c8);
-        const int64_t pk = i / c8;
-        const int k = (int)(pk % 9);
-        const int64_t p = pk / 9;
-        const int64_t n = p / hw;
-        const int64_t r = p - n * hw;
-        const int h = (int)(r / W), w = (int)(r - (int64_t)h * W);
+    const int xcd = blockIdx.x & 7;
+    const int64_t per_xcd = (int64_t)N * H * ((W + 7) / 8) * 9 * c8, stride = (int64_t)(gridDim.x >> 3) * blockDim.x;
+    for (int64_t q = (int64_t)(blockIdx.x >> 3) * blockDim.x + threadIdx.x; q < per_xcd; q += stride) {
+        const StripItem it = strip_item(q, xcd, N, H, W, c8);
+        if (!it.ok) continue;
+        const int oc = it.oc, k = it.k, h = it.h, w = it.w;
+        const int64_t n = it.n, pk = it.p * 9 + k;
         const int hn = h + k / 3 - 1, wn = w + k % 3 - 1;
         float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (hn >= 0 && hn < H && wn >= 0 && wn < W) {
@@ -140,7 +164,8 @@ __global__ __launch_bounds__(256) void meta_modulate_bwd_feat_kernel(const bf16_
 
 int grid_for(int64_t work) {
     int64_t b = (work + 255) / 256;
-    return (int)(b < 1 ? 1 : (b > 256 * 16 ? 256 * 16 : b));
+    b = (b + 7) & ~(int64_t)7;  // (the strip order deals whole rounds of 8 workgroups)
+    return (int)(b < 8 ? 8 : (b > 256 * 16 ? 256 * 16 : b));
 }
 
 }  // namespace

@@ -444,3 +444,28 @@ def test_batch_nms_device_path_equals_per_class_loop_and_oracle():
         hnms.FUSED_CLASSES_MAX = old
     for a, b_ in zip(small, loop):
         assert torch.equal(a, b_)
+
+
+@pytest.mark.parametrize("n_cls,k", [(1, 2500), (3, 4001)])
+def test_batch_nms_device_path_few_large_classes(n_cls, k):
+    """Waymo-like class counts: one / three classes with thousands of boxes each (class segments spanning dozens of mask words,
+    i.e. many blocks of the blocked scan) -- rows equal the per-class loop over the FFI bit for bit."""
+    from range_view_3d_detection_amd.math.ops import nms as hnms
+
+    cubs, scs, cats = [], [], []
+    for b in range(2):
+        cub, s = _random_boxes(k, 300 + b, 35.0)
+        cubs.append(cub)
+        scs.append(s)
+        cats.append(torch.randint(0, n_cls, (k,), generator=torch.Generator().manual_seed(20 + b)))
+    args = (torch.stack(cubs).to(DEV), torch.stack(scs).to(DEV), torch.stack(cats).to(DEV), 50000, 300, 0.3, 0.1, "weighted")
+    fast = hnms.batched_multiclass_nms(*args, n_classes=n_cls)
+    old = hnms.FUSED_CLASSES_MAX
+    hnms.FUSED_CLASSES_MAX = 0
+    try:
+        loop = hnms.batched_multiclass_nms(*args, n_classes=n_cls)
+    finally:
+        hnms.FUSED_CLASSES_MAX = old
+    assert fast[0].shape == loop[0].shape and fast[0].shape[0] >= 2 * n_cls * 100
+    for a, b_ in zip(fast, loop):
+        assert torch.equal(a, b_)
