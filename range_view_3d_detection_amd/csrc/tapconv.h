@@ -61,5 +61,5 @@ int rv_tapconv4_launch(const TapConvArgs& a, size_t lds, int bn, hipStream_t str
 
 // fifth-generation kernel (tapconv5.hip): 256 x 256 tiles with the input halo of a channel chunk resident in LDS for all
 // taps (multi-tap layers); stats rows = 2 * tiles
-bool rv_tapconv5_plan(TapConvArgs* a, int* tiles, size_t* lds);
-int rv_tapconv5_launch(const TapConvArgs& a, size_t lds, hipStream_t stream);
+bool rv_tapconv5_plan(TapConvArgs* a, int* tiles, size_t* lds, int* bn);
+int rv_tapconv5_launch(const TapConvArgs& a, size_t lds, int bn, hipStream_t stream);

@@ -442,20 +442,20 @@ static int tap_launch(const rvTapGeom* g, const rvTapShape* s, bool scatter, con
 
     // multi-tap layers with 256-channel output tiles: input halo resident in LDS across the taps (tapconv5.hip)
     if (g_tapconv5_enable && getenv("RV3D_NO_TAPCONV5") == nullptr) {
-        int tiles;
+        int tiles, bn5;
         size_t lds5;
         TapConvArgs a5 = a;
-        if (rv_tapconv5_plan(&a5, &tiles, &lds5)) {
+        if (rv_tapconv5_plan(&a5, &tiles, &lds5, &bn5)) {
             if (stats_rows) *stats_rows = tiles * 2;
             if (bnb_rows) *bnb_rows = tiles;
             if (info) {
                 info[0] = 5;
-                info[1] = 256;
+                info[1] = bn5;
                 info[2] = tiles;
                 info[3] = a5.n_tiles;
             }
             if (dry_run) return 0;
-            return rv_tapconv5_launch(a5, lds5, (hipStream_t)stream);
+            return rv_tapconv5_launch(a5, lds5, bn5, (hipStream_t)stream);
         }
     }
     if (a.flags & RV_OUT_BNB) {  // only the fifth-generation kernel carries that epilogue

@@ -35,7 +35,6 @@ namespace {
 constexpr int kTC = 32;                  // tile columns
 constexpr int kTR = 8;                   // tile rows
 constexpr int kBK = 64;                  // K tile (channels of one tap)
-constexpr int kBN = 256;                 // channels per workgroup
 constexpr int kPitch = 36;               // halo row pitch in pixel slots (>= 34 used columns).  36 = 4 (mod 8): the swizzle of
                                          // row r+1 is the swizzle of row r with the two 64-byte halves of the line swapped,
                                          // so ONE address computation per K tile serves all four rows a wave reads
@@ -53,6 +52,7 @@ __device__ __attribute__((aligned(256))) uint32_t g_zero_page5[64];
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
+template <int kBN>  // channels per workgroup: 256, or 128 (narrow layers: one weight piece per K tile, two phases)
 __global__ __launch_bounds__(512, 2) void tapconv5_kernel(const TapConvArgs a) {
     constexpr int NJ = kBN / 64;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -107,14 +107,15 @@ __global__ __launch_bounds__(512, 2) void tapconv5_kernel(const TapConvArgs a) {
     // are wave-uniform.
     const int64_t w_img = (int64_t)a.C_dst * a.C_src;
     const bf16_t* w_ph = a.w + (int64_t)a.tt.w_first[ph] * w_img;
-    const int b_voff = (n0 + (wave >> 2) * 64 + (wave & 3) * 8 + s_row) * a.C_src + kq8;
-    const int b_halfstep = 128 * a.C_src, b_nqstep = 32 * a.C_src;
+    // (kBN = 128: a piece is the whole K tile -- wave column e >> 2 owns 32 channels, no channel halves)
+    const int b_voff = (n0 + (wave >> 2) * (kBN / 4) + (wave & 3) * 8 + s_row) * a.C_src + kq8;
+    const int b_halfstep = (kBN / 2) * a.C_src, b_nqstep = kBN == 256 ? 32 * a.C_src : 0;
 
     // B piece number j (0, 1, 2, ...) = (K tile j >> 1, channel half j & 1) lives in ring slot j & 3.
     int bq = 0, bt = 0;  // K tile / tap of the piece pair being issued
     int b_so = 0;        // element offset of its (tap image, chunk) in the packed weight -- kept scalar
     auto stage_b = [&](int j, int half) {  // this wave's instruction of one half of piece j
-        const int so = __builtin_amdgcn_readfirstlane(b_so + (j & 1) * b_nqstep + half * b_halfstep);
+        const int so = __builtin_amdgcn_readfirstlane(b_so + (kBN == 256 ? (j & 1) * b_nqstep : 0) + half * b_halfstep);
         const bf16_t* p = w_ph + so + b_voff;
         __builtin_amdgcn_global_load_lds((glb_void_t*)p, (lds_void_t*)(smem + kRing + (j & 3) * kPiece + (half * 8 + wave) * 1024), 16, 0, 0);
     };
@@ -201,6 +202,7 @@ __global__ __launch_bounds__(512, 2) void tapconv5_kernel(const TapConvArgs a) {
     __builtin_amdgcn_s_barrier();
 #define RV_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 
+    if constexpr (kBN == 256) {
     // ---- prologue: halo of chunk 0, weight pieces 0, 1, 2 and the first half of 3 --------------------------------------
 #pragma unroll
     for (int i = 0; i < 6; ++i) stage_halo(0, i, 0);
@@ -273,6 +275,69 @@ __global__ __launch_bounds__(512, 2) void tapconv5_kernel(const TapConvArgs a) {
     if (wr == 0) __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    } else {
+    // ---- kBN = 128: piece j IS K tile j.  Two phases per K tile (pixel halves MQ = 0, 1 against the one weight fragment
+    // set), one weight instruction per wave and phase as above: phase 0 issues the second half of piece kt+3, phase 1 the first
+    // half of piece kt+4 (into the slot of piece kt, read in phase 0).  The next chunk's halo goes out one instruction per
+    // phase during K tiles U = 0, 1, 2 of the current chunk.  One counted wait per K tile, in phase 1 (a wave's wait + the
+    // barrier that follows make piece kt+1 visible to the reads of the next K tile's phase 0): five younger weight instructions
+    // plus the halo instructions issued among them -- those of positions U-2, U-1, U: 2, 4, 6, 4, 2 at U = 0..4, none after
+    // (hence T >= 6: the last K tile of a chunk waits with 5, which also retires the next chunk's halo).
+#pragma unroll
+    for (int i = 0; i < 6; ++i) stage_halo(0, i, 0);
+    stage_b(0, 0);
+    stage_b(0, 1);
+    advance_b();
+    stage_b(1, 0);
+    stage_b(1, 1);
+    advance_b();
+    stage_b(2, 0);
+    stage_b(2, 1);
+    advance_b();
+    stage_b(3, 0);
+    RV_WAIT_VM(0);
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();  // the second half of the workgroup runs one barrier behind the first
+
+    int kt = 0, kc = 0;
+    int sh = sh0, ix = 0;
+#define RV_KTILE128(U, W)                                                                                          \
+    {                                                                                                              \
+        const int hbuf = (kc + 1) & 1;                                                                             \
+        stage_b(kt + 3, 1);                                                                                        \
+        advance_b();                                                                                               \
+        if constexpr ((U) <= 2) stage_halo(hbuf, 2 * (U), kc + 1);                                                 \
+        addr_a((kc & 1) * kHaloBytes, sh);                                                                         \
+        read_b(fb0, kt);                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+        read_a(0);                                                                                                 \
+        RV_PHASE_COMPUTE(0, 0, fb0);                                                                               \
+        stage_b(kt + 4, 0);                                                                                        \
+        if constexpr ((U) <= 2) stage_halo(hbuf, 2 * (U) + 1, kc + 1);                                             \
+        read_a(1);                                                                                                 \
+        RV_WAIT_VM(W);                                                                                             \
+        RV_PHASE_COMPUTE(1, 0, fb0);                                                                               \
+        ++kt;                                                                                                      \
+        const bool wrap = ix + 1 == ncol;                                                                          \
+        sh += wrap ? sh_drow : sh_dcol;                                                                            \
+        ix = wrap ? 0 : ix + 1;                                                                                    \
+    }
+    for (; kc + 1 < nkc; ++kc) {
+        RV_KTILE128(0, 7)
+        RV_KTILE128(1, 9)
+        RV_KTILE128(2, 11)
+        RV_KTILE128(3, 9)
+        RV_KTILE128(4, 7)
+        for (int t = 5; t < T; ++t) RV_KTILE128(5, 5)
+        sh = sh0;
+        ix = 0;
+    }
+    for (int t = 0; t < T; ++t) RV_KTILE128(5, 5)  // last chunk: no halo to load
+#undef RV_KTILE128
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    }
 #undef RV_MFMA_HALF
 #undef RV_PHASE_COMPUTE
 #undef RV_WAIT_VM
@@ -348,7 +413,7 @@ __global__ __launch_bounds__(512, 2) void tapconv5_kernel(const TapConvArgs a) {
     const bool bnb = a.flags & RV_OUT_BNB;
     float bsc[8], bsh[8], bmu[8], bis[8], s0[8], s1[8];
     if (bnb) {
-        const int c = n0 + (tid & (kChunks - 1)) * 8;
+        const int c = n0 + (tid & (kChunks - 1)) * 8;  // (512 % kChunks == 0: the chunk of a thread is the same in every pass)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             bsc[j] = a.bnb_scale[c + j];
@@ -405,27 +470,32 @@ __global__ __launch_bounds__(512, 2) void tapconv5_kernel(const TapConvArgs a) {
         }
     }
     if (bnb) {
-        // lanes l and l + 32 of a wave hold the same chunk; then the eight waves through LDS (the staged tile is dead now)
+        // lanes kChunks apart hold the same chunk; then the eight waves through LDS (the staged tile is dead now)
         __syncthreads();
-        float* red = (float*)smem;  // [8 waves][32 chunks][16]
+        float* red = (float*)smem;  // [8 waves][kChunks][16]
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            s0[j] += __shfl_xor(s0[j], 32, 64);
-            s1[j] += __shfl_xor(s1[j], 32, 64);
+#pragma unroll
+            for (int d = kChunks; d < 64; d <<= 1) {
+                s0[j] += __shfl_xor(s0[j], d, 64);
+                s1[j] += __shfl_xor(s1[j], d, 64);
+            }
         }
-        if (lane < 32) {
+        if (lane < kChunks) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                red[(wave * 32 + lane) * 16 + j] = s0[j];
-                red[(wave * 32 + lane) * 16 + 8 + j] = s1[j];
+                red[(wave * kChunks + lane) * 16 + j] = s0[j];
+                red[(wave * kChunks + lane) * 16 + 8 + j] = s1[j];
             }
         }
         __syncthreads();
-        const int chunk = tid >> 4, jj = tid & 15;  // 32 chunks x 16 values = 512 threads
-        float sum = 0.f;
+        const int chunk = tid >> 4, jj = tid & 15;  // kChunks x 16 values
+        if (chunk < kChunks) {
+            float sum = 0.f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) sum += red[(w * 32 + chunk) * 16 + jj];
-        a.bnb_partial[((int64_t)tile * 2 + (jj >> 3)) * a.C_dst + n0 + chunk * 8 + (jj & 7)] = sum;
+            for (int w = 0; w < 8; ++w) sum += red[(w * kChunks + chunk) * 16 + jj];
+            a.bnb_partial[((int64_t)tile * 2 + (jj >> 3)) * a.C_dst + n0 + chunk * 8 + (jj & 7)] = sum;
+        }
     }
 }
 
@@ -434,16 +504,19 @@ __global__ __launch_bounds__(512, 2) void tapconv5_kernel(const TapConvArgs a) {
 extern int g_tapconv4_min_blocks;
 
 // returns false when the layer is not eligible (caller falls back to tapconv4 / tapconv3 / ...)
-bool rv_tapconv5_plan(TapConvArgs* a, int* tiles, size_t* lds) {
+bool rv_tapconv5_plan(TapConvArgs* a, int* tiles, size_t* lds, int* bn) {
     if (a->step != 1) return false;
     if (a->flags & (RV_IN_AFFINE | RV_IN_RELU | RV_OUT_F32)) return false;  // the DMA path has no register prologue
     if ((a->flags & RV_OUT_BNB) && (a->flags & RV_OUT_ACCUM)) return false;   // the sums are formed from this launch's values only
-    if (a->C_src % kBK != 0 || a->C_dst % kBN != 0) return false;
+    if (a->C_src % kBK != 0 || a->C_dst % 128 != 0) return false;
+    const int kBN = a->C_dst % 256 == 0 ? 256 : 128;  // narrow layers: 128-channel tiles, one weight piece per K tile
+    const int min_taps = kBN == 256 ? 3 : 6;          // (K tiles the next chunk's halo needs to land, see the kernel)
+    *bn = kBN;
     const int wm_total = a->W_dst / a->phases;
     if (wm_total < kTC || a->H < kTR) return false;
     if (kTR + a->tt.rows - 1 > kHaloRows) return false;
     for (int r = 0; r < a->phases; ++r) {
-        if (a->tt.ntaps[r] < 3 || a->tt.ntaps[r] > 16) return false;  // (the halo of the next chunk needs three K tiles to land)
+        if (a->tt.ntaps[r] < min_taps || a->tt.ntaps[r] > 16) return false;
         const int hw = kTC + a->tt.dw_max[r] - a->tt.dw_min[r];
         if (hw > 34) return false;
         // the kernel steps through the taps as a (rows x columns) grid: check that this phase's table is one
@@ -478,13 +551,17 @@ bool rv_tapconv5_plan(TapConvArgs* a, int* tiles, size_t* lds) {
     return true;
 }
 
-int rv_tapconv5_launch(const TapConvArgs& a, size_t lds, hipStream_t stream) {
+int rv_tapconv5_launch(const TapConvArgs& a, size_t lds, int bn, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)tapconv5_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)tapconv5_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)tapconv5_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(tapconv5_kernel, dim3(8 * a.tiles_per_xcd * a.n_tiles), dim3(512), lds, stream, a);
+    if (bn == 256)
+        hipLaunchKernelGGL(tapconv5_kernel<256>, dim3(8 * a.tiles_per_xcd * a.n_tiles), dim3(512), lds, stream, a);
+    else
+        hipLaunchKernelGGL(tapconv5_kernel<128>, dim3(8 * a.tiles_per_xcd * a.n_tiles), dim3(512), lds, stream, a);
     RV_CHECK_LAUNCH("tapconv5_kernel");
     return 0;
 }

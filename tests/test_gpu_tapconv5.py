@@ -48,7 +48,12 @@ def _run(module, x, stats=False):
                                                  (128, 512, 2, 64, 256, True),    # two channel tiles, two chunks, bias
                                                  (192, 256, 4, 17, 1030, False),  # three chunks, one-row last tile row
                                                  (512, 256, 1, 64, 288, False),   # eight chunks
-                                                 (64, 256, 8, 8, 32, False)])     # a single tile per image
+                                                 (64, 256, 8, 8, 32, False),      # a single tile per image
+                                                 # 128-channel tiles (one weight piece per K tile, two phases, its own wait counts)
+                                                 (64, 128, 4, 30, 520, False),    # one chunk
+                                                 (128, 128, 2, 64, 256, True),    # two chunks, bias
+                                                 (320, 128, 3, 17, 1030, False),  # five chunks, ragged
+                                                 (128, 384, 1, 16, 96, False)])   # three channel tiles of 128
 def test_gather_3x3_exact(cin, cout, N, H, W, bias):
     g = torch.Generator().manual_seed(cin + W)
     m = torch.nn.Conv2d(cin, cout, 3, padding=1, bias=bias)
@@ -82,9 +87,10 @@ def test_gather_other_kernels_exact(kh, kw):
 
 @pytest.mark.parametrize("kernel,stride,padding,N,H,W", [((3, 4), (1, 2), (1, 1), 4, 16, 512), ((3, 8), (1, 4), (1, 2), 4, 16, 256),
                                                          ((3, 4), (1, 2), (1, 1), 3, 21, 600)])
-def test_scatter_conv_transpose_exact(kernel, stride, padding, N, H, W):
+@pytest.mark.parametrize("cout", [256, 128])
+def test_scatter_conv_transpose_exact(kernel, stride, padding, N, H, W, cout):
     g = torch.Generator().manual_seed(W)
-    m = torch.nn.ConvTranspose2d(128, 256, kernel_size=kernel, stride=stride, padding=padding, bias=False)
+    m = torch.nn.ConvTranspose2d(128, cout, kernel_size=kernel, stride=stride, padding=padding, bias=False)
     m.weight.data = _ints(m.weight.shape, g, -2, 3)
     x = _ints((N, 128, H, W), g)
     ref = F.conv_transpose2d(x, m.weight.data, stride=stride, padding=padding)
@@ -119,11 +125,12 @@ def test_input_gradient_and_accumulate_exact():
         assert torch.equal(got, want)
 
 
-def test_repeatable_on_random_data():
+@pytest.mark.parametrize("cout", [512, 128])
+def test_repeatable_on_random_data(cout):
     """Race screen (see test_gpu_tapconv4.py): fixed summation order => repeated launches on random data agree bit for bit;
     a halo or weight piece read before its DMA landed, or overwritten while still being read, shows up as a difference."""
     g = torch.Generator().manual_seed(9)
-    m = torch.nn.Conv2d(512, 512, 3, padding=1, bias=False)
+    m = torch.nn.Conv2d(512, cout, 3, padding=1, bias=False)
     m.weight.data = torch.randn(m.weight.shape, generator=g) * 0.05
     m = m.to(DEV)
     x = torch.randn(4, 512, 64, 1024, generator=g).bfloat16().float().to(DEV)
@@ -135,7 +142,8 @@ def test_repeatable_on_random_data():
         assert torch.equal(first, again)
 
 
-@pytest.mark.parametrize("cin,c,N,H,W,relu", [(64, 256, 2, 24, 200, True), (64, 512, 1, 17, 96, True), (128, 256, 2, 16, 64, False)])
+@pytest.mark.parametrize("cin,c,N,H,W,relu", [(64, 256, 2, 24, 200, True), (64, 512, 1, 17, 96, True), (128, 256, 2, 16, 64, False),
+                                              (64, 128, 2, 24, 200, True)])
 def test_data_grad_launch_forms_the_batchnorm_backward_sums(cin, c, N, H, W, relu, monkeypatch):
     """conv -> BatchNorm(+ReLU) -> conv: the second conv's backward-data launch (``rv_tap_data_grad_bnb``) also emits
     sum(g), sum(g*xhat) of the BatchNorm between them, so ``rv_bn_bwd_reduce`` is not launched.  Same tape run both ways:
