@@ -86,6 +86,8 @@ int rv_unpack_weight_grad(const rvTapGeom* g, const float* packed, float* dT, in
 #define RV_OUT_BIAS 8    /* dst += bias[c] */
 #define RV_OUT_STATS 16  /* write per-block partial sum / sum-of-squares of the fp32 result */
 #define RV_OUT_ACCUM 32  /* dst += result (gradient fan-in); bf16 dst only */
+#define RV_WGRAD_TORCH_LAYOUT 128 /* rv_tap_wgrad only: dT_packed receives the torch layout dT[cu][cv][kh][kw] (cu*cv*kh*kw fp32,
+                                  * no padding) straight from the split-K reduction -- no rv_unpack_weight_grad pass */
 
 typedef struct {
     int32_t N, H, Wu, Wv; /* U is (N,H,Wu), V is (N,H,Wv) */

@@ -215,8 +215,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
         }
 }
 
+// torch layout of the result (RV_WGRAD_TORCH_LAYOUT): dT[cu][cv][kh][kw] instead of the packed [tap][cu_pad][cv_pad]
+struct UnpackTo {
+    int32_t on, cu, cv, cu_pad, cv_pad, taps;
+};
+
 // sum of the split-K slabs in slab order (bitwise reproducible); elems is a multiple of 1024 (padded channel counts)
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, int ksplit, int64_t elems, float* out) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, int ksplit, int64_t elems, float* out, const UnpackTo up) {
     const int64_t n4 = elems >> 2;
     const f32x4* in = (const f32x4*)slabs;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
@@ -228,7 +233,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, i
             s = (((s + a) + b) + c) + d;
         }
         for (; k < ksplit; ++k) s += in[(int64_t)k * n4 + i];
-        ((f32x4*)out)[i] = s;
+        if (!up.on) {
+            ((f32x4*)out)[i] = s;
+            continue;
+        }
+        // packed index (tap, u, v0..v0+3) -> dT[(u*cv + v)*taps + tap]; the padding rows / columns are dropped
+        const int64_t e = i * 4;
+        const int v0 = (int)(e % up.cv_pad);
+        const int64_t r = e / up.cv_pad;
+        const int u = (int)(r % up.cu_pad), tap = (int)(r / up.cu_pad);
+        if (u >= up.cu) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (v0 + j < up.cv) out[((int64_t)u * up.cv + v0 + j) * up.taps + tap] = s[j];
     }
 }
 
@@ -771,6 +788,13 @@ extern "C" int rv_tap_wgrad(const rvTapGeom* g, const rvTapShape* s, const void*
     RV_REQUIRE(g->kh * g->kw <= kMaxTaps, "rv_tap_wgrad: kernel %dx%d unsupported", g->kh, g->kw);
     WgradPlan p;
     plan(g, s, &p);
+    UnpackTo up;
+    up.on = (s->flags & RV_WGRAD_TORCH_LAYOUT) ? 1 : 0;
+    up.cu = g->cu;
+    up.cv = g->cv;
+    up.cu_pad = rv_pad32(g->cu);
+    up.cv_pad = rv_pad32(g->cv);
+    up.taps = g->kh * g->kw;
     if (p.v2) {
         Wgrad2Args b;
         memset(&b, 0, sizeof(b));
@@ -794,7 +818,7 @@ extern "C" int rv_tap_wgrad(const rvTapGeom* g, const rvTapShape* s, const void*
         b.chunks = p.chunks;
         b.tiles_u = p.tiles_u;
         b.tiles_v = p.tiles_v;
-        b.flags = s->flags;
+        b.flags = s->flags & ~RV_WGRAD_TORCH_LAYOUT;
         b.v_affine = v_affine;
         b.xcd_remap = 1;
         int gi = 0;
@@ -824,7 +848,7 @@ extern "C" int rv_tap_wgrad(const rvTapGeom* g, const rvTapShape* s, const void*
             RV_CHECK_LAUNCH("wgrad2_kernel");
         }
         const int rb2 = (int)((p.elems / 4 + 255) / 256 < 4096 ? (p.elems / 4 + 255) / 256 : 4096);
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb2), dim3(256), 0, st2, (const float*)workspace, p.ksplit, p.elems, dT_packed);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb2), dim3(256), 0, st2, (const float*)workspace, p.ksplit, p.elems, dT_packed, up);
         RV_CHECK_LAUNCH("wgrad_reduce_kernel");
         return 0;
     }
@@ -850,7 +874,7 @@ extern "C" int rv_tap_wgrad(const rvTapGeom* g, const rvTapShape* s, const void*
     a.k_per_split = p.k_per_split;
     a.tiles_u = p.tiles_u;
     a.tiles_v = p.tiles_v;
-    a.flags = s->flags;
+    a.flags = s->flags & ~RV_WGRAD_TORCH_LAYOUT;
     a.v_affine = v_affine;
     for (int ky = 0; ky < g->kh; ++ky)
         for (int kx = 0; kx < g->kw; ++kx) {
@@ -862,7 +886,7 @@ extern "C" int rv_tap_wgrad(const rvTapGeom* g, const rvTapShape* s, const void*
     hipLaunchKernelGGL(wgrad_kernel, dim3(grid), dim3(256), 0, st, a);
     RV_CHECK_LAUNCH("wgrad_kernel");
     const int rb = (int)((p.elems / 4 + 255) / 256 < 4096 ? (p.elems / 4 + 255) / 256 : 4096);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, st, (const float*)workspace, p.ksplit, p.elems, dT_packed);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, st, (const float*)workspace, p.ksplit, p.elems, dT_packed, up);
     RV_CHECK_LAUNCH("wgrad_reduce_kernel");
     return 0;
 }

@@ -98,13 +98,12 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
         u, v, v_affine = dout, src, 1
     else:
         u, v, v_affine = src, dout, 0
-    wshape = L.TapShape(sp.N, sp.H, sp.Wu, sp.Wv, 0, 0, in_flags)
+    wshape = L.TapShape(sp.N, sp.H, sp.Wu, sp.Wv, 0, 0, in_flags | L.WGRAD_TORCH_LAYOUT)
 
     def run_wgrad() -> None:
         ws_bytes = L.load().rv_tap_wgrad_workspace_bytes(ctypes.byref(g), ctypes.byref(wshape))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=t.device)
-        cu_p, cv_p = pad32(g.cu), pad32(g.cv)
-        packed = torch.empty((g.kh * g.kw, cu_p, cv_p), dtype=torch.float32, device=t.device)
+        grad = torch.empty((g.cu, g.cv, g.kh, g.kw), dtype=torch.float32, device=t.device)
         wname = "wgrad_kernel(+reduce)"
         if E.PROFILE is not None:
             winfo = (ctypes.c_int32 * 4)()
@@ -112,11 +111,10 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
             wname = ("wgrad_kernel", "wgrad_kernel", "wgrad2_kernel", "wgrad3_kernel")[winfo[0]] + "(+reduce)"
         if os.environ.get("RV3D_PROFILE_SHAPES"):
             wname += f" k{g.kh}x{g.kw}s{g.stride_w} {g.cu}<->{g.cv} {wshape.N}x{wshape.H}x{wshape.Wu}"
+        # the split-K reduction writes the torch layout dT[cu][cv][kh][kw] itself (RV_WGRAD_TORCH_LAYOUT): no unpack pass
         E._launch(wname, E.tap_flops(g, wshape),
                   lambda: L.call("rv_tap_wgrad", ctypes.byref(g), ctypes.byref(wshape), u.ptr(), L.i32(u.ld), v.ptr(), L.i32(v.ld),
-                                 L.ptr(sc), L.ptr(sh), L.i32(v_affine), L.ptr(packed), L.ptr(ws), L.stream_ptr()))
-        grad = torch.empty((g.cu, g.cv, g.kh, g.kw), dtype=torch.float32, device=t.device)
-        L.call("rv_unpack_weight_grad", ctypes.byref(g), L.ptr(packed), L.ptr(grad), L.i32(0), L.stream_ptr())
+                                 L.ptr(sc), L.ptr(sh), L.i32(v_affine), L.ptr(grad), L.ptr(ws), L.stream_ptr()))
         t.add_param_grad(layer.weight, layer.unpermute_grad(grad))
 
     if E.OVERLAP_WGRAD:
