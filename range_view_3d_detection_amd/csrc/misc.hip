@@ -35,7 +35,12 @@ struct PackArgs {
     int phases;
 };
 
-__global__ void pack_weight_kernel(const PackArgs a) {
+struct PackArgs2 {  // both forms in one launch: blockIdx.y selects
+    PackArgs f[2];
+};
+
+__global__ void pack_weight_kernel(const PackArgs2 both) {
+    const PackArgs& a = both.f[blockIdx.y];
     const int taps = a.kh * a.kw;
     const int64_t per_img = (int64_t)a.cu_pad * a.cv_pad;
     const int64_t total = per_img * taps;
@@ -86,11 +91,13 @@ extern "C" int64_t rv_packed_weight_bytes(const rvTapGeom* g) {
 
 extern "C" int rv_pack_weight(const rvTapGeom* g, const float* T, void* gather_w, void* scatter_w, rvStream stream) {
     RV_REQUIRE(g && T, "rv_pack_weight: null argument");
+    PackArgs2 both;
+    memset(&both, 0, sizeof(both));
+    int n = 0;
     for (int form = 0; form < 2; ++form) {
         void* out = form ? scatter_w : gather_w;
         if (!out) continue;
-        PackArgs a;
-        memset(&a, 0, sizeof(a));
+        PackArgs& a = both.f[n++];
         int step;
         if (rv_build_tap_table(g, form == 1, &a.tt, &a.phases, &step)) return 1;
         a.T = T;
@@ -102,11 +109,12 @@ extern "C" int rv_pack_weight(const rvTapGeom* g, const float* T, void* gather_w
         a.kh = g->kh;
         a.kw = g->kw;
         a.scatter = form;
-        const int64_t total = (int64_t)a.kh * a.kw * a.cu_pad * a.cv_pad;
-        const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-        hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
-        RV_CHECK_LAUNCH("pack_weight_kernel");
     }
+    if (n == 0) return 0;
+    const int64_t total = (int64_t)g->kh * g->kw * rv_pad32(g->cu) * rv_pad32(g->cv);
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, both);  // one launch for both forms
+    RV_CHECK_LAUNCH("pack_weight_kernel");
     return 0;
 }
 

@@ -375,11 +375,12 @@ class TapLayer:
             self._version = ver
         if form not in self._packed:
             nbytes = L.load().rv_packed_weight_bytes(ctypes.byref(self.geom))
-            buf = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=self.weight.device)
             w = self._torch_weight()
-            g, s = (buf, None) if form == "gather" else (None, buf)
-            L.call("rv_pack_weight", ctypes.byref(self.geom), L.ptr(w), L.ptr(g), L.ptr(s), L.stream_ptr())
-            self._packed[form] = buf
+            # a training step needs both images (forward in one form, backward-data in the other): one launch writes both
+            forms = ("gather", "scatter") if (torch.is_grad_enabled() and self.weight.requires_grad and not self._packed) else (form,)
+            bufs = {f: torch.empty(nbytes // 2, dtype=torch.bfloat16, device=self.weight.device) for f in forms}
+            L.call("rv_pack_weight", ctypes.byref(self.geom), L.ptr(w), L.ptr(bufs.get("gather")), L.ptr(bufs.get("scatter")), L.stream_ptr())
+            self._packed.update(bufs)
         return self._packed[form]
 
 
