@@ -113,6 +113,11 @@ class Detector(torch.nn.Module):
         return losses["loss"]
 
 
+def _progress(msg: str) -> None:
+    """Progress lines on stderr (stdout carries the one JSON line): a long silent run looks hung to whoever launched it."""
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def _cpu_model() -> str:
     try:
         with open("/proc/cpuinfo") as f:
@@ -139,6 +144,12 @@ def cpu_baseline(seconds_budget: float = 45.0, full: bool = False):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
+    try:  # a cgroup CPU quota below the affinity mask (a shared GPU box): more threads than the quota only get throttled
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, int(math.ceil(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        pass
     H, W_full = 64, 2048
     backbone, head = build_model("rv-av2", AV2_CLASSES)
     sd = {**{f"backbone.{k}": v for k, v in backbone.state_dict().items()}, **{f"head.{k}": v for k, v in head.state_dict().items()}}
@@ -161,6 +172,7 @@ def cpu_baseline(seconds_budget: float = 45.0, full: bool = False):
         torch.set_num_threads(th)
         run(32)  # warm-up (allocator, thread pool), discarded
         probes[th] = run(32)
+        _progress(f"cpu_baseline probe: 64x32 crop on {th} threads {probes[th]:.2f} s")
     threads = min(probes, key=probes.get)
     torch.set_num_threads(threads)
     W = W_full
@@ -168,8 +180,12 @@ def cpu_baseline(seconds_budget: float = 45.0, full: bool = False):
         W = 32
         while W < W_full and probes[threads] * (2 * W / 32) * 3 < seconds_budget:  # warm-up + two timed iterations within the budget
             W *= 2
-    run(W)  # warm-up at the timed size
-    times = [run(W), run(W)]
+    _progress(f"cpu_baseline: 64x{W} crop on {threads} threads, 1 warm-up + 2 timed iterations")
+    times = []
+    for i in range(3):  # the first one is the warm-up at the timed size
+        times.append(run(W))
+        _progress(f"cpu_baseline iteration {i}: {times[-1]:.1f} s")
+    times = times[1:]
     dt = sum(times) / len(times)
     return {
         "value": (W / W_full) / dt, "unit": "sweeps/s", "cores": threads, "kind": "port",
@@ -265,9 +281,11 @@ def main() -> None:
         sched.step()
         return loss
 
+    _progress(f"model on {dev}, {args.batch} sweeps of {args.height}x{args.width}x{args.features}; warm-up")
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    _progress("warm-up done; timed region")
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -281,6 +299,7 @@ def main() -> None:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    _progress(f"timed region done: {1e3 * elapsed / args.steps:.1f} ms per step")
     prof = E.PROFILE
     sync_calls, sync_bytes = E.COLLECTIVES.calls / args.steps, E.COLLECTIVES.bytes / args.steps
     # the same per-kernel events once more, outside the timed region, with the weight-gradient side stream off: with

@@ -204,6 +204,7 @@ int rv_ew_combine(int64_t pixels, int32_t c, const void* a, int32_t ld_a, const 
  * Replaces cuDNN BatchNorm backward + ReLU backward + the add's gradient fan-out. */
 #define RV_BNB_RELU_Z 1
 #define RV_BNB_RES_ACCUM 2
+#define RV_BNB_Y_FROM_INPUT 4 /* rv_bn_bwd_smallk*: y (may be NULL) is recomputed as W v from the conv input and w_packed */
 int32_t rv_bn_bwd_rows(int64_t pixels);
 int rv_bn_bwd_reduce(int64_t pixels, int32_t c, const void* dout, int32_t ld_dout, const void* out, int32_t ld_out,
                      const void* y, int32_t ld_y, const float* scale, const float* shift, const float* mean,
@@ -230,8 +231,8 @@ int rv_bn_bwd_smallk(int64_t pixels, int32_t c, const void* dout, int32_t ld_dou
  * and (B) forms the gradients (global_s01 == NULL: single rank). */
 int rv_bn_bwd_smallk_sums(int64_t pixels, int32_t c, const void* dout, int32_t ld_dout, const void* out, int32_t ld_out,
                           const void* y, int32_t ld_y, const float* scale, const float* shift, const float* mean,
-                          const float* invstd, int32_t flags, const void* v, int32_t ld_v, int32_t cin, double* sums,
-                          double* moms, void* workspace, rvStream stream);
+                          const float* invstd, int32_t flags, const void* v, int32_t ld_v, int32_t cin, const void* w_packed,
+                          int32_t ld_w, double* sums, double* moms, void* workspace, rvStream stream);
 int rv_bn_bwd_smallk_from_sums(int32_t c, int32_t cin, const double* sums, const double* moms, const double* global_s01,
                                const void* w_packed, int32_t ld_w, const float* gamma, const float* stat_mean,
                                const float* stat_invstd, int64_t count, float* dgamma, float* dbeta, float* dW,
@@ -240,7 +241,9 @@ int rv_bn_bwd_smallk_from_sums(int32_t c, int32_t cin, const double* sums, const
  * in closed form from the data moments (m1 = sum v, M2 = sum v v^T: rv_smallk_moments writes cin_pad + cin_pad^2 doubles,
  * cin_pad = 4 or 8; the caller all-reduces them under SyncBN), so neither the raw conv output nor a statistics pass over
  * it exists.  moments == NULL: eval, scale/shift are inputs (rv_bn_fold_eval).  For the backward of such a layer call
- * rv_bn_bwd_smallk with y = h, scale = 1, shift = 0, mean = beta, invstd = 1/gamma, stat_* = the batch statistics.
+ * rv_bn_bwd_smallk with RV_BNB_Y_FROM_INPUT (y = NULL: the raw output is recomputed from v, 16 bytes per pixel instead of
+ * 2 C) and the layer's own scale / shift / mean / invstd; or, without the flag, with y = h, scale = 1, shift = 0,
+ * mean = beta, invstd = 1/gamma, stat_* = the batch statistics (xhat rebuilt from the activated output).
  * Replaces cuDNN conv2d + BatchNorm + ReLU (nn/stems/__init__.py:40-57, nn/blocks/__init__.py:38-51 on 5/6-channel input). */
 int64_t rv_smallk_forward_workspace_bytes(int32_t cin);
 int rv_smallk_moments(const void* v, int32_t ld_v, int64_t pixels, int32_t cin, double* moments, void* workspace,
@@ -284,6 +287,21 @@ int rv_meta_modulate(const void* pos_raw, const float* scale, const float* shift
 int rv_meta_modulate_bwd(const void* dgeo, const void* pos_raw, const float* scale, const float* shift,
                          const void* feat, int32_t ld_feat, int32_t N, int32_t H, int32_t W, int32_t C,
                          void* dpos_act, void* dfeat, int32_t ld_dfeat, rvStream stream);
+/* The same backward FUSED with the BatchNorm(+ReLU) backward of the positional layer whose output `pos_raw` is
+ * (training path; nn/stems/__init__.py:80-84 differentiated through Conv2dNormActivation's BatchNorm2d + ReLU):
+ *   z = dgeo * feat_nbr * [relu passed]  (never written),  S0 = sum z, S1 = sum z*xhat,  dfeat as above.
+ * _sums: one pass over (dgeo, pos_raw): dfeat and rv_meta_bwd_rows(N,H,W) partial rows [row][2][C] of (S0, S1) in the
+ *        layout rv_bn_bwd_finalize reads (allocate rows + RV_STATS_SCRATCH_ROWS).
+ * _apply: dy[n,h,w,tap,c] = coef0 (z - coef1 - xhat coef2) with `coef` from rv_bn_bwd_finalize.
+ * Two passes over the 9x-grid tensors instead of four, and z stays in registers. */
+int32_t rv_meta_bwd_rows(int32_t N, int32_t H, int32_t W);
+int rv_meta_modulate_bwd_sums(const void* dgeo, const void* pos_raw, const float* scale, const float* shift,
+                              const float* mean, const float* invstd, const void* feat, int32_t ld_feat, int32_t N,
+                              int32_t H, int32_t W, int32_t C, void* dfeat, int32_t ld_dfeat, float* partial,
+                              rvStream stream);
+int rv_meta_modulate_bwd_apply(const void* dgeo, const void* pos_raw, const float* scale, const float* shift,
+                               const float* mean, const float* invstd, const float* coef, const void* feat,
+                               int32_t ld_feat, int32_t N, int32_t H, int32_t W, int32_t C, void* dy, rvStream stream);
 
 /* ---------------------------------------------------------------------------------------
  * Decoder (nn/decoders/range_decoder.py:29-156, math/ops/coding.py:79-144,

@@ -299,15 +299,18 @@ __global__ __launch_bounds__(256) void ew_mask_grad_kernel(int64_t pixels, int c
 // with R[c][d] = sum_p g[p,c] v[p,d] and the data moments m1 = sum_p v, M2 = sum_p v v^T (y = W v is linear in v).
 // So dy is never written (2.4 GB on the stem) and the separate apply and weight-gradient passes disappear.
 // ---------------------------------------------------------------------------------------------
-template <int CIN>
-__global__ __launch_bounds__(256) void bn_bwd_smallk_reduce_kernel(const BnbArgs a, const bf16_t* v, int ld_v) {
+// RECOMP: y = W v is recomputed from the <= 8 input channels (16 bytes per pixel) instead of read back (2 C bytes per
+// pixel: 2.4 GB on the stem's 3 -> 256 positional layer), and the ReLU gate / xhat come from the fp32 value with the
+// layer's true statistics rather than from the bf16-rounded activated output.
+template <int CIN, bool RECOMP>
+__global__ __launch_bounds__(256) void bn_bwd_smallk_reduce_kernel(const BnbArgs a, const bf16_t* v, int ld_v, const bf16_t* w, int ld_w) {
     __shared__ float red[256][9];
     const int tid = threadIdx.x;
     const int lanes_px = 256 / a.c8;
     const int oct = tid % a.c8, pl = tid / a.c8;
     const bool active = pl < lanes_px;
     const int c0 = oct * 8;
-    float sc[8], sh[8], mu[8], is[8], s0[8], s1[8], r[CIN][8];
+    float sc[8], sh[8], mu[8], is[8], s0[8], s1[8], r[CIN][8], wt[RECOMP ? 8 : 1][CIN];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         sc[j] = a.scale[c0 + j];
@@ -318,40 +321,61 @@ __global__ __launch_bounds__(256) void bn_bwd_smallk_reduce_kernel(const BnbArgs
         s1[j] = 0.f;
 #pragma unroll
         for (int d = 0; d < CIN; ++d) r[d][j] = 0.f;
+        if (RECOMP) {
+#pragma unroll
+            for (int e = 0; e < CIN; ++e) wt[RECOMP ? j : 0][e] = bf2f(w[(int64_t)(c0 + j) * ld_w + e]);
+        }
     }
     const int64_t p0 = (int64_t)blockIdx.x * kPixPerBlock;
     const int64_t p1 = p0 + kPixPerBlock < a.pixels ? p0 + kPixPerBlock : a.pixels;
+    auto load = [&](int64_t px) {
+        BnbLoad l;
+        l.d = *(const u32x4*)(a.dout + px * a.ld_dout + c0);
+        if (!RECOMP) l.y = *(const u32x4*)(a.y + px * a.ld_y + c0);
+        if (a.out) l.o = *(const u32x4*)(a.out + px * a.ld_out + c0);
+        return l;
+    };
+    auto accumulate = [&](const BnbLoad& l, const u32x4 wv) {
+        float g[8], xh[8], vv[8];
+        unpack8(wv, vv);
+        if (RECOMP) {
+            float d[8];
+            unpack8(l.d, d);
+            if (a.out) {
+                float o[8];
+                unpack8(l.o, o);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d[j] = o[j] > 0.f ? d[j] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float y = 0.f;
+#pragma unroll
+                for (int e = 0; e < CIN; ++e) y += wt[RECOMP ? j : 0][e] * vv[e];
+                if ((a.flags & RV_BNB_RELU_Z) && !(y * sc[j] + sh[j] > 0.f)) d[j] = 0.f;
+                g[j] = d[j];
+                xh[j] = (y - mu[j]) * is[j];
+            }
+        } else {
+            masked_grad(a, l, sc, sh, mu, is, g, xh);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            s0[j] += g[j];
+            s1[j] += g[j] * xh[j];
+#pragma unroll
+            for (int d = 0; d < CIN; ++d) r[d][j] += g[j] * vv[d];
+        }
+    };
     if (active) {
         int64_t px = p0 + pl;
         for (; px + lanes_px < p1; px += 2 * lanes_px) {
-            const BnbLoad l0 = load_px(a, px, c0), l1 = load_px(a, px + lanes_px, c0);
+            const BnbLoad l0 = load(px), l1 = load(px + lanes_px);
             const u32x4 w0 = *(const u32x4*)(v + px * ld_v), w1 = *(const u32x4*)(v + (px + lanes_px) * ld_v);
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                float g[8], xh[8], vv[8];
-                masked_grad(a, u ? l1 : l0, sc, sh, mu, is, g, xh);
-                unpack8(u ? w1 : w0, vv);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    s0[j] += g[j];
-                    s1[j] += g[j] * xh[j];
-#pragma unroll
-                    for (int d = 0; d < CIN; ++d) r[d][j] += g[j] * vv[d];
-                }
-            }
+            accumulate(l0, w0);
+            accumulate(l1, w1);
         }
-        for (; px < p1; px += lanes_px) {
-            float g[8], xh[8], vv[8];
-            masked_grad(a, load_px(a, px, c0), sc, sh, mu, is, g, xh);
-            unpack8(*(const u32x4*)(v + px * ld_v), vv);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                s0[j] += g[j];
-                s1[j] += g[j] * xh[j];
-#pragma unroll
-                for (int d = 0; d < CIN; ++d) r[d][j] += g[j] * vv[d];
-            }
-        }
+        for (; px < p1; px += lanes_px) accumulate(load(px), *(const u32x4*)(v + px * ld_v));
     }
     // planes 0 (S0), 1 (S1), 2 + d (R[.][d]): block sums over the pixel lanes, one plane at a time through LDS
     for (int plane = 0; plane < 2 + CIN; ++plane) {
@@ -526,7 +550,7 @@ int grid_for(int64_t work) {
 int fill(BnbArgs* a, int64_t pixels, int32_t c, const void* dout, int32_t ld_dout, const void* out, int32_t ld_out,
          const void* y, int32_t ld_y, const float* scale, const float* shift, const float* mean, const float* invstd,
          int32_t flags) {
-    RV_REQUIRE(dout && y && scale && shift && mean && invstd, "bn backward: null argument");
+    RV_REQUIRE(dout && (y || (flags & RV_BNB_Y_FROM_INPUT)) && scale && shift && mean && invstd, "bn backward: null argument");
     RV_REQUIRE(c % 8 == 0 && c / 8 <= 256 && ld_dout % 8 == 0 && ld_y % 8 == 0 && (!out || ld_out % 8 == 0), "bn backward: channels / strides must be multiples of 8 (c <= 2048)");
     memset(a, 0, sizeof(*a));
     a->dout = (const bf16_t*)dout;
@@ -626,11 +650,14 @@ extern "C" int64_t rv_bn_bwd_smallk_workspace_bytes(int64_t pixels, int32_t c, i
 // phase A: local sums.  sums = (2 + CIN) * c doubles (planes S0, S1, R[.][d]), moms = CIN + CIN*CIN doubles.
 extern "C" int rv_bn_bwd_smallk_sums(int64_t pixels, int32_t c, const void* dout, int32_t ld_dout, const void* out, int32_t ld_out,
                                      const void* y, int32_t ld_y, const float* scale, const float* shift, const float* mean,
-                                     const float* invstd, int32_t flags, const void* v, int32_t ld_v, int32_t cin, double* sums,
-                                     double* moms, void* workspace, rvStream stream) {
+                                     const float* invstd, int32_t flags, const void* v, int32_t ld_v, int32_t cin, const void* w_packed,
+                                     int32_t ld_w, double* sums, double* moms, void* workspace, rvStream stream) {
     BnbArgs a;
     if (fill(&a, pixels, c, dout, ld_dout, out, ld_out, y, ld_y, scale, shift, mean, invstd, flags)) return 1;
     RV_REQUIRE(v && sums && moms && workspace, "rv_bn_bwd_smallk_sums: null argument");
+    const bool recomp = (flags & RV_BNB_Y_FROM_INPUT) != 0;
+    RV_REQUIRE(!recomp || (w_packed && ld_w >= cin), "rv_bn_bwd_smallk_sums: RV_BNB_Y_FROM_INPUT needs the packed weight");
+    const bf16_t* wq = (const bf16_t*)w_packed;
     RV_REQUIRE(cin >= 1 && cin <= 8 && ld_v % 8 == 0 && ld_v >= 8, "rv_bn_bwd_smallk: 1 <= cin <= 8, input rows of at least 8 channels");
     const int CIN = cin <= 4 ? 4 : 8;
     const int rows = rv_bn_bwd_rows(pixels), planes = 2 + CIN, mcols = CIN + CIN * CIN;
@@ -642,10 +669,12 @@ extern "C" int rv_bn_bwd_smallk_sums(int64_t pixels, int32_t c, const void* dout
     hipStream_t st = (hipStream_t)stream;
     a.partial = part_g;
     if (CIN == 4) {
-        hipLaunchKernelGGL(bn_bwd_smallk_reduce_kernel<4>, dim3(rows), dim3(256), 0, st, a, (const bf16_t*)v, ld_v);
+        if (recomp) hipLaunchKernelGGL((bn_bwd_smallk_reduce_kernel<4, true>), dim3(rows), dim3(256), 0, st, a, (const bf16_t*)v, ld_v, wq, ld_w);
+        else hipLaunchKernelGGL((bn_bwd_smallk_reduce_kernel<4, false>), dim3(rows), dim3(256), 0, st, a, (const bf16_t*)v, ld_v, wq, ld_w);
         hipLaunchKernelGGL(smallk_moments_kernel<4>, dim3(mblocks), dim3(256), 0, st, (const bf16_t*)v, ld_v, pixels, part_m);
     } else {
-        hipLaunchKernelGGL(bn_bwd_smallk_reduce_kernel<8>, dim3(rows), dim3(256), 0, st, a, (const bf16_t*)v, ld_v);
+        if (recomp) hipLaunchKernelGGL((bn_bwd_smallk_reduce_kernel<8, true>), dim3(rows), dim3(256), 0, st, a, (const bf16_t*)v, ld_v, wq, ld_w);
+        else hipLaunchKernelGGL((bn_bwd_smallk_reduce_kernel<8, false>), dim3(rows), dim3(256), 0, st, a, (const bf16_t*)v, ld_v, wq, ld_w);
         hipLaunchKernelGGL(smallk_moments_kernel<8>, dim3(mblocks), dim3(256), 0, st, (const bf16_t*)v, ld_v, pixels, part_m);
     }
     RV_CHECK_LAUNCH("bn_bwd_smallk reduce kernels");
@@ -688,8 +717,8 @@ extern "C" int rv_bn_bwd_smallk(int64_t pixels, int32_t c, const void* dout, int
     const int CIN = cin <= 4 ? 4 : 8;
     double* sums = (double*)((uint8_t*)workspace + rv_bn_bwd_smallk_workspace_bytes(pixels, c, cin) - (int64_t)((2 + CIN) * c + 80) * 8);
     double* moms = sums + (int64_t)(2 + CIN) * c;
-    if (rv_bn_bwd_smallk_sums(pixels, c, dout, ld_dout, out, ld_out, y, ld_y, scale, shift, mean, invstd, flags, v, ld_v, cin, sums, moms,
-                              workspace, stream))
+    if (rv_bn_bwd_smallk_sums(pixels, c, dout, ld_dout, out, ld_out, y, ld_y, scale, shift, mean, invstd, flags, v, ld_v, cin, w_packed, ld_w,
+                              sums, moms, workspace, stream))
         return 1;
     return rv_bn_bwd_smallk_from_sums(c, cin, sums, moms, nullptr, w_packed, ld_w, gamma, stat_mean ? stat_mean : mean,
                                       stat_invstd ? stat_invstd : invstd, count, dgamma, dbeta, dW, stream);

@@ -162,6 +162,146 @@ __global__ __launch_bounds__(256) void meta_modulate_bwd_feat_kernel(const bf16_
     }
 }
 
+// -----------------------------------------------------------------------------------------------------------------
+// Backward of the modulation FUSED with the BatchNorm(+ReLU) backward of the positional layer that feeds it.
+//   P = relu(scale*y + shift),  geo[p][k] = P[p][k] * feat[nbr_k(p)]
+//   z[p][k]  = dgeo[p][k] * feat[nbr_k(p)] * [P > 0]                 gradient w.r.t. the BatchNorm output
+//   dfeat[q] = sum_k dgeo[q - off_k][k] * P[q - off_k][k]
+//   dy[p][k] = k0 (z - S0/n - xhat S1/n),  S0 = sum z, S1 = sum z*xhat, xhat = (y - mean) invstd
+// Two passes over (dgeo, y) instead of the four the unfused chain made (modulate-backward x2, BatchNorm reduce, apply),
+// and z is never written: 5 instead of 9 transfers of the 9x-grid tensor (2.4 GB each at 4 x 64 x 2048 x 256).
+// Pass 1 walks TARGET pixels q: every (p, k) whose neighbour lies inside the image is the k-th source of exactly one q, so
+// one thread sees dgeo/y of that pair once, multiplies by ITS OWN feat[q] (no neighbour gather at all) for S0/S1 and by P
+// for dfeat.  Pairs whose neighbour is outside the image have z = 0 and contribute to neither.
+// Thread = (pixel lane, channel octet) as in bnbwd.hip: per-channel constants stay in registers.
+// -----------------------------------------------------------------------------------------------------------------
+constexpr int kMetaPixPerBlock = 512;  // 1024 partial rows at 4 x 64 x 2048: the single-launch finalize takes them
+
+struct MetaBwdArgs {
+    const bf16_t *dgeo, *y, *feat;
+    const float *scale, *shift, *mean, *invstd, *coef;
+    int N, H, W, C, c8, ld_feat, ld_dfeat;
+    bf16_t* dfeat;
+    float* partial;
+    bf16_t* dy;
+};
+
+__global__ __launch_bounds__(256) void meta_bwd_sums_kernel(const MetaBwdArgs a) {
+    __shared__ float red[256][17];
+    const int tid = threadIdx.x;
+    const int lanes_px = 256 / a.c8;
+    const int oct = tid % a.c8, pl = tid / a.c8;
+    const bool active = pl < lanes_px;
+    const int c0 = oct * 8, C = a.C, H = a.H, W = a.W;
+    const int64_t hw = (int64_t)H * W, pixels = (int64_t)a.N * hw;
+    float sc[8], sh[8], mu[8], is[8], s0[8], s1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        sc[j] = a.scale[c0 + j];
+        sh[j] = a.shift[c0 + j];
+        mu[j] = a.mean[c0 + j];
+        is[j] = a.invstd[c0 + j];
+        s0[j] = 0.f;
+        s1[j] = 0.f;
+    }
+    const int64_t p0 = (int64_t)blockIdx.x * kMetaPixPerBlock;
+    const int64_t p1 = p0 + kMetaPixPerBlock < pixels ? p0 + kMetaPixPerBlock : pixels;
+    if (active) {
+        for (int64_t q = p0 + pl; q < p1; q += lanes_px) {
+            const int64_t n = q / hw, r = q - n * hw;
+            const int h = (int)(r / W), w = (int)(r - (int64_t)h * W);
+            u32x4 gv[9], yv[9];
+            // all 18 loads of the target in flight before the first use (sources outside the image: zeros)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int hp = h - (k / 3 - 1), wp = w - (k % 3 - 1);
+                const bool in = hp >= 0 && hp < H && wp >= 0 && wp < W;
+                const int64_t pk = in ? ((q - (int64_t)(k / 3 - 1) * W - (k % 3 - 1)) * 9 + k) : 0;
+                gv[k] = *(const u32x4*)(a.dgeo + pk * C + c0);
+                yv[k] = *(const u32x4*)(a.y + pk * C + c0);
+                if (!in) gv[k] = u32x4{0u, 0u, 0u, 0u};
+            }
+            float f[8], acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            unpack8(*(const u32x4*)(a.feat + q * a.ld_feat + c0), f);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                float g[8], y[8];
+                unpack8(gv[k], g);
+                unpack8(yv[k], y);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float act = y[j] * sc[j] + sh[j];
+                    const float gp = act > 0.f ? g[j] : 0.f;  // dgeo where the ReLU passed
+                    acc[j] += gp * act;
+                    const float z = gp * f[j];
+                    s0[j] += z;
+                    s1[j] += z * ((y[j] - mu[j]) * is[j]);
+                }
+            }
+            *(u32x4*)(a.dfeat + q * a.ld_dfeat + c0) = pack8(acc);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        red[tid][j] = s0[j];
+        red[tid][8 + j] = s1[j];
+    }
+    __syncthreads();
+    for (int i = tid; i < a.c8 * 16; i += 256) {
+        const int o = i / 16, j = i - o * 16;
+        float s = 0.f;
+        for (int l = 0; l < lanes_px; ++l) s += red[l * a.c8 + o][j];
+        a.partial[((int64_t)blockIdx.x * 2 + (j >> 3)) * C + o * 8 + (j & 7)] = s;
+    }
+}
+
+// Pass 2: dy for every (p, k), in the XCD column-strip order of the forward gather (feat rows stay in the XCD's L2).
+__global__ __launch_bounds__(256) void meta_bwd_apply_kernel(const MetaBwdArgs a) {
+    const int tid = threadIdx.x;
+    const int lanes_px = 256 / a.c8;
+    const int oct = tid % a.c8, pl = tid / a.c8;
+    if (pl >= lanes_px) return;
+    const int c0 = oct * 8, C = a.C, H = a.H, W = a.W;
+    const int64_t hw = (int64_t)H * W;
+    float sc[8], sh[8], mu[8], is[8], k0[8], k1[8], k2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        sc[j] = a.scale[c0 + j];
+        sh[j] = a.shift[c0 + j];
+        mu[j] = a.mean[c0 + j];
+        is[j] = a.invstd[c0 + j];
+        k0[j] = a.coef[c0 + j];
+        k1[j] = a.coef[C + c0 + j];
+        k2[j] = a.coef[2 * C + c0 + j];
+    }
+    const int xcd = blockIdx.x & 7, ws = (W + 7) / 8;
+    const int64_t items = (int64_t)a.N * H * ws * 9, step = (int64_t)(gridDim.x >> 3) * lanes_px;
+    for (int64_t it = (int64_t)(blockIdx.x >> 3) * lanes_px + pl; it < items; it += step) {
+        const int k = (int)(it % 9);
+        const int64_t t = it / 9;
+        const int w = xcd * ws + (int)(t % ws);
+        if (w >= W) continue;
+        const int64_t row = t / ws, n = row / H;
+        const int h = (int)(row - n * H);
+        const int64_t pk = ((n * H + h) * (int64_t)W + w) * 9 + k;
+        const int hn = h + k / 3 - 1, wn = w + k % 3 - 1;
+        const bool in = hn >= 0 && hn < H && wn >= 0 && wn < W;
+        float g[8], y[8], f[8], o[8];
+        const u32x4 gv = *(const u32x4*)(a.dgeo + pk * C + c0);
+        const u32x4 yv = *(const u32x4*)(a.y + pk * C + c0);
+        const u32x4 fv = *(const u32x4*)(a.feat + (in ? (n * hw + (int64_t)hn * W + wn) : 0) * a.ld_feat + c0);
+        unpack8(gv, g);
+        unpack8(yv, y);
+        unpack8(fv, f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float z = (in && y[j] * sc[j] + sh[j] > 0.f) ? g[j] * f[j] : 0.f;
+            o[j] = k0[j] * (z - k1[j] - (y[j] - mu[j]) * is[j] * k2[j]);
+        }
+        *(u32x4*)(a.dy + pk * C + c0) = pack8(o);
+    }
+}
+
 int grid_for(int64_t work) {
     int64_t b = (work + 255) / 256;
     b = (b + 7) & ~(int64_t)7;  // (the strip order deals whole rounds of 8 workgroups)
@@ -200,5 +340,42 @@ extern "C" int rv_meta_modulate_bwd(const void* dgeo, const void* pos_raw, const
     hipLaunchKernelGGL(meta_modulate_bwd_feat_kernel, dim3(grid_for((int64_t)N * H * W * (C / 8))), dim3(256), 0, st,
                        (const bf16_t*)dgeo, (const bf16_t*)pos_raw, scale, shift, N, H, W, C, (bf16_t*)dfeat, ld_dfeat);
     RV_CHECK_LAUNCH("meta_modulate_bwd kernels");
+    return 0;
+}
+
+extern "C" int32_t rv_meta_bwd_rows(int32_t N, int32_t H, int32_t W) {
+    return (int32_t)(((int64_t)N * H * W + kMetaPixPerBlock - 1) / kMetaPixPerBlock);
+}
+
+extern "C" int rv_meta_modulate_bwd_sums(const void* dgeo, const void* pos_raw, const float* scale, const float* shift,
+                                         const float* mean, const float* invstd, const void* feat, int32_t ld_feat, int32_t N,
+                                         int32_t H, int32_t W, int32_t C, void* dfeat, int32_t ld_dfeat, float* partial,
+                                         rvStream stream) {
+    RV_REQUIRE(dgeo && pos_raw && scale && shift && mean && invstd && feat && dfeat && partial,
+               "rv_meta_modulate_bwd_sums: null argument");
+    RV_REQUIRE(C % 8 == 0 && C <= 2048 && ld_feat % 8 == 0 && ld_dfeat % 8 == 0,
+               "rv_meta_modulate_bwd_sums: channels must be a multiple of 8 (at most 2048)");
+    MetaBwdArgs a{};
+    a.dgeo = (const bf16_t*)dgeo, a.y = (const bf16_t*)pos_raw, a.feat = (const bf16_t*)feat;
+    a.scale = scale, a.shift = shift, a.mean = mean, a.invstd = invstd;
+    a.N = N, a.H = H, a.W = W, a.C = C, a.c8 = C / 8, a.ld_feat = ld_feat, a.ld_dfeat = ld_dfeat;
+    a.dfeat = (bf16_t*)dfeat, a.partial = partial;
+    hipLaunchKernelGGL(meta_bwd_sums_kernel, dim3(rv_meta_bwd_rows(N, H, W)), dim3(256), 0, (hipStream_t)stream, a);
+    RV_CHECK_LAUNCH("meta_bwd_sums_kernel");
+    return 0;
+}
+
+extern "C" int rv_meta_modulate_bwd_apply(const void* dgeo, const void* pos_raw, const float* scale, const float* shift,
+                                          const float* mean, const float* invstd, const float* coef, const void* feat,
+                                          int32_t ld_feat, int32_t N, int32_t H, int32_t W, int32_t C, void* dy, rvStream stream) {
+    RV_REQUIRE(dgeo && pos_raw && scale && shift && mean && invstd && coef && feat && dy, "rv_meta_modulate_bwd_apply: null argument");
+    RV_REQUIRE(C % 8 == 0 && C <= 2048 && ld_feat % 8 == 0, "rv_meta_modulate_bwd_apply: channels must be a multiple of 8 (at most 2048)");
+    MetaBwdArgs a{};
+    a.dgeo = (const bf16_t*)dgeo, a.y = (const bf16_t*)pos_raw, a.feat = (const bf16_t*)feat;
+    a.scale = scale, a.shift = shift, a.mean = mean, a.invstd = invstd, a.coef = coef;
+    a.N = N, a.H = H, a.W = W, a.C = C, a.c8 = C / 8, a.ld_feat = ld_feat;
+    a.dy = (bf16_t*)dy;
+    hipLaunchKernelGGL(meta_bwd_apply_kernel, dim3(grid_for((int64_t)N * H * W * 9 * (C / 8))), dim3(256), 0, (hipStream_t)stream, a);
+    RV_CHECK_LAUNCH("meta_bwd_apply_kernel");
     return 0;
 }

@@ -399,6 +399,7 @@ class Tape:
         self.written: set = set()                # ids of gradient Acts (roots) already holding a value
         self.lazy_in: Dict[int, Tuple[Act, Optional[Act]]] = {}  # id(Lazy) -> (dOut, OUT mask source)
         self.lazy_sums: Dict[int, Tuple[Tensor, int]] = {}  # id(Lazy) -> BatchNorm-backward partial sums its ONE writer formed, rows
+        self.meta_in: Dict[int, tuple] = {}      # id(Lazy) -> (dgeo, feat, partial sums, rows): MetaKernel modulation fused into the BatchNorm backward
         self.raw_grad: Dict[int, Act] = {}       # id(raw Act) -> gradient w.r.t. the raw conv output
         self.param_grads: Dict[int, Tensor] = {}  # id(param) -> fp32 gradient
         self.params: Dict[int, nn.Parameter] = {}
@@ -648,6 +649,7 @@ class SmallKOp(Op):
         self.gamma_p, self.beta_p = _padded(bn.weight, cp), _padded(bn.bias, cp)
         scale = torch.empty(cp, dtype=torch.float32, device=dev)
         shift = torch.empty(cp, dtype=torch.float32, device=dev)
+        self.scale, self.shift = scale, shift  # (backward recomputes y = W x and gates / normalises it with these)
         self.out = Act.empty(x.N, x.H, x.W, c, dev)
         wp = layer.packed("gather")
         rm, rv = _padded(bn.running_mean, cp), _padded(bn.running_var, cp, 1.0)
@@ -686,24 +688,9 @@ class SmallKOp(Op):
         engine_bwd.smallk_backward(self, t)
 
 
-SMALLK_MIN_GAMMA = 1e-3
-_GAMMA_OK: Dict[int, Tuple[int, bool]] = {}
-
-
-def smallk_gamma_ok(bn: nn.Module) -> bool:
-    """min |gamma| >= SMALLK_MIN_GAMMA, cached per parameter version (one tiny device->host read per optimiser step)."""
-    key, ver = id(bn.weight), bn.weight._version
-    hit = _GAMMA_OK.get(key)
-    if hit is None or hit[0] != ver:
-        hit = (ver, bool(bn.weight.detach().abs().min() >= SMALLK_MIN_GAMMA))
-        _GAMMA_OK[key] = hit
-    return hit[1]
-
-
 def _smallk_eligible(layer: TapLayer, x: Operand, relu: bool, need_input_grad: bool) -> bool:
-    """(The backward of this path rebuilds xhat as (h - beta) / gamma from the stored activated output: exact in fp32 up to
-    the bf16 rounding of h times |beta / gamma|.  ``SMALLK_MIN_GAMMA`` -- checked once per optimiser step by
-    ``smallk_gamma_ok`` -- sends a layer whose BatchNorm has a vanishing gamma to the generic path instead.)"""
+    """(The backward of this path recomputes the raw output y = W x from the <= 8 input channels -- RV_BNB_Y_FROM_INPUT -- so
+    the ReLU gate and xhat come from fp32 values with the layer's own batch statistics, whatever gamma is.)"""
     g = layer.geom
     return (SMALLK_FORWARD and relu and not need_input_grad and isinstance(x, Act) and layer.fwd_form == "gather" and g.kh == 1
             and g.kw == 1 and g.stride_w == 1 and layer.c_in <= 8 and layer.in_perm is None and layer.bias is None)
@@ -713,7 +700,7 @@ def conv_bn(t: Tape, layer: TapLayer, x: Operand, bn: nn.BatchNorm2d, relu: bool
             need_input_grad: bool = True, smallk: bool = True) -> Operand:
     """conv -> BatchNorm (-> ReLU).  ``smallk=False`` keeps a small-K layer on the generic path (a Lazy result), for consumers
     that fold the BatchNorm themselves (MetaModulateOp)."""
-    if smallk and _smallk_eligible(layer, x, relu, need_input_grad) and (not t.training or smallk_gamma_ok(bn)):
+    if smallk and _smallk_eligible(layer, x, relu, need_input_grad):
         return SmallKOp(t, layer, x, bn).out
     conv = ConvOp(t, layer, x, stats=t.training, need_input_grad=need_input_grad)
     return BnOp(t, conv, bn, relu).lazy

@@ -129,7 +129,7 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
         run_wgrad()
 
 
-def _smallk_grads(t: Tape, pixels: int, cp: int, dout: Act, mask: Optional[Act], y: Act, scale, shift, mean, invstd, flags: int, v: Act,
+def _smallk_grads(t: Tape, pixels: int, cp: int, dout: Act, mask: Optional[Act], y: Optional[Act], scale, shift, mean, invstd, flags: int, v: Act,
                   lay, gamma_p, stat_mean, stat_invstd, count: int, sync: bool):
     """(dgamma, dbeta, dW) of a small-K conv + BatchNorm from one pass (``rv_bn_bwd_smallk``); under SyncBN the two-phase
     form with the all-reduce of (sum g, sum g*xhat) in between."""
@@ -141,8 +141,8 @@ def _smallk_grads(t: Tape, pixels: int, cp: int, dout: Act, mask: Optional[Act],
     dw = torch.empty((cp, cin), dtype=torch.float32, device=dev)
     wp = lay.packed("gather")
     head = (L.i64(pixels), L.i32(cp), dout.ptr(), L.i32(dout.ld), mask.ptr() if mask is not None else None,
-            L.i32(mask.ld if mask is not None else 0), y.ptr(), L.i32(y.ld), L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd),
-            L.i32(flags), v.ptr(), L.i32(v.ld), L.i32(cin))
+            L.i32(mask.ld if mask is not None else 0), y.ptr() if y is not None else None, L.i32(y.ld if y is not None else 0), L.ptr(scale),
+            L.ptr(shift), L.ptr(mean), L.ptr(invstd), L.i32(flags), v.ptr(), L.i32(v.ld), L.i32(cin), L.ptr(wp), L.i32(E.pad32(cin)))
     if sync:
         cin_pad = 4 if cin <= 4 else 8
         sums = torch.empty((2 + cin_pad) * cp, dtype=torch.float64, device=dev)
@@ -154,7 +154,7 @@ def _smallk_grads(t: Tape, pixels: int, cp: int, dout: Act, mask: Optional[Act],
         L.call("rv_bn_bwd_smallk_from_sums", L.i32(cp), L.i32(cin), L.ptr(sums), L.ptr(moms), L.ptr(g01), L.ptr(wp), L.i32(E.pad32(cin)),
                L.ptr(gamma_p), L.ptr(stat_mean), L.ptr(stat_invstd), L.i64(count), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dw), L.stream_ptr())
     else:
-        L.call("rv_bn_bwd_smallk", *head, L.ptr(wp), L.i32(E.pad32(cin)), L.ptr(gamma_p), L.ptr(stat_mean), L.ptr(stat_invstd), L.i64(count),
+        L.call("rv_bn_bwd_smallk", *head, L.ptr(gamma_p), L.ptr(stat_mean), L.ptr(stat_invstd), L.i64(count),
                L.ptr(dgamma), L.ptr(dbeta), L.ptr(dw), L.ptr(ws), L.stream_ptr())
     return dgamma, dbeta, dw
 
@@ -164,6 +164,9 @@ SMALLK_FUSION = os.environ.get("RV3D_NO_SMALLK") is None
 
 def bn_backward(op: "E.BnOp", t: Tape) -> None:
     lazy = op.lazy
+    meta = t.meta_in.pop(id(lazy), None)
+    if meta is not None:
+        return _bn_backward_meta(op, t, meta)
     entry = t.lazy_in.pop(id(lazy), None)
     if entry is None:
         return
@@ -197,6 +200,23 @@ def bn_backward(op: "E.BnOp", t: Tape) -> None:
         rows = L.load().rv_bn_bwd_rows(L.i64(pixels))
         partial = torch.empty((rows + L.STATS_SCRATCH_ROWS, 2, cp), dtype=torch.float32, device=t.device)
         L.call("rv_bn_bwd_reduce", *common, L.i32(flags), L.ptr(partial), L.stream_ptr())
+    dgamma, dbeta, coef = _bn_finalize(op, t, partial, rows, pixels)
+    dy = raw.like()
+    if res is not None:
+        rg, racc = res
+        L.call("rv_bn_bwd_apply", *common, L.ptr(coef), L.i32(flags | (L.BNB_RES_ACCUM if racc else 0)), dy.ptr(), L.i32(dy.ld),
+               rg.ptr(), L.i32(rg.ld), L.stream_ptr())
+    else:
+        L.call("rv_bn_bwd_apply", *common, L.ptr(coef), L.i32(flags), dy.ptr(), L.i32(dy.ld), None, L.i32(0), L.stream_ptr())
+    t.raw_grad[id(raw)] = dy
+    c = st.module.num_features
+    t.add_param_grad(st.module.weight, dgamma[:c])
+    t.add_param_grad(st.module.bias, dbeta[:c])
+
+
+def _bn_finalize(op: "E.BnOp", t: Tape, partial: Tensor, rows: int, pixels: int):
+    """(dgamma, dbeta, coef) from the partial (sum g, sum g*xhat) rows; SyncBN: the coefficients from the all-reduced totals."""
+    st, cp = op.lazy.bn, op.lazy.raw.cp
     dgamma = torch.empty(cp, dtype=torch.float32, device=t.device)
     dbeta = torch.empty(cp, dtype=torch.float32, device=t.device)
     coef = torch.empty((3, cp), dtype=torch.float32, device=t.device)
@@ -211,13 +231,18 @@ def bn_backward(op: "E.BnOp", t: Tape) -> None:
     else:
         L.call("rv_bn_bwd_finalize", L.ptr(partial), L.i32(rows), L.i32(cp), L.i64(st.count), L.ptr(op.gamma_p), L.ptr(st.invstd),
                L.ptr(dgamma), L.ptr(dbeta), L.i32(0), L.ptr(coef), L.stream_ptr())
+    return dgamma, dbeta, coef
+
+
+def _bn_backward_meta(op: "E.BnOp", t: Tape, meta) -> None:
+    """BatchNorm backward of the positional layer behind the MetaKernel modulation (sums formed by modulate_backward)."""
+    dgeo, feat, partial, rows = meta
+    lazy = op.lazy
+    st, raw = lazy.bn, lazy.raw
+    dgamma, dbeta, coef = _bn_finalize(op, t, partial, rows, raw.pixels)
     dy = raw.like()
-    if res is not None:
-        rg, racc = res
-        L.call("rv_bn_bwd_apply", *common, L.ptr(coef), L.i32(flags | (L.BNB_RES_ACCUM if racc else 0)), dy.ptr(), L.i32(dy.ld),
-               rg.ptr(), L.i32(rg.ld), L.stream_ptr())
-    else:
-        L.call("rv_bn_bwd_apply", *common, L.ptr(coef), L.i32(flags), dy.ptr(), L.i32(dy.ld), None, L.i32(0), L.stream_ptr())
+    L.call("rv_meta_modulate_bwd_apply", dgeo.ptr(), raw.ptr(), L.ptr(st.scale), L.ptr(st.shift), L.ptr(st.mean), L.ptr(st.invstd),
+           L.ptr(coef), feat.ptr(), L.i32(feat.ld), L.i32(feat.N), L.i32(feat.H), L.i32(feat.W), L.i32(feat.cp), dy.ptr(), L.stream_ptr())
     t.raw_grad[id(raw)] = dy
     c = st.module.num_features
     t.add_param_grad(st.module.weight, dgamma[:c])
@@ -251,14 +276,29 @@ def combine_backward(op: "E.CombineOp", t: Tape) -> None:
         t.mark_written(x)
 
 
+META_BWD_FUSE = os.environ.get("RV3D_NO_META_FUSE") is None
+
+
 def modulate_backward(op: "E.MetaModulateOp", t: Tape) -> None:
     g, have = t.grad_buffer(op.out)
     if not have:
         return
     pos, feat = op.pos, op.feat
-    dpos = pos.raw.like()
     gf, have_f = t.grad_buffer(feat)
     assert not have_f, "MetaKernel projection output has a single consumer"
+    st = pos.bn
+    if META_BWD_FUSE and pos.relu and st.mean is not None and id(pos) not in t.lazy_in:
+        # fused with the BatchNorm(+ReLU) backward of the positional layer: this pass forms dfeat and the (sum z, sum z*xhat)
+        # rows; bn_backward finalizes them and a second pass writes dy -- the activated-gradient tensor is never written
+        rows = L.load().rv_meta_bwd_rows(L.i32(feat.N), L.i32(feat.H), L.i32(feat.W))
+        partial = torch.empty((rows + L.STATS_SCRATCH_ROWS, 2, feat.cp), dtype=torch.float32, device=t.device)
+        L.call("rv_meta_modulate_bwd_sums", g.ptr(), pos.raw.ptr(), L.ptr(st.scale), L.ptr(st.shift), L.ptr(st.mean), L.ptr(st.invstd),
+               feat.ptr(), L.i32(feat.ld), L.i32(feat.N), L.i32(feat.H), L.i32(feat.W), L.i32(feat.cp), gf.ptr(), L.i32(gf.ld),
+               L.ptr(partial), L.stream_ptr())
+        t.mark_written(feat)
+        t.meta_in[id(pos)] = (g, feat, partial, rows)
+        return
+    dpos = pos.raw.like()
     L.call("rv_meta_modulate_bwd", g.ptr(), pos.raw.ptr(), L.ptr(pos.bn.scale), L.ptr(pos.bn.shift), feat.ptr(), L.i32(feat.ld),
            L.i32(feat.N), L.i32(feat.H), L.i32(feat.W), L.i32(feat.cp), dpos.ptr(), gf.ptr(), L.i32(gf.ld), L.stream_ptr())
     t.mark_written(feat)
@@ -267,7 +307,8 @@ def modulate_backward(op: "E.MetaModulateOp", t: Tape) -> None:
 
 
 def smallk_backward(op: "E.SmallKOp", t: Tape) -> None:
-    """Backward of ``h = relu(bn(W x))`` from the activated output: mask = [h > 0], xhat = (h - beta) / gamma there."""
+    """Backward of ``h = relu(bn(W x))``: the raw output is recomputed from the <= 8 input channels inside the one pass over
+    dOut (RV_BNB_Y_FROM_INPUT) -- the stored activation is not read back."""
     dout, have = t.grad_buffer(op.out)
     if not have:
         return
@@ -275,12 +316,8 @@ def smallk_backward(op: "E.SmallKOp", t: Tape) -> None:
         raise L.RvError("BatchNorm backward needs batch statistics (module was run in eval mode)")
     lay, bn, h, v = op.layer, op.bn, op.out, op.x
     cp, cin, pixels = h.cp, lay.c_in, h.pixels
-    ones = torch.ones(cp, dtype=torch.float32, device=t.device)
-    zeros = torch.zeros(cp, dtype=torch.float32, device=t.device)
-    safe_gamma = torch.where(op.gamma_p.abs() < 1e-20, torch.full_like(op.gamma_p, 1e-20), op.gamma_p)
-    inv_gamma = 1.0 / safe_gamma
-    dgamma, dbeta, dw = _smallk_grads(t, pixels, cp, dout, None, h, ones, zeros, op.beta_p, inv_gamma, L.BNB_RELU_Z, v, lay, op.gamma_p,
-                                      op.mean, op.invstd, op.count, op.sync_world > 1)
+    dgamma, dbeta, dw = _smallk_grads(t, pixels, cp, dout, None, None, op.scale, op.shift, op.mean, op.invstd, L.BNB_RELU_Z | L.BNB_Y_FROM_INPUT,
+                                      v, lay, op.gamma_p, op.mean, op.invstd, op.count, op.sync_world > 1)
     c = bn.num_features
     t.add_param_grad(bn.weight, dgamma[:c])
     t.add_param_grad(bn.bias, dbeta[:c])

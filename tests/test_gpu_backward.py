@@ -331,3 +331,82 @@ def test_meta_kernel_single_positional_layer():
     m.eval()
     with torch.no_grad():
         assert torch.isfinite(m(feats.to(DEV), cart.to(DEV)).float()).all()
+
+
+@pytest.mark.parametrize("N,H,W,C", [(2, 5, 37, 32), (1, 4, 64, 256), (2, 3, 21, 96)])
+def test_meta_modulate_backward_fused_kernels_vs_fp32(N, H, W, C):
+    """rv_meta_modulate_bwd_sums / _apply (modulation backward fused with the positional layer's BatchNorm+ReLU backward:
+    two passes over the 9x-grid tensors, the activated gradient never written) against the same formulas in fp32 torch ops
+    on the bf16 inputs: dfeat and dy one bf16 rounding (4e-3 of max), the (sum z, sum z*xhat) rows 1e-4 of their scale.
+    Widths that are not multiples of 8 exercise the XCD column strips, C = 96 a channel count that does not divide 256."""
+    from range_view_3d_detection_amd import _lib as L
+
+    gen = torch.Generator().manual_seed(N * 1000 + W)
+    bf = lambda *s: torch.randn(*s, generator=gen).to(torch.bfloat16).to(DEV)
+    dgeo, y, feat = bf(N, H, W, 9, C), bf(N, H, W, 9, C), bf(N, H, W, C)
+    scale = (0.5 + torch.rand(C, generator=gen)).to(DEV)
+    shift = (0.3 * torch.randn(C, generator=gen)).to(DEV)
+    mean = (0.2 * torch.randn(C, generator=gen)).to(DEV)
+    invstd = (0.5 + torch.rand(C, generator=gen)).to(DEV)
+    coef = torch.stack([0.5 + torch.rand(C, generator=gen), 0.1 * torch.randn(C, generator=gen), 0.1 * torch.randn(C, generator=gen)]).to(DEV)
+    lib = L.load()
+    rows = lib.rv_meta_bwd_rows(L.i32(N), L.i32(H), L.i32(W))
+    partial = torch.zeros((rows + L.STATS_SCRATCH_ROWS, 2, C), dtype=torch.float32, device=DEV)
+    dfeat = torch.empty_like(feat)
+    dy = torch.empty_like(y)
+    L.call("rv_meta_modulate_bwd_sums", L.ptr(dgeo), L.ptr(y), L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd), L.ptr(feat), L.i32(C),
+           L.i32(N), L.i32(H), L.i32(W), L.i32(C), L.ptr(dfeat), L.i32(C), L.ptr(partial), L.stream_ptr())
+    L.call("rv_meta_modulate_bwd_apply", L.ptr(dgeo), L.ptr(y), L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd), L.ptr(coef), L.ptr(feat),
+           L.i32(C), L.i32(N), L.i32(H), L.i32(W), L.i32(C), L.ptr(dy), L.stream_ptr())
+    torch.cuda.synchronize()
+    # fp32 restatement: nbr[n,h,w,k] = feat[n, h+k//3-1, w+k%3-1] (zero outside), exactly F.unfold's neighbourhood order
+    fp = F.pad(feat.float(), (0, 0, 1, 1, 1, 1))
+    nbr = torch.stack([fp[:, k // 3 : k // 3 + H, k % 3 : k % 3 + W] for k in range(9)], dim=3)
+    inside = F.pad(torch.ones(N, H, W, 1, device=DEV), (0, 0, 1, 1, 1, 1))
+    inside = torch.stack([inside[:, k // 3 : k // 3 + H, k % 3 : k % 3 + W] for k in range(9)], dim=3)
+    act = y.float() * scale + shift
+    gate = (act > 0).float() * inside
+    z = dgeo.float() * nbr * gate
+    xhat = (y.float() - mean) * invstd
+    s0, s1 = z.sum((0, 1, 2, 3)), (z * xhat).sum((0, 1, 2, 3))
+    got = partial[:rows].double().sum(0)
+    for a, b in ((got[0], s0), (got[1], s1)):
+        assert float((a - b.double()).abs().max()) < 1e-4 * float(z.abs().sum((0, 1, 2, 3)).max()), (a, b)
+    # dfeat[q] = sum_k dgeo[q - off_k][k] * relu(act)[q - off_k][k]: scatter the per-(p, k) products to the neighbour
+    contrib = F.pad(torch.zeros(N, H, W, C, device=DEV), (0, 0, 1, 1, 1, 1))
+    prod = dgeo.float() * torch.relu(act) * inside
+    for k in range(9):
+        contrib[:, k // 3 : k // 3 + H, k % 3 : k % 3 + W] += prod[:, :, :, k]
+    want_dfeat = contrib[:, 1:-1, 1:-1]
+    assert rel_err(dfeat.float(), want_dfeat) < 4e-3, rel_err(dfeat.float(), want_dfeat)
+    want_dy = coef[0] * (z - coef[1] - xhat * coef[2])
+    assert rel_err(dy.float(), want_dy) < 4e-3, rel_err(dy.float(), want_dy)
+
+
+def test_meta_kernel_backward_fused_matches_unfused():
+    """MetaKernel training step with the fused modulation/BatchNorm backward against the unfused chain it replaces
+    (rv_meta_modulate_bwd -> rv_bn_bwd_reduce -> rv_bn_bwd_apply): same parameter gradients up to the one bf16 rounding of
+    the activated gradient the unfused chain stores (cosine > 0.999, 2e-2 of max)."""
+    from range_view_3d_detection_amd import engine_bwd
+    from range_view_3d_detection_amd.nn.stems import MetaKernel
+
+    gen = torch.Generator().manual_seed(11)
+    m = MetaKernel(5, 64, 3, 2).to(DEV).train()
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    feats = torch.randn(2, 5, 8, 72, generator=gen).to(DEV)
+    cart = (torch.randn(2, 3, 8, 72, generator=gen) * 5).to(DEV)
+    probe = torch.randn(2, 64, 8, 72, generator=gen).to(DEV)
+
+    def run(fused: bool):
+        engine_bwd.META_BWD_FUSE = fused
+        try:
+            m.load_state_dict(sd)
+            m.zero_grad(set_to_none=True)
+            (m(feats, cart).float() * probe).sum().backward()
+            return {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()}
+        finally:
+            engine_bwd.META_BWD_FUSE = True
+
+    a, b = run(True), run(False)
+    for k in a:
+        assert _cos(a[k], b[k]) > 0.999 and rel_err(a[k], b[k]) < 2e-2, (k, _cos(a[k], b[k]), rel_err(a[k], b[k]))
