@@ -241,16 +241,18 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    dist_on = world > 1 or os.environ.get("RV3D_FORCE_DIST") is not None  # (forced: the RCCL path with one rank, tests/test_gpu_ddp.py)
+    if dist_on:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29655")
         backend = os.environ.get("RV3D_DIST_BACKEND", "nccl")  # "gloo": the 2-ranks-on-one-GPU test of this script
         local_rank %= max(torch.cuda.device_count(), 1)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"), rank=rank, world_size=world)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -261,9 +263,9 @@ def main() -> None:
     torch.manual_seed(0)
     backbone, head = build_model(args.widths, args.classes, args.features)
     model = Detector(backbone, head).to(dev).train()
-    E.SYNC_BN = world > 1 and not args.no_sync_bn  # explicit: sync every BatchNorm (what Lightning's sync_batchnorm: true does) / local
+    E.SYNC_BN = dist_on and not args.no_sync_bn  # explicit: sync every BatchNorm (what Lightning's sync_batchnorm: true does) / local
     step_model = model
-    if world > 1:
+    if dist_on:
         step_model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], gradient_as_bucket_view=True, static_graph=True)
     params = [p for p in model.parameters()]
     # the reference's recipe (nn/meta/arch.py:48-75): AdamW(1e-3) + OneCycleLR(max_lr = 0.00075 * sqrt(devices * batch)), per step
@@ -286,7 +288,7 @@ def main() -> None:
         step()
     torch.cuda.synchronize()
     _progress("warm-up done; timed region")
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     E.PROFILE = E.KernelProfile()  # events around each tap-conv / wgrad launch inside the timed region
@@ -295,7 +297,7 @@ def main() -> None:
     for _ in range(args.steps):
         loss = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -312,7 +314,7 @@ def main() -> None:
     torch.cuda.synchronize()
     E.OVERLAP_WGRAD = overlap
     E.PROFILE = None
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -329,7 +331,7 @@ def main() -> None:
                        "global_batch": args.batch * world, "sweep": [args.height, args.width, args.features], "parallelism": f"dp{world}",
                        "sync_bn": bool(E.SYNC_BN), "loss": float(loss.detach().item()),
                        "collectives": {"per_step": {"sync_bn_all_reduce": {"calls": sync_calls, "bytes": sync_bytes},
-                                                    "gradient_all_reduce_bytes": 4 * sum(p.numel() for p in params) if world > 1 else 0},
+                                                    "gradient_all_reduce_bytes": 4 * sum(p.numel() for p in params) if dist_on else 0},
                                        "note": "SyncBN: one all-reduce of (2C+1) fp32 per BatchNorm layer and direction; gradients: DDP buckets"},
                        "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 2)},
             "roofline": roofline(prof, iso),
@@ -338,7 +340,7 @@ def main() -> None:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(full=args.cpu_baseline == "full")
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         torch.distributed.destroy_process_group()
 
 

@@ -33,6 +33,9 @@ BN_MOMENTUM = 0.1
 #   SYNC_BN = True  sync every BatchNorm regardless of the holder's class (what bench.py sets for N > 1);
 #   SYNC_BN = False per-rank statistics (torch DDP semantics with plain BatchNorm2d).
 SYNC_BN: Optional[bool] = None
+# Test hook: with SYNC_BN = True, take the synchronised code path (device reduce -> all-reduce -> finalize from the totals)
+# even in a process group of ONE rank -- the only way to run the RCCL collectives of this path on a one-GPU box.
+SYNC_WORLD1 = os.environ.get("RV3D_SYNC_WORLD1") is not None
 
 
 def _dist_world() -> int:
@@ -44,6 +47,8 @@ def _dist_world() -> int:
 def bn_sync_world(bn: nn.Module, training: bool) -> int:
     """World size the statistics of ``bn`` are reduced over (1 = local)."""
     world = _dist_world()
+    if SYNC_WORLD1 and SYNC_BN is True and training and torch.distributed.is_initialized():
+        return max(world, 2)  # (callers only test `> 1`; the counts travel through the all-reduce)
     if world == 1 or not training or SYNC_BN is False:
         return 1
     if SYNC_BN is True or isinstance(bn, nn.SyncBatchNorm):

@@ -46,3 +46,19 @@ class DenseHead(nn.Module):
             return [a], [program.dense_head_program(t, self, a)]
 
         return program.run(build, self, [x])[0]
+
+
+def forward_pair(cls_head: DenseHead, reg_head: DenseHead, x: Tensor):
+    """Classification and regression towers of one (stride, task) as ONE program on one tape: both read the same feature
+    tensor, and in backward the second tower's input gradient accumulates into the first one's buffer inside its
+    backward-data launch -- run as two autograd nodes, autograd adds the two 268 MB gradients in a pass of its own."""
+    from ... import program
+    from ...engine import Act
+
+    def build(t, xin):
+        a = Act.from_nchw(xin)
+        return [a], [program.dense_head_program(t, cls_head, a), program.dense_head_program(t, reg_head, a)]
+
+    params = [p for p in cls_head.parameters()] + [p for p in reg_head.parameters()]
+    logits, regressands = program._ProgramFn.apply(build, cls_head.training, 1, x, *params)
+    return logits, regressands

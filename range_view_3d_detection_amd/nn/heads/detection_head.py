@@ -23,7 +23,7 @@ from torch import Tensor, nn
 
 from ... import _lib as L
 from ...engine import _require_cuda
-from .dense_head import DenseHead
+from .dense_head import DenseHead, forward_pair
 
 COLS = ("tx_m", "ty_m", "tz_m", "length_m", "width_m", "height_m", "qw", "qx", "qy", "qz", "task_id", "offset", "batch_index")
 FOCAL_PRIOR_PROB = 0.01
@@ -195,8 +195,8 @@ class DetectionHead(nn.Module):
             if _cfg_get(self.targets_config, "fpn_assignment_method") == "RANGE":
                 raise NotImplementedError("RANGE fpn assignment is not selected by any shipped rv-* config")
             for task_id in self.tasks_cfg.keys():
-                logits = self.classification_head[str(stride)][str(task_id)](feats, cart, mask)
-                regressands = self.regression_head[str(stride)][str(task_id)](feats, cart, mask)
+                logits, regressands = forward_pair(self.classification_head[str(stride)][str(task_id)],
+                                                   self.regression_head[str(stride)][str(task_id)], feats)
                 multiscale_outputs[s][task_id] = {"logits": logits, "regressands": regressands}
         losses: Dict[str, Any] = {}
         if return_loss:

@@ -113,3 +113,29 @@ def test_two_rank_sync_bn_equals_single_rank_on_the_concatenated_batch(tmp_path)
         assert abs(a - b) / abs(b) < 1e-3, (digests, one["logit_digest"])
     for k in ("rm0", "rm_last"):
         assert abs(two[0][k] - one[k]) / abs(one[k]) < 1e-3 and abs(two[0][k] - two[1][k]) / abs(one[k]) < 1e-6, (k, two[0][k], two[1][k], one[k])
+
+
+def test_one_rank_rccl_sync_path_matches_the_local_run():
+    """The N > 1 code path of bench.py over the REAL backend (``nccl`` = RCCL), as far as one GPU allows: a process group of one
+    rank, DistributedDataParallel around the model, and -- ``RV3D_SYNC_WORLD1`` -- every BatchNorm on the synchronised path
+    (device row-reduce -> RCCL all-reduce of (2C+1) floats -> finalize from the all-reduced totals with the device-side
+    count; fp64 moments of the small-K layers).  With one rank the all-reduced totals ARE the local totals, so the loss must
+    equal the plain single-process run's (third optimiser step, 1e-2: fp32 totals vs partial rows summed in fp64 inside the
+    finalize kernel move a statistic in its last bits, which bf16 storage can turn into a flipped rounding downstream),
+    and the engine must have issued its ~160 collectives per step."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29671", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    args = [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--widths", "c32", "--width", "512", "--height", "16",
+            "--batch", "2", "--classes", "5", "--no-cpu-baseline"]
+
+    def run(extra_env):
+        out = subprocess.run([sys.executable, *args], env=dict(env, **extra_env), cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-3000:]
+        return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+
+    local = run({})
+    rccl = run({"RV3D_FORCE_DIST": "1", "RV3D_SYNC_WORLD1": "1", "RV3D_DIST_BACKEND": "nccl"})
+    assert rccl["config"]["sync_bn"] is True and local["config"]["sync_bn"] is False
+    calls = rccl["config"]["collectives"]["per_step"]["sync_bn_all_reduce"]["calls"]
+    assert calls > 100, calls
+    assert rccl["config"]["collectives"]["per_step"]["gradient_all_reduce_bytes"] > 0
+    assert abs(rccl["config"]["loss"] - local["config"]["loss"]) < 1e-2 * abs(local["config"]["loss"]), (rccl["config"]["loss"], local["config"]["loss"])
