@@ -271,15 +271,18 @@ def main() -> None:
     # the reference's recipe (nn/meta/arch.py:48-75): AdamW(1e-3) + OneCycleLR(max_lr = 0.00075 * sqrt(devices * batch)), per step
     from range_view_3d_detection_amd.nn.meta.arch import configure_optimizers
 
-    opt, sched = configure_optimizers(params, num_devices=world, batch_size=args.batch, total_steps=args.warmup + args.steps + 8)
+    fused_opt = os.environ.get("RV3D_TORCH_OPTIMIZER") is None  # (A/B: torch.optim.AdamW + clip_grad_norm_, ~10 foreach launches)
+    opt, sched = configure_optimizers(params, num_devices=world, batch_size=args.batch, total_steps=args.warmup + args.steps + 8,
+                                      fused=fused_opt, max_grad_norm=35.0 if fused_opt else None)
     batch = synthetic_batch(args.batch, args.height, args.width, seed=1234 + rank, device=dev, n_feat=args.features, n_cls=args.classes)
 
     def step():
         opt.zero_grad(set_to_none=True)
         loss = step_model(batch)
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(params, 35.0)
-        opt.step()
+        if not fused_opt:
+            torch.nn.utils.clip_grad_norm_(params, 35.0)
+        opt.step()  # fused: gradient clipping at 35.0 + AdamW in two launches (rv_adamw_step)
         sched.step()
         return loss
 

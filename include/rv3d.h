@@ -75,6 +75,14 @@ int64_t rv_packed_weight_bytes(const rvTapGeom* g);
  * internally); it is what keeps `state_dict()` in the reference's OIHW layout. */
 int rv_pack_weight(const rvTapGeom* g, const float* T, void* gather_w, void* scatter_w, rvStream stream);
 
+/* All layers of a model in ONE launch (every packed image is stale after an optimiser step; ~160 layers on the rv-* models).
+ * The caller keeps a table of 2 entries per layer (gather image, scatter image; rv_pack_batch_entry_bytes() each): filled on
+ * the HOST by rv_pack_batch_fill (pointers are device pointers), copied to the device once, and re-used every step for as
+ * long as the parameter and image buffers stay where they are. */
+int64_t rv_pack_batch_entry_bytes(void);
+int rv_pack_batch_fill(const rvTapGeom* g, const float* T, void* gather_w, void* scatter_w, void* host_entries);
+int rv_pack_batch(const void* dev_table, int32_t n_entries, rvStream stream);
+
 /* fp32 packed weight gradient [kh*kw][cu_pad][cv_pad] -> accumulate/store into torch layout
  * dT[cu][cv][kh][kw] (fp32).  accumulate != 0: dT += value. */
 int rv_unpack_weight_grad(const rvTapGeom* g, const float* packed, float* dT, int32_t accumulate, rvStream stream);
@@ -302,6 +310,21 @@ int rv_meta_modulate_bwd_sums(const void* dgeo, const void* pos_raw, const float
 int rv_meta_modulate_bwd_apply(const void* dgeo, const void* pos_raw, const float* scale, const float* shift,
                                const float* mean, const float* invstd, const float* coef, const void* feat,
                                int32_t ld_feat, int32_t N, int32_t H, int32_t W, int32_t C, void* dy, rvStream stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Optimiser step of the recipe (nn/meta/arch.py:57 -> torch.optim.AdamW via conf/model/range_view.yaml:52-55; gradient
+ * clipping = Lightning's gradient_clip_val 35.0, conf/trainer/train.yaml) for ALL parameters in two launches.
+ * tensors: n_tensors x {float* p; const float* g; float* m; float* v; int64 n} (device table), chunks: n_chunks x
+ * {int32 tensor; int32 chunk} with chunk < ceil(n / rv_optim_chunk_elems()), partial: n_chunks floats of scratch.
+ * Arithmetic = torch/optim/adamw.py (foreach, non-capturable) in fp32, `step` = the 1-based step count of the bias
+ * corrections; max_norm > 0: g is scaled by min(1, max_norm / (||g||_2 + 1e-6)) on the fly (torch.nn.utils.clip_grad_norm_;
+ * the stored gradients stay untouched), total_norm (optional) receives ||g||_2.
+ * Replaces ATen's foreach norm / mul / lerp / addcmul / sqrt / div / addcdiv launches.
+ * ------------------------------------------------------------------------------------- */
+int32_t rv_optim_chunk_elems(void);
+int rv_adamw_step(const void* tensors, const void* chunks, int32_t n_chunks, float* partial, double lr, double beta1,
+                  double beta2, double eps, double weight_decay, int64_t step, double max_norm, float* total_norm,
+                  rvStream stream);
 
 /* ---------------------------------------------------------------------------------------
  * Decoder (nn/decoders/range_decoder.py:29-156, math/ops/coding.py:79-144,

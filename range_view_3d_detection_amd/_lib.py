@@ -72,7 +72,7 @@ def load() -> ctypes.CDLL:
         torch.cuda.init()
     lib = ctypes.CDLL(LIB_PATH)
     lib.rv_last_error.restype = ctypes.c_char_p
-    for name in ("rv_packed_weight_bytes", "rv_decode_num_candidates", "rv_wnms_workspace_bytes", "rv_tap_wgrad_workspace_bytes", "rv_bn_bwd_smallk_workspace_bytes", "rv_smallk_forward_workspace_bytes", "rv_nms_sweeps_workspace_bytes"):
+    for name in ("rv_packed_weight_bytes", "rv_decode_num_candidates", "rv_wnms_workspace_bytes", "rv_tap_wgrad_workspace_bytes", "rv_bn_bwd_smallk_workspace_bytes", "rv_smallk_forward_workspace_bytes", "rv_nms_sweeps_workspace_bytes", "rv_pack_batch_entry_bytes"):
         if hasattr(lib, name):
             getattr(lib, name).restype = ctypes.c_int64
     _lib = lib

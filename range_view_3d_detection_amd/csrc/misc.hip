@@ -39,12 +39,11 @@ struct PackArgs2 {  // both forms in one launch: blockIdx.y selects
     PackArgs f[2];
 };
 
-__global__ void pack_weight_kernel(const PackArgs2 both) {
-    const PackArgs& a = both.f[blockIdx.y];
+__device__ __forceinline__ void pack_one(const PackArgs& a, int64_t first, int64_t stride) {
     const int taps = a.kh * a.kw;
     const int64_t per_img = (int64_t)a.cu_pad * a.cv_pad;
     const int64_t total = per_img * taps;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = first; i < total; i += stride) {
         const int img = (int)(i / per_img);
         const int64_t rem = i - img * per_img;
         int ky, kx, u, v;
@@ -65,6 +64,15 @@ __global__ void pack_weight_kernel(const PackArgs2 both) {
         if (u < a.cu && v < a.cv) w = a.T[(((int64_t)u * a.cv + v) * a.kh + ky) * a.kw + kx];
         a.out[i] = f2bf(w);
     }
+}
+
+__global__ void pack_weight_kernel(const PackArgs2 both) {
+    pack_one(both.f[blockIdx.y], blockIdx.x * (int64_t)blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
+}
+
+// every layer of a model in ONE launch (after an optimiser step all packed images are stale): blockIdx.y = table entry
+__global__ void pack_weight_batch_kernel(const PackArgs* items) {
+    pack_one(items[blockIdx.y], blockIdx.x * (int64_t)blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
 }
 
 __global__ void unpack_wgrad_kernel(const float* packed, float* dT, int cu, int cv, int cu_pad, int cv_pad, int kh,
@@ -115,6 +123,37 @@ extern "C" int rv_pack_weight(const rvTapGeom* g, const float* T, void* gather_w
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, both);  // one launch for both forms
     RV_CHECK_LAUNCH("pack_weight_kernel");
+    return 0;
+}
+
+static int fill_pack_args(const rvTapGeom* g, const float* T, void* out, int form, PackArgs* a) {
+    int step;
+    memset(a, 0, sizeof(*a));
+    if (rv_build_tap_table(g, form == 1, &a->tt, &a->phases, &step)) return 1;
+    a->T = T;
+    a->out = (bf16_t*)out;
+    a->cu = g->cu;
+    a->cv = g->cv;
+    a->cu_pad = rv_pad32(g->cu);
+    a->cv_pad = rv_pad32(g->cv);
+    a->kh = g->kh;
+    a->kw = g->kw;
+    a->scatter = form;
+    return 0;
+}
+
+extern "C" int64_t rv_pack_batch_entry_bytes(void) { return (int64_t)sizeof(PackArgs); }
+
+extern "C" int rv_pack_batch_fill(const rvTapGeom* g, const float* T, void* gather_w, void* scatter_w, void* host_entries) {
+    RV_REQUIRE(g && T && gather_w && scatter_w && host_entries, "rv_pack_batch_fill: null argument");
+    PackArgs* e = (PackArgs*)host_entries;
+    return fill_pack_args(g, T, gather_w, 0, e) || fill_pack_args(g, T, scatter_w, 1, e + 1);
+}
+
+extern "C" int rv_pack_batch(const void* dev_table, int32_t n_entries, rvStream stream) {
+    RV_REQUIRE(dev_table && n_entries > 0 && n_entries <= 65535, "rv_pack_batch: bad table");
+    hipLaunchKernelGGL(pack_weight_batch_kernel, dim3(64, n_entries), dim3(256), 0, (hipStream_t)stream, (const PackArgs*)dev_table);
+    RV_CHECK_LAUNCH("pack_weight_batch_kernel");
     return 0;
 }
 

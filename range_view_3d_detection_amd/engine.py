@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import weakref
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple, Union
 
@@ -316,6 +317,51 @@ def _dma_eligible(geom, n: int, h: int, wu: int, wv: int, ld_src: int, ld_dst: i
 # ---------------------------------------------------------------------------------------------
 # conv layers: geometry + packed weights
 # ---------------------------------------------------------------------------------------------
+_LAYERS: "weakref.WeakSet[TapLayer]" = weakref.WeakSet()
+_PACK_TABLES: Dict[tuple, Tensor] = {}
+BATCH_PACK = os.environ.get("RV3D_NO_BATCH_PACK") is None
+
+
+def prepack_stale() -> None:
+    """Re-pack every layer whose parameter changed since its images were made (= all of them after an optimiser step) in ONE
+    launch (``rv_pack_batch``) instead of one ``rv_pack_weight`` launch per layer when the layer is next used (~160 launches
+    per training step on the rv-* models).  Called at the start of a training-mode program; layers seen for the first time,
+    layers with a permuted weight (``in_perm``) and non-fp32 parameters stay on the lazy per-layer path."""
+    if not (BATCH_PACK and torch.is_grad_enabled()):
+        return
+    stale = []
+    for l in _LAYERS:
+        w = l.weight
+        if (l._version is None or l.in_perm is not None or not w.requires_grad or not w.is_cuda or w.dtype != torch.float32
+                or not w.is_contiguous() or len(l._packed) != 2):
+            continue
+        if (w._version, w.data_ptr()) != l._version:
+            stale.append(l)
+    if len(stale) < 2:
+        return
+    stale.sort(key=id)
+    dev = stale[0].weight.device
+    for l in stale:
+        if not l._images:
+            n = L.load().rv_packed_weight_bytes(ctypes.byref(l.geom)) // 2
+            l._images = {f: torch.empty(n, dtype=torch.bfloat16, device=dev) for f in ("gather", "scatter")}
+    key = tuple((id(l), l.weight.data_ptr(), l._images["gather"].data_ptr(), l._images["scatter"].data_ptr()) for l in stale)
+    table = _PACK_TABLES.get(key)
+    if table is None:
+        eb = L.load().rv_pack_batch_entry_bytes()
+        host = (ctypes.c_uint8 * (2 * eb * len(stale)))()
+        for i, l in enumerate(stale):
+            L.call("rv_pack_batch_fill", ctypes.byref(l.geom), L.ptr(l.weight), L.ptr(l._images["gather"]), L.ptr(l._images["scatter"]),
+                   ctypes.byref(host, 2 * eb * i))
+        _PACK_TABLES.clear()  # one live table (a second model in the process rebuilds it: cheap)
+        table = torch.frombuffer(host, dtype=torch.uint8).clone().to(dev)
+        _PACK_TABLES[key] = table
+    L.call("rv_pack_batch", L.ptr(table), L.i32(2 * len(stale)), L.stream_ptr())
+    for l in stale:
+        l._packed = dict(l._images)
+        l._version = (l.weight._version, l.weight.data_ptr())
+
+
 class TapLayer:
     """Geometry and packed bf16 weight images of one nn.Conv2d / nn.ConvTranspose2d parameter."""
 
@@ -333,6 +379,8 @@ class TapLayer:
         self.cu, self.cv = cu, cv
         self._packed: Dict[str, Tensor] = {}
         self._version = None
+        self._images: Dict[str, Tensor] = {}  # persistent buffers of the batched re-pack (prepack_stale)
+        _LAYERS.add(self)
 
     # forward direction of the torch module: conv = gather, conv-transpose = scatter
     @property

@@ -138,6 +138,8 @@ class _ProgramFn(torch.autograd.Function):
                 E._require_cuda(x, "input tensor")
         dev = next(x.device for x in inputs if isinstance(x, Tensor))
         tape = Tape(training, dev)
+        if training:
+            E.prepack_stale()  # weight images of every layer the optimiser touched, one launch
         in_acts, outs = build(tape, *inputs)
         if tape.bn_counters:
             torch._foreach_add_(tape.bn_counters, 1)  # num_batches_tracked of every BatchNorm on the tape, one launch

@@ -469,3 +469,80 @@ def test_batch_nms_device_path_few_large_classes(n_cls, k):
     assert fast[0].shape == loop[0].shape and fast[0].shape[0] >= 2 * n_cls * 100
     for a, b_ in zip(fast, loop):
         assert torch.equal(a, b_)
+
+
+def test_batched_weight_repack_equals_the_per_layer_pack():
+    """``engine.prepack_stale`` (every stale layer's gather + scatter image in ONE ``rv_pack_batch`` launch at the start of a
+    training step) writes bit for bit what ``rv_pack_weight`` writes layer by layer, for every geometry of the model (3x3,
+    1x1, strided, transposed (3,8)/s4 and (3,4)/s2), and leaves layers it does not cover (permuted weights) to the lazy path."""
+    import ctypes
+
+    from bench import Detector, build_model, synthetic_batch
+    from range_view_3d_detection_amd import _lib as L
+    from range_view_3d_detection_amd import engine as E
+
+    torch.manual_seed(0)
+    backbone, head = build_model("c32", 5)
+    model = Detector(backbone, head).to(DEV).train()
+    batch = synthetic_batch(1, 16, 128, seed=2, device=DEV, boxes_per_sweep=4, n_cls=5)
+    model(batch).backward()  # first step: every layer packs itself (both forms)
+    layers = [l for l in E._LAYERS if any(l.weight is p for p in model.parameters())]
+    assert len(layers) > 40
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(0.01 * torch.randn_like(p))  # an optimiser step: every image is stale now
+    E.prepack_stale()
+    covered = 0
+    for l in layers:
+        if l.in_perm is not None:
+            assert l._version != (l.weight._version, l.weight.data_ptr())  # still stale: the lazy path repacks it
+            continue
+        assert l._version == (l.weight._version, l.weight.data_ptr()) and set(l._packed) == {"gather", "scatter"}
+        n = L.load().rv_packed_weight_bytes(ctypes.byref(l.geom)) // 2
+        ref = {f: torch.empty(n, dtype=torch.bfloat16, device=DEV) for f in ("gather", "scatter")}
+        L.call("rv_pack_weight", ctypes.byref(l.geom), L.ptr(l.weight.detach().contiguous()), L.ptr(ref["gather"]), L.ptr(ref["scatter"]), L.stream_ptr())
+        for f in ref:
+            assert torch.equal(l._packed[f].view(torch.int16), ref[f].view(torch.int16)), (f, l.geom.kh, l.geom.kw, l.geom.stride_w)
+        covered += 1
+    assert covered > 40
+    loss = model(batch)  # and the next step runs on the batched images
+    assert torch.isfinite(loss)
+
+
+def test_fused_adamw_matches_torch_adamw_with_clipping():
+    """``optim.AdamW`` (clip_grad_norm_ + AdamW of all parameters in two launches, ``rv_adamw_step``) against
+    ``torch.nn.utils.clip_grad_norm_`` + ``torch.optim.AdamW`` under the recipe's ``OneCycleLR`` (which moves lr AND beta1
+    every step): parameters and both moments within 2e-6 of their scale after five steps, the reported total norm 1e-6;
+    tensor sizes straddle the 65536-element chunk, the 4-element vector width and a tensor of one element; the large
+    gradients of step 2 make the clip active, the small ones of the other steps leave it inactive."""
+    from range_view_3d_detection_amd.optim import AdamW
+
+    gen = torch.Generator().manual_seed(0)
+    sizes = [(1,), (3,), (7, 11), (1000,), (65536 + 5,), (3, 70001), (256, 256, 3, 3)]
+    base = [torch.randn(s, generator=gen) for s in sizes]
+    a = [torch.nn.Parameter(b.clone().to(DEV)) for b in base]
+    b = [torch.nn.Parameter(b.clone().to(DEV)) for b in base]
+    oa = AdamW(a, lr=1e-3, max_grad_norm=35.0)
+    ob = torch.optim.AdamW(b, lr=1e-3)
+    sa = torch.optim.lr_scheduler.OneCycleLR(oa, max_lr=0.0015, total_steps=20)
+    sb = torch.optim.lr_scheduler.OneCycleLR(ob, max_lr=0.0015, total_steps=20)
+    for it in range(5):
+        grads = [torch.randn(s, generator=gen) * (5.0 if it == 2 else 0.01) for s in sizes]
+        for p, q, g in zip(a, b, grads):
+            p.grad = g.clone().to(DEV)
+            q.grad = g.clone().to(DEV)
+        want_norm = torch.nn.utils.clip_grad_norm_(b, 35.0)
+        oa.step()
+        ob.step()
+        sa.step()
+        sb.step()
+        assert abs(float(oa.last_grad_norm) - float(want_norm)) < 1e-6 * float(want_norm)
+        assert (float(want_norm) > 35.0) == (it == 2)
+        assert oa.param_groups[0]["betas"] == ob.param_groups[0]["betas"] and oa.param_groups[0]["lr"] == ob.param_groups[0]["lr"]
+    for p, q in zip(a, b):
+        for x, y in ((p, q), (oa.state[p]["exp_avg"], ob.state[q]["exp_avg"]), (oa.state[p]["exp_avg_sq"], ob.state[q]["exp_avg_sq"])):
+            err = float((x.detach() - y.detach()).abs().max())
+            assert err <= 2e-6 * max(float(y.detach().abs().max()), 1e-30), (tuple(p.shape), err)
+        assert float(oa.state[p]["step"]) == float(ob.state[q]["step"]) == 5.0
+    sd = oa.state_dict()  # the state keys / layout torch.optim.AdamW checkpoints carry
+    assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and sd["param_groups"][0]["weight_decay"] == 1e-2
