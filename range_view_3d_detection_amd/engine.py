@@ -326,14 +326,15 @@ def prepack_stale() -> None:
     """Re-pack every layer whose parameter changed since its images were made (= all of them after an optimiser step) in ONE
     launch (``rv_pack_batch``) instead of one ``rv_pack_weight`` launch per layer when the layer is next used (~160 launches
     per training step on the rv-* models).  Called at the start of a training-mode program; layers seen for the first time,
-    layers with a permuted weight (``in_perm``) and non-fp32 parameters stay on the lazy per-layer path."""
-    if not (BATCH_PACK and torch.is_grad_enabled()):
+    layers with a permuted weight (``in_perm``) and non-fp32 parameters stay on the lazy per-layer path.  Both images of a
+    layer are written (a layer whose input needs no gradient never reads its scatter image: a few small ones)."""
+    if not BATCH_PACK:  # (no grad-mode test here: inside an autograd.Function's forward grad mode is off)
         return
     stale = []
     for l in _LAYERS:
         w = l.weight
         if (l._version is None or l.in_perm is not None or not w.requires_grad or not w.is_cuda or w.dtype != torch.float32
-                or not w.is_contiguous() or len(l._packed) != 2):
+                or not w.is_contiguous() or not l._packed):
             continue
         if (w._version, w.data_ptr()) != l._version:
             stale.append(l)

@@ -103,5 +103,8 @@ class AdamW(torch.optim.Optimizer):
                    L.f64(float(group["lr"])), L.f64(float(beta1)), L.f64(float(beta2)), L.f64(float(group["eps"])),
                    L.f64(float(group["weight_decay"])), L.i64(step), L.f64(float(self.max_grad_norm) if self.max_grad_norm is not None else 0.0),
                    L.ptr(plan["norm"]), L.stream_ptr())
+            # the kernel wrote the parameters and moments behind torch's back: tell autograd (and everything keyed on
+            # Tensor._version, e.g. the packed bf16 weight images of engine.TapLayer) that they changed
+            torch.autograd.graph.increment_version(ps)
             self.last_grad_norm = plan["norm"]
         return loss

@@ -507,6 +507,17 @@ def test_batched_weight_repack_equals_the_per_layer_pack():
     assert covered > 40
     loss = model(batch)  # and the next step runs on the batched images
     assert torch.isfinite(loss)
+    # inside a training step: an optimiser step that writes the parameters through raw pointers (optim.AdamW) must make
+    # every image stale, and the next forward must re-pack them in the one batched launch
+    from range_view_3d_detection_amd.optim import AdamW
+
+    opt = AdamW(list(model.parameters()), lr=1e-2)
+    loss.backward()
+    before = {id(l): l._packed["gather"].clone() for l in layers if l.in_perm is None}
+    opt.step()
+    model(batch)
+    changed = sum(int(not torch.equal(before[id(l)], l._packed["gather"])) for l in layers if l.in_perm is None)
+    assert changed == len(before), (changed, len(before))
 
 
 def test_fused_adamw_matches_torch_adamw_with_clipping():
