@@ -207,14 +207,36 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_finalize_kernel(const float
     coef[2 * c + ch] = (float)(s1 * inv_count);
 }
 
-__device__ __forceinline__ void apply_px(const BnbArgs& a, int64_t px, int c0, const BnbLoad& r, const u32x4 old,
-                                         const float* sc, const float* sh, const float* mu, const float* is,
-                                         const float* k0, const float* k1, const float* k2) {
+// Each workgroup walks ONE CONTIGUOUS pixel range (a grid-stride comb of 4 KB pieces read + wrote at 4.4-4.7 TB/s, contiguous
+// ranges reach 5.2-5.5: profiles/r02_hbm_kernels.md).  MODE 1: streaming (non-temporal) loads / stores, chosen for tensors
+// that exceed the 256 MB Infinity Cache anyway (+2..25 % there, -15 % on small ones, same file).
+template <int MODE>
+__device__ __forceinline__ u32x4 ld16(const bf16_t* p) {
+    if (MODE & 1) return __builtin_nontemporal_load((const u32x4*)p);
+    return *(const u32x4*)p;
+}
+template <int MODE>
+__device__ __forceinline__ void st16(bf16_t* p, const u32x4 v) {
+    if (MODE & 1) __builtin_nontemporal_store(v, (u32x4*)p);
+    else *(u32x4*)p = v;
+}
+template <int MODE>
+__device__ __forceinline__ BnbLoad load_px_m(const BnbArgs& a, int64_t px, int c0) {
+    BnbLoad r;
+    r.d = ld16<MODE>(a.dout + px * a.ld_dout + c0);
+    r.y = ld16<MODE>(a.y + px * a.ld_y + c0);
+    if (a.out) r.o = ld16<MODE>(a.out + px * a.ld_out + c0);
+    return r;
+}
+template <int MODE>
+__device__ __forceinline__ void apply_px_m(const BnbArgs& a, int64_t px, int c0, const BnbLoad& r, const u32x4 old,
+                                           const float* sc, const float* sh, const float* mu, const float* is,
+                                           const float* k0, const float* k1, const float* k2) {
     float g[8], xh[8], o[8];
     masked_grad(a, r, sc, sh, mu, is, g, xh);
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = k0[j] * (g[j] - k1[j] - xh[j] * k2[j]);
-    *(u32x4*)(a.dy + px * a.ld_dy + c0) = pack8(o);
+    st16<MODE>(a.dy + px * a.ld_dy + c0, pack8(o));
     if (a.dres) {
         if (a.flags & RV_BNB_RES_ACCUM) {
             float prev[8];
@@ -222,10 +244,11 @@ __device__ __forceinline__ void apply_px(const BnbArgs& a, int64_t px, int c0, c
 #pragma unroll
             for (int j = 0; j < 8; ++j) g[j] += prev[j];
         }
-        *(u32x4*)(a.dres + px * a.ld_dres + c0) = pack8(g);
+        st16<MODE>(a.dres + px * a.ld_dres + c0, pack8(g));
     }
 }
 
+template <int MODE>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnbArgs a) {
     const int tid = threadIdx.x;
     const int lanes_px = 256 / a.c8;
@@ -244,23 +267,25 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnbArgs a) {
         k2[j] = a.coef[2 * a.c + c0 + j];
     }
     const bool acc = a.dres && (a.flags & RV_BNB_RES_ACCUM);
-    const int64_t step = (int64_t)gridDim.x * lanes_px;
-    int64_t px = (int64_t)blockIdx.x * lanes_px + pl;
-    for (; px + step < a.pixels; px += 2 * step) {
-        const BnbLoad r0 = load_px(a, px, c0), r1 = load_px(a, px + step, c0);
+    const int64_t per = ((a.pixels + gridDim.x - 1) / gridDim.x + lanes_px - 1) / lanes_px * lanes_px;
+    const int64_t end = (int64_t)(blockIdx.x + 1) * per < a.pixels ? (int64_t)(blockIdx.x + 1) * per : a.pixels;
+    const int64_t step = lanes_px;
+    int64_t px = (int64_t)blockIdx.x * per + pl;
+    for (; px + step < end; px += 2 * step) {
+        const BnbLoad r0 = load_px_m<MODE>(a, px, c0), r1 = load_px_m<MODE>(a, px + step, c0);
         u32x4 o0 = {}, o1 = {};
         if (acc) {
             o0 = *(const u32x4*)(a.dres + px * a.ld_dres + c0);
             o1 = *(const u32x4*)(a.dres + (px + step) * a.ld_dres + c0);
         }
-        apply_px(a, px, c0, r0, o0, sc, sh, mu, is, k0, k1, k2);
-        apply_px(a, px + step, c0, r1, o1, sc, sh, mu, is, k0, k1, k2);
+        apply_px_m<MODE>(a, px, c0, r0, o0, sc, sh, mu, is, k0, k1, k2);
+        apply_px_m<MODE>(a, px + step, c0, r1, o1, sc, sh, mu, is, k0, k1, k2);
     }
-    if (px < a.pixels) {
-        const BnbLoad r0 = load_px(a, px, c0);
+    if (px < end) {
+        const BnbLoad r0 = load_px_m<MODE>(a, px, c0);
         u32x4 o0 = {};
         if (acc) o0 = *(const u32x4*)(a.dres + px * a.ld_dres + c0);
-        apply_px(a, px, c0, r0, o0, sc, sh, mu, is, k0, k1, k2);
+        apply_px_m<MODE>(a, px, c0, r0, o0, sc, sh, mu, is, k0, k1, k2);
     }
 }
 
@@ -622,7 +647,10 @@ extern "C" int rv_bn_bwd_apply(int64_t pixels, int32_t c, const void* dout, int3
     const int lanes_px = 256 / a.c8;
     int64_t blocks = (pixels + lanes_px - 1) / lanes_px;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    if ((int64_t)pixels * c * 2 >= ((int64_t)256 << 20))
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<0>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, a);
     RV_CHECK_LAUNCH("bn_bwd_apply_kernel");
     return 0;
 }

@@ -430,6 +430,67 @@ __global__ __launch_bounds__(256) void ew_combine_kernel(const EwArgs e) {
     }
 }
 
+// The same map with thread = (pixel lane, channel octet): the folded-BatchNorm constants of the thread's octet stay in
+// registers, and every workgroup walks one CONTIGUOUS pixel range with two pixels in flight (see bn_bwd_apply_kernel:
+// contiguous ranges read + write ~15 % faster than a grid-stride comb).  c8 <= 256.
+__global__ __launch_bounds__(256) void ew_combine_rows_kernel(const EwArgs e) {
+    const int tid = threadIdx.x;
+    const int lanes_px = 256 / e.c8;
+    const int oct = tid % e.c8, pl = tid / e.c8;
+    if (pl >= lanes_px) return;
+    const int c = oct * 8;
+    float as[8], ah[8], bs[8], bh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        as[j] = e.a_scale ? e.a_scale[c + j] : 1.f;
+        ah[j] = e.a_scale ? e.a_shift[c + j] : 0.f;
+        bs[j] = e.b_scale ? e.b_scale[c + j] : 1.f;
+        bh[j] = e.b_scale ? e.b_shift[c + j] : 0.f;
+    }
+    const int64_t per = ((e.pixels + gridDim.x - 1) / gridDim.x + lanes_px - 1) / lanes_px * lanes_px;
+    const int64_t end = (int64_t)(blockIdx.x + 1) * per < e.pixels ? (int64_t)(blockIdx.x + 1) * per : e.pixels;
+    auto finish = [&](int64_t px, const u32x4 ra, const u32x4 rb) {
+        float va[8], vb[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            va[2 * j] = bf_lo(ra[j]);
+            va[2 * j + 1] = bf_hi(ra[j]);
+            vb[2 * j] = bf_lo(rb[j]);
+            vb[2 * j + 1] = bf_hi(rb[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float x = e.a_scale ? va[j] * as[j] + ah[j] : va[j];
+            if (e.flags & RV_EW_RELU_A) x = fmaxf(x, 0.f);
+            if (e.b) {
+                float y = e.b_scale ? vb[j] * bs[j] + bh[j] : vb[j];
+                if (e.flags & RV_EW_RELU_B) y = fmaxf(y, 0.f);
+                x += y;
+            }
+            if (e.flags & RV_EW_RELU_OUT) x = fmaxf(x, 0.f);
+            va[j] = x;
+        }
+        store8(e.out + px * e.ld_out + c, va);
+    };
+    int64_t px = (int64_t)blockIdx.x * per + pl;
+    for (; px + lanes_px < end; px += 2 * lanes_px) {
+        const u32x4 a0 = *(const u32x4*)(e.a + px * e.ld_a + c), a1 = *(const u32x4*)(e.a + (px + lanes_px) * e.ld_a + c);
+        u32x4 b0 = {}, b1 = {};
+        if (e.b) {
+            b0 = *(const u32x4*)(e.b + px * e.ld_b + c);
+            b1 = *(const u32x4*)(e.b + (px + lanes_px) * e.ld_b + c);
+        }
+        finish(px, a0, b0);
+        finish(px + lanes_px, a1, b1);
+    }
+    if (px < end) {
+        const u32x4 a0 = *(const u32x4*)(e.a + px * e.ld_a + c);
+        u32x4 b0 = {};
+        if (e.b) b0 = *(const u32x4*)(e.b + px * e.ld_b + c);
+        finish(px, a0, b0);
+    }
+}
+
 }  // namespace
 
 static int ew_grid(int64_t work) {
@@ -444,7 +505,16 @@ extern "C" int rv_ew_combine(int64_t pixels, int32_t c, const void* a, int32_t l
     RV_REQUIRE(c % 8 == 0 && ld_a % 8 == 0 && ld_out % 8 == 0 && (!b || ld_b % 8 == 0), "rv_ew_combine: channels / strides must be multiples of 8");
     RV_REQUIRE((a_scale == nullptr) == (a_shift == nullptr) && (b_scale == nullptr) == (b_shift == nullptr), "rv_ew_combine: scale and shift go together");
     EwArgs e{(const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, a_scale, a_shift, b_scale, b_shift, pixels, c / 8, ld_a, ld_b, ld_out, flags};
-    hipLaunchKernelGGL(ew_combine_kernel, dim3(ew_grid(pixels * (c / 8))), dim3(256), 0, (hipStream_t)stream, e);
+    // (measured, profiles/r02_hbm_kernels.md: the row-range kernel wins on tensors beyond the Infinity Cache, 4.9-5.2 vs 4.7-4.8 TB/s;
+    //  on small ones its per-thread constant prologue costs more than the comb's address arithmetic, 2.9 vs 6.2 TB/s)
+    if (e.c8 <= 256 && pixels * c * 2 >= ((int64_t)256 << 20)) {
+        const int lanes_px = 256 / e.c8;
+        int64_t blocks = (pixels + lanes_px - 1) / lanes_px;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(ew_combine_rows_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, e);
+    } else {
+        hipLaunchKernelGGL(ew_combine_kernel, dim3(ew_grid(pixels * (c / 8))), dim3(256), 0, (hipStream_t)stream, e);
+    }
     RV_CHECK_LAUNCH("ew_combine_kernel");
     return 0;
 }
