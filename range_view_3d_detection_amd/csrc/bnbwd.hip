@@ -543,8 +543,11 @@ __global__ __launch_bounds__(256) void smallk_apply_kernel(const bf16_t* v, int 
 #pragma unroll
         for (int e = 0; e < CIN; ++e) wt[j][e] = bf2f(w[(int64_t)(c0 + j) * ld_w + e]);
     }
-    const int64_t step = (int64_t)gridDim.x * lanes_px;
-    for (int64_t px = (int64_t)blockIdx.x * lanes_px + pl; px < pixels; px += step) {
+    // one contiguous pixel range per workgroup, streaming stores beyond the Infinity Cache (see bn_bwd_apply_kernel)
+    const bool nt = pixels * c8 * 16 >= ((int64_t)256 << 20);
+    const int64_t per = ((pixels + gridDim.x - 1) / gridDim.x + lanes_px - 1) / lanes_px * lanes_px;
+    const int64_t end = (int64_t)(blockIdx.x + 1) * per < pixels ? (int64_t)(blockIdx.x + 1) * per : pixels;
+    for (int64_t px = (int64_t)blockIdx.x * per + pl; px < end; px += lanes_px) {
         float vv[8], o[8];
         unpack8(*(const u32x4*)(v + px * ld_v), vv);
 #pragma unroll
@@ -555,7 +558,8 @@ __global__ __launch_bounds__(256) void smallk_apply_kernel(const bf16_t* v, int 
             y = y * sc[j] + sh[j];
             o[j] = relu ? fmaxf(y, 0.f) : y;
         }
-        *(u32x4*)(h + px * ld_h + c0) = pack8(o);
+        if (nt) __builtin_nontemporal_store(pack8(o), (u32x4*)(h + px * ld_h + c0));
+        else *(u32x4*)(h + px * ld_h + c0) = pack8(o);
     }
 }
 
@@ -806,7 +810,7 @@ extern "C" int rv_smallk_forward(const void* v, int32_t ld_v, int64_t pixels, in
     }
     const int c8 = c / 8, lanes_px = 256 / c8;
     int64_t blocks = (pixels + lanes_px - 1) / lanes_px;
-    if (blocks > 8192) blocks = 8192;
+    if (blocks > 4096) blocks = 4096;
     if (CIN == 4)
         hipLaunchKernelGGL(smallk_apply_kernel<4>, dim3((int)blocks), dim3(256), 0, st, (const bf16_t*)v, ld_v, pixels, c8, (const bf16_t*)w_packed, ld_w,
                            scale, shift, relu, (bf16_t*)h, ld_h);

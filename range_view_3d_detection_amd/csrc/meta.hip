@@ -4,6 +4,8 @@
 // consecutive octets (coalesced 512-byte pixel rows for C = 256).
 //
 // Tap order follows F.unfold: k = ky*3 + kx, neighbour = (h + ky - 1, w + kx - 1), zero padded.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -76,29 +78,51 @@ __device__ __forceinline__ StripItem strip_item(int64_t q, int xcd, int N, int H
     return it;
 }
 
-// geo[p][k*C + c] = relu(scale*pos[p*9+k][c] + shift) * feat[nbr_k(p)][c]
+// Items of an XCD's column strip in (row, column, tap) order are consecutive in memory within a row segment.  A workgroup
+// takes PIECES of kPieceItems consecutive items (64 KB at C = 256: long contiguous runs read + write ~15 % faster than
+// 4 KB pieces, profiles/r02_hbm_kernels.md) round-robin over the strip, so that the workgroups of an XCD still sweep the
+// strip row after row together and the three feature rows they need stay in its L2.
+constexpr int kPieceItems = 128;
+
+// geo[p][k*C + c] = relu(scale*pos[p*9+k][c] + shift) * feat[nbr_k(p)][c];  thread = (item lane, channel octet)
 __global__ __launch_bounds__(256) void meta_modulate_kernel(const bf16_t* pos, const float* scale, const float* shift,
                                                             const bf16_t* feat, int ld_feat, int N, int H, int W, int C,
-                                                            bf16_t* geo) {
+                                                            bf16_t* geo, int piece) {
     const int c8 = C / 8;
+    const int lanes = 256 / c8;
+    const int oct = threadIdx.x % c8, pl = threadIdx.x / c8;
+    if (pl >= lanes) return;
+    const int c0 = oct * 8;
     const int64_t hw = (int64_t)H * W;
-    const int xcd = blockIdx.x & 7;
-    const int64_t per_xcd = (int64_t)N * H * ((W + 7) / 8) * 9 * c8, stride = (int64_t)(gridDim.x >> 3) * blockDim.x;
-    for (int64_t q = (int64_t)(blockIdx.x >> 3) * blockDim.x + threadIdx.x; q < per_xcd; q += stride) {
-        const StripItem it = strip_item(q, xcd, N, H, W, c8);
-        if (!it.ok) continue;
-        const int oc = it.oc, k = it.k, h = it.h, w = it.w;
-        const int64_t n = it.n, pk = it.p * 9 + k;
-        const int hn = h + k / 3 - 1, wn = w + k % 3 - 1;
-        float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (hn >= 0 && hn < H && wn >= 0 && wn < W) {
-            float a[8], f[8];
-            unpack8(*(const u32x4*)(pos + pk * C + oc * 8), a);
-            unpack8(*(const u32x4*)(feat + (n * hw + (int64_t)hn * W + wn) * ld_feat + oc * 8), f);
+    float sc[8], sh[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = fmaxf(a[j] * scale[oc * 8 + j] + shift[oc * 8 + j], 0.f) * f[j];
+    for (int j = 0; j < 8; ++j) {
+        sc[j] = scale[c0 + j];
+        sh[j] = shift[c0 + j];
+    }
+    const int xcd = blockIdx.x & 7, ws = (W + 7) / 8;
+    const int64_t items = (int64_t)N * H * ws * 9, pieces = (items + piece - 1) / piece;
+    for (int64_t pc = blockIdx.x >> 3; pc < pieces; pc += gridDim.x >> 3) {
+        const int64_t hi = (pc + 1) * piece < items ? (pc + 1) * piece : items;
+        for (int64_t it = pc * piece + pl; it < hi; it += lanes) {
+            const int k = (int)(it % 9);
+            const int64_t t = it / 9;
+            const int w = xcd * ws + (int)(t % ws);
+            if (w >= W) continue;
+            const int64_t row = t / ws, n = row / H;
+            const int h = (int)(row - n * H);
+            const int64_t pk = ((n * H + h) * (int64_t)W + w) * 9 + k;
+            const int hn = h + k / 3 - 1, wn = w + k % 3 - 1;
+            float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (hn >= 0 && hn < H && wn >= 0 && wn < W) {
+                float a[8], f[8];
+                unpack8(*(const u32x4*)(pos + pk * C + c0), a);
+                unpack8(*(const u32x4*)(feat + (n * hw + (int64_t)hn * W + wn) * ld_feat + c0), f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = fmaxf(a[j] * sc[j] + sh[j], 0.f) * f[j];
+            }
+            *(u32x4*)(geo + pk * C + c0) = pack8(o);
         }
-        *(u32x4*)(geo + pk * C + oc * 8) = pack8(o);
     }
 }
 
@@ -180,7 +204,7 @@ constexpr int kMetaPixPerBlock = 512;  // 1024 partial rows at 4 x 64 x 2048: th
 struct MetaBwdArgs {
     const bf16_t *dgeo, *y, *feat;
     const float *scale, *shift, *mean, *invstd, *coef;
-    int N, H, W, C, c8, ld_feat, ld_dfeat;
+    int N, H, W, C, c8, ld_feat, ld_dfeat, piece;
     bf16_t* dfeat;
     float* partial;
     bf16_t* dy;
@@ -275,8 +299,9 @@ __global__ __launch_bounds__(256) void meta_bwd_apply_kernel(const MetaBwdArgs a
         k2[j] = a.coef[2 * C + c0 + j];
     }
     const int xcd = blockIdx.x & 7, ws = (W + 7) / 8;
-    const int64_t items = (int64_t)a.N * H * ws * 9, step = (int64_t)(gridDim.x >> 3) * lanes_px;
-    for (int64_t it = (int64_t)(blockIdx.x >> 3) * lanes_px + pl; it < items; it += step) {
+    const int64_t items = (int64_t)a.N * H * ws * 9, pieces = (items + a.piece - 1) / a.piece;
+    for (int64_t pc = blockIdx.x >> 3; pc < pieces; pc += gridDim.x >> 3)
+    for (int64_t it = pc * a.piece + pl, hi = (pc + 1) * a.piece < items ? (pc + 1) * a.piece : items; it < hi; it += lanes_px) {
         const int k = (int)(it % 9);
         const int64_t t = it / 9;
         const int w = xcd * ws + (int)(t % ws);
@@ -302,6 +327,11 @@ __global__ __launch_bounds__(256) void meta_bwd_apply_kernel(const MetaBwdArgs a
     }
 }
 
+int meta_piece() {  // RV3D_META_PIECE: experiment switch (items per contiguous piece)
+    static const int v = getenv("RV3D_META_PIECE") ? atoi(getenv("RV3D_META_PIECE")) : kPieceItems;
+    return v > 0 ? v : kPieceItems;
+}
+
 int grid_for(int64_t work) {
     int64_t b = (work + 255) / 256;
     b = (b + 7) & ~(int64_t)7;  // (the strip order deals whole rounds of 8 workgroups)
@@ -322,9 +352,10 @@ extern "C" int rv_meta_modulate(const void* pos_raw, const float* scale, const f
                                 int32_t ld_feat, int32_t N, int32_t H, int32_t W, int32_t C, void* geo, rvStream stream) {
     RV_REQUIRE(pos_raw && scale && shift && feat && geo, "rv_meta_modulate: null argument");
     RV_REQUIRE(C % 8 == 0 && ld_feat % 8 == 0, "rv_meta_modulate: channels must be a multiple of 8");
+    RV_REQUIRE(C <= 2048, "rv_meta_modulate: at most 2048 channels");
     hipLaunchKernelGGL(meta_modulate_kernel, dim3(grid_for((int64_t)N * H * W * 9 * (C / 8))), dim3(256), 0,
                        (hipStream_t)stream, (const bf16_t*)pos_raw, scale, shift, (const bf16_t*)feat, ld_feat, N, H, W, C,
-                       (bf16_t*)geo);
+                       (bf16_t*)geo, meta_piece());
     RV_CHECK_LAUNCH("meta_modulate_kernel");
     return 0;
 }
@@ -375,6 +406,7 @@ extern "C" int rv_meta_modulate_bwd_apply(const void* dgeo, const void* pos_raw,
     a.scale = scale, a.shift = shift, a.mean = mean, a.invstd = invstd, a.coef = coef;
     a.N = N, a.H = H, a.W = W, a.C = C, a.c8 = C / 8, a.ld_feat = ld_feat;
     a.dy = (bf16_t*)dy;
+    a.piece = meta_piece();
     hipLaunchKernelGGL(meta_bwd_apply_kernel, dim3(grid_for((int64_t)N * H * W * 9 * (C / 8))), dim3(256), 0, (hipStream_t)stream, a);
     RV_CHECK_LAUNCH("meta_bwd_apply_kernel");
     return 0;
