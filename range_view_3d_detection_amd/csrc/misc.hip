@@ -39,30 +39,30 @@ struct PackArgs2 {  // both forms in one launch: blockIdx.y selects
     PackArgs f[2];
 };
 
+// One thread per (u, v) channel pair: its kh*kw taps are contiguous in the torch layout (one run of reads), and every tap
+// image receives consecutive 2-byte elements from consecutive threads (v fastest in the gather images, u in the scatter ones).
 __device__ __forceinline__ void pack_one(const PackArgs& a, int64_t first, int64_t stride) {
     const int taps = a.kh * a.kw;
-    const int64_t per_img = (int64_t)a.cu_pad * a.cv_pad;
-    const int64_t total = per_img * taps;
-    for (int64_t i = first; i < total; i += stride) {
-        const int img = (int)(i / per_img);
-        const int64_t rem = i - img * per_img;
-        int ky, kx, u, v;
+    const int64_t pairs = (int64_t)a.cu_pad * a.cv_pad;
+    for (int64_t pair = first; pair < pairs; pair += stride) {
+        int u, v;
         if (!a.scatter) {  // [tap][cu_pad][cv_pad]
-            ky = img / a.kw;
-            kx = img - ky * a.kw;
-            u = (int)(rem / a.cv_pad);
-            v = (int)(rem - (int64_t)u * a.cv_pad);
+            u = (int)(pair / a.cv_pad);
+            v = (int)(pair - (int64_t)u * a.cv_pad);
         } else {  // [phase-major tap][cv_pad][cu_pad]
-            int r = 0, idx = img;
-            while (r < a.phases - 1 && idx >= a.tt.ntaps[r]) idx -= a.tt.ntaps[r++];
-            ky = a.tt.ky[r][idx];
-            kx = a.tt.kx[r][idx];
-            v = (int)(rem / a.cu_pad);
-            u = (int)(rem - (int64_t)v * a.cu_pad);
+            v = (int)(pair / a.cu_pad);
+            u = (int)(pair - (int64_t)v * a.cu_pad);
         }
-        float w = 0.f;
-        if (u < a.cu && v < a.cv) w = a.T[(((int64_t)u * a.cv + v) * a.kh + ky) * a.kw + kx];
-        a.out[i] = f2bf(w);
+        const bool in = u < a.cu && v < a.cv;
+        const float* src = a.T + ((int64_t)u * a.cv + v) * taps;
+        if (!a.scatter) {
+            for (int t = 0; t < taps; ++t) a.out[(int64_t)t * pairs + pair] = f2bf(in ? src[t] : 0.f);
+        } else {
+            int img = 0;
+            for (int r = 0; r < a.phases; ++r)
+                for (int idx = 0; idx < a.tt.ntaps[r]; ++idx, ++img)
+                    a.out[(int64_t)img * pairs + pair] = f2bf(in ? src[a.tt.ky[r][idx] * a.kw + a.tt.kx[r][idx]] : 0.f);
+        }
     }
 }
 
@@ -119,7 +119,7 @@ extern "C" int rv_pack_weight(const rvTapGeom* g, const float* T, void* gather_w
         a.scatter = form;
     }
     if (n == 0) return 0;
-    const int64_t total = (int64_t)g->kh * g->kw * rv_pad32(g->cu) * rv_pad32(g->cv);
+    const int64_t total = (int64_t)rv_pad32(g->cu) * rv_pad32(g->cv);  // one thread per channel pair
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, both);  // one launch for both forms
     RV_CHECK_LAUNCH("pack_weight_kernel");
@@ -152,7 +152,7 @@ extern "C" int rv_pack_batch_fill(const rvTapGeom* g, const float* T, void* gath
 
 extern "C" int rv_pack_batch(const void* dev_table, int32_t n_entries, rvStream stream) {
     RV_REQUIRE(dev_table && n_entries > 0 && n_entries <= 65535, "rv_pack_batch: bad table");
-    hipLaunchKernelGGL(pack_weight_batch_kernel, dim3(64, n_entries), dim3(256), 0, (hipStream_t)stream, (const PackArgs*)dev_table);
+    hipLaunchKernelGGL(pack_weight_batch_kernel, dim3(128, n_entries), dim3(256), 0, (hipStream_t)stream, (const PackArgs*)dev_table);
     RV_CHECK_LAUNCH("pack_weight_batch_kernel");
     return 0;
 }
