@@ -385,6 +385,7 @@ int rv_build_tap_table(const rvTapGeom* g, bool scatter, TapTable* tt, int* phas
     return 0;
 }
 
+extern int g_tapconv5_persist;
 static int g_tapconv5_enable = 1;  // rv_set_option("tapconv5_enable", 0): multi-tap layers stay on tapconv4 (tests of that kernel)
 
 static int tap_launch(const rvTapGeom* g, const rvTapShape* s, bool scatter, const void* src, const float* in_scale,
@@ -564,6 +565,11 @@ int32_t rv_set_option(const char* key, int32_t value) {
     if (key && strcmp(key, "tapconv5_enable") == 0) {
         const int32_t old = g_tapconv5_enable;
         if (value >= 0) g_tapconv5_enable = value ? 1 : 0;
+        return old;
+    }
+    if (key && strcmp(key, "tapconv5_persist_blocks") == 0) {
+        const int32_t old = g_tapconv5_persist;
+        if (value >= 0) g_tapconv5_persist = value;
         return old;
     }
     rv_set_error("rv_set_option: unknown key '%s'", key ? key : "(null)");

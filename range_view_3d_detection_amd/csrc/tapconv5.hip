@@ -61,11 +61,16 @@ __global__ __launch_bounds__(512, 2) void tapconv5_kernel(const TapConvArgs a) {
     const int wr = wave >> 2, wc = wave & 3;
     const int l15 = lane & 15, lg = lane >> 4;
 
-    // XCD-aware block order (see tapconv3.hip)
+    // XCD-aware block order (see tapconv3.hip).  PERSISTENT workgroups: the launch has (a multiple of 8, at most the tile
+    // count) workgroups, each walks the virtual block indices vb = blockIdx.x, blockIdx.x + gridDim.x, ... -- same XCD every
+    // time (gridDim.x % 8 == 0) -- so a CU pays the workgroup dispatch (LDS allocation, wave start, kernel-argument loads)
+    // once per launch instead of once per tile (16 tiles per CU on the 512-channel layers).
     const int gy = a.n_tiles;
-    const int xcd = blockIdx.x & 7, xslot = blockIdx.x >> 3;
+    const int vtotal = 8 * a.tiles_per_xcd * gy;
+    for (int vb = blockIdx.x; vb < vtotal; vb += gridDim.x) {
+    const int xcd = vb & 7, xslot = vb >> 3;
     const int tile = xcd * a.tiles_per_xcd + xslot / gy;
-    if (tile >= a.total_tiles) return;
+    if (tile >= a.total_tiles) continue;
     const int n0 = (xslot % gy) * kBN;
     int bx = tile;
     const int tc = bx % a.m_tiles;
@@ -497,11 +502,14 @@ __global__ __launch_bounds__(512, 2) void tapconv5_kernel(const TapConvArgs a) {
             a.bnb_partial[((int64_t)tile * 2 + (jj >> 3)) * a.C_dst + n0 + chunk * 8 + (jj & 7)] = sum;
         }
     }
+    __syncthreads();  // the staged output / BatchNorm sums of this tile are dead before the next tile's loads land in LDS
+    }  // persistent tile loop
 }
 
 }  // namespace
 
 extern int g_tapconv4_min_blocks;
+int g_tapconv5_persist = 256;  // rv_set_option("tapconv5_persist_blocks"): workgroups of a persistent launch (0: one workgroup per tile)
 
 // returns false when the layer is not eligible (caller falls back to tapconv4 / tapconv3 / ...)
 bool rv_tapconv5_plan(TapConvArgs* a, int* tiles, size_t* lds, int* bn) {
@@ -558,10 +566,12 @@ int rv_tapconv5_launch(const TapConvArgs& a, size_t lds, int bn, hipStream_t str
         (void)hipFuncSetAttribute((const void*)tapconv5_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
+    int grid = 8 * a.tiles_per_xcd * a.n_tiles;
+    if (g_tapconv5_persist > 0 && grid > g_tapconv5_persist) grid = g_tapconv5_persist & ~7;  // one workgroup per CU (154 KB of LDS each)
     if (bn == 256)
-        hipLaunchKernelGGL(tapconv5_kernel<256>, dim3(8 * a.tiles_per_xcd * a.n_tiles), dim3(512), lds, stream, a);
+        hipLaunchKernelGGL(tapconv5_kernel<256>, dim3(grid), dim3(512), lds, stream, a);
     else
-        hipLaunchKernelGGL(tapconv5_kernel<128>, dim3(8 * a.tiles_per_xcd * a.n_tiles), dim3(512), lds, stream, a);
+        hipLaunchKernelGGL(tapconv5_kernel<128>, dim3(grid), dim3(512), lds, stream, a);
     RV_CHECK_LAUNCH("tapconv5_kernel");
     return 0;
 }
