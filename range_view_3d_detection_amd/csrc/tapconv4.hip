@@ -54,11 +54,14 @@ __global__ __launch_bounds__(512, 2) void tapconv4_kernel(const TapConvArgs a) {
     const int wr = wave >> 2, wc = wave & 3;
     const int l15 = lane & 15, lg = lane >> 4;
 
-    // XCD-aware block order (see tapconv3.hip)
+    // XCD-aware block order (see tapconv3.hip); persistent workgroups as in tapconv5.hip (a 1x1 layer has only four K tiles
+    // per tile: the per-workgroup dispatch is a large share of a tile's life here)
     const int gy = a.n_tiles;
-    const int xcd = blockIdx.x & 7, xslot = blockIdx.x >> 3;
+    const int vtotal = 8 * a.tiles_per_xcd * gy;
+    for (int vb = blockIdx.x; vb < vtotal; vb += gridDim.x) {
+    const int xcd = vb & 7, xslot = vb >> 3;
     const int tile = xcd * a.tiles_per_xcd + xslot / gy;
-    if (tile >= a.total_tiles) return;
+    if (tile >= a.total_tiles) continue;
     const int n0 = (xslot % gy) * BN;
     int bx = tile;
     const int tc = bx % a.m_tiles;
@@ -339,9 +342,13 @@ __global__ __launch_bounds__(512, 2) void tapconv4_kernel(const TapConvArgs a) {
         }
         *(u32x4*)p = v;
     }
+    __syncthreads();  // the staged output of this tile is dead before the next tile's loads land in LDS
+    }  // persistent tile loop
 }
 
 }  // namespace
+
+extern int g_tapconv5_persist;
 
 // Smallest grid (workgroups) the DMA kernel is chosen for: below one round of 256 CUs the register-staged kernels with
 // their smaller tiles fill the chip better.  A speed heuristic only -- rv_set_option("tapconv4_min_blocks", 1) lets the
@@ -380,10 +387,12 @@ int rv_tapconv4_launch(const TapConvArgs& a, size_t lds, int bn, hipStream_t str
         (void)hipFuncSetAttribute((const void*)tapconv4_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
+    int grid = 8 * a.tiles_per_xcd * a.n_tiles;
+    if (g_tapconv5_persist > 0 && grid > g_tapconv5_persist) grid = g_tapconv5_persist & ~7;
     if (bn == 256)
-        hipLaunchKernelGGL(tapconv4_kernel<256>, dim3(8 * a.tiles_per_xcd * a.n_tiles), dim3(512), lds, stream, a);
+        hipLaunchKernelGGL(tapconv4_kernel<256>, dim3(grid), dim3(512), lds, stream, a);
     else
-        hipLaunchKernelGGL(tapconv4_kernel<128>, dim3(8 * a.tiles_per_xcd * a.n_tiles), dim3(512), lds, stream, a);
+        hipLaunchKernelGGL(tapconv4_kernel<128>, dim3(grid), dim3(512), lds, stream, a);
     RV_CHECK_LAUNCH("tapconv4_kernel");
     return 0;
 }
