@@ -248,7 +248,8 @@ int rv_bn_bwd_smallk_from_sums(int32_t c, int32_t cin, const double* sums, const
 /* Forward of the same layers: h = relu?(BatchNorm(W v)) as ONE element-wise pass; in training the batch statistics come
  * in closed form from the data moments (m1 = sum v, M2 = sum v v^T: rv_smallk_moments writes cin_pad + cin_pad^2 doubles,
  * cin_pad = 4 or 8; the caller all-reduces them under SyncBN), so neither the raw conv output nor a statistics pass over
- * it exists.  moments == NULL: eval, scale/shift are inputs (rv_bn_fold_eval).  For the backward of such a layer call
+ * it exists.  moments == NULL: eval, scale/shift are inputs (rv_bn_fold_eval).  h == NULL: statistics only (the caller
+ * applies them itself: rv_pos_forward).  For the backward of such a layer call
  * rv_bn_bwd_smallk with RV_BNB_Y_FROM_INPUT (y = NULL: the raw output is recomputed from v, 16 bytes per pixel instead of
  * 2 C) and the layer's own scale / shift / mean / invstd; or, without the flag, with y = h, scale = 1, shift = 0,
  * mean = beta, invstd = 1/gamma, stat_* = the batch statistics (xhat rebuilt from the activated output).
@@ -310,6 +311,19 @@ int rv_meta_modulate_bwd_sums(const void* dgeo, const void* pos_raw, const float
 int rv_meta_modulate_bwd_apply(const void* dgeo, const void* pos_raw, const float* scale, const float* shift,
                                const float* mean, const float* invstd, const float* coef, const void* feat,
                                int32_t ld_feat, int32_t N, int32_t H, int32_t W, int32_t C, void* dy, rvStream stream);
+
+/* The two positional layers of the MetaKernel stem (nn/stems/__init__.py:41-49, 80: Conv2dNormActivation(3, C, 1) ->
+ * Conv2dNormActivation(C, C, 1) on the 9x neighbour grid) as ONE persistent streaming GEMM, C = 256:
+ *   h1 = relu(scale1 * (W1 rel) + shift1)   generated in the K-operand staging from `rel` (bf16 [pixels][ld_rel], cin <= 3
+ *                                           channels used) and written once (the second layer's weight gradient reads it),
+ *   y2 = W2 h1                              raw bf16, with fp32 (sum, sum of squares) rows of the accumulators in
+ *                                           stats_partial [rv_pos_forward_rows(pixels) + RV_STATS_SCRATCH_ROWS][2][C] (NULL: eval).
+ * scale1 / shift1: the first layer's folded BatchNorm (rv_smallk_forward with h == NULL forms them in closed form).
+ * Replaces rv_smallk_forward's apply pass + rv_tap_gather of the second layer (cuDNN conv2d x2 + BatchNorm + ReLU). */
+int32_t rv_pos_forward_rows(int64_t pixels);
+int rv_pos_forward(const void* rel, int32_t ld_rel, int32_t cin, int64_t pixels, const void* w1_packed, int32_t ld_w1,
+                   const float* scale1, const float* shift1, const void* w2_packed, int32_t c, void* h1, void* y2,
+                   float* stats_partial, rvStream stream);
 
 /* ---------------------------------------------------------------------------------------
  * Optimiser step of the recipe (nn/meta/arch.py:57 -> torch.optim.AdamW via conf/model/range_view.yaml:52-55; gradient

@@ -793,7 +793,7 @@ extern "C" int rv_smallk_forward(const void* v, int32_t ld_v, int64_t pixels, in
                                  int32_t c, const double* moments, int64_t count, const float* gamma, const float* beta, float eps,
                                  float momentum, float* running_mean, float* running_var, float* scale, float* shift, float* mean,
                                  float* invstd, int32_t relu, void* h, int32_t ld_h, rvStream stream) {
-    RV_REQUIRE(v && w_packed && scale && shift && h, "rv_smallk_forward: null argument");
+    RV_REQUIRE(v && w_packed && scale && shift, "rv_smallk_forward: null argument");  // h == NULL: statistics only (rv_pos_forward applies)
     RV_REQUIRE(cin >= 1 && cin <= 8 && ld_v % 8 == 0 && ld_v >= 8 && c % 8 == 0 && c / 8 <= 256 && ld_h % 8 == 0, "rv_smallk_forward: bad shape");
     const int CIN = cin <= 4 ? 4 : 8;
     hipStream_t st = (hipStream_t)stream;
@@ -808,6 +808,7 @@ extern "C" int rv_smallk_forward(const void* v, int32_t ld_v, int64_t pixels, in
                                1.0 / (double)count, unbias, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, invstd);
         RV_CHECK_LAUNCH("smallk_stats_kernel");
     }
+    if (!h) return 0;
     const int c8 = c / 8, lanes_px = 256 / c8;
     int64_t blocks = (pixels + lanes_px - 1) / lanes_px;
     if (blocks > 4096) blocks = 4096;

@@ -568,7 +568,9 @@ class ConvOp(Op):
     """``out = layer(x)``: tap-conv forward; optional batch statistics, bias, fp32 output."""
 
     def __init__(self, t: Tape, layer: TapLayer, x: Operand, stats: bool = False, out_f32: bool = False,
-                 out: Optional[Act] = None, need_input_grad: bool = True) -> None:
+                 out: Optional[Act] = None, need_input_grad: bool = True, precomputed: Optional[Tuple[Optional[Tensor], int]] = None) -> None:
+        """``precomputed`` = (partial statistics rows, rows): ``out`` already holds the layer's output (a fused kernel wrote it);
+        the op only records what backward needs."""
         self.layer, self.x, self.need_input_grad = layer, x, need_input_grad
         src, sc, sh, flags = _operand_parts(x)
         form = layer.fwd_form
@@ -614,7 +616,10 @@ class ConvOp(Op):
         wp = layer.packed(form)
         call = lambda: L.call("rv_tap_" + form, ctypes.byref(g), ctypes.byref(self.shape), src.ptr(), L.ptr(sc), L.ptr(sh),
                               L.ptr(wp), L.ptr(bias_p), dst_ptr, L.ptr(self.partial), L.stream_ptr())
-        if PROFILE is not None:
+        if precomputed is not None:
+            assert out is not None and not out_f32 and bias is None
+            self.partial, self.rows = precomputed
+        elif PROFILE is not None:
             _launch(tap_kernel_name(g, self.shape, form == "scatter"), tap_flops(g, self.shape), call)
         else:
             call()
@@ -694,7 +699,9 @@ class SmallKOp(Op):
     (``rv_smallk_forward``), and backward is ``rv_bn_bwd_smallk`` (BatchNorm backward + weight gradient in one pass).
     Returns a plain ``Act`` -- the consumer conv then runs on the LDS-DMA kernels."""
 
-    def __init__(self, t: Tape, layer: TapLayer, x: Act, bn: nn.BatchNorm2d) -> None:
+    def __init__(self, t: Tape, layer: TapLayer, x: Act, bn: nn.BatchNorm2d, apply: bool = True) -> None:
+        """``apply=False``: only the statistics / folded scale and shift are formed; the caller's fused kernel writes ``out``
+        (``PosPair``: rv_pos_forward generates it in the second layer's operand staging)."""
         self.layer, self.x, self.bn = layer, x, bn
         self.sync_world = 1
         c, cin = bn.num_features, layer.c_in
@@ -723,7 +730,7 @@ class SmallKOp(Op):
             L.call("rv_smallk_forward", x.ptr(), L.i32(x.ld), L.i64(x.pixels), L.i32(cin), L.ptr(wp), L.i32(pad32(cin)), L.i32(cp),
                    L.ptr(moments), L.i64(self.count), L.ptr(self.gamma_p), L.ptr(self.beta_p), L.f32(bn.eps),
                    L.f32(bn.momentum if bn.momentum is not None else 0.1), L.ptr(rm), L.ptr(rv), L.ptr(scale), L.ptr(shift),
-                   L.ptr(self.mean), L.ptr(self.invstd), L.i32(1), self.out.ptr(), L.i32(self.out.ld), L.stream_ptr())
+                   L.ptr(self.mean), L.ptr(self.invstd), L.i32(1), self.out.ptr() if apply else None, L.i32(self.out.ld), L.stream_ptr())
             if bn.running_mean.shape[0] != cp:
                 bn.running_mean.copy_(rm[:c])
                 bn.running_var.copy_(rv[:c])
@@ -731,9 +738,10 @@ class SmallKOp(Op):
         else:
             L.call("rv_bn_fold_eval", L.i32(cp), L.ptr(self.gamma_p), L.ptr(self.beta_p), L.ptr(rm), L.ptr(rv), L.f32(bn.eps),
                    L.ptr(scale), L.ptr(shift), L.stream_ptr())
-            L.call("rv_smallk_forward", x.ptr(), L.i32(x.ld), L.i64(x.pixels), L.i32(cin), L.ptr(wp), L.i32(pad32(cin)), L.i32(cp),
-                   None, L.i64(self.count), None, None, L.f32(bn.eps), L.f32(0.1), None, None, L.ptr(scale), L.ptr(shift), None, None,
-                   L.i32(1), self.out.ptr(), L.i32(self.out.ld), L.stream_ptr())
+            if apply:
+                L.call("rv_smallk_forward", x.ptr(), L.i32(x.ld), L.i64(x.pixels), L.i32(cin), L.ptr(wp), L.i32(pad32(cin)), L.i32(cp),
+                       None, L.i64(self.count), None, None, L.f32(bn.eps), L.f32(0.1), None, None, L.ptr(scale), L.ptr(shift), None, None,
+                       L.i32(1), self.out.ptr(), L.i32(self.out.ld), L.stream_ptr())
         t.ops.append(self)
 
     def backward(self, t: Tape) -> None:
@@ -758,6 +766,36 @@ def conv_bn(t: Tape, layer: TapLayer, x: Operand, bn: nn.BatchNorm2d, relu: bool
         return SmallKOp(t, layer, x, bn).out
     conv = ConvOp(t, layer, x, stats=t.training, need_input_grad=need_input_grad)
     return BnOp(t, conv, bn, relu).lazy
+
+
+POS_FUSE = os.environ.get("RV3D_NO_POS_FUSE") is None
+
+
+def pos_pair_eligible(l0: TapLayer, l1: TapLayer, x: Operand) -> bool:
+    """3 -> 256 -> 256 positional pair of the MetaKernel stem on a plain 9x-grid input: the pair runs as rv_pos_forward."""
+    g0, g1 = l0.geom, l1.geom
+    return (POS_FUSE and SMALLK_FORWARD and isinstance(x, Act) and _smallk_eligible(l0, x, True, False) and l0.c_in <= 3 and l0.c_out == 256
+            and l1.fwd_form == "gather" and g1.kh == 1 and g1.kw == 1 and g1.stride_w == 1 and l1.c_in == 256 and l1.c_out == 256
+            and l1.bias is None and l1.in_perm is None and x.ld >= 4)
+
+
+def pos_pair(t: Tape, l0: TapLayer, bn0: nn.BatchNorm2d, l1: TapLayer, bn1: nn.BatchNorm2d, x: Act) -> "Lazy":
+    """``relu(bn1(conv1(relu(bn0(conv0(x))))))`` of the two positional layers: closed-form statistics of the first layer, then ONE
+    persistent kernel that generates its activated output in the second layer's operand staging (rv_pos_forward).  The ops
+    recorded on the tape are the ordinary SmallKOp / ConvOp / BnOp, so backward is unchanged."""
+    sk = SmallKOp(t, l0, x, bn0, apply=False)
+    h1 = sk.out
+    y2 = Act.empty(x.N, x.H, x.W, l1.c_out, t.device)
+    rows = L.load().rv_pos_forward_rows(L.i64(x.pixels))
+    partial = torch.empty((rows + L.STATS_SCRATCH_ROWS, 2, y2.cp), dtype=torch.float32, device=t.device) if t.training else None
+    call = lambda: L.call("rv_pos_forward", x.ptr(), L.i32(x.ld), L.i32(l0.c_in), L.i64(x.pixels), L.ptr(l0.packed("gather")), L.i32(pad32(l0.c_in)),
+                          L.ptr(sk.scale), L.ptr(sk.shift), L.ptr(l1.packed("gather")), L.i32(y2.cp), h1.ptr(), y2.ptr(), L.ptr(partial), L.stream_ptr())
+    if PROFILE is not None:
+        _launch("pos_fwd_kernel", 2.0 * x.pixels * 256 * 256, call)
+    else:
+        call()
+    conv = ConvOp(t, l1, h1, stats=t.training, out=y2, precomputed=(partial, rows))
+    return BnOp(t, conv, bn1, True).lazy
 
 
 # ---------------------------------------------------------------------------------------------

@@ -58,7 +58,12 @@ def meta_kernel_program(t: Tape, m: nn.Module, features: Act, cart: Tensor, out:
     rel = E.MetaRelativeOp(t, cart).out
     pos: Operand = rel
     n_pos = len(m.positional_kernel)
-    for i, blk in enumerate(m.positional_kernel):
+    blocks = list(m.positional_kernel)
+    if n_pos == 2 and E.pos_pair_eligible(E.tap_layer(blocks[0][0]), E.tap_layer(blocks[1][0]), rel):
+        # 3 -> 256 -> 256: both layers in one persistent streaming kernel (csrc/posconv.hip)
+        pos = E.pos_pair(t, E.tap_layer(blocks[0][0]), blocks[0][1], E.tap_layer(blocks[1][0]), blocks[1][1], rel)
+        blocks = []
+    for i, blk in enumerate(blocks):
         # the LAST positional layer feeds MetaModulateOp, which folds its BatchNorm+ReLU itself and needs the Lazy form
         # (num_layers == 1: that is the 3 -> C layer, which would otherwise take the small-K fast path)
         pos = E.conv_bn(t, E.tap_layer(blk[0]), pos, blk[1], relu=True, need_input_grad=(i > 0), smallk=(i + 1 < n_pos))

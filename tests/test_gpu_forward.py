@@ -454,3 +454,74 @@ def test_raw_sweep_path_on_device(golden):
         got[3], got[4], got[5] = got[3].astype(np.uint8), got[4].astype(np.uint8), got[5] != 0  # RANGE_VIEW_SCHEMA casts (utils.py:16-25)
         want = g.np("range_view/image")
         assert np.array_equal(got, want), int((got != want).sum())
+
+
+@pytest.mark.parametrize("P", [999, 41472])
+def test_pos_forward_kernel_vs_fp32(P):
+    """rv_pos_forward (both positional layers of the MetaKernel stem in one persistent streaming GEMM: the first layer is
+    generated in the second one's operand staging) against fp32 torch ops: h1 one bf16 rounding of relu(s1 (W1 rel) + t1)
+    (4e-3 of max), y2 = W2 h1 from the kernel's own bf16 h1 one bf16 rounding (4e-3), the (sum, sum of squares) rows of the
+    fp32 accumulators 1e-4 of their scale.  P = 999: one partial step per workgroup; 41472: 324 steps over 256 persistent
+    workgroups (both LDS images, the generate-next-while-multiplying path)."""
+    from range_view_3d_detection_amd import _lib as L
+
+    gen = torch.Generator().manual_seed(P)
+    C = 256
+    rel = torch.zeros(P, 32, dtype=torch.bfloat16)
+    rel[:, :3] = (torch.randn(P, 3, generator=gen) * 2).to(torch.bfloat16)
+    w1 = torch.zeros(C, 32, dtype=torch.bfloat16)
+    w1[:, :3] = torch.randn(C, 3, generator=gen).to(torch.bfloat16)
+    w2 = (torch.randn(C, C, generator=gen) / 16).to(torch.bfloat16)
+    s1, t1 = 0.5 + torch.rand(C, generator=gen), 0.3 * torch.randn(C, generator=gen)
+    rel, w1, w2, s1, t1 = (x.to(DEV) for x in (rel, w1, w2, s1, t1))
+    h1 = torch.full((P, C), float("nan"), dtype=torch.bfloat16, device=DEV)
+    y2 = torch.full((P, C), float("nan"), dtype=torch.bfloat16, device=DEV)
+    rows = L.load().rv_pos_forward_rows(L.i64(P))
+    partial = torch.zeros((rows + L.STATS_SCRATCH_ROWS, 2, C), dtype=torch.float32, device=DEV)
+    L.call("rv_pos_forward", L.ptr(rel), L.i32(32), L.i32(3), L.i64(P), L.ptr(w1), L.i32(32), L.ptr(s1), L.ptr(t1), L.ptr(w2), L.i32(C),
+           L.ptr(h1), L.ptr(y2), L.ptr(partial), L.stream_ptr())
+    torch.cuda.synchronize()
+    want_h1 = torch.relu((rel[:, :3].float() @ w1[:, :3].float().t()) * s1 + t1)
+    assert rel_err(h1.float(), want_h1) < 4e-3, rel_err(h1.float(), want_h1)
+    want_y2 = h1.float() @ w2.float().t()
+    assert rel_err(y2.float(), want_y2) < 4e-3, rel_err(y2.float(), want_y2)
+    got = partial[:rows].double().sum(0)
+    scale = float(want_y2.abs().sum(0).max())
+    assert float((got[0] - want_y2.double().sum(0)).abs().max()) < 1e-4 * scale
+    assert float((got[1] - (want_y2.double() ** 2).sum(0)).abs().max()) < 1e-4 * float((want_y2.double() ** 2).sum(0).max())
+
+
+def test_meta_kernel_positional_pair_fused_matches_unfused():
+    """MetaKernel at the rv-av2 stem width (C = 256): rv_pos_forward against the SmallKOp + 1x1 tap-conv pair it replaces --
+    output and running statistics within bf16 rounding (2e-2 / 2e-3 of max), every parameter gradient (backward is shared; bf16
+    roundings of h1 / y2 differ in the last place and flip a few ReLU gates) cosine 0.9999, 4e-2 of max."""
+    from range_view_3d_detection_amd import engine as E
+    from range_view_3d_detection_amd.nn.stems import MetaKernel
+
+    gen = torch.Generator().manual_seed(21)
+    m = MetaKernel(5, 256, 3, 2).to(DEV).train()
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    feats = torch.randn(1, 5, 16, 160, generator=gen).to(DEV)
+    cart = (torch.randn(1, 3, 16, 160, generator=gen) * 5).to(DEV)
+    probe = torch.randn(1, 256, 16, 160, generator=gen).to(DEV)
+
+    def run(fused: bool):
+        E.POS_FUSE = fused
+        try:
+            m.load_state_dict(sd)
+            m.zero_grad(set_to_none=True)
+            out = m(feats, cart).float()
+            (out * probe).sum().backward()
+            stats = {k: v.detach().cpu().clone() for k, v in m.state_dict().items() if "running_" in k}
+            return out.detach().cpu(), {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()}, stats
+        finally:
+            E.POS_FUSE = True
+
+    out_a, ga, st_a = run(True)
+    out_b, gb, st_b = run(False)
+    assert rel_err(out_a, out_b) < 2e-2, rel_err(out_a, out_b)
+    for k in st_a:
+        assert rel_err(st_a[k], st_b[k]) < 2e-3, (k, rel_err(st_a[k], st_b[k]))
+    for k in ga:
+        cos = float(torch.nn.functional.cosine_similarity(ga[k].flatten().double(), gb[k].flatten().double(), dim=0))
+        assert cos > 0.9999 and rel_err(ga[k], gb[k]) < 4e-2, (k, cos, rel_err(ga[k], gb[k]))
