@@ -325,6 +325,16 @@ int rv_pos_forward(const void* rel, int32_t ld_rel, int32_t cin, int64_t pixels,
                    const float* scale1, const float* shift1, const void* w2_packed, int32_t c, void* h1, void* y2,
                    float* stats_partial, rvStream stream);
 
+/* Backward of the same pair: the second layer's backward-data GEMM dh1 = dy2 W2 fused with phase (A) of the first layer's
+ * small-K BatchNorm backward (rv_bn_bwd_smallk_sums with RV_BNB_Y_FROM_INPUT): dh1 is consumed in registers and never
+ * written -- 2.4 GB less to store and 2.4 GB less to read back at 4 x 64 x 2048.  w2_scatter = the second layer's packed
+ * scatter image; sums / moms / workspace as rv_bn_bwd_smallk_sums (cin_pad = 4); continue with rv_bn_bwd_smallk_from_sums.
+ * Replaces rv_tap_scatter of the second layer + rv_bn_bwd_smallk_sums of the first (ATen conv backward-data + BatchNorm
+ * backward + conv backward-weight). */
+int rv_pos_backward_sums(int64_t pixels, int32_t c, const void* dy2, const void* w2_scatter, const void* rel, int32_t ld_rel,
+                         int32_t cin, const void* w1_packed, int32_t ld_w1, const float* scale1, const float* shift1,
+                         const float* mean1, const float* invstd1, double* sums, double* moms, void* workspace, rvStream stream);
+
 /* ---------------------------------------------------------------------------------------
  * Optimiser step of the recipe (nn/meta/arch.py:57 -> torch.optim.AdamW via conf/model/range_view.yaml:52-55; gradient
  * clipping = Lightning's gradient_clip_val 35.0, conf/trainer/train.yaml) for ALL parameters in two launches.

@@ -32,3 +32,18 @@ def conv():
     E.ConvOp(tp, lay, x, stats=True); tp.ops.clear()
 t2_ = bench(conv)
 print(f"smallk apply + 1x1 conv   {t1_*1e3:7.1f} + {t2_*1e3:7.1f} = {(t1_+t2_)*1e3:7.1f} us")
+# ---- backward: rv_pos_backward_sums against the 1x1 backward-data conv + rv_bn_bwd_smallk_sums it replaces
+dy2 = torch.randn(P, C, device=dev).bfloat16()
+mu, isd = torch.randn(C, device=dev) * 0.1, torch.rand(C, device=dev) + 0.5
+ws = torch.empty(L.load().rv_bn_bwd_smallk_workspace_bytes(L.i64(P), L.i32(C), L.i32(3)), dtype=torch.uint8, device=dev)
+sums = torch.zeros(6 * C, dtype=torch.float64, device=dev); moms = torch.zeros(20, dtype=torch.float64, device=dev)
+tb = bench(lambda: L.call("rv_pos_backward_sums", L.i64(P), L.i32(C), L.ptr(dy2), L.ptr(w2), L.ptr(rel), L.i32(32), L.i32(3), L.ptr(w1), L.i32(32), L.ptr(s1), L.ptr(t1),
+                          L.ptr(mu), L.ptr(isd), L.ptr(sums), L.ptr(moms), L.ptr(ws), L.stream_ptr()))
+print(f"rv_pos_backward_sums      {tb*1e3:7.1f} us   {T/tb:5.2f} TB/s read")
+dh1 = torch.empty(P, C, dtype=torch.bfloat16, device=dev)
+g = lay.geom
+shape = L.TapShape(4, 64, 2048 * 9, 2048 * 9, C, C, 0)
+t3 = bench(lambda: L.call("rv_tap_scatter", ctypes.byref(g), ctypes.byref(shape), L.ptr(dy2), None, None, L.ptr(lay.packed("scatter")), None, L.ptr(dh1), None, L.stream_ptr()))
+t4 = bench(lambda: L.call("rv_bn_bwd_smallk_sums", L.i64(P), L.i32(C), L.ptr(dh1), L.i32(C), None, L.i32(0), None, L.i32(0), L.ptr(s1), L.ptr(t1), L.ptr(mu), L.ptr(isd),
+                          L.i32(L.BNB_RELU_Z | L.BNB_Y_FROM_INPUT), L.ptr(rel), L.i32(32), L.i32(3), L.ptr(w1), L.i32(32), L.ptr(sums), L.ptr(moms), L.ptr(ws), L.stream_ptr()))
+print(f"1x1 dgrad + smallk sums   {t3*1e3:7.1f} + {t4*1e3:7.1f} = {(t3+t4)*1e3:7.1f} us")

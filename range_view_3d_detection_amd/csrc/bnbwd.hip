@@ -719,6 +719,42 @@ extern "C" int rv_bn_bwd_smallk_sums(int64_t pixels, int32_t c, const void* dout
     return 0;
 }
 
+// The same phase A for the first positional layer of the MetaKernel stem when its output gradient does not exist in memory:
+// dOut = dy2 W2 is formed on the fly by pos_bwd_kernel (posconv.hip), which writes the per-workgroup rows of the planes.
+int rv_pos_bwd_launch(int64_t pixels, const void* dy2, const void* w2_scatter, const void* rel, int32_t ld_rel, int32_t cin,
+                      const void* w1_packed, int32_t ld_w1, const float* scale1, const float* shift1, const float* mean1,
+                      const float* invstd1, float* partial, int32_t planes, int32_t max_rows, int32_t* rows, hipStream_t stream);
+
+extern "C" int rv_pos_backward_sums(int64_t pixels, int32_t c, const void* dy2, const void* w2_scatter, const void* rel, int32_t ld_rel,
+                                    int32_t cin, const void* w1_packed, int32_t ld_w1, const float* scale1, const float* shift1,
+                                    const float* mean1, const float* invstd1, double* sums, double* moms, void* workspace,
+                                    rvStream stream) {
+    RV_REQUIRE(dy2 && w2_scatter && rel && w1_packed && scale1 && shift1 && mean1 && invstd1 && sums && moms && workspace,
+               "rv_pos_backward_sums: null argument");
+    RV_REQUIRE(c == 256 && cin >= 1 && cin <= 3 && ld_rel % 8 == 0 && ld_rel >= 8 && pixels > 0, "rv_pos_backward_sums: built for 256 channels, cin <= 3");
+    const int CIN = 4, planes = 2 + CIN, mcols = CIN + CIN * CIN;
+    const int rows_max = rv_bn_bwd_rows(pixels);  // the workspace layout of rv_bn_bwd_smallk_workspace_bytes
+    float* part_g = (float*)workspace;
+    double* scr_g = (double*)(part_g + (int64_t)rows_max * planes * c);
+    float* part_m = (float*)(scr_g + (int64_t)64 * planes * c);
+    const int mblocks = pixels >= 1024 * 256 ? 1024 : (int)((pixels + 255) / 256);
+    double* scr_m = (double*)(part_m + (int64_t)1024 * mcols);
+    hipStream_t st = (hipStream_t)stream;
+    int rows = 0;
+    if (rv_pos_bwd_launch(pixels, dy2, w2_scatter, rel, ld_rel, cin, w1_packed, ld_w1, scale1, shift1, mean1, invstd1, part_g, planes, rows_max,
+                          &rows, st))
+        return 1;
+    hipLaunchKernelGGL(smallk_moments_kernel<4>, dim3(mblocks), dim3(256), 0, st, (const bf16_t*)rel, ld_rel, pixels, part_m);
+    RV_CHECK_LAUNCH("smallk_moments_kernel");
+    int groups_g, groups_m;
+    if (rv_col_reduce(part_g, rows, planes * c, scr_g, &groups_g, st)) return 1;
+    if (rv_col_reduce(part_m, mblocks, mcols, scr_m, &groups_m, st)) return 1;
+    hipLaunchKernelGGL(sum_rows_f64_kernel, dim3(rv_ceil_div(planes * c, 128)), dim3(128), 0, st, scr_g, groups_g, planes * c, sums);
+    hipLaunchKernelGGL(sum_rows_f64_kernel, dim3(1), dim3(128), 0, st, scr_m, groups_m, mcols, moms);
+    RV_CHECK_LAUNCH("sum_rows_f64_kernel");
+    return 0;
+}
+
 // phase B: gradients from the sums.  global_s01 (2 * c doubles, optional): all-reduced (sum g, sum g*xhat) under SyncBN.
 extern "C" int rv_bn_bwd_smallk_from_sums(int32_t c, int32_t cin, const double* sums, const double* moms, const double* global_s01,
                                           const void* w_packed, int32_t ld_w, const float* gamma, const float* stat_mean,

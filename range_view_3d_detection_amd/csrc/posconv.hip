@@ -223,7 +223,189 @@ __global__ __launch_bounds__(512, 1) void pos_fwd_kernel(const PosFwdArgs a) {
     }
 }
 
+// -----------------------------------------------------------------------------------------------------------------
+// Backward: the second layer's backward-data GEMM fused with the first layer's small-K BatchNorm backward.
+//   dh1[p][ci] = sum_co dy2[p][co] W2[co][ci]            (never written: 2.4 GB less to store AND to read back)
+//   g = dh1 * [s1 y1 + t1 > 0],  y1 = W1 rel (recomputed),  xhat = (y1 - mean1) invstd1
+//   planes per channel: S0 = sum g, S1 = sum g xhat, R[d] = sum g rel[d]     (what bn_bwd_smallk_reduce_kernel forms)
+// Same persistent structure as pos_fwd_kernel (weights W2^T of the wave's 32 channels in registers, 128-pixel steps
+// through a double-buffered LDS image), with three differences: the image is filled by LDS-DMA straight from dy2 (the
+// swizzle applied to the per-lane SOURCE address); the loop has no store at all, so ordinary vector loads and their
+// vmcnt waits are harmless; and the MFMA orientation is D = X W^T (pixels x channels): a lane owns TWO channels for the
+// whole launch, its sums stay in 10 registers, and the eight waves own disjoint channels -- no cross-wave reduction.
+// -----------------------------------------------------------------------------------------------------------------
+struct PosBwdArgs {
+    const bf16_t* dy2;  // [P][C]
+    const bf16_t* w2s;  // packed SCATTER image of the second layer [ci][co], K = co contiguous
+    const bf16_t* rel;  // [P][ld_rel]
+    const bf16_t* w1;   // packed gather image of the first layer [C][ld_w1]
+    const float *scale1, *shift1, *mean1, *invstd1;
+    float* partial;     // [gridDim.x][planes][C]
+    int64_t P;
+    int ld_rel, ld_w1, cin, planes;
+};
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+__global__ __launch_bounds__(512, 1) void pos_bwd_kernel(const PosBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15_ = lane & 15, lg_ = lane >> 4;
+    const int l15 = l15_, lg = lg_;
+    uint8_t* const relbuf = smem + 2 * kBuf;  // [2][128 pixels][8 bytes]
+
+    // B operand: row n = l15 of tile j is input channel ci = 32 wn + 16 j + l15
+    bf16x8 fw[2][8];
+    f32x2 w1c[3], sc, sh, mu, is;  // the lane's two channels (j = 0, 1) side by side: v_pk_* arithmetic in the epilogue
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int ci = wn * 32 + j * 16 + l15;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) fw[j][ks] = *(const bf16x8*)(a.w2s + (int64_t)ci * kC + ks * 32 + lg * 8);
+#pragma unroll
+        for (int e = 0; e < 3; ++e) w1c[e][j] = e < a.cin ? bf2f(a.w1[(int64_t)ci * a.ld_w1 + e]) : 0.f;
+        sc[j] = a.scale1[ci];
+        sh[j] = a.shift1[ci];
+        mu[j] = a.mean1[ci];
+        is[j] = a.invstd1[ci];
+    }
+    f32x2 s0 = {0.f, 0.f}, s1 = {0.f, 0.f}, rx = {0.f, 0.f}, ry = {0.f, 0.f}, rz = {0.f, 0.f};
+
+    const int64_t steps = (a.P + kTM - 1) / kTM;
+    // image fill: DMA instruction q (0..63) of a step moves pixels 2q, 2q+1 (lane = pixel-in-pair x 32 slots); wave w issues
+    // q = w, w + 8, ...  The LDS side is lane-linear, so slot s of pixel p receives source octet s ^ (p & 15).
+    __device__ __attribute__((aligned(256))) static uint32_t zero_page[64];
+    auto fill = [&](int64_t step, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int q = wn + 8 * i;
+            const int pl = 2 * q + (lane >> 5), slot = lane & 31;
+            const int64_t px = step * kTM + pl;
+            const bf16_t* src = px < a.P ? a.dy2 + px * kC + ((slot ^ (pl & 15)) * 8) : (const bf16_t*)zero_page + (lane & 7) * 8;
+            __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(smem + buf * kBuf + q * 1024), 16, 0, 0);
+        }
+    };
+    auto load_rel = [&](int64_t step) __attribute__((always_inline)) {
+        u32x2 rv = {0u, 0u};
+        const int64_t px = step * kTM + tid;
+        if (tid < kTM && px < a.P) rv = *(const u32x2*)(a.rel + px * a.ld_rel);
+        return rv;
+    };
+    if ((int64_t)blockIdx.x < steps) {
+        fill(blockIdx.x, 0);
+        const u32x2 r0 = load_rel(blockIdx.x);
+        if (tid < kTM) *(u32x2*)(relbuf + tid * 8) = r0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    for (int64_t s = blockIdx.x; s < steps; s += gridDim.x) {
+        const int64_t nxt = s + gridDim.x;
+        const bool has_next = nxt < steps;
+        u32x2 rel_next = {0u, 0u};
+        if (has_next) {
+            fill(nxt, cur ^ 1);
+            rel_next = load_rel(nxt);
+        }
+        const uint8_t* img = smem + cur * kBuf;
+        const uint8_t* rel_s = relbuf + cur * (kTM * 8);
+        const int64_t left = a.P - s * kTM;
+        int l15 = l15_, lg = lg_;
+        asm volatile("" : "+v"(l15), "+v"(lg));  // (no hoisting of the per-position LDS offsets out of the step loop: registers)
+#pragma unroll 1  // (rolled: unrolled x4 the allocator spilled the weight fragments)
+        for (int quarter = 0; quarter < 4; ++quarter) {  // 32 pixels at a time
+            f32x4 acc[2][2];
+            bf16x8 fa[2][2];
+            auto read_fa = [&](int ks, bf16x8 (&f)[2]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    f[i] = *(const bf16x8*)(img + ((quarter * 2 + i) * 16 + l15) * 512 + (((ks * 4 + lg) ^ l15) * 16));
+            };
+            read_fa(0, fa[0]);
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                if (ks + 1 < 8) read_fa(ks + 1, fa[(ks + 1) & 1]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const f32x4 c0 = ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[i][j];
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks & 1][i], fw[j][ks], c0, 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // lane: channel ci(j) = 32 wn + 16 j + l15, pixels (quarter*2 + i)*16 + 4 lg + r
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int pl = (quarter * 2 + i) * 16 + lg * 4 + r;
+                    const u32x2 rv = *(const u32x2*)(rel_s + pl * 8);
+                    const float x = bf_lo(rv[0]), y = bf_hi(rv[0]), z = bf_lo(rv[1]);
+                    const bool ok = pl < left;
+                    const f32x2 xx = {x, x}, yy = {y, y}, zz = {z, z};
+                    const f32x2 y1 = w1c[0] * xx + w1c[1] * yy + w1c[2] * zz;
+                    const f32x2 act = y1 * sc + sh;
+                    f32x2 g = {acc[i][0][r], acc[i][1][r]};
+                    g[0] = (ok && act[0] > 0.f) ? g[0] : 0.f;
+                    g[1] = (ok && act[1] > 0.f) ? g[1] : 0.f;
+                    s0 += g;
+                    s1 += g * ((y1 - mu) * is);
+                    rx += g * xx;
+                    ry += g * yy;
+                    rz += g * zz;
+                    __builtin_amdgcn_sched_barrier(0);  // one pixel at a time
+                }
+        }
+        if (has_next && tid < kTM) *(u32x2*)(relbuf + (cur ^ 1) * (kTM * 8) + tid * 8) = rel_next;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the next image has landed (no stores in this loop)
+        __syncthreads();
+        cur ^= 1;
+    }
+    // lanes lg = 0..3 of a channel hold disjoint pixels: sum them, then one row of `planes` x C per workgroup
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        float v[5] = {s0[j], s1[j], rx[j], ry[j], rz[j]};
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            v[q] += __shfl_xor(v[q], 16, 64);
+            v[q] += __shfl_xor(v[q], 32, 64);
+        }
+        if (lg == 0) {
+            const int ci = wn * 32 + j * 16 + l15;
+            float* row = a.partial + (int64_t)blockIdx.x * a.planes * kC + ci;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) row[(int64_t)q * kC] = v[q];
+            for (int q = 5; q < a.planes; ++q) row[(int64_t)q * kC] = 0.f;
+        }
+    }
+}
+
 }  // namespace
+
+// launcher used by rv_pos_backward_sums (bnbwd.hip, which owns the small-K reduction workspace layout)
+int rv_pos_bwd_launch(int64_t pixels, const void* dy2, const void* w2_scatter, const void* rel, int32_t ld_rel, int32_t cin,
+                      const void* w1_packed, int32_t ld_w1, const float* scale1, const float* shift1, const float* mean1,
+                      const float* invstd1, float* partial, int32_t planes, int32_t max_rows, int32_t* rows, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)pos_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kBuf + 2 * kTM * 8);
+        attr_set = true;
+    }
+    PosBwdArgs a{};
+    a.dy2 = (const bf16_t*)dy2, a.w2s = (const bf16_t*)w2_scatter, a.rel = (const bf16_t*)rel, a.w1 = (const bf16_t*)w1_packed;
+    a.scale1 = scale1, a.shift1 = shift1, a.mean1 = mean1, a.invstd1 = invstd1;
+    a.partial = partial, a.P = pixels, a.ld_rel = ld_rel, a.ld_w1 = ld_w1, a.cin = cin, a.planes = planes;
+    const int64_t steps = (pixels + kTM - 1) / kTM;
+    int grid = (int)(steps < 256 ? steps : 256);
+    if (grid > max_rows) grid = max_rows;  // (the caller's partial-row buffer; a persistent workgroup takes any number of steps)
+    *rows = grid;
+    hipLaunchKernelGGL(pos_bwd_kernel, dim3(*rows), dim3(512), 2 * kBuf + 2 * kTM * 8, stream, a);
+    RV_CHECK_LAUNCH("pos_bwd_kernel");
+    return 0;
+}
 
 extern "C" int32_t rv_pos_forward_rows(int64_t pixels) {
     const int64_t steps = (pixels + kTM - 1) / kTM;

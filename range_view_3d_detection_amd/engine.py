@@ -572,6 +572,7 @@ class ConvOp(Op):
         """``precomputed`` = (partial statistics rows, rows): ``out`` already holds the layer's output (a fused kernel wrote it);
         the op only records what backward needs."""
         self.layer, self.x, self.need_input_grad = layer, x, need_input_grad
+        self.pos_first: Optional["SmallKOp"] = None
         src, sc, sh, flags = _operand_parts(x)
         form = layer.fwd_form
         g = layer.geom
@@ -704,6 +705,7 @@ class SmallKOp(Op):
         (``PosPair``: rv_pos_forward generates it in the second layer's operand staging)."""
         self.layer, self.x, self.bn = layer, x, bn
         self.sync_world = 1
+        self.grads_done = False  # set when the consumer's backward already produced this layer's parameter gradients (pos pair)
         c, cin = bn.num_features, layer.c_in
         cp = pad32(c)
         dev = t.device
@@ -795,6 +797,7 @@ def pos_pair(t: Tape, l0: TapLayer, bn0: nn.BatchNorm2d, l1: TapLayer, bn1: nn.B
     else:
         call()
     conv = ConvOp(t, l1, h1, stats=t.training, out=y2, precomputed=(partial, rows))
+    conv.pos_first = sk  # backward: this conv's input gradient is consumed by `sk`'s BatchNorm backward inside one kernel
     return BnOp(t, conv, bn1, True).lazy
 
 

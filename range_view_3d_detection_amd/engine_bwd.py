@@ -66,7 +66,12 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
     bwd = "scatter" if fwd == "gather" else "gather"
     sp = op.shape
     # ---- input gradient: the opposite tap form -------------------------------------------------
-    if op.need_input_grad:
+    fused_first = POS_BWD_FUSE and op.pos_first is not None and op.need_input_grad and t.training and op.pos_first.sync_world == 1
+    if fused_first:
+        # second positional layer of the MetaKernel stem: dh1 = dy2 W2 is consumed in registers by the first layer's BatchNorm
+        # backward + weight gradient (rv_pos_backward_sums) -- no input-gradient tensor, no second pass over it
+        _pos_pair_backward(op, t, dout)
+    elif op.need_input_grad:
         if isinstance(op.x, Lazy):
             dst, accumulate = t.lazy_grad_target(op.x)
             dst._rv_owned = True
@@ -127,6 +132,39 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
         t.used_side_stream = True
     else:
         run_wgrad()
+
+
+POS_BWD_FUSE = os.environ.get("RV3D_NO_POS_BWD_FUSE") is None
+
+
+def _pos_pair_backward(op: "E.ConvOp", t: Tape, dy2: Act) -> None:
+    """Parameter gradients of the FIRST positional layer (conv 3 -> C, BatchNorm) from the second layer's output gradient."""
+    sk = op.pos_first
+    lay0, bn0, rel = sk.layer, sk.bn, sk.x
+    l1 = op.layer
+    cp, cin, pixels = sk.out.cp, lay0.c_in, sk.out.pixels
+    dev = t.device
+    ws = torch.empty(L.load().rv_bn_bwd_smallk_workspace_bytes(L.i64(pixels), L.i32(cp), L.i32(cin)), dtype=torch.uint8, device=dev)
+    sums = torch.empty((2 + 4) * cp, dtype=torch.float64, device=dev)
+    moms = torch.empty(4 + 16, dtype=torch.float64, device=dev)
+    wp0 = lay0.packed("gather")
+    call = lambda: L.call("rv_pos_backward_sums", L.i64(pixels), L.i32(cp), dy2.ptr(), L.ptr(l1.packed("scatter")), rel.ptr(), L.i32(rel.ld), L.i32(cin),
+                          L.ptr(wp0), L.i32(E.pad32(cin)), L.ptr(sk.scale), L.ptr(sk.shift), L.ptr(sk.mean), L.ptr(sk.invstd), L.ptr(sums),
+                          L.ptr(moms), L.ptr(ws), L.stream_ptr())
+    if E.PROFILE is not None:
+        E._launch("pos_bwd_kernel", 2.0 * pixels * 256 * 256, call)
+    else:
+        call()
+    dgamma = torch.empty(cp, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(cp, dtype=torch.float32, device=dev)
+    dw = torch.empty((cp, cin), dtype=torch.float32, device=dev)
+    L.call("rv_bn_bwd_smallk_from_sums", L.i32(cp), L.i32(cin), L.ptr(sums), L.ptr(moms), None, L.ptr(wp0), L.i32(E.pad32(cin)),
+           L.ptr(sk.gamma_p), L.ptr(sk.mean), L.ptr(sk.invstd), L.i64(sk.count), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dw), L.stream_ptr())
+    c = bn0.num_features
+    t.add_param_grad(bn0.weight, dgamma[:c])
+    t.add_param_grad(bn0.bias, dbeta[:c])
+    t.add_param_grad(lay0.weight, lay0.unpermute_grad(dw[: lay0.c_out].reshape(lay0.c_out, cin, 1, 1).contiguous()))
+    sk.grads_done = True
 
 
 def _smallk_grads(t: Tape, pixels: int, cp: int, dout: Act, mask: Optional[Act], y: Optional[Act], scale, shift, mean, invstd, flags: int, v: Act,
@@ -309,6 +347,8 @@ def modulate_backward(op: "E.MetaModulateOp", t: Tape) -> None:
 def smallk_backward(op: "E.SmallKOp", t: Tape) -> None:
     """Backward of ``h = relu(bn(W x))``: the raw output is recomputed from the <= 8 input channels inside the one pass over
     dOut (RV_BNB_Y_FROM_INPUT) -- the stored activation is not read back."""
+    if op.grads_done:  # the consumer's backward formed these gradients without materialising dOut (_pos_pair_backward)
+        return
     dout, have = t.grad_buffer(op.out)
     if not have:
         return

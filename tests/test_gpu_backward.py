@@ -410,3 +410,78 @@ def test_meta_kernel_backward_fused_matches_unfused():
     a, b = run(True), run(False)
     for k in a:
         assert _cos(a[k], b[k]) > 0.999 and rel_err(a[k], b[k]) < 2e-2, (k, _cos(a[k], b[k]), rel_err(a[k], b[k]))
+
+
+@pytest.mark.parametrize("P", [999, 41472])
+def test_pos_backward_sums_kernel_vs_fp64(P):
+    """rv_pos_backward_sums (second positional layer's backward-data GEMM fused with the first layer's small-K BatchNorm
+    backward sums: dh1 = dy2 W2 never written) against the same sums in fp64 torch ops on the bf16 inputs:
+    S0 = sum g, S1 = sum g xhat, R[d] = sum g rel[d] with g = dh1 [s1 y1 + t1 > 0], y1 = W1 rel -- 2e-4 of each plane's scale
+    (fp32 MFMA accumulation and fp32 running sums against fp64); the data moments of rel exactly as rv_bn_bwd_smallk_sums."""
+    from range_view_3d_detection_amd import _lib as L
+
+    gen = torch.Generator().manual_seed(P + 1)
+    C = 256
+    rel = torch.zeros(P, 32, dtype=torch.bfloat16)
+    rel[:, :3] = (torch.randn(P, 3, generator=gen) * 2).to(torch.bfloat16)
+    w1 = torch.zeros(C, 32, dtype=torch.bfloat16)
+    w1[:, :3] = torch.randn(C, 3, generator=gen).to(torch.bfloat16)
+    w2s = (torch.randn(C, C, generator=gen) / 16).to(torch.bfloat16)  # scatter image [ci][co]
+    dy2 = torch.randn(P, C, generator=gen).to(torch.bfloat16)
+    s1, t1 = 0.5 + torch.rand(C, generator=gen), 0.3 * torch.randn(C, generator=gen)
+    mu, isd = 0.2 * torch.randn(C, generator=gen), 0.5 + torch.rand(C, generator=gen)
+    rel, w1, w2s, dy2, s1, t1, mu, isd = (x.to(DEV) for x in (rel, w1, w2s, dy2, s1, t1, mu, isd))
+    ws = torch.empty(L.load().rv_bn_bwd_smallk_workspace_bytes(L.i64(P), L.i32(C), L.i32(3)), dtype=torch.uint8, device=DEV)
+    sums = torch.zeros(6 * C, dtype=torch.float64, device=DEV)
+    moms = torch.zeros(20, dtype=torch.float64, device=DEV)
+    L.call("rv_pos_backward_sums", L.i64(P), L.i32(C), L.ptr(dy2), L.ptr(w2s), L.ptr(rel), L.i32(32), L.i32(3), L.ptr(w1), L.i32(32), L.ptr(s1), L.ptr(t1),
+           L.ptr(mu), L.ptr(isd), L.ptr(sums), L.ptr(moms), L.ptr(ws), L.stream_ptr())
+    torch.cuda.synchronize()
+    r3 = rel[:, :3].double()
+    y1 = r3 @ w1[:, :3].double().t()
+    dh1 = dy2.double() @ w2s.double().t()  # dh1[p][ci] = sum_co dy2[p][co] * w2s[ci][co]
+    gate = (y1.float() * s1 + t1 > 0).double()  # the kernel gates in fp32
+    g = dh1 * gate
+    xhat = (y1 - mu.double()) * isd.double()
+    want = torch.stack([g.sum(0), (g * xhat).sum(0), (g * r3[:, 0:1]).sum(0), (g * r3[:, 1:2]).sum(0), (g * r3[:, 2:3]).sum(0), torch.zeros(C, dtype=torch.float64, device=DEV)])
+    scale = torch.stack([g.abs().sum(0), (g * xhat).abs().sum(0), (g * r3[:, 0:1]).abs().sum(0), (g * r3[:, 1:2]).abs().sum(0), (g * r3[:, 2:3]).abs().sum(0),
+                         torch.ones(C, dtype=torch.float64, device=DEV)])
+    got = sums.view(6, C)
+    err = ((got - want).abs() / scale.max(dim=1, keepdim=True).values).max(dim=1).values
+    assert float(err.max()) < 2e-4, err
+    m1 = torch.zeros(4, dtype=torch.float64, device=DEV)
+    m1[:3] = r3.sum(0)
+    assert float((moms[:4] - m1).abs().max()) < 1e-6 * float(r3.abs().sum())
+
+
+def test_meta_kernel_positional_pair_backward_fused_matches_unfused():
+    """MetaKernel at the rv-av2 stem width with the fused positional-pair backward against the chain it replaces
+    (rv_tap_scatter of the second layer -> rv_bn_bwd_smallk of the first): the first layer's conv / BatchNorm gradients within
+    the bf16 rounding of the input gradient the unfused chain stores (cosine 0.9999, 2e-2 of max); every other gradient
+    bit-identical (same kernels, same inputs)."""
+    from range_view_3d_detection_amd import engine_bwd
+    from range_view_3d_detection_amd.nn.stems import MetaKernel
+
+    gen = torch.Generator().manual_seed(23)
+    m = MetaKernel(5, 256, 3, 2).to(DEV).train()
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    feats = torch.randn(1, 5, 16, 160, generator=gen).to(DEV)
+    cart = (torch.randn(1, 3, 16, 160, generator=gen) * 5).to(DEV)
+    probe = torch.randn(1, 256, 16, 160, generator=gen).to(DEV)
+
+    def run(fused: bool):
+        engine_bwd.POS_BWD_FUSE = fused
+        try:
+            m.load_state_dict(sd)
+            m.zero_grad(set_to_none=True)
+            (m(feats, cart).float() * probe).sum().backward()
+            return {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()}
+        finally:
+            engine_bwd.POS_BWD_FUSE = True
+
+    a, b = run(True), run(False)
+    for k in a:
+        if k.startswith("positional_kernel.0."):
+            assert _cos(a[k], b[k]) > 0.9999 and rel_err(a[k], b[k]) < 2e-2, (k, _cos(a[k], b[k]), rel_err(a[k], b[k]))
+        else:
+            assert torch.equal(a[k], b[k]), k
