@@ -27,6 +27,8 @@
 // Eligible: stride-1 phases with 3..16 taps forming a rows x columns grid whose halo fits (<= 10 rows x 34 columns),
 // C_src % 64 == 0, C_dst % 256 == 0, plain bf16 input, bf16 output (+ stats / bias / accumulate).  1x1 layers stay on
 // tapconv4 (nothing to reuse).  Measured: +3..8 % over tapconv4 on the 3x3 layers of the rv-av2 model.
+#include <stdlib.h>
+
 #include "common.h"
 #include "tapconv.h"
 
@@ -66,9 +68,13 @@ __global__ __launch_bounds__(512, 2) void tapconv5_kernel(const TapConvArgs a) {
     // time (gridDim.x % 8 == 0) -- so a CU pays the workgroup dispatch (LDS allocation, wave start, kernel-argument loads)
     // once per launch instead of once per tile (16 tiles per CU on the 512-channel layers).
     const int gy = a.n_tiles;
-    const int vtotal = 8 * a.tiles_per_xcd * gy;
-    for (int vb = blockIdx.x; vb < vtotal; vb += gridDim.x) {
-    const int xcd = vb & 7, xslot = vb >> 3;
+    // (Measured and dropped: letting one workgroup take the two channel tiles of a pixel tile back to back.  Persistent
+    //  workgroups that start the two halves together drift apart, and the PMC passes then show the input fetched twice --
+    //  2.4 instead of 1.2 GB per average launch -- but the step time does not move: the kernel is not HBM-bound.)
+    const int xcd = blockIdx.x & 7, wslot = blockIdx.x >> 3, nslots = gridDim.x >> 3;  // (gridDim.x % 8 == 0)
+    for (int k = 0;; ++k) {
+    const int xslot = wslot + nslots * k;
+    if (xslot >= a.tiles_per_xcd * gy) break;
     const int tile = xcd * a.tiles_per_xcd + xslot / gy;
     if (tile >= a.total_tiles) continue;
     const int n0 = (xslot % gy) * kBN;
@@ -509,7 +515,7 @@ __global__ __launch_bounds__(512, 2) void tapconv5_kernel(const TapConvArgs a) {
 }  // namespace
 
 extern int g_tapconv4_min_blocks;
-int g_tapconv5_persist = 256;  // rv_set_option("tapconv5_persist_blocks"): workgroups of a persistent launch (0: one workgroup per tile)
+int g_tapconv5_persist = getenv("RV3D_TC_PERSIST") ? atoi(getenv("RV3D_TC_PERSIST")) : 256;  // rv_set_option("tapconv5_persist_blocks") / RV3D_TC_PERSIST: workgroups of a persistent launch (0: one workgroup per tile)
 
 // returns false when the layer is not eligible (caller falls back to tapconv4 / tapconv3 / ...)
 bool rv_tapconv5_plan(TapConvArgs* a, int* tiles, size_t* lds, int* bn) {
