@@ -84,6 +84,23 @@ __device__ __forceinline__ StripItem strip_item(int64_t q, int xcd, int N, int H
 // strip row after row together and the three feature rows they need stay in its L2.
 constexpr int kPieceItems = 128;
 
+struct MetaItem {
+    int64_t pk;   // (pixel, tap) index into the 9x-grid tensors; -1: the item does not exist (column past the image)
+    int64_t nbr;  // pixel index of the tap's neighbour, -1: outside the image (zero padding)
+};
+__device__ __forceinline__ MetaItem meta_item(int64_t it, int xcd, int ws, int H, int W) {
+    MetaItem m;
+    const int k = (int)(it % 9);
+    const int64_t t = it / 9;
+    const int w = xcd * ws + (int)(t % ws);
+    const int64_t row = t / ws, n = row / H;
+    const int h = (int)(row - n * H);
+    m.pk = w < W ? ((n * H + h) * (int64_t)W + w) * 9 + k : -1;
+    const int hn = h + k / 3 - 1, wn = w + k % 3 - 1;
+    m.nbr = (w < W && hn >= 0 && hn < H && wn >= 0 && wn < W) ? (n * H + hn) * (int64_t)W + wn : -1;
+    return m;
+}
+
 // geo[p][k*C + c] = relu(scale*pos[p*9+k][c] + shift) * feat[nbr_k(p)][c];  thread = (item lane, channel octet)
 __global__ __launch_bounds__(256) void meta_modulate_kernel(const bf16_t* pos, const float* scale, const float* shift,
                                                             const bf16_t* feat, int ld_feat, int N, int H, int W, int C,
@@ -93,7 +110,6 @@ __global__ __launch_bounds__(256) void meta_modulate_kernel(const bf16_t* pos, c
     const int oct = threadIdx.x % c8, pl = threadIdx.x / c8;
     if (pl >= lanes) return;
     const int c0 = oct * 8;
-    const int64_t hw = (int64_t)H * W;
     float sc[8], sh[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -104,24 +120,33 @@ __global__ __launch_bounds__(256) void meta_modulate_kernel(const bf16_t* pos, c
     const int64_t items = (int64_t)N * H * ws * 9, pieces = (items + piece - 1) / piece;
     for (int64_t pc = blockIdx.x >> 3; pc < pieces; pc += gridDim.x >> 3) {
         const int64_t hi = (pc + 1) * piece < items ? (pc + 1) * piece : items;
-        for (int64_t it = pc * piece + pl; it < hi; it += lanes) {
-            const int k = (int)(it % 9);
-            const int64_t t = it / 9;
-            const int w = xcd * ws + (int)(t % ws);
-            if (w >= W) continue;
-            const int64_t row = t / ws, n = row / H;
-            const int h = (int)(row - n * H);
-            const int64_t pk = ((n * H + h) * (int64_t)W + w) * 9 + k;
-            const int hn = h + k / 3 - 1, wn = w + k % 3 - 1;
-            float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (hn >= 0 && hn < H && wn >= 0 && wn < W) {
-                float a[8], f[8];
-                unpack8(*(const u32x4*)(pos + pk * C + c0), a);
-                unpack8(*(const u32x4*)(feat + (n * hw + (int64_t)hn * W + wn) * ld_feat + c0), f);
+        // two items per thread in flight (four 16-byte loads): one item's two loads per thread did not cover the HBM latency
+        for (int64_t it = pc * piece + pl; it < hi; it += 2 * lanes) {
+            MetaItem m[2];
+            u32x4 av[2], fv[2];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = fmaxf(a[j] * sc[j] + sh[j], 0.f) * f[j];
+            for (int u = 0; u < 2; ++u) {
+                m[u] = meta_item(it + u * lanes, xcd, ws, H, W);
+                if (it + u * lanes >= hi) m[u].pk = -1;
+                av[u] = fv[u] = u32x4{0u, 0u, 0u, 0u};
+                if (m[u].pk >= 0 && m[u].nbr >= 0) {
+                    av[u] = *(const u32x4*)(pos + m[u].pk * C + c0);
+                    fv[u] = *(const u32x4*)(feat + m[u].nbr * ld_feat + c0);
+                }
             }
-            *(u32x4*)(geo + pk * C + c0) = pack8(o);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (m[u].pk < 0) continue;
+                float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (m[u].nbr >= 0) {
+                    float a[8], f[8];
+                    unpack8(av[u], a);
+                    unpack8(fv[u], f);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = fmaxf(a[j] * sc[j] + sh[j], 0.f) * f[j];
+                }
+                *(u32x4*)(geo + m[u].pk * C + c0) = pack8(o);
+            }
         }
     }
 }
@@ -286,7 +311,6 @@ __global__ __launch_bounds__(256) void meta_bwd_apply_kernel(const MetaBwdArgs a
     const int oct = tid % a.c8, pl = tid / a.c8;
     if (pl >= lanes_px) return;
     const int c0 = oct * 8, C = a.C, H = a.H, W = a.W;
-    const int64_t hw = (int64_t)H * W;
     float sc[8], sh[8], mu[8], is[8], k0[8], k1[8], k2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -300,30 +324,38 @@ __global__ __launch_bounds__(256) void meta_bwd_apply_kernel(const MetaBwdArgs a
     }
     const int xcd = blockIdx.x & 7, ws = (W + 7) / 8;
     const int64_t items = (int64_t)a.N * H * ws * 9, pieces = (items + a.piece - 1) / a.piece;
-    for (int64_t pc = blockIdx.x >> 3; pc < pieces; pc += gridDim.x >> 3)
-    for (int64_t it = pc * a.piece + pl, hi = (pc + 1) * a.piece < items ? (pc + 1) * a.piece : items; it < hi; it += lanes_px) {
-        const int k = (int)(it % 9);
-        const int64_t t = it / 9;
-        const int w = xcd * ws + (int)(t % ws);
-        if (w >= W) continue;
-        const int64_t row = t / ws, n = row / H;
-        const int h = (int)(row - n * H);
-        const int64_t pk = ((n * H + h) * (int64_t)W + w) * 9 + k;
-        const int hn = h + k / 3 - 1, wn = w + k % 3 - 1;
-        const bool in = hn >= 0 && hn < H && wn >= 0 && wn < W;
-        float g[8], y[8], f[8], o[8];
-        const u32x4 gv = *(const u32x4*)(a.dgeo + pk * C + c0);
-        const u32x4 yv = *(const u32x4*)(a.y + pk * C + c0);
-        const u32x4 fv = *(const u32x4*)(a.feat + (in ? (n * hw + (int64_t)hn * W + wn) : 0) * a.ld_feat + c0);
-        unpack8(gv, g);
-        unpack8(yv, y);
-        unpack8(fv, f);
+    for (int64_t pc = blockIdx.x >> 3; pc < pieces; pc += gridDim.x >> 3) {
+        const int64_t hi = (pc + 1) * a.piece < items ? (pc + 1) * a.piece : items;
+        for (int64_t it = pc * a.piece + pl; it < hi; it += 2 * lanes_px) {  // two items (six 16-byte loads) in flight per thread
+            MetaItem m[2];
+            u32x4 gv[2], yv[2], fv[2];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float z = (in && y[j] * sc[j] + sh[j] > 0.f) ? g[j] * f[j] : 0.f;
-            o[j] = k0[j] * (z - k1[j] - (y[j] - mu[j]) * is[j] * k2[j]);
+            for (int u = 0; u < 2; ++u) {
+                m[u] = meta_item(it + u * lanes_px, xcd, ws, H, W);
+                if (it + u * lanes_px >= hi) m[u].pk = -1;
+                gv[u] = yv[u] = fv[u] = u32x4{0u, 0u, 0u, 0u};
+                if (m[u].pk >= 0) {
+                    gv[u] = *(const u32x4*)(a.dgeo + m[u].pk * C + c0);
+                    yv[u] = *(const u32x4*)(a.y + m[u].pk * C + c0);
+                    if (m[u].nbr >= 0) fv[u] = *(const u32x4*)(a.feat + m[u].nbr * a.ld_feat + c0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (m[u].pk < 0) continue;
+                const bool in = m[u].nbr >= 0;
+                float g[8], y[8], f[8], o[8];
+                unpack8(gv[u], g);
+                unpack8(yv[u], y);
+                unpack8(fv[u], f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float z = (in && y[j] * sc[j] + sh[j] > 0.f) ? g[j] * f[j] : 0.f;
+                    o[j] = k0[j] * (z - k1[j] - (y[j] - mu[j]) * is[j] * k2[j]);
+                }
+                *(u32x4*)(a.dy + m[u].pk * C + c0) = pack8(o);
+            }
         }
-        *(u32x4*)(a.dy + pk * C + c0) = pack8(o);
     }
 }
 
