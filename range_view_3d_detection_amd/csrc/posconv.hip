@@ -140,22 +140,24 @@ __global__ __launch_bounds__(512, 1) void pos_fwd_kernel(const PosFwdArgs a) {
 #pragma unroll
         for (int half = 0; half < 4; ++half) {  // 32 pixels at a time: 16 accumulator + 16 fragment registers
             f32x4 acc[2][2];
-            bf16x8 fa[2][2];
+            bf16x8 fa[4][2];
             auto read_fa = [&](int ks, bf16x8 (&f)[2]) __attribute__((always_inline)) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
                     f[i] = *(const bf16x8*)(img + ((half * 2 + i) * 16 + l15) * 512 + (((ks * 4 + lg) ^ l15) * 16));
             };
             read_fa(0, fa[0]);
+            read_fa(1, fa[1]);
+            read_fa(2, fa[2]);
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
-                if (ks + 1 < 8) read_fa(ks + 1, fa[(ks + 1) & 1]);  // one K-step ahead, and no further (sched_barrier below):
+                if (ks + 3 < 8) read_fa(ks + 3, fa[(ks + 3) & 3]);  // three K-steps ahead (4 MFMAs = 64 cycles per K-step against ~200 of LDS latency), and no further (sched_barrier below):
 #pragma unroll                                                       // hoisting all the fragment reads costs 128 registers -> spills,
                 for (int i = 0; i < 2; ++i)                          // and a scratch reload is a VMEM load: vmcnt(0) in the loop
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const f32x4 c0 = ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[i][j];
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j][ks], fa[ks & 1][i], c0, 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j][ks], fa[ks & 3][i], c0, 0, 0, 0);
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -317,22 +319,24 @@ __global__ __launch_bounds__(512, 1) void pos_bwd_kernel(const PosBwdArgs a) {
 #pragma unroll 1  // (rolled: unrolled x4 the allocator spilled the weight fragments)
         for (int quarter = 0; quarter < 4; ++quarter) {  // 32 pixels at a time
             f32x4 acc[2][2];
-            bf16x8 fa[2][2];
+            bf16x8 fa[4][2];
             auto read_fa = [&](int ks, bf16x8 (&f)[2]) __attribute__((always_inline)) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
                     f[i] = *(const bf16x8*)(img + ((quarter * 2 + i) * 16 + l15) * 512 + (((ks * 4 + lg) ^ l15) * 16));
             };
             read_fa(0, fa[0]);
+            read_fa(1, fa[1]);
+            read_fa(2, fa[2]);
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
-                if (ks + 1 < 8) read_fa(ks + 1, fa[(ks + 1) & 1]);
+                if (ks + 3 < 8) read_fa(ks + 3, fa[(ks + 3) & 3]);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const f32x4 c0 = ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[i][j];
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks & 1][i], fw[j][ks], c0, 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks & 3][i], fw[j][ks], c0, 0, 0, 0);
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }
