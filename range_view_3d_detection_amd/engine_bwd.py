@@ -66,7 +66,7 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
     bwd = "scatter" if fwd == "gather" else "gather"
     sp = op.shape
     # ---- input gradient: the opposite tap form -------------------------------------------------
-    fused_first = POS_BWD_FUSE and op.pos_first is not None and op.need_input_grad and t.training and op.pos_first.sync_world == 1
+    fused_first = POS_BWD_FUSE and op.pos_first is not None and op.need_input_grad and t.training
     if fused_first:
         # second positional layer of the MetaKernel stem: dh1 = dy2 W2 is consumed in registers by the first layer's BatchNorm
         # backward + weight gradient (rv_pos_backward_sums) -- no input-gradient tensor, no second pass over it
@@ -158,7 +158,12 @@ def _pos_pair_backward(op: "E.ConvOp", t: Tape, dy2: Act) -> None:
     dgamma = torch.empty(cp, dtype=torch.float32, device=dev)
     dbeta = torch.empty(cp, dtype=torch.float32, device=dev)
     dw = torch.empty((cp, cin), dtype=torch.float32, device=dev)
-    L.call("rv_bn_bwd_smallk_from_sums", L.i32(cp), L.i32(cin), L.ptr(sums), L.ptr(moms), None, L.ptr(wp0), L.i32(E.pad32(cin)),
+    g01 = None
+    if sk.sync_world > 1:  # SyncBN: the normalisation needs the GLOBAL (sum g, sum g*xhat); the other sums stay this rank's (as _smallk_grads)
+        g01 = sums[: 2 * cp].clone()
+        E.COLLECTIVES.add(g01)
+        torch.distributed.all_reduce(g01)
+    L.call("rv_bn_bwd_smallk_from_sums", L.i32(cp), L.i32(cin), L.ptr(sums), L.ptr(moms), L.ptr(g01), L.ptr(wp0), L.i32(E.pad32(cin)),
            L.ptr(sk.gamma_p), L.ptr(sk.mean), L.ptr(sk.invstd), L.i64(sk.count), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dw), L.stream_ptr())
     c = bn0.num_features
     t.add_param_grad(bn0.weight, dgamma[:c])

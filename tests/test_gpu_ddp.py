@@ -139,3 +139,21 @@ def test_one_rank_rccl_sync_path_matches_the_local_run():
     assert calls > 100, calls
     assert rccl["config"]["collectives"]["per_step"]["gradient_all_reduce_bytes"] > 0
     assert abs(rccl["config"]["loss"] - local["config"]["loss"]) < 1e-2 * abs(local["config"]["loss"]), (rccl["config"]["loss"], local["config"]["loss"])
+
+
+def test_one_rank_rccl_sync_path_at_the_rv_av2_widths():
+    """The same one-rank RCCL run at the benchmarked widths (256-channel stem: the positional pair runs as rv_pos_forward with
+    its statistics rows all-reduced, rv_pos_backward_sums with its (sum g, sum g xhat) all-reduced before the gradients are formed; 512-channel
+    towers on tapconv5 / wgrad3) on a 64 x 256 crop: finite loss equal to the local run's within 2e-2."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29673", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    args = [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--width", "256", "--batch", "1", "--no-cpu-baseline"]
+
+    def run(extra_env):
+        out = subprocess.run([sys.executable, *args], env=dict(env, **extra_env), cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-3000:]
+        return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+
+    local = run({})
+    rccl = run({"RV3D_FORCE_DIST": "1", "RV3D_SYNC_WORLD1": "1", "RV3D_DIST_BACKEND": "nccl"})
+    assert rccl["config"]["sync_bn"] is True and rccl["config"]["collectives"]["per_step"]["sync_bn_all_reduce"]["calls"] > 100
+    assert abs(rccl["config"]["loss"] - local["config"]["loss"]) < 2e-2 * abs(local["config"]["loss"]), (rccl["config"]["loss"], local["config"]["loss"])
