@@ -15,7 +15,7 @@ from typing import Dict, List, Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librv3d_hip.so")
+LIB_PATH = os.environ.get("RV3D_LIB") or os.path.join(_HERE, "librv3d_hip.so")  # (RV3D_LIB: A/B of two builds in one gpurun call)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "rv3d.h")
 
 # flags (mirror include/rv3d.h)
