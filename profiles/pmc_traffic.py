@@ -30,5 +30,5 @@ for name in fetch:
     short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
     res[short] = {"launches": n, "fetch_bytes_per_launch": 2.0 * 1024.0 * f / n, "write_bytes_per_launch": 1024.0 * w / n,
                   "hbm_bytes_per_launch": (2.0 * 1024.0 * f + 1024.0 * w) / n, "total_gb": (2.0 * 1024.0 * f + 1024.0 * w) / 1e9}
-res = dict(sorted(res.items(), key=lambda kv: -kv[1]["total_gb"])[:16])
+res = dict(sorted(res.items(), key=lambda kv: -kv[1]["total_gb"])[:28])
 print(json.dumps({"corrections": "FETCH_SIZE KiB x 1024 x 2 (gfx950 wide-read undercount), WRITE_SIZE KiB x 1024", "kernels": res}, indent=1))

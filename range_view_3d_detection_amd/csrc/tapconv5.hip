@@ -573,7 +573,7 @@ int rv_tapconv5_launch(const TapConvArgs& a, size_t lds, int bn, hipStream_t str
         attr_set = true;
     }
     int grid = 8 * a.tiles_per_xcd * a.n_tiles;
-    if (g_tapconv5_persist > 0 && grid > g_tapconv5_persist) grid = g_tapconv5_persist & ~7;  // one workgroup per CU (154 KB of LDS each)
+    if (g_tapconv5_persist > 0 && grid > g_tapconv5_persist) grid = g_tapconv5_persist >= 8 ? g_tapconv5_persist & ~7 : 8;  // one workgroup per CU (154 KB of LDS each)
     if (bn == 256)
         hipLaunchKernelGGL(tapconv5_kernel<256>, dim3(grid), dim3(512), lds, stream, a);
     else
