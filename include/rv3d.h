@@ -83,6 +83,19 @@ int64_t rv_pack_batch_entry_bytes(void);
 int rv_pack_batch_fill(const rvTapGeom* g, const float* T, void* gather_w, void* scatter_w, void* host_entries);
 int rv_pack_batch(const void* dev_table, int32_t n_entries, rvStream stream);
 
+/* FOLDED form of a stride-s layer (stride_w 2 or 4): the s fine pixels of a coarse pixel are contiguous in NHWC, so the fine
+ * tensor V (N,H,s*Wu,cv_pad) read as (N,H,Wu,s*cv_pad) turns U = GATHER_s(V) -- a strided Conv2d's forward, a
+ * ConvTranspose2d's backward-data -- and the layer's weight gradient into STRIDE-1 operations with kw' <= 3 column taps over
+ * s*cv_pad channels, which the LDS-DMA kernels take (the strided forms run on the generic kernel at a third of the rate; the
+ * zero entries of the folded weight cost 1.3-1.5x the FLOPs).  rv_fold_geom gives the folded geometry (use it with
+ * rv_tap_gather / rv_tap_wgrad, Wv = Wu, ld of V multiplied by s; requires ld(V) == cv_pad), rv_pack_weight_folded its packed
+ * gather image (rv_packed_weight_bytes(gf) bytes), rv_unfold_weight_grad maps a folded weight gradient (torch layout
+ * [cu][s*cv_pad][kh][kw']) back to dT[cu][cv][kh][kw]. */
+int rv_fold_geom(const rvTapGeom* g, rvTapGeom* folded);
+int rv_pack_weight_folded(const rvTapGeom* g, const float* T, void* gather_w_folded, rvStream stream);
+int rv_pack_batch_fill_folded(const rvTapGeom* g, const float* T, void* gather_w_folded, void* host_entry);
+int rv_unfold_weight_grad(const rvTapGeom* g, const float* dT_folded, float* dT, int32_t accumulate, rvStream stream);
+
 /* fp32 packed weight gradient [kh*kw][cu_pad][cv_pad] -> accumulate/store into torch layout
  * dT[cu][cv][kh][kw] (fp32).  accumulate != 0: dT += value. */
 int rv_unpack_weight_grad(const rvTapGeom* g, const float* packed, float* dT, int32_t accumulate, rvStream stream);

@@ -33,6 +33,12 @@ struct PackArgs {
     int scatter;
     TapTable tt;
     int phases;
+    // FOLDED gather image of a stride-s layer (fold_s > 0): the fine tensor V is read as (N, H, W/s, s*cv_pad) -- the s fine
+    // pixels of a coarse pixel are contiguous in NHWC -- which turns the stride-s gather into a STRIDE-1 one with
+    // kw' = jmax - jmin + 1 column taps over s*cv_pad channels: tap (ky, j') x folded channel r*cv_pad + c holds
+    // T[cu][c][ky][kx], kx = s (j' + jmin) + r + pad_w (zero where kx falls outside the kernel).  kh, kw, cv, cv_pad above then
+    // describe the folded image; fold_cv / fold_kw are the original channel count and kernel width.
+    int fold_s, fold_pw, fold_jmin, fold_cvp, fold_cv, fold_kw;
 };
 
 struct PackArgs2 {  // both forms in one launch: blockIdx.y selects
@@ -52,6 +58,17 @@ __device__ __forceinline__ void pack_one(const PackArgs& a, int64_t first, int64
         } else {  // [phase-major tap][cv_pad][cu_pad]
             v = (int)(pair / a.cu_pad);
             u = (int)(pair - (int64_t)v * a.cu_pad);
+        }
+        if (a.fold_s) {  // (gather image only)
+            const int r = v / a.fold_cvp, c = v - r * a.fold_cvp;
+            const bool in = u < a.cu && c < a.fold_cv && r < a.fold_s;
+            const float* src = a.T + ((int64_t)u * a.fold_cv + c) * (a.kh * a.fold_kw);
+            for (int t = 0; t < taps; ++t) {
+                const int ky = t / a.kw, jp = t - ky * a.kw;
+                const int kx = a.fold_s * (jp + a.fold_jmin) + r + a.fold_pw;
+                a.out[(int64_t)t * pairs + pair] = f2bf(in && kx >= 0 && kx < a.fold_kw ? src[ky * a.fold_kw + kx] : 0.f);
+            }
+            continue;
         }
         const bool in = u < a.cu && v < a.cv;
         const float* src = a.T + ((int64_t)u * a.cv + v) * taps;
@@ -139,6 +156,95 @@ static int fill_pack_args(const rvTapGeom* g, const float* T, void* out, int for
     a->kh = g->kh;
     a->kw = g->kw;
     a->scatter = form;
+    return 0;
+}
+
+static int floor_div(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
+
+extern "C" int rv_fold_geom(const rvTapGeom* g, rvTapGeom* gf) {
+    RV_REQUIRE(g && gf && g->stride_w > 1, "rv_fold_geom: a strided geometry is required");
+    const int s = g->stride_w, jmin = floor_div(-g->pad_w, s), jmax = floor_div(g->kw - 1 - g->pad_w, s);
+    gf->kh = g->kh;
+    gf->kw = jmax - jmin + 1;
+    gf->stride_w = 1;
+    gf->pad_h = g->pad_h;
+    gf->pad_w = -jmin;
+    gf->cu = g->cu;
+    gf->cv = s * rv_pad32(g->cv);
+    RV_REQUIRE(gf->kh * gf->kw <= kMaxTaps, "rv_fold_geom: folded kernel too large");
+    return 0;
+}
+
+static int fill_pack_args_folded(const rvTapGeom* g, const float* T, void* out, PackArgs* a) {
+    rvTapGeom gf;
+    if (rv_fold_geom(g, &gf)) return 1;
+    memset(a, 0, sizeof(*a));
+    a->T = T;
+    a->out = (bf16_t*)out;
+    a->cu = gf.cu;
+    a->cv = gf.cv;
+    a->cu_pad = rv_pad32(gf.cu);
+    a->cv_pad = gf.cv;  // already a multiple of 32
+    a->kh = gf.kh;
+    a->kw = gf.kw;
+    a->scatter = 0;
+    a->fold_s = g->stride_w;
+    a->fold_pw = g->pad_w;
+    a->fold_jmin = -gf.pad_w;
+    a->fold_cvp = rv_pad32(g->cv);
+    a->fold_cv = g->cv;
+    a->fold_kw = g->kw;
+    return 0;
+}
+
+extern "C" int rv_pack_weight_folded(const rvTapGeom* g, const float* T, void* gather_w_folded, rvStream stream) {
+    RV_REQUIRE(g && T && gather_w_folded, "rv_pack_weight_folded: null argument");
+    PackArgs2 both;
+    memset(&both, 0, sizeof(both));
+    if (fill_pack_args_folded(g, T, gather_w_folded, &both.f[0])) return 1;
+    const int64_t total = (int64_t)both.f[0].cu_pad * both.f[0].cv_pad;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks, 1), dim3(256), 0, (hipStream_t)stream, both);
+    RV_CHECK_LAUNCH("pack_weight_kernel");
+    return 0;
+}
+
+extern "C" int rv_pack_batch_fill_folded(const rvTapGeom* g, const float* T, void* gather_w_folded, void* host_entry) {
+    RV_REQUIRE(g && T && gather_w_folded && host_entry, "rv_pack_batch_fill_folded: null argument");
+    return fill_pack_args_folded(g, T, gather_w_folded, (PackArgs*)host_entry);
+}
+
+namespace {
+// dT[u][c][ky][kx] (+)= dTF[u][r*cvp + c][ky][j'],  kx = s (j' + jmin) + r + pad_w
+__global__ void unfold_wgrad_kernel(const float* dTF, float* dT, int cu, int cv, int kh, int kw, int s, int pw, int jmin, int cvp, int kwf,
+                                    int accumulate) {
+    const int64_t total = (int64_t)cu * cv * kh * kw;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t q = i;
+        const int kx = (int)(q % kw);
+        q /= kw;
+        const int ky = (int)(q % kh);
+        q /= kh;
+        const int c = (int)(q % cv);
+        const int u = (int)(q / cv);
+        const int d = kx - pw;
+        const int j = d >= 0 ? d / s : -((-d + s - 1) / s);
+        const int r = d - j * s;
+        const float g = dTF[(((int64_t)u * (s * cvp) + r * cvp + c) * kh + ky) * kwf + (j - jmin)];
+        dT[i] = accumulate ? dT[i] + g : g;
+    }
+}
+}  // namespace
+
+extern "C" int rv_unfold_weight_grad(const rvTapGeom* g, const float* dT_folded, float* dT, int32_t accumulate, rvStream stream) {
+    RV_REQUIRE(g && dT_folded && dT, "rv_unfold_weight_grad: null argument");
+    rvTapGeom gf;
+    if (rv_fold_geom(g, &gf)) return 1;
+    const int64_t total = (int64_t)g->cu * g->cv * g->kh * g->kw;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(unfold_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dT_folded, dT, g->cu, g->cv, g->kh, g->kw,
+                       g->stride_w, g->pad_w, -gf.pad_w, rv_pad32(g->cv), gf.kw, accumulate);
+    RV_CHECK_LAUNCH("unfold_wgrad_kernel");
     return 0;
 }
 

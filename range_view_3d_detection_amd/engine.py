@@ -320,6 +320,9 @@ def _dma_eligible(geom, n: int, h: int, wu: int, wv: int, ld_src: int, ld_dst: i
 _LAYERS: "weakref.WeakSet[TapLayer]" = weakref.WeakSet()
 _PACK_TABLES: Dict[tuple, Tensor] = {}
 BATCH_PACK = os.environ.get("RV3D_NO_BATCH_PACK") is None
+# Strided layers (stride-2 convs, the ConvTranspose2d up-samplers): run their strided gather and their weight gradient on the
+# stride-1 FOLDED view (fine tensor read as (N, H, W/s, s*C)) so that the LDS-DMA kernels take them.
+FOLD_STRIDED = os.environ.get("RV3D_NO_FOLD") is None
 
 
 def prepack_stale() -> None:
@@ -346,21 +349,28 @@ def prepack_stale() -> None:
         if not l._images:
             n = L.load().rv_packed_weight_bytes(ctypes.byref(l.geom)) // 2
             l._images = {f: torch.empty(n, dtype=torch.bfloat16, device=dev) for f in ("gather", "scatter")}
-    key = tuple((id(l), l.weight.data_ptr(), l._images["gather"].data_ptr(), l._images["scatter"].data_ptr()) for l in stale)
+    folded = [l for l in stale if l._fold_image is not None]  # (layers whose folded image has been used at least once)
+    key = tuple((id(l), l.weight.data_ptr(), l._images["gather"].data_ptr(), l._images["scatter"].data_ptr(),
+                 l._fold_image.data_ptr() if l._fold_image is not None else 0) for l in stale)
+    n_entries = 2 * len(stale) + len(folded)
     table = _PACK_TABLES.get(key)
     if table is None:
         eb = L.load().rv_pack_batch_entry_bytes()
-        host = (ctypes.c_uint8 * (2 * eb * len(stale)))()
+        host = (ctypes.c_uint8 * (eb * n_entries))()
         for i, l in enumerate(stale):
             L.call("rv_pack_batch_fill", ctypes.byref(l.geom), L.ptr(l.weight), L.ptr(l._images["gather"]), L.ptr(l._images["scatter"]),
                    ctypes.byref(host, 2 * eb * i))
+        for i, l in enumerate(folded):
+            L.call("rv_pack_batch_fill_folded", ctypes.byref(l.geom), L.ptr(l.weight), L.ptr(l._fold_image), ctypes.byref(host, eb * (2 * len(stale) + i)))
         _PACK_TABLES.clear()  # one live table (a second model in the process rebuilds it: cheap)
         table = torch.frombuffer(host, dtype=torch.uint8).clone().to(dev)
         _PACK_TABLES[key] = table
-    L.call("rv_pack_batch", L.ptr(table), L.i32(2 * len(stale)), L.stream_ptr())
+    L.call("rv_pack_batch", L.ptr(table), L.i32(n_entries), L.stream_ptr())
     for l in stale:
         l._packed = dict(l._images)
         l._version = (l.weight._version, l.weight.data_ptr())
+    for l in folded:
+        l._fold_version = l._version
 
 
 class TapLayer:
@@ -381,6 +391,9 @@ class TapLayer:
         self._packed: Dict[str, Tensor] = {}
         self._version = None
         self._images: Dict[str, Tensor] = {}  # persistent buffers of the batched re-pack (prepack_stale)
+        self._fold_geom = None
+        self._fold_image: Optional[Tensor] = None
+        self._fold_version = None
         _LAYERS.add(self)
 
     # forward direction of the torch module: conv = gather, conv-transpose = scatter
@@ -413,6 +426,29 @@ class TapLayer:
         cu = g.shape[0]
         return g.reshape(cu, taps, pad32(c))[..., :c].permute(0, 2, 1).reshape(self.weight.shape).contiguous()
 
+    # ---- folded (stride-1) form of a strided layer: csrc/misc.hip rv_fold_geom --------------------------------------
+    def fold_geom(self) -> Optional["L.TapGeom"]:
+        """Geometry of the stride-1 view of this layer's strided gather / weight gradient (None for stride-1 layers)."""
+        if self.geom.stride_w == 1 or not FOLD_STRIDED or self.in_perm is not None:
+            return None
+        if self._fold_geom is None:
+            gf = L.TapGeom()
+            L.call("rv_fold_geom", ctypes.byref(self.geom), ctypes.byref(gf))
+            self._fold_geom = gf
+        return self._fold_geom
+
+    def packed_folded(self) -> Tensor:
+        """bf16 gather image of the folded form; re-packed with the other images when the parameter changed."""
+        ver = (self.weight._version, self.weight.data_ptr())
+        if ver != self._fold_version or self._fold_image is None:
+            gf = self.fold_geom()
+            n = L.load().rv_packed_weight_bytes(ctypes.byref(gf)) // 2
+            if self._fold_image is None:
+                self._fold_image = torch.empty(n, dtype=torch.bfloat16, device=self.weight.device)
+            L.call("rv_pack_weight_folded", ctypes.byref(self.geom), L.ptr(self.weight.detach().contiguous().float()), L.ptr(self._fold_image), L.stream_ptr())
+            self._fold_version = ver
+        return self._fold_image
+
     def invalidate(self) -> None:
         """Drop the packed bf16 images.  They are re-packed automatically when ``weight._version`` or its storage changes
         (optimizer steps, ``load_state_dict``, ``copy_``); writes that bypass the version counter (``p.data.add_(...)``,
@@ -420,6 +456,7 @@ class TapLayer:
         after such surgery."""
         self._packed.clear()
         self._version = None
+        self._fold_version = None
 
     def packed(self, form: str) -> Tensor:
         """bf16 weight image for ``form``; re-packed when the parameter changed (optimizer step / load_state_dict)."""
@@ -590,6 +627,14 @@ class ConvOp(Op):
             self.x_plain = src = x.materialized()
             sc = sh = None
             flags = 0
+        elif (isinstance(x, Lazy) and MATERIALIZE_FOR_DMA and not out_f32 and form == "gather" and g.stride_w > 1 and g.kh * g.kw > 1
+              and layer.fold_geom() is not None and src.ld == src.cp
+              and _dma_eligible(layer.fold_geom(), src.N, src.H, wu, wu, g.stride_w * src.ld, pad32(layer.c_out), False)):
+            # strided multi-tap conv fed by a folded BatchNorm+ReLU: written out once, the FOLDED stride-1 form (forward and
+            # weight gradient) then runs on the LDS-DMA kernels instead of the generic strided ones
+            self.x_plain = src = x.materialized()
+            sc = sh = None
+            flags = 0
         self.out_f32 = out_f32
         if out_f32:
             self.out_t = torch.empty((src.N, src.H, w_out, pad32(layer.c_out)), dtype=torch.float32, device=t.device)
@@ -606,22 +651,30 @@ class ConvOp(Op):
         else:
             bias_p = None
         self.shape = L.TapShape(src.N, src.H, wu, wv, src.ld, ld_dst, flags | (L.OUT_STATS if stats else 0))
+        # a strided gather (stride-2 conv forward) runs on the stride-1 FOLDED view when the LDS-DMA kernels take that
+        lg, lshape, wp = g, self.shape, None
+        gf = layer.fold_geom() if (form == "gather" and g.stride_w > 1 and sc is None and flags & (L.IN_AFFINE | L.IN_RELU) == 0) else None
+        if gf is not None and src.ld == src.cp and _dma_eligible(gf, src.N, src.H, wu, wu, g.stride_w * src.ld, ld_dst, False):
+            lg = gf
+            lshape = L.TapShape(src.N, src.H, wu, wu, g.stride_w * src.ld, ld_dst, self.shape.flags)
+            wp = layer.packed_folded()
         self.partial = None
         self.rows = 0
         if stats:
-            self.rows = L.load().rv_tap_stats_rows(ctypes.byref(g), ctypes.byref(self.shape), 1 if form == "scatter" else 0)
+            self.rows = L.load().rv_tap_stats_rows(ctypes.byref(lg), ctypes.byref(lshape), 1 if form == "scatter" else 0)
             if self.rows < 0:
                 raise L.RvError("rv_tap_stats_rows: " + L.load().rv_last_error().decode())
             self.partial = torch.empty((self.rows + L.STATS_SCRATCH_ROWS, 2, pad32(layer.c_out)), dtype=torch.float32,
                                        device=t.device)
-        wp = layer.packed(form)
-        call = lambda: L.call("rv_tap_" + form, ctypes.byref(g), ctypes.byref(self.shape), src.ptr(), L.ptr(sc), L.ptr(sh),
+        if wp is None:
+            wp = layer.packed(form)
+        call = lambda: L.call("rv_tap_" + form, ctypes.byref(lg), ctypes.byref(lshape), src.ptr(), L.ptr(sc), L.ptr(sh),
                               L.ptr(wp), L.ptr(bias_p), dst_ptr, L.ptr(self.partial), L.stream_ptr())
         if precomputed is not None:
             assert out is not None and not out_f32 and bias is None
             self.partial, self.rows = precomputed
         elif PROFILE is not None:
-            _launch(tap_kernel_name(g, self.shape, form == "scatter"), tap_flops(g, self.shape), call)
+            _launch(tap_kernel_name(lg, lshape, form == "scatter"), tap_flops(g, self.shape), call)
         else:
             call()
         self.count = src.N * src.H * w_out

@@ -78,10 +78,18 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
         else:
             dst, accumulate = t.grad_buffer(op.x)
         shape = L.TapShape(sp.N, sp.H, sp.Wu, sp.Wv, dout.ld, dst.ld, L.OUT_ACCUM if accumulate else 0)
-        wp = layer.packed(bwd)
-        call = lambda: L.call("rv_tap_" + bwd, ctypes.byref(g), ctypes.byref(shape), dout.ptr(), None, None, L.ptr(wp), None,
+        bg, bshape = g, shape
+        gf = layer.fold_geom() if (bwd == "gather" and g.stride_w > 1) else None
+        if gf is not None and dout.ld == dout.cp and E._dma_eligible(gf, sp.N, sp.H, sp.Wu, sp.Wu, g.stride_w * dout.ld, dst.ld, False):
+            # backward-data of a ConvTranspose2d = a strided gather over dOut: stride-1 on the folded view (engine.FOLD_STRIDED)
+            bg = gf
+            bshape = L.TapShape(sp.N, sp.H, sp.Wu, sp.Wu, g.stride_w * dout.ld, dst.ld, shape.flags)
+            wp = layer.packed_folded()
+        else:
+            wp = layer.packed(bwd)
+        call = lambda: L.call("rv_tap_" + bwd, ctypes.byref(bg), ctypes.byref(bshape), dout.ptr(), None, None, L.ptr(wp), None,
                               dst.ptr(), None, L.stream_ptr())
-        if E.BNB_FUSE and isinstance(op.x, Lazy) and not accumulate and op.x.bn.mean is not None:
+        if E.BNB_FUSE and bg is g and isinstance(op.x, Lazy) and not accumulate and op.x.bn.mean is not None:
             # first (often only) consumer of relu(bn(y)): this launch can form that BatchNorm's backward sums on the way out
             rows = L.load().rv_tap_bnb_rows(ctypes.byref(g), ctypes.byref(shape), L.i32(1 if bwd == "scatter" else 0))
             if rows > 0:
@@ -93,7 +101,7 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
                                       L.ptr(wp), dst.ptr(), ctypes.byref(epi), L.stream_ptr())
                 t.lazy_sums[id(lz)] = (partial, rows, dst)
         if E.PROFILE is not None:
-            E._launch(E.tap_kernel_name(g, shape, bwd == "scatter"), E.tap_flops(g, shape), call)
+            E._launch(E.tap_kernel_name(bg, bshape, bwd == "scatter"), E.tap_flops(g, shape), call)
         else:
             call()
         if not isinstance(op.x, Lazy):
@@ -104,22 +112,31 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
     else:
         u, v, v_affine = src, dout, 0
     wshape = L.TapShape(sp.N, sp.H, sp.Wu, sp.Wv, 0, 0, in_flags | L.WGRAD_TORCH_LAYOUT)
+    # strided layers: the weight gradient on the stride-1 FOLDED view of the fine tensor (wgrad3 instead of the generic kernel),
+    # then rv_unfold_weight_grad picks the kernel's own entries out of the folded gradient
+    wg, wsh, ld_v = g, wshape, v.ld
+    gfw = layer.fold_geom() if (g.stride_w > 1 and sc is None and in_flags == 0 and v.ld == v.cp) else None
+    if gfw is not None:
+        wg, wsh, ld_v = gfw, L.TapShape(sp.N, sp.H, sp.Wu, sp.Wu, 0, 0, L.WGRAD_TORCH_LAYOUT), g.stride_w * v.ld
 
     def run_wgrad() -> None:
-        ws_bytes = L.load().rv_tap_wgrad_workspace_bytes(ctypes.byref(g), ctypes.byref(wshape))
+        ws_bytes = L.load().rv_tap_wgrad_workspace_bytes(ctypes.byref(wg), ctypes.byref(wsh))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=t.device)
-        grad = torch.empty((g.cu, g.cv, g.kh, g.kw), dtype=torch.float32, device=t.device)
+        grad = torch.empty((wg.cu, wg.cv, wg.kh, wg.kw), dtype=torch.float32, device=t.device)
         wname = "wgrad_kernel(+reduce)"
         if E.PROFILE is not None:
             winfo = (ctypes.c_int32 * 4)()
-            L.call("rv_tap_wgrad_info", ctypes.byref(g), ctypes.byref(wshape), winfo)
+            L.call("rv_tap_wgrad_info", ctypes.byref(wg), ctypes.byref(wsh), winfo)
             wname = ("wgrad_kernel", "wgrad_kernel", "wgrad2_kernel", "wgrad3_kernel")[winfo[0]] + "(+reduce)"
         if os.environ.get("RV3D_PROFILE_SHAPES"):
             wname += f" k{g.kh}x{g.kw}s{g.stride_w} {g.cu}<->{g.cv} {wshape.N}x{wshape.H}x{wshape.Wu}"
         # the split-K reduction writes the torch layout dT[cu][cv][kh][kw] itself (RV_WGRAD_TORCH_LAYOUT): no unpack pass
         E._launch(wname, E.tap_flops(g, wshape),
-                  lambda: L.call("rv_tap_wgrad", ctypes.byref(g), ctypes.byref(wshape), u.ptr(), L.i32(u.ld), v.ptr(), L.i32(v.ld),
+                  lambda: L.call("rv_tap_wgrad", ctypes.byref(wg), ctypes.byref(wsh), u.ptr(), L.i32(u.ld), v.ptr(), L.i32(ld_v),
                                  L.ptr(sc), L.ptr(sh), L.i32(v_affine), L.ptr(grad), L.ptr(ws), L.stream_ptr()))
+        if wg is not g:
+            folded, grad = grad, torch.empty((g.cu, g.cv, g.kh, g.kw), dtype=torch.float32, device=t.device)
+            L.call("rv_unfold_weight_grad", ctypes.byref(g), L.ptr(folded), L.ptr(grad), L.i32(0), L.stream_ptr())
         t.add_param_grad(layer.weight, layer.unpermute_grad(grad))
 
     if E.OVERLAP_WGRAD:
