@@ -15,8 +15,9 @@ with the backward of the earlier stage, BatchNorm statistics all-reduced (SyncBN
 conf/trainer/train.yaml:15).
 
 Rank 0 prints ONE JSON line (contract in the task statement) including
-  "roofline":     the dominant kernel (128x128-tile bf16 MFMA tap-conv) against the dense bf16 MFMA peak,
-                  timed live with events around each of its launches inside the timed region;
+  "roofline":     the dominant kernel (tapconv5: 256 x 256-tile bf16 MFMA tap-conv with the input halo resident in LDS)
+                  against the dense bf16 MFMA peak, timed live with events around each of its launches inside the timed
+                  region; `traffic` = its HBM-side bytes per launch from this round's PMC passes (profiles/);
   "cpu_baseline": the oracle (CPU restatement of the reference, ``oracle/``) timed on this box's host
                   cores on a bounded sample (N == 1 only).
 """
