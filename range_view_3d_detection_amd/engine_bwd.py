@@ -85,6 +85,16 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
             bg = gf
             bshape = L.TapShape(sp.N, sp.H, sp.Wu, sp.Wu, g.stride_w * dout.ld, dst.ld, shape.flags)
             wp = layer.packed_folded()
+        elif (E.FOLD_STRIDED and bwd == "scatter" and g.stride_w == 2 and g.kh == 1 and g.kw == 1 and g.pad_w == 0 and dst.ld == dst.cp
+              and dst.W == 2 * sp.Wu):
+            # backward-data of a 1x1 stride-2 conv: only the even columns receive anything -- a STRIDE-1 1x1 launch into the
+            # even-column view of the gradient (pixel pitch 2 ld; the one-tap scatter image is the same bytes), odd columns zeroed
+            # unless the buffer already holds another consumer's contribution
+            if not accumulate:
+                dst.data.zero_()
+            bg = L.TapGeom(1, 1, 1, 0, 0, g.cu, g.cv)
+            bshape = L.TapShape(sp.N, sp.H, sp.Wu, sp.Wu, dout.ld, 2 * dst.ld, shape.flags)
+            wp = layer.packed(bwd)
         else:
             wp = layer.packed(bwd)
         call = lambda: L.call("rv_tap_" + bwd, ctypes.byref(bg), ctypes.byref(bshape), dout.ptr(), None, None, L.ptr(wp), None,
