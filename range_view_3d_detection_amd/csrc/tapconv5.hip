@@ -54,7 +54,11 @@ __device__ __attribute__((aligned(256))) uint32_t g_zero_page5[64];
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
-template <int kBN>  // channels per workgroup: 256, or 128 (narrow layers: one weight piece per K tile, two phases)
+// kBN: channels per workgroup, 256 or 128 (narrow layers: one weight piece per K tile, two phases).  BNB: the launch carries the
+// BatchNorm-backward sum epilogue (RV_OUT_BNB) -- a template parameter because its 16 prefetch registers per pass and per-channel
+// constants, merely PRESENT in the code, cost every launch 154 spilled registers per tile (11 without: forward launches and
+// plain backward-data launches run the lean instance).
+template <int kBN, bool BNB>
 __global__ __launch_bounds__(512, 2) void tapconv5_kernel(const TapConvArgs a) {
     constexpr int NJ = kBN / 64;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -421,7 +425,7 @@ __global__ __launch_bounds__(512, 2) void tapconv5_kernel(const TapConvArgs a) {
     // with g = dOut * [scale*y+shift > 0], xhat = (y - mean) * invstd.  A thread keeps ONE 8-channel chunk through the store loop
     // (512 threads = 16 pixels x 32 chunks per pass), so the sums are formed here, from the bf16 values being stored, with one
     // extra 16-byte read of y per chunk: the separate reduce pass over (dOut, y) disappears (bnbwd.hip: bn_bwd_reduce_kernel).
-    const bool bnb = a.flags & RV_OUT_BNB;
+    constexpr bool bnb = BNB;
     float bsc[8], bsh[8], bmu[8], bis[8], s0[8], s1[8];
     if (bnb) {
         const int c = n0 + (tid & (kChunks - 1)) * 8;  // (512 % kChunks == 0: the chunk of a thread is the same in every pass)
@@ -568,16 +572,22 @@ bool rv_tapconv5_plan(TapConvArgs* a, int* tiles, size_t* lds, int* bn) {
 int rv_tapconv5_launch(const TapConvArgs& a, size_t lds, int bn, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)tapconv5_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)tapconv5_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)tapconv5_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)tapconv5_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)tapconv5_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)tapconv5_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     int grid = 8 * a.tiles_per_xcd * a.n_tiles;
     if (g_tapconv5_persist > 0 && grid > g_tapconv5_persist) grid = g_tapconv5_persist >= 8 ? g_tapconv5_persist & ~7 : 8;  // one workgroup per CU (154 KB of LDS each)
-    if (bn == 256)
-        hipLaunchKernelGGL(tapconv5_kernel<256>, dim3(grid), dim3(512), lds, stream, a);
-    else
-        hipLaunchKernelGGL(tapconv5_kernel<128>, dim3(grid), dim3(512), lds, stream, a);
+    const bool bnb = (a.flags & RV_OUT_BNB) != 0;
+    if (bn == 256) {
+        if (bnb) hipLaunchKernelGGL((tapconv5_kernel<256, true>), dim3(grid), dim3(512), lds, stream, a);
+        else hipLaunchKernelGGL((tapconv5_kernel<256, false>), dim3(grid), dim3(512), lds, stream, a);
+    } else {
+        if (bnb) hipLaunchKernelGGL((tapconv5_kernel<128, true>), dim3(grid), dim3(512), lds, stream, a);
+        else hipLaunchKernelGGL((tapconv5_kernel<128, false>), dim3(grid), dim3(512), lds, stream, a);
+    }
     RV_CHECK_LAUNCH("tapconv5_kernel");
     return 0;
 }
