@@ -213,9 +213,13 @@ def roofline(prof, iso) -> dict:
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), PMC_TRAFFIC)) as f:
             rows = json.load(f)["kernels"]
         name = r["kernel"].replace("(+reduce)", "")
-        k = rows.get(name) or rows.get(name.split("<")[0])  # (tapconv5_kernel is not a template: the profiler knows it without <256>)
-        if k:
-            r["traffic"] = k["hbm_bytes_per_launch"]
+        # the profiler names template instances in full ("tapconv5_kernel<256, false>", "... <256, true>": the launches of one
+        # kernel family and tile width): launch-weighted mean over the instances whose name starts like ours
+        stem = name[:-1] if name.endswith(">") else name
+        hits = [v for k, v in rows.items() if k == name or k.startswith(stem + ",") or k.startswith(stem + ">")] or [v for k, v in rows.items() if k == name.split("<")[0]]
+        if hits:
+            n = sum(v["launches"] for v in hits)
+            r["traffic"] = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hits) / n
             r["traffic_source"] = PMC_TRAFFIC + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 gfx950 correction)"
     except OSError:
         pass
