@@ -72,9 +72,9 @@ __global__ __launch_bounds__(512, 2) void tapconv5_kernel(const TapConvArgs a) {
     // time (gridDim.x % 8 == 0) -- so a CU pays the workgroup dispatch (LDS allocation, wave start, kernel-argument loads)
     // once per launch instead of once per tile (16 tiles per CU on the 512-channel layers).
     const int gy = a.n_tiles;
-    // (Measured and dropped: letting one workgroup take the two channel tiles of a pixel tile back to back.  Persistent
-    //  workgroups that start the two halves together drift apart, and the PMC passes then show the input fetched twice --
-    //  2.4 instead of 1.2 GB per average launch -- but the step time does not move: the kernel is not HBM-bound.)
+    // (Measured and dropped: letting one workgroup take the two channel tiles of a pixel tile back to back, and dealing the
+    //  channel tiles to different XCDs -- neither moved the step time.  The doubled HBM-side traffic that prompted both turned
+    //  out to be scratch traffic of spilled registers, see the BNB template parameter.)
     const int xcd = blockIdx.x & 7, wslot = blockIdx.x >> 3, nslots = gridDim.x >> 3;  // (gridDim.x % 8 == 0)
     for (int k = 0;; ++k) {
     const int xslot = wslot + nslots * k;
