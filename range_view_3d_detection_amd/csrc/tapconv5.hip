@@ -54,11 +54,12 @@ __device__ __attribute__((aligned(256))) uint32_t g_zero_page5[64];
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
-// kBN: channels per workgroup, 256 or 128 (narrow layers: one weight piece per K tile, two phases).  BNB: the launch carries the
-// BatchNorm-backward sum epilogue (RV_OUT_BNB) -- a template parameter because its 16 prefetch registers per pass and per-channel
-// constants, merely PRESENT in the code, cost every launch 154 spilled registers per tile (11 without: forward launches and
-// plain backward-data launches run the lean instance).
-template <int kBN, bool BNB>
+// kBN: channels per workgroup, 256 or 128 (narrow layers: one weight piece per K tile, two phases).  EPI: which epilogue the
+// launch carries -- template parameters because the BatchNorm-sum epilogue's 16 prefetch registers per pass and per-channel
+// constants, merely PRESENT in the code behind a run-time flag, cost every launch 154 spilled registers per tile (11 without:
+// forward launches and plain backward-data launches run the lean instance); the accumulate instance can then afford the
+// same prefetch for the old values it adds to.
+template <int kBN, int EPI>  // EPI: 0 plain store (+ statistics / bias), 1 BatchNorm-sum epilogue (RV_OUT_BNB), 2 accumulate (RV_OUT_ACCUM)
 __global__ __launch_bounds__(512, 2) void tapconv5_kernel(const TapConvArgs a) {
     constexpr int NJ = kBN / 64;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -420,12 +421,12 @@ __global__ __launch_bounds__(512, 2) void tapconv5_kernel(const TapConvArgs a) {
                 epi[pm * kEpi + pc] = f2bf(acc[i][j][r]);
             }
     constexpr int kChunks = kBN / 8;
-    const bool accum = a.flags & RV_OUT_ACCUM;
+    constexpr bool accum = EPI == 2;
     // RV_OUT_BNB: this launch writes dOut of a BatchNorm(+ReLU) layer -- its backward needs sum(g) and sum(g * xhat) per channel
     // with g = dOut * [scale*y+shift > 0], xhat = (y - mean) * invstd.  A thread keeps ONE 8-channel chunk through the store loop
     // (512 threads = 16 pixels x 32 chunks per pass), so the sums are formed here, from the bf16 values being stored, with one
     // extra 16-byte read of y per chunk: the separate reduce pass over (dOut, y) disappears (bnbwd.hip: bn_bwd_reduce_kernel).
-    constexpr bool bnb = BNB;
+    constexpr bool bnb = EPI == 1;
     float bsc[8], bsh[8], bmu[8], bis[8], s0[8], s1[8];
     if (bnb) {
         const int c = n0 + (tid & (kChunks - 1)) * 8;  // (512 % kChunks == 0: the chunk of a thread is the same in every pass)
@@ -451,6 +452,17 @@ __global__ __launch_bounds__(512, 2) void tapconv5_kernel(const TapConvArgs a) {
             if (m < Wm && hh < a.H) yv[it] = *(const u32x4*)(a.bnb_y + (((int64_t)(n * a.H + hh) * a.W_dst) + (a.phases * m + ph)) * a.ld_bnb_y + c);
         }
     }
+    if (accum) {  // the old values of this thread's sixteen chunks likewise: read inside the store loop each one waited out its
+                  // own round trip between two stores (+17 us per tile on the 256-channel layers)
+#pragma unroll
+        for (int it = 0; it < kPasses; ++it) {
+            const int q = tid + it * 512, pm = q / kChunks, c8 = q - pm * kChunks;
+            const int rr = pm / kTC, mm = pm - rr * kTC;
+            const int m = m0 + mm, c = n0 + c8 * 8, hh = h0 + rr;
+            yv[it] = u32x4{0u, 0u, 0u, 0u};
+            if (m < Wm && hh < a.H) yv[it] = *(const u32x4*)((const bf16_t*)a.dst + (((int64_t)(n * a.H + hh) * a.W_dst) + (a.phases * m + ph)) * a.ld_dst + c);
+        }
+    }
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < kPasses; ++it) {
@@ -463,7 +475,7 @@ __global__ __launch_bounds__(512, 2) void tapconv5_kernel(const TapConvArgs a) {
         const int64_t px = ((int64_t)(n * a.H + hh) * a.W_dst) + (a.phases * m + ph);
         bf16_t* p = (bf16_t*)a.dst + px * a.ld_dst + c;
         if (accum) {
-            const u32x4 o = *(const u32x4*)p;
+            const u32x4 o = yv[it];
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = pack_bf2(bf_lo(v[j]) + bf_lo(o[j]), bf_hi(v[j]) + bf_hi(o[j]));
         }
@@ -572,22 +584,28 @@ bool rv_tapconv5_plan(TapConvArgs* a, int* tiles, size_t* lds, int* bn) {
 int rv_tapconv5_launch(const TapConvArgs& a, size_t lds, int bn, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)tapconv5_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)tapconv5_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)tapconv5_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)tapconv5_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)tapconv5_kernel<256, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)tapconv5_kernel<128, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)tapconv5_kernel<256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)tapconv5_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)tapconv5_kernel<256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)tapconv5_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     int grid = 8 * a.tiles_per_xcd * a.n_tiles;
     if (g_tapconv5_persist > 0 && grid > g_tapconv5_persist) grid = g_tapconv5_persist >= 8 ? g_tapconv5_persist & ~7 : 8;  // one workgroup per CU (154 KB of LDS each)
-    const bool bnb = (a.flags & RV_OUT_BNB) != 0;
+    const int epi = (a.flags & RV_OUT_BNB) ? 1 : ((a.flags & RV_OUT_ACCUM) ? 2 : 0);  // (the plan refuses BNB together with ACCUM)
+#define RV_T5_LAUNCH(BN_, EPI_) hipLaunchKernelGGL((tapconv5_kernel<BN_, EPI_>), dim3(grid), dim3(512), lds, stream, a)
     if (bn == 256) {
-        if (bnb) hipLaunchKernelGGL((tapconv5_kernel<256, true>), dim3(grid), dim3(512), lds, stream, a);
-        else hipLaunchKernelGGL((tapconv5_kernel<256, false>), dim3(grid), dim3(512), lds, stream, a);
+        if (epi == 1) RV_T5_LAUNCH(256, 1);
+        else if (epi == 2) RV_T5_LAUNCH(256, 2);
+        else RV_T5_LAUNCH(256, 0);
     } else {
-        if (bnb) hipLaunchKernelGGL((tapconv5_kernel<128, true>), dim3(grid), dim3(512), lds, stream, a);
-        else hipLaunchKernelGGL((tapconv5_kernel<128, false>), dim3(grid), dim3(512), lds, stream, a);
+        if (epi == 1) RV_T5_LAUNCH(128, 1);
+        else if (epi == 2) RV_T5_LAUNCH(128, 2);
+        else RV_T5_LAUNCH(128, 0);
     }
+#undef RV_T5_LAUNCH
     RV_CHECK_LAUNCH("tapconv5_kernel");
     return 0;
 }
