@@ -45,7 +45,9 @@ struct Staged {   // the K tile a piece belongs to
     uint32_t vb;  // validity of the thread's four tile rows under this tap
 };
 
-template <int BN>  // channels per workgroup tile: 256 (two 16 KB weight pieces per K tile) or 128 (one)
+// BN: channels per workgroup tile, 256 (two 16 KB weight pieces per K tile) or 128 (one).  ACC: the launch accumulates into dst
+// (RV_OUT_ACCUM) -- a template parameter so that only that instance carries the prefetch registers of the old values.
+template <int BN, bool ACC>
 __global__ __launch_bounds__(512, 2) void tapconv4_kernel(const TapConvArgs a) {
     constexpr int NJ = BN / 64;  // 16-channel accumulator fragments per wave (wave tile = 128 pixels x BN/4 channels)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -325,10 +327,27 @@ __global__ __launch_bounds__(512, 2) void tapconv4_kernel(const TapConvArgs a) {
                 const int pc = wc * WN + j * 16 + l15;
                 epi[pm * kEpi + pc] = f2bf(acc[i][j][r]);
             }
-    __syncthreads();
     constexpr int kChunks = BN / 8;
-    const bool accum = a.flags & RV_OUT_ACCUM;
-    for (int q = tid; q < kTR * kTC * kChunks; q += 512) {
+    constexpr int kPasses = kTR * kTC * kChunks / 512;
+    constexpr bool accum = ACC;
+    // accumulate: the old values of this thread's chunks all in flight before the barrier that publishes the staged tile (read
+    // inside the store loop each one waited out its own round trip between two stores)
+    u32x4 ov[accum ? kPasses : 1];
+    if (accum) {
+#pragma unroll
+        for (int it = 0; it < kPasses; ++it) {
+            const int q = tid + it * 512, pm = q / kChunks, c8 = q - pm * kChunks;
+            const int rr = pm / kTC, mm = pm - rr * kTC;
+            const int m = m0 + mm, c = n0 + c8 * 8, hh = h0 + rr;
+            ov[accum ? it : 0] = u32x4{0u, 0u, 0u, 0u};
+            if (m < Wm && hh < a.H)
+                ov[accum ? it : 0] = *(const u32x4*)((const bf16_t*)a.dst + (((int64_t)(n * a.H + hh) * a.W_dst) + (a.phases * m + ph)) * a.ld_dst + c);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < kPasses; ++it) {
+        const int q = tid + it * 512;
         const int pm = q / kChunks, c8 = q - pm * kChunks;
         const int rr = pm / kTC, mm = pm - rr * kTC;
         const int m = m0 + mm, c = n0 + c8 * 8, hh = h0 + rr;
@@ -336,7 +355,7 @@ __global__ __launch_bounds__(512, 2) void tapconv4_kernel(const TapConvArgs a) {
         u32x4 v = *(const u32x4*)(epi + pm * kEpi + c8 * 8);
         bf16_t* p = (bf16_t*)a.dst + (((int64_t)(n * a.H + hh) * a.W_dst) + (a.phases * m + ph)) * a.ld_dst + c;
         if (accum) {
-            const u32x4 o = *(const u32x4*)p;
+            const u32x4 o = ov[accum ? it : 0];
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = pack_bf2(bf_lo(v[j]) + bf_lo(o[j]), bf_hi(v[j]) + bf_hi(o[j]));
         }
@@ -383,16 +402,22 @@ bool rv_tapconv4_plan(TapConvArgs* a, int* tiles, size_t* lds, int* bn) {
 int rv_tapconv4_launch(const TapConvArgs& a, size_t lds, int bn, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)tapconv4_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)tapconv4_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)tapconv4_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)tapconv4_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)tapconv4_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)tapconv4_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     int grid = 8 * a.tiles_per_xcd * a.n_tiles;
     if (g_tapconv5_persist > 0 && grid > g_tapconv5_persist) grid = g_tapconv5_persist >= 8 ? g_tapconv5_persist & ~7 : 8;
-    if (bn == 256)
-        hipLaunchKernelGGL(tapconv4_kernel<256>, dim3(grid), dim3(512), lds, stream, a);
-    else
-        hipLaunchKernelGGL(tapconv4_kernel<128>, dim3(grid), dim3(512), lds, stream, a);
+    const bool acc = (a.flags & RV_OUT_ACCUM) != 0;
+    if (bn == 256) {
+        if (acc) hipLaunchKernelGGL((tapconv4_kernel<256, true>), dim3(grid), dim3(512), lds, stream, a);
+        else hipLaunchKernelGGL((tapconv4_kernel<256, false>), dim3(grid), dim3(512), lds, stream, a);
+    } else {
+        if (acc) hipLaunchKernelGGL((tapconv4_kernel<128, true>), dim3(grid), dim3(512), lds, stream, a);
+        else hipLaunchKernelGGL((tapconv4_kernel<128, false>), dim3(grid), dim3(512), lds, stream, a);
+    }
     RV_CHECK_LAUNCH("tapconv4_kernel");
     return 0;
 }
