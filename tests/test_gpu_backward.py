@@ -485,3 +485,70 @@ def test_meta_kernel_positional_pair_backward_fused_matches_unfused():
             assert _cos(a[k], b[k]) > 0.9999 and rel_err(a[k], b[k]) < 2e-2, (k, _cos(a[k], b[k]), rel_err(a[k], b[k]))
         else:
             assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("kind,cin,cout,kernel,stride,pad,H,W", [
+    ("conv", 128, 128, (3, 3), 2, None, 8, 256),          # stride-2 3x3 conv: forward + weight gradient on the folded view
+    ("conv", 128, 256, (1, 1), 2, None, 8, 256),          # 1x1 stride-2 projection: weight gradient folded, backward-data into the even-column view
+    ("convT", 128, 256, (3, 8), 4, (1, 2), 8, 64),        # the (3,8)/s4 up-sampler: backward-data + weight gradient folded
+    ("convT", 128, 128, (3, 4), 2, (1, 1), 8, 128),       # the (3,4)/s2 up-sampler
+])
+def test_strided_layers_on_the_folded_view(kind, cin, cout, kernel, stride, pad, H, W):
+    """The FOLDED stride-1 form of the strided layers (rv_fold_geom / rv_pack_weight_folded / rv_unfold_weight_grad; the LDS-DMA
+    kernels are forced onto these small shapes with tapconv4_min_blocks = 1) against fp32 torch ops on bf16-representable
+    operands -- forward one bf16 rounding (8e-3 of max), input gradient 8e-3, weight gradient 2e-5 (exact products, summation
+    order only) -- and against the unfolded path of the same library (RV3D_NO_FOLD semantics: engine.FOLD_STRIDED = False)."""
+    import ctypes
+
+    from range_view_3d_detection_amd import _lib as L
+    from range_view_3d_detection_amd import engine as E
+    from range_view_3d_detection_amd import program
+
+    g = torch.Generator().manual_seed(cin + cout + stride)
+    if kind == "conv":
+        m = torch.nn.Conv2d(cin, cout, kernel, stride=(1, stride), padding=((kernel[0] - 1) // 2, (kernel[1] - 1) // 2), bias=False)
+    else:
+        m = torch.nn.ConvTranspose2d(cin, cout, kernel, stride=(1, stride), padding=pad, bias=False)
+    m.weight.data = bf16r(torch.randn(m.weight.shape, generator=g) * 0.1)
+    x = bf16r(torch.randn(2, cin, H, W, generator=g)).requires_grad_(True)
+    w = m.weight.data.clone().requires_grad_(True)
+    if kind == "conv":
+        y = F.conv2d(x, w, stride=(1, stride), padding=m.padding)
+    else:
+        y = F.conv_transpose2d(x, w, stride=(1, stride), padding=pad)
+    probe = bf16r(torch.randn(y.shape, generator=g))
+    (y * probe).sum().backward()
+    m = m.to(DEV)
+
+    def run(fold: bool):
+        E.FOLD_STRIDED = fold
+        m.__dict__.pop("_rv_layer", None)  # a fresh TapLayer: the folded geometry is cached on it
+        m.zero_grad(set_to_none=True)
+        old = L.load().rv_set_option(b"tapconv4_min_blocks", ctypes.c_int32(1))
+        try:
+            E.PROFILE = E.KernelProfile()
+
+            def build(t, xin):
+                a = E.Act.from_nchw(xin)
+                return [a], [E.ConvOp(t, E.tap_layer(m), a).out]
+
+            xd = x.detach().to(DEV).requires_grad_(True)
+            yd = program.run(build, m, [xd])[0]
+            (yd.float() * probe.to(DEV)).sum().backward()
+            torch.cuda.synchronize()
+            ran = sorted(set(name for name, *_ in E.PROFILE.records))
+            return yd.detach().float().cpu(), xd.grad.detach().float().cpu(), m.weight.grad.detach().cpu().clone(), ran
+        finally:
+            E.PROFILE = None
+            E.FOLD_STRIDED = True
+            L.load().rv_set_option(b"tapconv4_min_blocks", ctypes.c_int32(old))
+
+    y_f, dx_f, dw_f, ran_f = run(True)
+    y_u, dx_u, dw_u, ran_u = run(False)
+    # the folded run used the DMA kernels where the unfolded one used the generic strided ones
+    assert any(n.startswith("wgrad3") for n in ran_f) and not any(n.startswith("wgrad3") for n in ran_u), (ran_f, ran_u)
+    for got_y, got_dx, got_dw in ((y_f, dx_f, dw_f), (y_u, dx_u, dw_u)):
+        assert rel_err(got_y, bf16r(y.detach())) < 8e-3
+        assert rel_err(got_dx, bf16r(x.grad)) < 8e-3
+        assert rel_err(got_dw, w.grad) < 2e-5
+    assert rel_err(dw_f, dw_u) < 2e-5 and rel_err(y_f, y_u) < 8e-3 and rel_err(dx_f, dx_u) < 8e-3
