@@ -92,17 +92,22 @@ __global__ __launch_bounds__(256) void loss_kernel(const LossArgs a) {
             const float x = a.logits[i * a.ld_logits + c];
             const float t = (label == c) ? aff : 0.f;
             if (!BACKWARD && a.soft) a.soft[(b * a.n_cls + c) * hw + pix] = t;
-            const float p = 1.f / (1.f + expf(-x));
+            // one exponential per class serves the sigmoid and the softplus; p^gamma is a product for the recipe's gamma = 2
+            // (the transcendental functions, not the 34 floats per pixel, are what this kernel's time goes to)
+            const float e = expf(-fabsf(x));
+            const float p = x >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+            const float sp = fmaxf(x, 0.f) + log1pf(e);
+            const float pg = a.gamma == 2.f ? p * p : powf(p, a.gamma);
             if (!BACKWARD) {
-                const float bce = softplus(x) - x * t;  // BCE-with-logits
-                const float l = t > 0.f ? t * bce : a.alpha * powf(p, a.gamma) * bce;
+                const float bce = sp - x * t;  // BCE-with-logits
+                const float l = t > 0.f ? t * bce : a.alpha * pg * bce;
                 cls_sum += l;
             } else {
                 float g;
                 if (t > 0.f)
                     g = t * (p - t);
                 else
-                    g = a.alpha * powf(p, a.gamma) * (a.gamma * (1.f - p) * softplus(x) + p);
+                    g = a.alpha * pg * (a.gamma * (1.f - p) * sp + p);
                 a.d_logits[i * a.ld_logits + c] = (float)((double)(g * a.cls_w * m) / total_fg) * a.grad_scale;
             }
         }
