@@ -68,11 +68,16 @@ __global__ __launch_bounds__(256) void loss_kernel(const LossArgs a) {
         const float* cart = a.cart + b * 3 * hw;
         const float px = cart[pix], py = cart[hw + pix], pz = cart[2 * hw + pix];
         float r[8], tg[8];
+        {  // (rows are 128-byte aligned: stored channel counts are multiples of 32 -- two 16-byte loads instead of eight 4-byte ones)
+            const f32x4 r0 = *(const f32x4*)(a.reg + i * a.ld_reg), r1 = *(const f32x4*)(a.reg + i * a.ld_reg + 4);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            r[j] = a.reg[i * a.ld_reg + j];
-            tg[j] = a.reg_targets[(b * 8 + j) * hw + pix];
+            for (int j = 0; j < 4; ++j) {
+                r[j] = r0[j];
+                r[4 + j] = r1[j];
+            }
         }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tg[j] = a.reg_targets[(b * 8 + j) * hw + pix];
         const int64_t label = a.labels[i];
         const bool inst = a.panoptics[i] > 0;
         float aff = 0.f;
@@ -88,7 +93,42 @@ __global__ __launch_bounds__(256) void loss_kernel(const LossArgs a) {
         if (!BACKWARD && a.fg) a.fg[i] = fg ? 1.f : 0.f;
         // ---- classification: varifocal loss over the classes ----
         float cls_sum = 0.f;
-        for (int c = 0; c < a.n_cls; ++c) {
+        // A thread reads its pixel's logits: with 4-byte loads that is n_cls instructions of 64 lanes x 4 bytes, every lane on a
+        // line of its own (128-byte rows), and the same again for the gradient stores -- the rows thrash the 32 KB L1 and the
+        // kernel spent its time re-fetching lines.  Rows of 32 floats (the rv-* recipes: 26 / 3 classes) go through eight
+        // 16-byte loads / stores and a fully unrolled class loop instead.
+        const bool row32 = a.ld_logits == 32;
+        f32x4 lv[8], gv[8];
+        if (row32) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                lv[q] = *(const f32x4*)(a.logits + i * 32 + q * 4);
+                gv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            if (c >= (row32 ? a.n_cls : 0)) break;
+            const float x = lv[c >> 2][c & 3];
+            const float t = (label == c) ? aff : 0.f;
+            if (!BACKWARD && a.soft) a.soft[(b * a.n_cls + c) * hw + pix] = t;
+            const float e = expf(-fabsf(x));
+            const float p = x >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+            const float sp = fmaxf(x, 0.f) + log1pf(e);
+            const float pg = a.gamma == 2.f ? p * p : powf(p, a.gamma);
+            if (!BACKWARD) {
+                const float bce = sp - x * t;
+                cls_sum += t > 0.f ? t * bce : a.alpha * pg * bce;
+            } else {
+                const float g = t > 0.f ? t * (p - t) : a.alpha * pg * (a.gamma * (1.f - p) * sp + p);
+                gv[c >> 2][c & 3] = (float)((double)(g * a.cls_w * m) / total_fg) * a.grad_scale;
+            }
+        }
+        if (BACKWARD && row32) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) *(f32x4*)(a.d_logits + i * 32 + q * 4) = gv[q];
+        }
+        for (int c = row32 ? a.n_cls : 0; c < a.n_cls; ++c) {  // (other row lengths: the scalar loop)
             const float x = a.logits[i * a.ld_logits + c];
             const float t = (label == c) ? aff : 0.f;
             if (!BACKWARD && a.soft) a.soft[(b * a.n_cls + c) * hw + pix] = t;
@@ -124,20 +164,31 @@ __global__ __launch_bounds__(256) void loss_kernel(const LossArgs a) {
             for (int j = 0; j < 8; ++j)
                 if (reg_on) acc[4 + j] += (double)(fabsf(r[j] - tg[j]) * a.reg_w) * norm * (double)m * (double)a.coding[j] / 8.0;
         } else {
+            float dr[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float d = r[j] - tg[j];
                 const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
                 const double g = reg_on ? (double)(sgn * a.reg_w) * norm * (double)m * (double)a.coding[j] / 8.0 / total_obj : 0.0;
-                a.d_reg[i * a.ld_reg + j] = (float)g * a.grad_scale;
+                dr[j] = (float)g * a.grad_scale;
             }
+            *(f32x4*)(a.d_reg + i * a.ld_reg) = f32x4{dr[0], dr[1], dr[2], dr[3]};
+            *(f32x4*)(a.d_reg + i * a.ld_reg + 4) = f32x4{dr[4], dr[5], dr[6], dr[7]};
         }
     }
     if (!BACKWARD) {
+        // waves -> workgroup through LDS, then ONE fp64 atomic per workgroup and quantity (one per WAVE was 98 k atomics on
+        // twelve addresses: the forward pass spent most of its time queueing at them)
+        __shared__ double red[4][12];
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
             const double s = wave_sum_d(acc[j]);
-            if ((threadIdx.x & 63) == 0 && s != 0.0) atomicAdd(&a.sums[j], s);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][j] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < 12) {
+            const double s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+            if (s != 0.0) atomicAdd(&a.sums[threadIdx.x], s);
         }
     }
 }
@@ -155,7 +206,7 @@ int fill(LossArgs* a, const float* logits, int32_t ld_logits, const float* reg, 
          int32_t az_inv, double* sums) {
     RV_REQUIRE(logits && reg && cart && mask && labels && panoptics && reg_targets && ppo && num_objects && sums && host_coding_weights,
                "rv_detection_loss: null argument");
-    RV_REQUIRE(ld_logits >= n_cls && ld_reg >= 8, "rv_detection_loss: bad strides");
+    RV_REQUIRE(ld_logits >= n_cls && ld_reg >= 8 && ld_reg % 4 == 0, "rv_detection_loss: bad strides (rows of regressands must be 16-byte aligned)");
     memset(a, 0, sizeof(*a));
     a->logits = logits;
     a->reg = reg;
@@ -209,7 +260,8 @@ extern "C" int rv_detection_loss_forward(const float* logits, int32_t ld_logits,
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(sums, 0, 16 * sizeof(double), st);
     if (e != hipSuccess) RV_FAIL("rv_detection_loss_forward: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(loss_kernel<false>, dim3(grid_for((int64_t)B * H * W)), dim3(256), 0, st, a);
+    const int fwd_grid = grid_for((int64_t)B * H * W) < 512 ? grid_for((int64_t)B * H * W) : 512;  // (grid-stride: fewer, longer workgroups -> fewer atomics)
+    hipLaunchKernelGGL(loss_kernel<false>, dim3(fwd_grid), dim3(256), 0, st, a);
     hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1), 0, st, sums, num_objects, smoothing);
     RV_CHECK_LAUNCH("loss forward kernels");
     return 0;
