@@ -83,13 +83,52 @@ __device__ __forceinline__ void pack_one(const PackArgs& a, int64_t first, int64
     }
 }
 
-__global__ void pack_weight_kernel(const PackArgs2 both) {
-    pack_one(both.f[blockIdx.y], blockIdx.x * (int64_t)blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
+// Scatter images are [tap][cv_pad][cu_pad] (u fastest) while the torch layout has v next to the taps: one thread per pair with
+// u fastest reads a 36-byte run from a line of its own (64 lines per wave-instruction, 32x read amplification on a 3x3 layer).
+// Instead a 256-thread workgroup moves 32 (u) x 32 (v) tiles through LDS: read with v fastest (a wave covers 32 x taps
+// contiguous floats per u), written with u fastest.
+constexpr int kPackTile = 32;
+__device__ __forceinline__ void pack_scatter_tiles(const PackArgs& a, float (*tile)[kPackTile][kPackTile + 1], int first_tile, int tile_stride) {
+    const int taps = a.kh * a.kw;
+    const int tu = a.cu_pad / kPackTile, tv = a.cv_pad / kPackTile;  // (padded channel counts are multiples of 32)
+    const int64_t pairs = (int64_t)a.cu_pad * a.cv_pad;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;  // 32 x 8
+    for (int tl = first_tile; tl < tu * tv; tl += tile_stride) {
+        const int u0 = (tl / tv) * kPackTile, v0 = (tl % tv) * kPackTile;
+        for (int t0 = 0; t0 < taps; t0 += 8) {  // (LDS holds eight tap planes at a time)
+            const int nt = taps - t0 < 8 ? taps - t0 : 8;
+            __syncthreads();
+            for (int uu = ly; uu < kPackTile; uu += 8) {
+                const int u = u0 + uu, v = v0 + lx;
+                const bool in = u < a.cu && v < a.cv;
+                const float* src = a.T + ((int64_t)u * a.cv + v) * taps;
+                for (int t = 0; t < nt; ++t) {
+                    // tap image t0 + t in phase-major order -> its (ky, kx)
+                    int r = 0, idx = t0 + t;
+                    while (r < a.phases - 1 && idx >= a.tt.ntaps[r]) idx -= a.tt.ntaps[r++];
+                    tile[t][uu][lx] = in ? src[a.tt.ky[r][idx] * a.kw + a.tt.kx[r][idx]] : 0.f;
+                }
+            }
+            __syncthreads();
+            for (int vv = ly; vv < kPackTile; vv += 8)
+                for (int t = 0; t < nt; ++t) a.out[(int64_t)(t0 + t) * pairs + (int64_t)(v0 + vv) * a.cu_pad + u0 + lx] = f2bf(tile[t][lx][vv]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_weight_kernel(const PackArgs2 both) {
+    __shared__ float tile[8][kPackTile][kPackTile + 1];
+    const PackArgs& a = both.f[blockIdx.y];
+    if (a.scatter && !a.fold_s) pack_scatter_tiles(a, tile, blockIdx.x, gridDim.x);
+    else pack_one(a, blockIdx.x * (int64_t)blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
 }
 
 // every layer of a model in ONE launch (after an optimiser step all packed images are stale): blockIdx.y = table entry
-__global__ void pack_weight_batch_kernel(const PackArgs* items) {
-    pack_one(items[blockIdx.y], blockIdx.x * (int64_t)blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
+__global__ __launch_bounds__(256) void pack_weight_batch_kernel(const PackArgs* items) {
+    __shared__ float tile[8][kPackTile][kPackTile + 1];
+    const PackArgs& a = items[blockIdx.y];
+    if (a.scatter && !a.fold_s) pack_scatter_tiles(a, tile, blockIdx.x, gridDim.x);
+    else pack_one(a, blockIdx.x * (int64_t)blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
 }
 
 __global__ void unpack_wgrad_kernel(const float* packed, float* dT, int cu, int cv, int cu_pad, int cv_pad, int kh,
