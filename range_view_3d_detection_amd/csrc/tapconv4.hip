@@ -22,6 +22,8 @@
 //
 // Eligible layers: stride-1 phases (1x1 included: 1.8-2.1x tapconv2 on the 256-channel pointwise convs), C_src % 64 == 0, C_dst % 256 == 0, plain bf16 input (no folded
 // BatchNorm on the way in -- the DMA bypasses the registers), bf16 output (+ stats / bias / accumulate).
+#include <stdlib.h>
+
 #include "common.h"
 #include "tapconv.h"
 
@@ -372,7 +374,7 @@ extern int g_tapconv5_persist;
 // Smallest grid (workgroups) the DMA kernel is chosen for: below one round of 256 CUs the register-staged kernels with
 // their smaller tiles fill the chip better.  A speed heuristic only -- rv_set_option("tapconv4_min_blocks", 1) lets the
 // parity tests run the production kernels on crops the CPU oracle can afford.
-int g_tapconv4_min_blocks = 256;
+int g_tapconv4_min_blocks = getenv("RV3D_TC4_MIN_BLOCKS") ? atoi(getenv("RV3D_TC4_MIN_BLOCKS")) : 256;  // rv_set_option("tapconv4_min_blocks") / RV3D_TC4_MIN_BLOCKS
 
 // returns false when the layer is not eligible (caller falls back to tapconv3 / tapconv2 / the generic kernel)
 bool rv_tapconv4_plan(TapConvArgs* a, int* tiles, size_t* lds, int* bn) {
