@@ -556,8 +556,132 @@ def gen_raw_sweep() -> None:
     save("raw_sweep", **out)
 
 
+def _install_wnms_stand_in():
+    """``weighted_nms_ext.wnms_gpu`` (TorchEx, absent) bound to a CPU callable with the extension's own signature
+    (``math/ops/nms.py:161-170``): fills ``output`` / ``keep`` / ``count`` IN PLACE and returns ``num_out``, running the
+    DECLARED kernel semantics (``oracle/c/oracle.c::rvo_weighted_nms``, ``oracle/nms.py`` header).  Everything AROUND
+    that call -- the class loop over ``unique()``, both ``topk`` cuts, the ``[6,1,1,1]`` split, ``atan2``, float categories
+    and batch index, the ``min_confidence`` filter, the empty-result shapes -- is then the REFERENCE's own Python."""
+    import ctypes
+
+    import weighted_nms_ext  # the stub module registered by _ref_stubs.install()
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import nms as onms
+
+    lib = onms.lib()
+
+    def wnms_gpu(boxes, data2merge_score, output, keep, count, nms_thresh, merge_thresh, device_index):
+        assert boxes.dtype == torch.float32 and boxes.is_contiguous() and data2merge_score.is_contiguous()
+        assert output.is_contiguous() and keep.dtype == torch.long and count.dtype == torch.long
+        n, d = data2merge_score.shape
+        fp, ip = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int64)
+        cast = lambda t, ty: ctypes.cast(t.data_ptr(), ty)  # noqa: E731
+        return int(lib.rvo_weighted_nms(cast(boxes, fp), cast(data2merge_score, fp), ctypes.c_int64(n), ctypes.c_int(d),
+                                        ctypes.c_float(nms_thresh), ctypes.c_float(merge_thresh), cast(output, fp), cast(keep, ip),
+                                        cast(count, ip)))
+
+    weighted_nms_ext.wnms_gpu = wnms_gpu
+    # nms.py:171 moves ``keep`` with ``.cuda(boxes.device)``: on this CPU run that is the identity
+    torch.Tensor.cuda = lambda self, *a, **k: self
+
+
+def gen_nms_wrapper() -> None:
+    """The reference's OWN weighted-NMS wrapper logic (``math/ops/nms.py:64-123, 126-177, 181-266``,
+    ``nn/decoders/range_decoder.py:100-124``) run over the stand-in above.  The inner kernel's arithmetic stays
+    declared (parity unpinned, TorchEx source absent); what these fixtures pin is every line of the reference that
+    surrounds it."""
+    from torchbox3d.math.ops import nms as ref_nms
+
+    _install_wnms_stand_in()
+    g = torch.Generator().manual_seed(41)
+    out: dict = {}
+
+    def candidates(B, K, n_cls, absent, heavy, cluster_frac=0.6):
+        """(B,K,7) boxes in clusters around a few hundred centres (so that merging and suppression both happen), scores,
+        int64 categories.  ``absent``: a class id that never occurs; ``heavy``: a class that gets half of the candidates."""
+        centres = (torch.rand(B, 160, 2, generator=g) - 0.5) * 120.0
+        which = torch.randint(0, 160, (B, K), generator=g)
+        ctr = torch.gather(centres, 1, which[..., None].expand(B, K, 2))
+        scattered = torch.rand(B, K, generator=g) > cluster_frac
+        ctr = torch.where(scattered[..., None], (torch.rand(B, K, 2, generator=g) - 0.5) * 150.0, ctr + 0.35 * torch.randn(B, K, 2, generator=g))
+        z = torch.randn(B, K, 1, generator=g)
+        lwh = torch.tensor([4.5, 2.0, 1.7]) * (1.0 + 0.15 * torch.randn(B, K, 3, generator=g)).clamp(0.5, 1.6)
+        yaw = (torch.rand(B, K, 1, generator=g) * 2 - 1) * math.pi
+        yaw_c = torch.gather((torch.rand(B, 160, generator=g) * 2 - 1) * math.pi, 1, which)[..., None] + 0.05 * torch.randn(B, K, 1, generator=g)
+        yaw = torch.where(scattered[..., None], yaw, yaw_c)
+        cub = torch.cat([ctr, z, lwh, yaw], dim=-1).float()
+        sc = torch.rand(B, K, generator=g).pow(2.0).float()
+        cat = torch.randint(0, n_cls, (B, K), generator=g)
+        cat = torch.where(torch.rand(B, K, generator=g) < 0.5, torch.full_like(cat, heavy), cat)
+        cat = torch.where(cat == absent, torch.full_like(cat, (absent + 1) % n_cls), cat)
+        return cub, sc, cat
+
+    # ---- (a) 3 sweeps x 2000 candidates x 5 classes ----
+    B, K, NCLS = 3, 2000, 5
+    cub, sc, cat = candidates(B, K, NCLS, absent=3, heavy=1)
+    sc[1] = sc[1] * 0.0999  # sweep 1: nothing reaches min_confidence = 0.1 (nms.py:218-220 skips it)
+    # sweep 2: exact score ties inside a class, between overlapping boxes (members of one cluster) and between far-apart boxes
+    tie = torch.arange(0, 400, 4)
+    sc[2, tie] = sc[2, tie + 1]
+    sc[2, 800:840] = 0.5
+    out["a/cuboids"], out["a/scores"], out["a/categories"] = cub, sc, cat
+    for tag, pre, post in (("post1000", 50000, 1000), ("post40", 50000, 40), ("pre150", 150, 1000)):
+        p, s, c, b = ref_nms.batched_multiclass_nms(cub.clone(), sc.clone(), cat.clone(), num_pre_nms=pre, num_post_nms=post,
+                                                    iou_threshold=0.3, min_confidence=0.1, nms_mode="weighted")
+        out[f"a/{tag}/params"], out[f"a/{tag}/scores"], out[f"a/{tag}/categories"], out[f"a/{tag}/batch_index"] = p, s, c, b
+        out[f"a/{tag}/cfg"] = np.array([pre, post, 0.3, 0.1])
+        print("a", tag, tuple(p.shape), s.dtype, c.dtype, b.dtype, "rows per sweep", [int((b == i).sum()) for i in range(B)],
+              "rows per class", [int((c == j).sum()) for j in range(NCLS)])
+    # one sweep, one call of weighted_multiclass_nms (nms.py:64-123) and of weighted_nms (nms.py:126-177) themselves
+    m = sc[0] >= 0.1
+    p, s, c = ref_nms.weighted_multiclass_nms(cub[0, m], sc[0, m], cat[0, m], iou_threshold=0.3, num_pre_nms=50000, num_post_nms=40)
+    out["a/multiclass/params"], out["a/multiclass/scores"], out["a/multiclass/categories"] = p, s, c
+    sel = m & (cat[0] == 1)
+    b1 = cub[0, sel]
+    rect = torch.cat([b1[:, :2] - b1[:, 3:5] / 2, b1[:, :2] + b1[:, 3:5] / 2, b1[:, 6:7]], dim=-1)
+    data = torch.cat([b1[:, :6], b1[:, 6:7].sin(), b1[:, 6:7].cos()], dim=1)
+    keep, merged, count = ref_nms.weighted_nms(rect, data, sc[0, sel], nms_threshold=0.3, merge_thresh=0.5)
+    out["a/wnms/boxes"], out["a/wnms/data"], out["a/wnms/scores"] = rect, data, sc[0, sel]
+    out["a/wnms/keep"], out["a/wnms/output"], out["a/wnms/count"] = keep, merged, count
+    # all sweeps empty: the (0,7) / (0,1) results of nms.py:248-251
+    p, s, c, b = ref_nms.batched_multiclass_nms(cub[1:2].clone(), sc[1:2].clone(), cat[1:2].clone(), num_pre_nms=50000, num_post_nms=1000,
+                                                iou_threshold=0.3, min_confidence=0.1, nms_mode="WEIGHTED")
+    out["a/empty/params_shape"], out["a/empty/scores_shape"] = np.array(p.shape), np.array(s.shape)
+    out["a/empty/categories_shape"], out["a/empty/batch_index_shape"] = np.array(c.shape), np.array(b.shape)
+    out["a/empty/categories_is_int64"] = np.array(c.dtype == torch.int64)
+
+    # ---- (b) RangeDecoder.decode(use_nms=True) on the tiny model's eval outputs (tests/golden/tiny_model.npz) ----
+    tm = np.load(os.path.join(HERE, "tiny_model.npz"))
+    NC = tm["eval/logits"].shape[1]
+    tasks = DictConfig({0: ListConfig([f"C{i}" for i in range(NC)])})
+    dec = RangeDecoder(True, True, ListConfig([0, 15, 30]), ListConfig([15, 30, math.inf]), ListConfig([8, 2, 1]))
+    post = DictConfig(num_pre_nms=50000, num_post_nms=1000, nms_threshold=0.3, min_confidence=0.1, nms_mode="WEIGHTED")
+    mo = {1: {"cart": torch.as_tensor(tm["cart"]), "mask": torch.as_tensor(tm["mask"]),
+              0: {"logits": torch.as_tensor(tm["eval/logits"]), "regressands": torch.as_tensor(tm["eval/regressands"])}}}
+    p, s, c, b = dec.decode(mo, post, tasks, use_nms=True)
+    out["b/tiny/params"], out["b/tiny/scores"], out["b/tiny/categories"], out["b/tiny/batch_index"] = p, s, c, b
+    print("b tiny", tuple(p.shape), "from", int((torch.as_tensor(tm["eval/dec_scores"]) >= 0.1).sum()), "candidates")
+    # and on the decode fixture's dense logits (7 classes, exact class ties, 20 % dropped pixels), dense + sampled decoders
+    dg = np.load(os.path.join(HERE, "decode.npz"))
+    mo = {1: {"cart": torch.as_tensor(dg["cart"]), "mask": torch.as_tensor(dg["mask"]),
+              0: {"logits": torch.as_tensor(dg["logits"]), "regressands": torch.as_tensor(dg["regressands"])}}}
+    tasks7 = DictConfig({0: ListConfig(["c"] * dg["logits"].shape[1])})
+    for tag, sample, postn in (("sampled", True, 1000), ("dense", False, 25)):
+        d = RangeDecoder(True, sample, ListConfig([0, 15, 30]), ListConfig([15, 30, math.inf]), ListConfig([8, 2, 1]))
+        cfg = DictConfig(num_pre_nms=50000, num_post_nms=postn, nms_threshold=0.3, min_confidence=0.1, nms_mode="WEIGHTED")
+        p, s, c, b = d.decode(mo, cfg, tasks7, use_nms=True)
+        out[f"b/{tag}/params"], out[f"b/{tag}/scores"], out[f"b/{tag}/categories"], out[f"b/{tag}/batch_index"] = p, s, c, b
+        out[f"b/{tag}/num_post_nms"] = np.array(postn)
+        print("b", tag, tuple(p.shape), "rows per class", [int((c == j).sum()) for j in range(7)])
+    save("nms_wrapper", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "nms_wrapper":  # needs tiny_model.npz and decode.npz (reads their arrays)
+        gen_nms_wrapper()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "raw_sweep":
         gen_raw_sweep()
         sys.exit(0)

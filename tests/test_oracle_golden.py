@@ -332,3 +332,46 @@ def test_raw_sweep_path_matches_the_reference(golden):
     got = img.astype(np.float64)
     got[3], got[4], got[5] = got[3].astype(np.uint8), got[4].astype(np.uint8), got[5] != 0
     assert np.array_equal(got, want), int((got != want).sum())
+
+
+# ----------------------------------------------------------------------------- N1 (wrapper logic pinned; N2 stays declared)
+def test_nms_wrapper_matches_the_reference_wrapper(golden):
+    """``oracle.nms`` / ``oracle.decode.range_decode(use_nms=True)`` against what the REFERENCE's own
+    ``batched_multiclass_nms`` / ``weighted_multiclass_nms`` / ``weighted_nms`` / ``RangeDecoder.decode(use_nms=True)`` returned
+    (``math/ops/nms.py:64-123,126-177,181-266``, ``range_decoder.py:100-124``) when run in the build container over a
+    ``wnms_gpu`` stand-in with the declared kernel semantics (``tests/golden/make_golden.py::gen_nms_wrapper``).  Pins the
+    wrapper logic: class order, both top-k cuts, merged-score ranking, float categories / batch index, empty shapes.  The
+    kernel arithmetic (N2) remains declared -- the same C function sits under both sides here."""
+    from oracle import nms as onms
+
+    g = golden("nms_wrapper")
+    cub, sc, cat = g["a/cuboids"], g["a/scores"], g["a/categories"]
+    for tag in ("post1000", "post40", "pre150"):
+        pre, post, thr, conf = g.np(f"a/{tag}/cfg").tolist()
+        p, s, c, b = onms.batched_multiclass_nms(cub, sc, cat, int(pre), int(post), thr, conf)
+        assert torch.equal(c, g[f"a/{tag}/categories"]) and torch.equal(b, g[f"a/{tag}/batch_index"]), tag
+        assert c.dtype == torch.float32 and b.dtype == torch.float32
+        assert torch.equal(p, g[f"a/{tag}/params"]) and torch.equal(s, g[f"a/{tag}/scores"]), tag
+    m = sc[0] >= 0.1
+    p, s, c = onms.weighted_multiclass_nms(cub[0, m], sc[0, m], cat[0, m], 0.3, 50000, 40)
+    assert torch.equal(p, g["a/multiclass/params"]) and torch.equal(s, g["a/multiclass/scores"]) and torch.equal(c, g["a/multiclass/categories"])
+    keep, merged, count = onms.weighted_nms(g["a/wnms/boxes"], g["a/wnms/data"], g["a/wnms/scores"], 0.3, 0.5)
+    assert torch.equal(keep, g["a/wnms/keep"]) and torch.equal(merged, g["a/wnms/output"]) and torch.equal(count, g["a/wnms/count"])
+    p, s, c, b = onms.batched_multiclass_nms(cub[1:2], sc[1:2], cat[1:2], 50000, 1000, 0.3, 0.1)
+    assert list(p.shape) == g.np("a/empty/params_shape").tolist() and list(s.shape) == g.np("a/empty/scores_shape").tolist()
+    assert list(c.shape) == g.np("a/empty/categories_shape").tolist() and list(b.shape) == g.np("a/empty/batch_index_shape").tolist()
+    assert (c.dtype == torch.int64) == bool(g.np("a/empty/categories_is_int64"))
+    # RangeDecoder.decode(use_nms=True)
+    t = golden("tiny_model")
+    post = {"num_pre_nms": 50000, "num_post_nms": 1000, "nms_threshold": 0.3, "min_confidence": 0.1}
+    p, s, c, b = odec.range_decode(t["eval/logits"], t["eval/regressands"], t["cart"], t["mask"], post, use_nms=True)
+    assert torch.equal(c, g["b/tiny/categories"]) and torch.equal(b, g["b/tiny/batch_index"])
+    close(p, g["b/tiny/params"], 1e-6, "tiny params")
+    close(s, g["b/tiny/scores"], 1e-7, "tiny scores")
+    d = golden("decode")
+    for tag, sample in (("sampled", True), ("dense", False)):
+        post["num_post_nms"] = int(g.np(f"b/{tag}/num_post_nms"))
+        p, s, c, b = odec.range_decode(d["logits"], d["regressands"], d["cart"], d["mask"], post, use_nms=True, enable_sample_by_range=sample)
+        assert torch.equal(c, g[f"b/{tag}/categories"]) and torch.equal(b, g[f"b/{tag}/batch_index"]), tag
+        close(p, g[f"b/{tag}/params"], 1e-6, f"{tag} params")
+        close(s, g[f"b/{tag}/scores"], 1e-7, f"{tag} scores")
