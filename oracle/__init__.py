@@ -15,7 +15,9 @@ Pinning status:
   run in the build container and committed as ``tests/golden/*.npz`` (generator:
   ``tests/golden/make_golden.py``); ``tests/test_oracle_golden.py`` checks the oracle
   against those fixtures.
-* ``oracle.nms.weighted_nms`` -- **parity unpinned**: the arithmetic lives in the
+* ``oracle.nms`` wrapper logic (class loop, top-k cuts, merged-score ranking, float categories / batch index) is pinned by
+  ``tests/golden/nms_wrapper.npz`` (the reference's own wrapper functions run over a stand-in for the absent extension).
+* ``oracle.nms.weighted_nms``'s inner kernel -- **parity unpinned**: the arithmetic lives in the
   un-vendored, un-pinned third-party CUDA extension ``weighted_nms_ext`` (TorchEx),
   whose source and binary are absent.  The oracle states its own semantics (see
   ``oracle/nms.py``) and is checked against the reference's in-tree post-conditions

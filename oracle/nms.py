@@ -6,6 +6,12 @@ Wrapper logic follows the reference exactly (relative to ``/root/reference/src/t
 * ``math/ops/nms.py:64-123``   weighted_multiclass_nms  -> :func:`weighted_multiclass_nms`
 * ``math/ops/nms.py:126-177``  weighted_nms (wrapper around ``weighted_nms_ext.wnms_gpu``)
 
+**Wrapper logic PINNED** (round 3): ``tests/golden/nms_wrapper.npz`` holds what the reference's own
+``batched_multiclass_nms`` / ``weighted_multiclass_nms`` / ``weighted_nms`` / ``RangeDecoder.decode(use_nms=True)``
+returned in the build container over a ``wnms_gpu`` stand-in running ``rvo_weighted_nms``
+(``tests/golden/make_golden.py::gen_nms_wrapper``); ``tests/test_oracle_golden.py::test_nms_wrapper_matches_the_reference_wrapper``
+requires this file's functions to equal those arrays bit for bit.
+
 **PARITY UNPINNED for the inner kernel.**  ``weighted_nms_ext`` is TorchEx
 (github.com/Abyssaledge/TorchEx, installed ad hoc per ``README.md:22``, no version or
 commit pin, source and binary absent from ``/root/reference``), and the reference holds

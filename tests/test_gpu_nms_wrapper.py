@@ -35,9 +35,25 @@ def _both_paths(fn):
     return {"rv_nms_sweeps": fast, "per-class loop": loop}
 
 
+def _canonical(p, s, c, b):
+    """Rows with EXACTLY equal (sweep, class, merged score) come out of ``scores.topk`` (``nms.py:116``) in an order torch does
+    not define (its CPU and device kernels differ); the device path breaks such ties by candidate index.  Everything the
+    reference defines -- sweep order, class order, descending score -- is compared in place; inside a tie group the rows
+    are compared as a set (ordered by their box centre here)."""
+    import numpy as np
+
+    p, s, c, b = (t.detach().cpu() for t in (p, s, c, b))
+    if s.dim() != 1 or s.numel() == 0:
+        return p, s, c, b
+    same = (s[1:] == s[:-1]) & (c[1:] == c[:-1]) & (b[1:] == b[:-1])
+    group = torch.cat([torch.zeros(1, dtype=torch.long), (~same).long().cumsum(0)])
+    order = torch.from_numpy(np.lexsort((p[:, 1].numpy(), p[:, 0].numpy(), group.numpy())))
+    return p[order], s, c, b
+
+
 def _same_rows(got, ref, what):
-    p, s, c, b = got
-    rp, rs, rc, rb = ref
+    p, s, c, b = _canonical(*got)
+    rp, rs, rc, rb = _canonical(*ref)
     assert p.shape == rp.shape and s.shape == rs.shape, (what, tuple(p.shape), tuple(rp.shape))
     assert c.dtype == rc.dtype and b.dtype == rb.dtype, (what, c.dtype, b.dtype)
     assert torch.equal(c.cpu(), rc), f"{what}: categories / row order differ"
