@@ -304,16 +304,20 @@ def _names_of(columns):
     return out
 
 
+_NPDT = {"Float32": np.float32, "Float64": np.float64, "UInt8": np.uint8, "UInt32": np.uint32, "Boolean": np.bool_, "Int64": np.int64,
+         "Int32": np.int32}
+
+
 class _PlFrame:
     """Columnar frame: name -> 1-D numpy array (dtype kept per column, as polars does).  Eager and "lazy" are the same object."""
 
-    def __init__(self, data: Dict[str, Sequence[Any]], schema=None, **_: Any) -> None:
-        npdt = {"Float32": np.float32, "Float64": np.float64, "UInt8": np.uint8, "Boolean": np.bool_, "Int64": np.int64, "Int32": np.int32}
+    def __init__(self, data: Dict[str, Sequence[Any]], schema=None, schema_overrides=None, **_: Any) -> None:
+        schema = schema if schema is not None else schema_overrides  # (overrides: only the columns present are cast)
         self._data = {}
         for k, v in data.items():
             v = v.values if isinstance(v, _PlSeries) else np.asarray(v)
-            if schema is not None and k in schema:
-                v = v.astype(npdt.get(schema[k], schema[k]))
+            if schema is not None and k in schema and schema[k] != "Utf8":
+                v = v.astype(_NPDT.get(schema[k], schema[k]))
             self._data[k] = v
 
     def select(self, *columns) -> "_PlFrame":
@@ -352,6 +356,35 @@ class _PlFrame:
 
     def with_row_count(self, name: str = "row_nr") -> "_PlFrame":
         return _PlFrame({name: np.arange(self.shape[0], dtype=np.uint32), **self._data})
+
+    def cast(self, dtypes: Dict[str, Any]) -> "_PlFrame":
+        return _PlFrame({k: (v.astype(_NPDT.get(dtypes[k], dtypes[k])) if k in dtypes else v) for k, v in self._data.items()})
+
+    def drop(self, columns) -> "_PlFrame":
+        gone = set(_names_of(columns))
+        return _PlFrame({k: v for k, v in self._data.items() if k not in gone})
+
+    def join(self, other: "_PlFrame", on: str, how: str = "inner") -> "_PlFrame":
+        """Inner join on one key: rows in LEFT order (each left row once per matching right row, right rows in their order);
+        columns = the left frame's, then the right frame's non-key columns -- polars' inner-join output."""
+        assert how == "inner"
+        lk, rk = self._data[on], other._data[on]
+        li, ri = [], []
+        for i, key in enumerate(lk.tolist()):
+            for j in np.nonzero(rk == key)[0].tolist():
+                li.append(i)
+                ri.append(j)
+        li, ri = np.asarray(li, dtype=np.int64), np.asarray(ri, dtype=np.int64)
+        out = {k: v[li] for k, v in self._data.items()}
+        for k, v in other._data.items():
+            if k != on:
+                out[k if k not in out else k + "_right"] = v[ri]
+        return _PlFrame(out)
+
+    def sort(self, by) -> "_PlFrame":
+        keys = [self._data[k] for k in reversed(_names_of(by))]
+        order = np.lexsort(keys) if self.shape[0] else np.zeros(0, dtype=np.int64)  # lexsort is stable, last key primary
+        return _PlFrame({k: v[order] for k, v in self._data.items()})
 
     def row(self, index: int):
         return tuple(v[index].item() if hasattr(v[index], "item") else v[index] for v in self._data.values())

@@ -677,10 +677,134 @@ def gen_nms_wrapper() -> None:
     save("nms_wrapper", **out)
 
 
+def gen_loader_train_item() -> None:
+    """``DataLoader.__getitem__`` with ``split_name == "train"`` (prototype/loader.py:568-705): ROI filter -> augmentations on
+    the UNPADDED table (:598-603, :514-549) -> table -> image -> ``range_view *= mask`` + W padding (``subsample_range_view``,
+    :792-815) -> annotations joined with the task frame and sorted (:699-704).  Run by the reference itself on the synthetic
+    tables of ``gen_loader_item``; the augmentation parameters are recovered by re-seeding ``random`` and drawing in the
+    reference's order.  AV2: the shipped chain (conf/model/baseline.yaml:12-21) + a translation, circular padding; Waymo: a
+    translation BEFORE the scale (the scale then recomputes ``range`` from translated coordinates: pixels without a return
+    get range = |s t| > 0 and count as valid -- the reference's behaviour, kept), constant padding."""
+    import random
+    import tempfile
+    import types
+    from pathlib import Path
+
+    import polars as pl  # stub
+    import pyarrow as pa
+    import pyarrow.feather as feather
+    from torchbox3d.prototype import loader as ref_loader
+
+    pl.scan_ipc = _ref_stubs._pl_scan_ipc
+    H, W = 8, 64
+    out = {}
+    cats = ["BUS", "REGULAR_VEHICLE", "PEDESTRIAN"]
+    for tag, ds, names, roi, mode, aug, seed in (
+        ("av2", "av2", ["intensity", "range", "x", "y", "z"], True, "circular",
+         {"flip_azimuth": {"p": 1.0}, "random_rotation": {"low": -0.78539816, "high": 0.78539816, "p": 1.0},
+          "random_global_scale": {"low": 0.95, "high": 1.05}, "random_global_translation": {"std_x": 0.5, "std_y": 0.5, "std_z": 0.2}}, 11),
+        ("waymo", "waymo", ["elongation", "intensity", "range", "x", "y", "z"], False, "constant",
+         {"random_rotation": {"low": 2.0, "high": 3.0, "p": 1.0}, "random_global_translation": {"std_x": 0.5, "std_y": 0.5, "std_z": 0.2},
+          "random_global_scale": {"low": 0.95, "high": 1.05}}, 12)):
+        rng = np.random.default_rng(51 if ds == "av2" else 52)
+        inc = np.linspace(0.2, -0.4, H)[:, None]
+        az = np.linspace(math.pi, -math.pi, W)[None, :]
+        r = (20.0 + 15.0 * np.sin(3 * az) + 10.0 * np.cos(7 * inc) + rng.random((H, W))).astype(np.float32)
+        keep = rng.random((H, W)) >= 0.1
+        r = (r * keep).astype(np.float32)
+        cols = {"x": (r * np.cos(inc) * np.cos(az)).astype(np.float32), "y": (r * np.cos(inc) * np.sin(az)).astype(np.float32),
+                "z": (r * np.sin(inc) * np.ones_like(az)).astype(np.float32), "range": r,
+                "intensity": ((rng.random((H, W)) * (255.0 if ds == "av2" else 3.0)) * keep).astype(np.float32),
+                "elongation": (rng.random((H, W)) * keep).astype(np.float32)}
+        if roi:
+            cols["is_within_roi"] = rng.random((H, W)) >= 0.25
+        tmp = Path(tempfile.mkdtemp())
+        lidar = tmp / "sweep.feather"
+        feather.write_feather(pa.table({k: v.reshape(-1) for k, v in cols.items()}), str(lidar), compression="uncompressed")
+        M = 7
+        yaw = rng.uniform(-math.pi, math.pi, M)
+        ann = {"timestamp_ns": np.array([7, 7, 7, 8, 7, 7, 7], dtype=np.int64), "num_interior_pts": np.array([5, 3, 0, 9, 2, 4, 6], dtype=np.int64),
+               "category": np.array(["REGULAR_VEHICLE", "BUS", "BUS", "BUS", "PEDESTRIAN", "BOLLARD", "BUS"]),
+               "tx_m": rng.normal(0, 20, M), "ty_m": rng.normal(0, 20, M), "tz_m": rng.normal(0, 1, M), "length_m": rng.uniform(1, 6, M),
+               "width_m": rng.uniform(1, 3, M), "height_m": rng.uniform(1, 3, M), "qw": np.cos(yaw / 2), "qx": np.zeros(M), "qy": np.zeros(M),
+               "qz": np.sin(yaw / 2)}
+        annp = tmp / "annotations.feather"
+        feather.write_feather(pa.table(ann), str(annp), compression="uncompressed")
+        tcfg = DictConfig({"tasks": DictConfig({0: ListConfig(["REGULAR_VEHICLE", "BUS"]), 1: ListConfig(["PEDESTRIAN"])})})
+        me = types.SimpleNamespace(
+            metadata=pl.DataFrame({"log_id": np.array(["log0"]), "timestamp_ns": np.array([7], dtype=np.int64)}),
+            categories=cats, annotations_path=lambda log_id: annp, lidar_path=lambda log_id, ts: lidar,
+            range_view_config=DictConfig({"feature_column_names": names, "filter_roi": roi, "height": H, "width": W}),
+            split_name="train", augmentations_config=DictConfig({k: DictConfig(v) for k, v in aug.items()}), dataset_name=ds,
+            enable_database=False, db_config=None, x_stride=1, padding_mode=mode, targets_config=tcfg)
+        me.apply_augmentations = types.MethodType(ref_loader.DataLoader.apply_augmentations, me)
+        me.tasks_frame = ref_loader.DataLoader.tasks_frame.func(me)
+        random.seed(seed)
+        datum = ref_loader.DataLoader.__getitem__(me, 0)
+        # the same draws, in the reference's order (flip: random(); rotation: random(), uniform; scale: uniform; translation: 3 x normalvariate)
+        random.seed(seed)
+        for k, v in aug.items():
+            if k == "flip_azimuth":
+                random.random()
+            elif k == "random_rotation":
+                random.random()
+                out[f"{tag}/theta"] = np.float64(random.uniform(v["low"], v["high"]))
+            elif k == "random_global_scale":
+                out[f"{tag}/scale"] = np.float64(random.uniform(v["low"], v["high"]))
+            else:
+                out[f"{tag}/t"] = np.array([random.normalvariate(0, v["std_x"]), random.normalvariate(0, v["std_y"]), random.normalvariate(0, v["std_z"])])
+        for k, v in cols.items():
+            out[f"{tag}/table/{k}"] = v.reshape(-1)
+        for k, v in ann.items():
+            out[f"{tag}/ann_in/{k}"] = v
+        out[f"{tag}/feature_column_names"] = np.array(names)
+        out[f"{tag}/padding_mode"], out[f"{tag}/filter_roi"] = np.array(mode), np.array(roi)
+        out[f"{tag}/augmentation_order"] = np.array(list(aug))
+        out[f"{tag}/seed"] = np.array(seed)
+        out[f"{tag}/features"], out[f"{tag}/cart"], out[f"{tag}/mask"] = datum["features"].numpy(), datum["cart"].numpy(), datum["mask"].numpy()
+        a = datum["annotations"]
+        out[f"{tag}/ann_columns"] = np.array(a.columns)
+        for k in a.columns:
+            out[f"{tag}/ann_out/{k}"] = np.asarray(a[k])
+        print(tag, "features", tuple(datum["features"].shape), "valid", float(datum["mask"].float().mean()), "annotations", a.shape, a.columns)
+    save("loader_train_item", **out)
+
+
+def gen_detections_frame() -> None:
+    """``build_dataframe`` (math/ops/coding.py:31-76) run by the reference itself (over the polars stand-in: dtype casts of
+    ``schema_overrides``, ``with_row_count`` + ``cast``, two inner joins, ``drop``) on the decoder rows of
+    ``nms_wrapper.npz`` (b/tiny: float categories / batch index as ``decode(use_nms=True)`` returns them), a uuid frame that
+    knows only sweep 0 (the rows of sweep 1 fall out of the inner join) and the loader's task frame."""
+    import polars as pl  # stub
+    from torchbox3d.math.ops.coding import build_dataframe
+
+    nw = np.load(os.path.join(HERE, "nms_wrapper.npz"))
+    params, scores = torch.as_tensor(nw["b/tiny/params"]), torch.as_tensor(nw["b/tiny/scores"])
+    cats, bidx = torch.as_tensor(nw["b/tiny/categories"]), torch.as_tensor(nw["b/tiny/batch_index"])
+    names = ["REGULAR_VEHICLE", "PEDESTRIAN", "BUS", "BICYCLE", "TRUCK"]
+    task_frame = pl.DataFrame({"task_id": np.zeros(5, dtype=np.int64), "offset": np.arange(5, dtype=np.int64), "category": np.array(names)})
+    uuids = pl.DataFrame({"batch_index": np.array([0], dtype=np.int32), "log_id": np.array(["log-a"]),
+                          "timestamp_ns": np.array([315969904359876000], dtype=np.uint64)})
+    frame = build_dataframe(params, scores, cats, bidx, uuids, task_frame)
+    out = {"columns": np.array(frame.columns), "dtypes": np.array([str(np.asarray(frame[c]).dtype) for c in frame.columns]),
+           "category_names": np.array(names), "uuids/batch_index": np.array([0], dtype=np.int32), "uuids/log_id": np.array(["log-a"]),
+           "uuids/timestamp_ns": np.array([315969904359876000], dtype=np.int64)}
+    for c in frame.columns:
+        out[f"col/{c}"] = np.asarray(frame[c])
+    print("detections frame", frame.shape, frame.columns)
+    save("detections_frame", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     if len(sys.argv) > 1 and sys.argv[1] == "nms_wrapper":  # needs tiny_model.npz and decode.npz (reads their arrays)
         gen_nms_wrapper()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "loader_train_item":
+        gen_loader_train_item()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "detections_frame":  # needs nms_wrapper.npz
+        gen_detections_frame()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "raw_sweep":
         gen_raw_sweep()
