@@ -47,3 +47,42 @@ def range_view_from_table(table: Mapping[str, np.ndarray], feature_column_names:
     features = features * mask
     return {"features": _pad_w(features, pad, padding_mode)[:, :, ::x_stride], "mask": _pad_w(mask, pad, padding_mode)[:, :, ::x_stride],
             "cart": _pad_w(cart, pad, padding_mode)[:, :, ::x_stride]}
+
+
+def train_item_from_table(table: Mapping[str, np.ndarray], feature_column_names: Sequence[str], height: int, width: int, dataset_name: str,
+                          filter_roi: bool, augmentations: Sequence[tuple], x_stride: int = 1, padding_mode: str = "constant") -> Dict[str, np.ndarray]:
+    """``__getitem__`` with ``split_name == "train"`` (``loader.py:594-697``): the ROI filter, then the augmentations on the
+    UNPADDED table (``:598-603``; every column travels through flips / rolls, ``x y z range`` are rewritten), then the feature /
+    cart / mask images (mask = AUGMENTED ``range`` > 0) and ``subsample_range_view``.  ``augmentations``: the chain with its
+    draws, e.g. ``[("flip",), ("rotate", theta), ("scale", s), ("translate", (tx, ty, tz))]``.  Pinned by
+    ``tests/golden/loader_train_item.npz``."""
+    from . import augment as oaug
+
+    cols = [n for n in table if n != "is_within_roi"]
+    roi = np.asarray(table["is_within_roi"]).astype(np.float32) if filter_roi else np.float32(1.0)
+    sweep = np.stack([np.asarray(table[n], dtype=np.float32) * roi for n in cols]).reshape(len(cols), height, width).astype(np.float64)
+    ann = np.zeros((10, 0))
+    for op in augmentations:
+        if op[0] == "flip":
+            sweep, _ = oaug.flip(sweep, cols, ann)
+        elif op[0] == "rotate":
+            sweep, _ = oaug.rotate(sweep, cols, ann, op[1])
+        elif op[0] == "scale":
+            sweep, _ = oaug.scale(sweep, cols, ann, op[1])
+        elif op[0] == "translate":
+            sweep, _ = oaug.translate(sweep, cols, ann, op[1])
+        else:
+            raise KeyError(op[0])
+    aug = {n: sweep[i].reshape(-1).astype(np.float32) for i, n in enumerate(cols)}
+    return range_view_from_table(aug, feature_column_names, height, width, dataset_name, False, x_stride, padding_mode)
+
+
+def annotations_for_sweep(table: Mapping[str, np.ndarray], timestamp_ns: int, tasks: Mapping[int, Sequence[str]]):
+    """``loader.py:583-589, 553-565, 699-704``: rows with this timestamp, ``num_interior_pts > 0`` and a configured category, joined
+    with the task frame (offset = index in the task's SORTED category list), stably sorted by (task_id, offset).  Returns the
+    kept row indices in output order and their (task_id, offset)."""
+    frame = {c: (int(k), o) for k, cats in tasks.items() for o, c in enumerate(sorted(cats))}
+    cat = [str(c) for c in np.asarray(table["category"]).tolist()]
+    rows = [i for i in range(len(cat)) if int(table["timestamp_ns"][i]) == int(timestamp_ns) and int(table["num_interior_pts"][i]) > 0 and cat[i] in frame]
+    rows.sort(key=lambda i: frame[cat[i]])
+    return rows, [frame[cat[i]] for i in rows]

@@ -29,8 +29,9 @@ def decode_range_view(regressands: Tensor, cart: Tensor, enable_azimuth_invarian
 # Detections wire / on-disk format: ``build_dataframe`` (``coding.py:11-76``) and the per-sweep
 # feather files ``Detector.validation_step`` writes (``nn/arch/detector.py:366-380``).  The reference builds polars
 # frames; polars is not in this image, so the same table is an Arrow table (``pyarrow``), which is what
-# ``DataFrame.write_ipc`` puts on disk anyway (Arrow IPC file format == feather v2).  Parity unpinned against the
-# reference function itself (it needs polars to run); the schema and join rules below restate it line by line.
+# ``DataFrame.write_ipc`` puts on disk anyway (Arrow IPC file format == feather v2).  Pinned by
+# ``tests/golden/detections_frame.npz``: the reference's own ``build_dataframe`` run in the build container over a stand-in for
+# polars (column order, dtypes, rows; ``tests/test_host_cpu.py::test_detections_table_matches_the_reference_build_dataframe``).
 # ---------------------------------------------------------------------------------------------
 DETECTION_COLUMNS = ("tx_m", "ty_m", "tz_m", "length_m", "width_m", "height_m", "qw", "qx", "qy", "qz")
 
@@ -81,7 +82,6 @@ def write_detections(table, dst_dir: str, run_uuid: str):
     import os
 
     import pyarrow as pa
-    import pyarrow.feather as feather
 
     logs, stamps = table.column("log_id").to_pylist(), table.column("timestamp_ns").to_pylist()
     groups = {}
@@ -91,6 +91,8 @@ def write_detections(table, dst_dir: str, run_uuid: str):
     for (log_id, ts), rows in groups.items():
         dst = os.path.join(dst_dir, "predictions", run_uuid, log_id, f"{ts}.feather")
         os.makedirs(os.path.dirname(dst), exist_ok=True)
-        feather.write_feather(table.take(pa.array(rows, type=pa.int64())), dst, compression="uncompressed")
+        part = table.take(pa.array(rows, type=pa.int64()))
+        with pa.OSFile(dst, "wb") as sink, pa.ipc.new_file(sink, part.schema) as w:  # Arrow IPC file == feather v2, uncompressed
+            w.write_table(part)
         paths.append(dst)
     return paths

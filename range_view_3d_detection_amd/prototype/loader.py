@@ -50,10 +50,12 @@ def read_sweep_table(path) -> Dict[str, "np.ndarray"]:
 
 
 def range_view_from_table(table: Mapping[str, Any], range_view_config: Mapping[str, Any], dataset_name: str, x_stride: int = 1,
-                          padding_mode: str = "constant", device="cuda") -> Dict[str, Tensor]:
+                          padding_mode: str = "constant", device="cuda", pad: bool = True) -> Dict[str, Tensor]:
     """``DataLoader.__getitem__`` from the sweep table on (``loader.py:594-690``): ``table`` maps column names to H*W-row
     arrays (numpy or tensors); returns ``features`` (F,H,W'), ``mask`` (1,H,W') bool, ``cart`` (3,H,W') on ``device`` with W'
-    the padded width.  The needed columns cross PCIe once, as ONE (n_cols, H*W) fp32 block; ROI filter, tanh(intensity)
+    the padded width.  ``pad=False`` stops BEFORE ``subsample_range_view`` (``loader.py:684-691``): width = the configured width,
+    ``features`` not yet multiplied by the mask -- the state the reference's augmentations see (``loader.py:598-603``); finish with
+    :func:`pad_batch`.  The needed columns cross PCIe once, as ONE (n_cols, H*W) fp32 block; ROI filter, tanh(intensity)
     (Waymo), the 1e-9 of ``timedelta_ns``, the (F,H,W) layout and the mask are one kernel (``rv_table_to_range_view``).
     The ``view`` feature (``loader.py:611-624``) is not selected by any shipped config and is not implemented."""
     import numpy as np
@@ -89,8 +91,24 @@ def range_view_from_table(table: Mapping[str, Any], range_view_config: Mapping[s
         L.call("rv_table_to_range_view", L.ptr(block), L.i32(len(need)), L.i64(h * w), L.i32(len(names)), feat_col, feat_op, cart_col,
                L.i32(need.index("range")), L.i32(need.index("is_within_roi") if roi else -1), L.ptr(features), L.ptr(cart), L.ptr(mask),
                L.stream_ptr())
+        if not pad:
+            return {"features": features, "mask": mask.bool(), "cart": cart}
         features, m, cart = subsample_range_view(features, mask.bool(), cart, dataset_name, x_stride, padding_mode)
     return {"features": features, "mask": m > 0.5 if m.dtype != torch.bool else m, "cart": cart}
+
+
+def pad_batch(batch: Mapping[str, Any], dataset_name: str, x_stride: int = 1, padding_mode: str = "constant") -> Dict[str, Any]:
+    """``subsample_range_view`` (``loader.py:792-815``) over an UNPADDED batch dict: ``features`` (B,F,H,W) ``*= mask``, then
+    ``features`` / ``mask`` / ``cart`` padded in W.  Other keys pass through."""
+    out = dict(batch)
+    fs, ms, cs = [], [], []
+    for b in range(batch["features"].shape[0]):
+        f, m, c = subsample_range_view(batch["features"][b], batch["mask"][b], batch["cart"][b], dataset_name, x_stride, padding_mode)
+        fs.append(f)
+        ms.append(m > 0.5)
+        cs.append(c)
+    out["features"], out["mask"], out["cart"] = torch.stack(fs), torch.stack(ms), torch.stack(cs)
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -220,19 +238,30 @@ def apply_sweep_transforms(x: Tensor, transforms: Sequence[SweepTransform], xyz_
 
 
 def augment_batch(batch: Dict[str, Any], feature_column_names: Sequence[str], augmentations_config: Mapping[str, Mapping[str, float]],
-                  rng=_random) -> Dict[str, Any]:
+                  rng=_random, width: Optional[int] = None) -> Dict[str, Any]:
     """Batch-dict contract of the reference's loader (``loader.py:568-705, 245-248``): ``features`` (B, F, H, W) fp32 with the
     channels named by ``feature_column_names`` (``conf/model/range_view.yaml:141-146``: x, y, z and range among them),
     ``cart`` (B, 3, H, W) fp32, ``mask`` (B, 1, H, W) bool (= range > 0), ``annotations`` (M, 13) fp64 rows in ``COLS`` order,
-    sorted by sweep (``batch_index`` last).  Returns a new dict with all four augmented consistently, sweep by sweep."""
+    sorted by sweep (``batch_index`` last).  Returns a new dict with all four augmented consistently, sweep by sweep.
+
+    The batch must be UNPADDED (W = ``range_view_config["width"]``: 1800 / 2650, not 1808 / 2656): the reference augments the
+    table before ``subsample_range_view`` pads it (``loader.py:598-603`` then ``:684-691``), and the roll of ``random_rotation``
+    is modulo the configured width.  Pass ``width`` (the configured width) to have that checked; :func:`train_batch_from_tables`
+    is the whole chain.  The mask is recomputed as the reference does (``range > 0`` on the augmented table): it follows the
+    column map, except that a ``random_global_scale`` re-derives ``range`` from the coordinates at that point of the chain."""
     names = list(feature_column_names)
     feats, cart, mask = batch["features"], batch["cart"], batch["mask"]
+    if width is not None and feats.shape[-1] != int(width):
+        raise L.RvError(f"augment_batch on a batch of width {feats.shape[-1]}, configured width {width}: augment BEFORE the W padding "
+                        "(range_view_from_table(..., pad=False) -> augment_batch -> pad_batch)")
     trs = [draw_sweep_transform(feats.shape[-1], augmentations_config, rng) for _ in range(feats.shape[0])]
     xyz = [names.index(n) for n in ("x", "y", "z")] if all(n in names for n in ("x", "y", "z")) else None
     out = dict(batch)
     out["features"] = apply_sweep_transforms(feats, trs, xyz, names.index("range") if "range" in names and xyz is not None else -1)
     out["cart"] = apply_sweep_transforms(cart, trs, (0, 1, 2))
-    out["mask"] = apply_sweep_transforms(mask, trs)
+    # mask' = (augmented range > 0): [x, y, z, valid] through the same kernel with `valid` in the range slot
+    aux = apply_sweep_transforms(torch.cat([cart.float(), mask.float()], dim=1), trs, (0, 1, 2), 3)
+    out["mask"] = aux[:, 3:4] > 0
     ann = batch.get("annotations")
     if ann is not None and ann.shape[0] > 0:
         ann = torch.as_tensor(ann).double()
@@ -240,3 +269,43 @@ def augment_batch(batch: Dict[str, Any], feature_column_names: Sequence[str], au
         out["annotations"] = torch.cat(parts) if parts else ann
     out["transforms"] = trs
     return out
+
+
+def annotations_for_sweep(table: Mapping[str, Any], timestamp_ns: int, tasks: Mapping[int, Sequence[str]], batch_index: int = 0) -> Tensor:
+    """The annotation rows ``__getitem__`` keeps for one sweep (``loader.py:583-589, 699-704``): ``timestamp_ns`` equal,
+    ``num_interior_pts > 0``, category among the configured tasks; joined with the task frame (``task_id``, ``offset`` = index in
+    the SORTED category list of the task, ``loader.py:553-565``) and stably sorted by (task_id, offset).  Returns (M, 13) fp64
+    rows in ``COLS`` order (host work on a handful of rows)."""
+    import numpy as np
+
+    frame = {}
+    for k, cats in tasks.items():
+        for offset, c in enumerate(sorted(cats)):
+            frame[c] = (int(k), offset)
+    ts = np.asarray(table["timestamp_ns"])
+    npts = np.asarray(table["num_interior_pts"])
+    cat = [str(c) for c in np.asarray(table["category"]).tolist()]
+    rows = [i for i in range(len(cat)) if int(ts[i]) == int(timestamp_ns) and int(npts[i]) > 0 and cat[i] in frame]
+    rows.sort(key=lambda i: frame[cat[i]])  # Python's sort is stable, as polars' ``sort``
+    out = torch.zeros((len(rows), 13), dtype=torch.float64)
+    for j, name in enumerate(COLS[:10]):
+        col = np.asarray(table[name], dtype=np.float64)
+        out[:, j] = torch.from_numpy(col[rows]) if rows else out[:, j]
+    for r, i in enumerate(rows):
+        out[r, 10], out[r, 11], out[r, 12] = frame[cat[i]][0], frame[cat[i]][1], batch_index
+    return out
+
+
+def train_batch_from_tables(tables: Sequence[Mapping[str, Any]], annotations: Optional[Tensor], range_view_config: Mapping[str, Any],
+                            dataset_name: str, augmentations_config: Optional[Mapping[str, Mapping[str, float]]], x_stride: int = 1,
+                            padding_mode: str = "constant", rng=_random, device="cuda") -> Dict[str, Any]:
+    """The train-split item chain of ``DataLoader.__getitem__`` (``loader.py:594-705``) for a batch of sweep tables, in the
+    reference's order: ROI filter + table -> image (unpadded) -> augmentations -> ``features *= mask`` + W padding.
+    ``annotations``: (M, 13) fp64 rows in ``COLS`` order (``batch_index`` = position in ``tables``) or None."""
+    items = [range_view_from_table(t, range_view_config, dataset_name, x_stride, padding_mode, device, pad=False) for t in tables]
+    batch: Dict[str, Any] = {k: torch.stack([it[k] for it in items]) for k in ("features", "mask", "cart")}
+    if annotations is not None:
+        batch["annotations"] = annotations
+    if augmentations_config:
+        batch = augment_batch(batch, range_view_config["feature_column_names"], augmentations_config, rng, width=int(range_view_config["width"]))
+    return pad_batch(batch, dataset_name, x_stride, padding_mode)

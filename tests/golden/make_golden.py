@@ -50,7 +50,8 @@ ref_conv = _ref_stubs.load_converter_utils()
 
 
 def npy(t):
-    return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+    a = t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+    return a.astype(str) if a.dtype == object else a  # string columns read back from feather files
 
 
 def save(name: str, **arrays) -> None:

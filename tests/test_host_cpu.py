@@ -223,6 +223,33 @@ def test_detections_table_and_feather_files(tmp_path):
     assert a.schema == t.schema and a.num_rows == 3 and a.column("score").to_pylist() == [t.column("score")[i].as_py() for i in (0, 1, 5)]
 
 
+def test_detections_table_matches_the_reference_build_dataframe(golden):
+    """f2 pinned: ``build_dataframe`` (math/ops/coding.py:31-76) was run by the reference itself in the build container
+    (``tests/golden/make_golden.py::gen_detections_frame``, over the polars stand-in) on the decoder rows of
+    ``nms_wrapper.npz``; column order, dtypes and every row of this package's Arrow table must equal that frame."""
+    import numpy as np
+    import torch
+
+    from range_view_3d_detection_amd.math.ops.coding import build_dataframe
+
+    g, nw = golden("detections_frame"), golden("nms_wrapper")
+    uuids = {"batch_index": g.np("uuids/batch_index").tolist(), "log_id": [str(x) for x in g.np("uuids/log_id")],
+             "timestamp_ns": g.np("uuids/timestamp_ns").tolist()}
+    t = build_dataframe(nw["b/tiny/params"], nw["b/tiny/scores"], nw["b/tiny/categories"], nw["b/tiny/batch_index"], uuids,
+                        [str(x) for x in g.np("category_names")])
+    cols = [str(c) for c in g.np("columns")]
+    assert t.column_names == cols
+    arrow = {"float32": "float", "int32": "int32", "int64": "int64"}
+    for c, dt in zip(cols, [str(d) for d in g.np("dtypes")]):
+        want = g.np(f"col/{c}")
+        if dt.startswith("<U") or dt.startswith("|S") or dt == "object":
+            assert str(t.schema.field(c).type) == "string" and t.column(c).to_pylist() == [str(x) for x in want], c
+        else:
+            assert str(t.schema.field(c).type) == arrow[dt], (c, dt)
+            assert np.array_equal(np.asarray(t.column(c)), want), c
+    assert 0 < t.num_rows < nw["b/tiny/params"].shape[0]  # sweep 1 has no uuid row: dropped by the inner join
+
+
 def test_wnms_gpu_shim_importable_and_refuses_cpu_tensors():
     """The reference's ``import weighted_nms_ext`` resolves to compat/weighted_nms_ext.py; there is no CPU fallback."""
     import sys

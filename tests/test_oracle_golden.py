@@ -375,3 +375,57 @@ def test_nms_wrapper_matches_the_reference_wrapper(golden):
         assert torch.equal(c, g[f"b/{tag}/categories"]) and torch.equal(b, g[f"b/{tag}/batch_index"]), tag
         close(p, g[f"b/{tag}/params"], 1e-6, f"{tag} params")
         close(s, g[f"b/{tag}/scores"], 1e-7, f"{tag} scores")
+
+
+def _train_item_case(g, tag):
+    names = [str(n) for n in g.np(f"{tag}/feature_column_names")]
+    table = {k[len(f"{tag}/table/"):]: g.np(k) for k in g.keys if k.startswith(f"{tag}/table/")}
+    ann_in = {k[len(f"{tag}/ann_in/"):]: g.np(k) for k in g.keys if k.startswith(f"{tag}/ann_in/")}
+    chain = []
+    for k in [str(n) for n in g.np(f"{tag}/augmentation_order")]:
+        chain.append({"flip_azimuth": ("flip",), "random_rotation": ("rotate", float(g.np(f"{tag}/theta")) if f"{tag}/theta" in g else 0.0),
+                      "random_global_scale": ("scale", float(g.np(f"{tag}/scale")) if f"{tag}/scale" in g else 1.0),
+                      "random_global_translation": ("translate", tuple(g.np(f"{tag}/t").tolist()) if f"{tag}/t" in g else (0, 0, 0))}[k])
+    return names, table, ann_in, chain, bool(g.np(f"{tag}/filter_roi")), str(g.np(f"{tag}/padding_mode"))
+
+
+TRAIN_TASKS = {0: ["REGULAR_VEHICLE", "BUS"], 1: ["PEDESTRIAN"]}
+
+
+def test_loader_train_item_augments_before_padding(golden):
+    """The train-split ``__getitem__`` of the reference (augmentations on the unpadded table, THEN features *= mask and the W
+    padding; annotations filtered, joined with the task frame and sorted) against ``oracle.loader.train_item_from_table``:
+    placement channels exact, geometry 1e-6, mask exact -- including the Waymo chain whose scale follows a translation (empty
+    pixels become valid there, as in the reference)."""
+    from oracle import augment as oaug
+    from oracle import loader as old
+
+    g = golden("loader_train_item")
+    for tag, ds in (("av2", "av2"), ("waymo", "waymo")):
+        names, table, ann_in, chain, roi, mode = _train_item_case(g, tag)
+        got = old.train_item_from_table(table, names, 8, 64, ds, roi, chain, 1, mode)
+        assert np.array_equal(got["mask"], g.np(f"{tag}/mask")), tag
+        ref_f, ref_c = g.np(f"{tag}/features"), g.np(f"{tag}/cart")
+        assert got["features"].shape == ref_f.shape and got["features"].shape[-1] == 64 + (8 if ds == "av2" else 6)
+        for i, n in enumerate(names):
+            tol = 1e-6 * max(1.0, float(np.abs(ref_f[i]).max()))
+            if n in ("x", "y", "z", "range") or (n == "intensity" and ds == "waymo"):
+                assert np.max(np.abs(got["features"][i] - ref_f[i])) <= tol, (tag, n)
+            else:
+                assert np.array_equal(got["features"][i].astype(np.float32), ref_f[i]), (tag, n)
+        assert np.max(np.abs(got["cart"] - ref_c)) <= 1e-6 * max(1.0, float(np.abs(ref_c).max())), tag
+        # annotations: filter + join + sort, then the same chain
+        rows, keys = old.annotations_for_sweep(ann_in, 7, TRAIN_TASKS)
+        assert [k[0] for k in keys] == g.np(f"{tag}/ann_out/task_id").tolist() and [k[1] for k in keys] == g.np(f"{tag}/ann_out/offset").tolist()
+        assert [str(ann_in["category"][i]) for i in rows] == [str(c) for c in g.np(f"{tag}/ann_out/category")]
+        cols = ("tx_m", "ty_m", "tz_m", "length_m", "width_m", "height_m", "qw", "qx", "qy", "qz")
+        a = np.stack([np.asarray(ann_in[c], dtype=np.float64)[rows] for c in cols])
+        s = np.zeros((6, 1, 1))
+        for op in chain:
+            _, a = {"flip": lambda: oaug.flip(s, ["x", "y", "z", "range", "i", "e"], a), "rotate": lambda: oaug.rotate(s, ["x", "y", "z", "range", "i", "e"], a, op[1]),
+                    "scale": lambda: oaug.scale(s, ["x", "y", "z", "range", "i", "e"], a, op[1]),
+                    "translate": lambda: oaug.translate(s, ["x", "y", "z", "range", "i", "e"], a, op[1])}[op[0]]()
+        ref_a = np.stack([g.np(f"{tag}/ann_out/{c}") for c in cols])
+        assert np.max(np.abs(a[:6] - ref_a[:6])) <= 1e-9 * max(1.0, np.max(np.abs(ref_a[:6]))), tag
+        dyaw = oaug.yaw_of(a[6:10]) - oaug.yaw_of(ref_a[6:10])
+        assert np.max(np.abs(np.arctan2(np.sin(dyaw), np.cos(dyaw)))) < 1e-9, tag
