@@ -101,13 +101,21 @@ class KernelProfile:
 
 PROFILE: Optional[KernelProfile] = None
 
-# Weight gradients can run on a second HIP stream (RV3D_OVERLAP=free): wgrad(L) is independent of the main backward chain
-# (dgrad(L) -> BatchNorm backward(L-1) -> dgrad(L-1) ...).  Round-2 A/B on one device (profiles/r02_overlap_ab.md): the free
-# overlap is worth +3 % step throughput, but the two MFMA-bound kernel families then split the CUs (each kernel's own
-# launch-to-completion time grows by 25-40 %); restricting the overlap to the HBM-bound BatchNorm-backward passes, or giving
-# the main chain a high-priority stream, is slower than one stream.  Default: one stream -- every kernel runs alone at its
-# isolated speed, and the per-kernel figures bench.py reports are the kernels' own.
-OVERLAP_WGRAD = os.environ.get("RV3D_OVERLAP", "") == "free" and os.environ.get("RV3D_NO_OVERLAP") is None
+# Weight gradients can run on a second HIP stream: wgrad(L) is independent of the main backward chain (dgrad(L) -> BatchNorm
+# backward(L-1) -> dgrad(L-1) ...).
+#   RV3D_OVERLAP=free        every weight gradient on the side stream.  Round-3 A/B on the final kernels
+#                            (profiles/r03_overlap_ab.md): 3.6 % SLOWER than one stream -- two persistent one-workgroup-per-CU
+#                            kernels with 150 KB of LDS each cannot share a CU, the big layers only take turns;
+#   RV3D_OVERLAP=small[:T]   (DEFAULT, T = 0.1) only the weight gradients of layers below T TFLOP (the 128-channel DLA stages at
+#                            W <= 1024 and the 1x1 layers, whose kernels have fewer tiles than the chip has CUs) -- they run
+#                            beside the equally small backward-data / BatchNorm kernels of the main chain on CUs those leave
+#                            idle: -2.0 ms per step (103.1 / 103.3 -> 101.1 at T = 0.1, 101.2 / 101.7 at 0.35, 101.9 at 0.7);
+#   RV3D_OVERLAP=off         one stream.
+_OVERLAP = os.environ.get("RV3D_OVERLAP", "small")
+if os.environ.get("RV3D_NO_OVERLAP") is not None:
+    _OVERLAP = "off"
+OVERLAP_WGRAD = _OVERLAP == "free" or _OVERLAP.startswith("small")
+OVERLAP_MAX_TFLOP: Optional[float] = (float(_OVERLAP.split(":")[1]) if ":" in _OVERLAP else 0.1) if _OVERLAP.startswith("small") else None
 _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 
 

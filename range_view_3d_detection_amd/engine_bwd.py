@@ -149,7 +149,7 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
             L.call("rv_unfold_weight_grad", ctypes.byref(g), L.ptr(folded), L.ptr(grad), L.i32(0), L.stream_ptr())
         t.add_param_grad(layer.weight, layer.unpermute_grad(grad))
 
-    if E.OVERLAP_WGRAD:
+    if E.OVERLAP_WGRAD and (E.OVERLAP_MAX_TFLOP is None or E.tap_flops(g, wshape) < 1e12 * E.OVERLAP_MAX_TFLOP):
         side = E.side_stream(t.device)
         ready = torch.cuda.Event()
         ready.record()  # dout (and everything before it on the main stream) is complete at this point of the main stream
