@@ -411,14 +411,21 @@ int rv_wnms_classes(const float* boxes, const float* data, const int32_t* cats, 
  * compaction, (class, score) ordering, class-segmented weighted NMS (one scan workgroup per class), per-class top-k by
  * merged score, final compaction in the reference's output order (math/ops/nms.py:64-123, 181-266: sweeps in order, classes
  * ascending, merged score descending).  scores (B,K) f32, cats (B,K) i64 in [0, n_classes), cuboids (B,K,7) f32
- * [x,y,z,l,w,h,yaw]; `cap` = candidate capacity per sweep (multiple of 64, <= 32768; workspace:
- * rv_nms_sweeps_workspace_bytes).  Outputs (device): out_boxes (B,cap,7), out_scores (B,cap), out_cats (B,cap),
- * out_counts (B,2) = {rows written, or -1 when the sweep had more than `cap` candidates; candidates >= min_confidence}.
+ * [x,y,z,l,w,h,yaw]; `cap` = candidate capacity per sweep (multiple of 64, <= 262144: the decoder emits 212 992 per
+ * 64 x 2048 sweep; per-candidate workspace: rv_nms_sweeps_workspace_bytes, ~117 bytes per candidate).  The pair masks are
+ * class-relative and live in `mask_workspace`: B x 2 x `mask_words` 64-bit words; a sweep whose classes need more than
+ * `mask_words` (= sum over classes of n_c * ceil(n_c / 64), n_c cut at num_pre_nms: the reference's per-class pre-NMS top-k,
+ * nms.py:83-84) reports the number and is redone by a call with `resume` != 0 over a buffer of that size (the ordering
+ * stages are not repeated; `workspace` must be untouched in between).  Outputs (device): out_boxes (B,out_cap,7),
+ * out_scores (B,out_cap), out_cats (B,out_cap), out_cap >= min(cap, n_classes * num_post_nms);
+ * out_counts (B,4) i64 = {rows written, or -1: mask budget exceeded, -2: more than `cap` candidates;
+ * candidates >= min_confidence; boxes kept by the NMS; mask words the sweep needs}.
  * Asynchronous: the caller reads out_counts back once for the whole batch. */
 int64_t rv_nms_sweeps_workspace_bytes(int32_t B, int32_t cap);
 int rv_nms_sweeps(const float* scores, const int64_t* cats, const float* cuboids, int32_t B, int64_t K, int32_t n_classes,
-                  float min_confidence, float nms_thresh, float merge_thresh, int32_t num_post_nms, int32_t cap,
-                  float* out_boxes, float* out_scores, int32_t* out_cats, int32_t* out_counts, void* workspace, rvStream stream);
+                  float min_confidence, float nms_thresh, float merge_thresh, int32_t num_pre_nms, int32_t num_post_nms,
+                  int32_t cap, int32_t out_cap, float* out_boxes, float* out_scores, int32_t* out_cats, int64_t* out_counts,
+                  void* workspace, void* mask_workspace, int64_t mask_words, int32_t resume, rvStream stream);
 int rv_rotated_iou(const float* a, int64_t n, const float* b, int64_t m, float* out, rvStream stream);
 
 /* ---------------------------------------------------------------------------------------

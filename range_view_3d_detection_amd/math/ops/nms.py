@@ -38,44 +38,61 @@ def weighted_nms(boxes: Tensor, data2merge: Tensor, scores: Tensor, nms_threshol
 
 
 # Device-resident path (``rv_nms_sweeps``, csrc/nms2.hip): all sweeps of a batch in one set of launches, one device->host
-# read at the end.  Candidate capacity per sweep: the pair masks take cap^2 / 4 bytes; a sweep with more candidates than
-# that (or a recipe whose ``num_pre_nms`` is below the capacity: the per-class pre-NMS cut would matter) takes the
-# reference-shaped per-class loop below.
-FUSED_CLASSES_MAX = 16384
+# read at the end.  The per-candidate arrays are sized for every candidate of the sweep (up to ``FUSED_CLASSES_MAX``; the
+# decoder emits 212 992 per 64 x 2048 sweep); the class-relative pair masks get a word budget (``MASK_WORDS`` per sweep and
+# mask: 32 MB each), and a batch in which some sweep needs more -- tens of thousands of candidates in ONE class -- is redone
+# over a buffer of the size the kernels report (second read; the ordering stages are not repeated).  The reference's
+# per-class pre-NMS cut (``topk(num_pre_nms)``, nms.py:83-84) is applied on device.  Only a sweep with more candidates than
+# ``FUSED_CLASSES_MAX`` (or more than 64 classes) takes the reference-shaped per-class loop over the FFI below.
+FUSED_CLASSES_MAX = 262144
+MASK_WORDS = 4 * 1024 * 1024
 
 
 def nms_sweeps(cuboids: Tensor, scores: Tensor, categories: Tensor, n_classes: int, iou_threshold: float, min_confidence: float,
-               num_post_nms: int, cap: int) -> Tuple[Tensor, Tensor, Tensor, List[int]]:
-    """(B,K,7), (B,K), (B,K) -> padded (B,cap,7) boxes, (B,cap) scores, (B,cap) int32 classes and the per-sweep row counts
-    (-1: the sweep had more than ``cap`` candidates -- its rows are not valid)."""
+               num_post_nms: int, cap: int, num_pre_nms: int = 2**31 - 1) -> Tuple[Tensor, Tensor, Tensor, List[int]]:
+    """(B,K,7), (B,K), (B,K) -> padded (B,R,7) boxes, (B,R) scores, (B,R) int32 classes and the per-sweep row counts
+    (-2: the sweep had more than ``cap`` candidates -- its rows are not valid)."""
     _require_cuda(cuboids, "cuboids")
     dev = cuboids.device
     B, K, _ = cuboids.shape
     cub = cuboids.detach().float().contiguous()
     sc = scores.detach().float().contiguous()
     ct = categories.detach().to(torch.int64).contiguous()
-    ob = torch.empty((B, cap, 7), dtype=torch.float32, device=dev)
-    os_ = torch.empty((B, cap), dtype=torch.float32, device=dev)
-    oc = torch.empty((B, cap), dtype=torch.int32, device=dev)
-    counts = torch.empty((B, 2), dtype=torch.int32, device=dev)
+    out_cap = min(cap, n_classes * num_post_nms)
+    ob = torch.empty((B, out_cap, 7), dtype=torch.float32, device=dev)
+    os_ = torch.empty((B, out_cap), dtype=torch.float32, device=dev)
+    oc = torch.empty((B, out_cap), dtype=torch.int32, device=dev)
+    counts = torch.empty((B, 4), dtype=torch.int64, device=dev)
     ws = torch.empty(L.load().rv_nms_sweeps_workspace_bytes(L.i32(B), L.i32(cap)), dtype=torch.uint8, device=dev)
-    L.call("rv_nms_sweeps", L.ptr(sc), L.ptr(ct), L.ptr(cub), L.i32(B), L.i64(K), L.i32(n_classes), L.f32(min_confidence), L.f32(iou_threshold),
-           L.f32(0.5), L.i32(num_post_nms), L.i32(cap), L.ptr(ob), L.ptr(os_), L.ptr(oc), L.ptr(counts), L.ptr(ws), L.stream_ptr())
-    return ob, os_, oc, counts[:, 0].tolist()  # the one device->host read of the batch
+    num_pre = int(min(num_pre_nms, 2**31 - 1))
+
+    def run(mask_words: int, resume: int) -> List[List[int]]:
+        masks = torch.empty((B, 2, mask_words), dtype=torch.int64, device=dev)
+        L.call("rv_nms_sweeps", L.ptr(sc), L.ptr(ct), L.ptr(cub), L.i32(B), L.i64(K), L.i32(n_classes), L.f32(min_confidence), L.f32(iou_threshold),
+               L.f32(0.5), L.i32(num_pre), L.i32(num_post_nms), L.i32(cap), L.i32(out_cap), L.ptr(ob), L.ptr(os_), L.ptr(oc), L.ptr(counts), L.ptr(ws),
+               L.ptr(masks), L.i64(mask_words), L.i32(resume), L.stream_ptr())
+        return counts.tolist()  # the one device->host read of the batch (a second one only when the mask budget was exceeded)
+
+    budget = int(min(MASK_WORDS, max(1, (cap // 64 + 1) * cap)))  # (small inputs: no more than one class could need)
+    rows = run(budget, 0)
+    if any(r[0] == -1 for r in rows):
+        rows = run(max(r[3] for r in rows), 1)
+    return ob, os_, oc, [int(r[0]) for r in rows]
 
 
 def _capacity(k: int) -> int:
-    return max(64, min(FUSED_CLASSES_MAX, (k + 63) // 64 * 64))
+    return max(64, (min(k, FUSED_CLASSES_MAX) + 63) // 64 * 64)
 
 
 def weighted_multiclass_nms(cuboids_i: Tensor, scores_i: Tensor, categories_i: Tensor, iou_threshold: float, num_pre_nms: int,
                             num_post_nms: int) -> Tuple[Tensor, Tensor, Tensor]:
     """Per class (ascending ``unique``): top-k pre, weighted NMS with merge threshold 0.5 (``nms.py:105-106``), top-k post."""
     n = scores_i.shape[0]
-    if 0 < n <= min(FUSED_CLASSES_MAX, num_pre_nms) and FUSED_CLASSES_MAX > 0:
+    if 0 < n <= FUSED_CLASSES_MAX:
         n_cls = int(categories_i.max().item()) + 1
         if n_cls <= 64:
-            b, s, c, cnt = nms_sweeps(cuboids_i[None], scores_i[None], categories_i[None], n_cls, iou_threshold, -math.inf, num_post_nms, _capacity(n))
+            b, s, c, cnt = nms_sweeps(cuboids_i[None], scores_i[None], categories_i[None], n_cls, iou_threshold, -math.inf, num_post_nms, _capacity(n),
+                                      num_pre_nms)
             return b[0, : cnt[0]], s[0, : cnt[0]], c[0, : cnt[0]].to(s.dtype)
     out_b: List[Tensor] = []
     out_s: List[Tensor] = []
@@ -109,9 +126,9 @@ def batched_multiclass_nms(cuboids: Tensor, scores: Tensor, categories: Tensor, 
     B, K = scores.shape
     fast = None
     cap = _capacity(K)
-    if FUSED_CLASSES_MAX > 0 and n_classes is not None and n_classes <= 64 and cap <= num_pre_nms:
+    if FUSED_CLASSES_MAX > 0 and n_classes is not None and n_classes <= 64:
         # device-resident path for the whole batch; sweeps that overflow its capacity fall through to the loop below
-        fast = nms_sweeps(cuboids, scores, categories, n_classes, iou_threshold, min_confidence, num_post_nms, cap)
+        fast = nms_sweeps(cuboids, scores, categories, n_classes, iou_threshold, min_confidence, num_post_nms, cap, num_pre_nms)
     for i in range(B):
         if fast is not None and fast[3][i] >= 0:
             k = fast[3][i]

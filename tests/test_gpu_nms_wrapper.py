@@ -124,3 +124,66 @@ def test_range_decoder_with_nms_against_the_reference(golden, tag, sample):
     assert ref[0].shape[0] > 50
     for name, got in _both_paths(lambda: dec.decode(mo, post, {0: ["c"] * logits.shape[1]}, use_nms=True)).items():
         _same_rows(got, ref, f"{tag} / {name}")
+
+
+@pytest.mark.parametrize("n_cls,k,num_pre", [(26, 60000, 50000), (3, 60000, 50000), (3, 30000, 4000)])
+def test_large_sweeps_stay_on_the_device_path(n_cls, k, num_pre):
+    """Sweeps far beyond the old 16 384-candidate capacity (the decoder emits 212 992 candidates per sweep and early-training
+    logits put most of them over ``min_confidence``): 4 sweeps x 60 000 candidates never leave ``rv_nms_sweeps`` -- per-candidate
+    arrays for every candidate, class-relative pair masks, the 3-class case exceeds the default mask budget and is RESUMED over
+    a buffer of the reported size (ordering stages not repeated); ``num_pre_nms`` = 4000 below the class sizes exercises the
+    pre-NMS top-k cut on device.  Rows must equal the reference-shaped per-class loop over the FFI bit for bit."""
+    from range_view_3d_detection_amd.math.ops import nms as hnms
+    from test_gpu_model import _random_boxes
+
+    cubs, scs, cats = [], [], []
+    for b in range(4):
+        cub, s = _random_boxes(k, 900 + b, 600.0)
+        cubs.append(cub)
+        scs.append(s)
+        cats.append(torch.randint(0, n_cls, (k,), generator=torch.Generator().manual_seed(40 + b)))
+    args = (torch.stack(cubs).to(DEV), torch.stack(scs).to(DEV), torch.stack(cats).to(DEV), num_pre, 300, 0.3, 0.1, "weighted")
+    calls = []
+    orig = hnms.nms_sweeps
+
+    def spy(*a, **kw):
+        out = orig(*a, **kw)
+        calls.append(out[3])
+        return out
+
+    hnms.nms_sweeps = spy
+    try:
+        fast = hnms.batched_multiclass_nms(*args, n_classes=n_cls)
+    finally:
+        hnms.nms_sweeps = orig
+    assert len(calls) == 1 and all(c >= 0 for c in calls[0]), calls  # every sweep was finished on device
+    old = hnms.FUSED_CLASSES_MAX
+    hnms.FUSED_CLASSES_MAX = 0
+    try:
+        loop = hnms.batched_multiclass_nms(*args, n_classes=n_cls)
+    finally:
+        hnms.FUSED_CLASSES_MAX = old
+    assert fast[0].shape == loop[0].shape and fast[0].shape[0] == 4 * n_cls * 300
+    for a, b_ in zip(fast, loop):
+        assert torch.equal(a, b_)
+
+
+def test_mask_budget_resume_equals_one_pass():
+    """A mask word budget too small for the batch: the kernels report the words each sweep needs, the host resumes the mask
+    stages over a buffer of that size -- same rows as a run whose budget sufficed."""
+    from range_view_3d_detection_amd.math.ops import nms as hnms
+    from test_gpu_model import _random_boxes
+
+    cub, s = _random_boxes(5000, 77, 80.0)
+    cat = torch.randint(0, 4, (5000,), generator=torch.Generator().manual_seed(3))
+    args = (cub[None].to(DEV), s[None].to(DEV), cat[None].to(DEV), 50000, 100, 0.3, 0.1, "weighted")
+    ref = hnms.batched_multiclass_nms(*args, n_classes=4)
+    old = hnms.MASK_WORDS
+    hnms.MASK_WORDS = 1000
+    try:
+        small = hnms.batched_multiclass_nms(*args, n_classes=4)
+    finally:
+        hnms.MASK_WORDS = old
+    assert ref[0].shape[0] == 400
+    for a, b_ in zip(small, ref):
+        assert torch.equal(a, b_)
