@@ -195,6 +195,10 @@ int rv_tap_wgrad(const rvTapGeom* g, const rvTapShape* s, const void* U, int32_t
 /* Column sums of `rows` partial rows ([rows][cols] fp32, accumulated in fp64) -> out[cols]; `partial` must have the
  * scratch rows of the convention above behind it.  SyncBN: totals written straight into the all-reduce buffer. */
 int rv_reduce_rows(const float* partial, int32_t rows, int32_t cols, float* out, rvStream stream);
+/* The same in the layout of one SyncBN collective: out[0 : cols] = the totals, out[cols] = `count` (this rank's element count,
+ * summed by the all-reduce with the totals); out_copy (may be NULL) receives the LOCAL totals too -- in the backward pass
+ * they are this rank's (dbeta, dgamma), which stay local (DDP averages parameter gradients).  One launch. */
+int rv_reduce_rows_count(const float* partial, int32_t rows, int32_t cols, float count, float* out, float* out_copy, rvStream stream);
 /* count < 0 (SyncBN, rows == 1): the element count is read from the device, partial[2*c] (fp32), where it travelled with
  * the all-reduced totals -- ranks may hold different numbers of pixels.  Same convention in rv_bn_bwd_finalize. */
 int rv_bn_finalize(const float* partial, int32_t rows, int32_t c, int64_t count, const float* gamma,

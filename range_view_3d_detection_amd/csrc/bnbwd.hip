@@ -458,10 +458,11 @@ __global__ __launch_bounds__(256) void smallk_moments_kernel(const bf16_t* v, in
 template <int CIN>
 __global__ void bn_bwd_smallk_finalize_kernel(const double* red_g, int groups, const double* red_m, int groups_m, int c, int cin,
                                               double inv_count, const float* gamma, const float* mean, const float* invstd,
-                                              const bf16_t* w, int ld_w, const double* global_s01, float* dgamma, float* dbeta,
-                                              float* dW) {
+                                              const bf16_t* w, int ld_w, const double* global_s01, const double* count_dev,
+                                              float* dgamma, float* dbeta, float* dW) {
     const int ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= c) return;
+    if (count_dev) inv_count = 1.0 / *count_dev;  // SyncBN: the all-reduced pixel count, read on device (no host sync)
     double S[2 + CIN];
     for (int p = 0; p < 2 + CIN; ++p) {
         double s = 0.0;
@@ -496,11 +497,16 @@ __global__ void bn_bwd_smallk_finalize_kernel(const double* red_g, int groups, c
 // ---------------------------------------------------------------------------------------------
 template <int CIN>
 __global__ void smallk_stats_kernel(const double* red_m, int groups_m, int c, int cin, const bf16_t* w, int ld_w, double inv_count,
-                                    double unbias, const float* gamma, const float* beta, float eps, float momentum,
+                                    double unbias, const double* count_dev, const float* gamma, const float* beta, float eps, float momentum,
                                     float* running_mean, float* running_var, float* scale, float* shift, float* mean_out,
                                     float* invstd_out) {
     const int ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= c) return;
+    if (count_dev) {  // SyncBN: the all-reduced pixel count travels with the moments and is read here (no host sync)
+        const double n = *count_dev;
+        inv_count = 1.0 / n;
+        unbias = n > 1.0 ? n / (n - 1.0) : 1.0;
+    }
     double m[CIN + CIN * CIN];
     for (int i = 0; i < CIN + CIN * CIN; ++i) {
         double s = 0.0;
@@ -627,6 +633,7 @@ extern "C" int rv_bn_bwd_finalize(const float* partial, int32_t rows, int32_t c,
         RV_CHECK_LAUNCH("bn_bwd_reduce_finalize_kernel");
         return 0;
     }
+    RV_REQUIRE(count > 0, "rv_bn_bwd_finalize: the two-stage path (RV3D_NO_FUSED_FINALIZE / > 1024 rows) takes a host-side count only");
     double* scratch = (double*)(partial + (int64_t)rows * 2 * c);
     int groups;
     if (rv_col_reduce(partial, rows, 2 * c, scratch, &groups, (hipStream_t)stream)) return 1;
@@ -761,14 +768,17 @@ extern "C" int rv_bn_bwd_smallk_from_sums(int32_t c, int32_t cin, const double* 
                                           const float* stat_invstd, int64_t count, float* dgamma, float* dbeta, float* dW,
                                           rvStream stream) {
     RV_REQUIRE(sums && moms && w_packed && gamma && stat_mean && stat_invstd && dgamma && dbeta && dW, "rv_bn_bwd_smallk_from_sums: null argument");
-    RV_REQUIRE(cin >= 1 && cin <= 8 && count > 0, "rv_bn_bwd_smallk_from_sums: bad shape");
+    RV_REQUIRE(cin >= 1 && cin <= 8 && (count > 0 || global_s01), "rv_bn_bwd_smallk_from_sums: bad shape (count < 0 needs global_s01)");
     hipStream_t st = (hipStream_t)stream;
+    // count < 0 (SyncBN): the global pixel count is the double behind the all-reduced sums, global_s01[2 c]
+    const double* count_dev = count < 0 ? global_s01 + 2 * (int64_t)c : nullptr;
+    const double inv = count > 0 ? 1.0 / (double)count : 0.0;
     if (cin <= 4)
-        hipLaunchKernelGGL(bn_bwd_smallk_finalize_kernel<4>, dim3(rv_ceil_div(c, 64)), dim3(64), 0, st, sums, 1, moms, 1, c, cin, 1.0 / (double)count,
-                           gamma, stat_mean, stat_invstd, (const bf16_t*)w_packed, ld_w, global_s01, dgamma, dbeta, dW);
+        hipLaunchKernelGGL(bn_bwd_smallk_finalize_kernel<4>, dim3(rv_ceil_div(c, 64)), dim3(64), 0, st, sums, 1, moms, 1, c, cin, inv,
+                           gamma, stat_mean, stat_invstd, (const bf16_t*)w_packed, ld_w, global_s01, count_dev, dgamma, dbeta, dW);
     else
-        hipLaunchKernelGGL(bn_bwd_smallk_finalize_kernel<8>, dim3(rv_ceil_div(c, 64)), dim3(64), 0, st, sums, 1, moms, 1, c, cin, 1.0 / (double)count,
-                           gamma, stat_mean, stat_invstd, (const bf16_t*)w_packed, ld_w, global_s01, dgamma, dbeta, dW);
+        hipLaunchKernelGGL(bn_bwd_smallk_finalize_kernel<8>, dim3(rv_ceil_div(c, 64)), dim3(64), 0, st, sums, 1, moms, 1, c, cin, inv,
+                           gamma, stat_mean, stat_invstd, (const bf16_t*)w_packed, ld_w, global_s01, count_dev, dgamma, dbeta, dW);
     RV_CHECK_LAUNCH("bn_bwd_smallk_finalize_kernel");
     return 0;
 }
@@ -834,14 +844,17 @@ extern "C" int rv_smallk_forward(const void* v, int32_t ld_v, int64_t pixels, in
     const int CIN = cin <= 4 ? 4 : 8;
     hipStream_t st = (hipStream_t)stream;
     if (moments) {  // training: batch statistics in closed form from the moments (already all-reduced by the caller under SyncBN)
-        RV_REQUIRE(gamma && beta && count > 0, "rv_smallk_forward: statistics need gamma, beta and the pixel count");
+        RV_REQUIRE(gamma && beta && count != 0, "rv_smallk_forward: statistics need gamma, beta and the pixel count");
+        // count < 0 (SyncBN): the all-reduced pixel count is the double behind the moments, moments[cin_pad + cin_pad^2]
+        const double* count_dev = count < 0 ? moments + (CIN + CIN * CIN) : nullptr;
         const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
+        const double inv = count > 0 ? 1.0 / (double)count : 0.0;
         if (CIN == 4)
             hipLaunchKernelGGL(smallk_stats_kernel<4>, dim3(rv_ceil_div(c, 64)), dim3(64), 0, st, moments, 1, c, cin, (const bf16_t*)w_packed, ld_w,
-                               1.0 / (double)count, unbias, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, invstd);
+                               inv, unbias, count_dev, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, invstd);
         else
             hipLaunchKernelGGL(smallk_stats_kernel<8>, dim3(rv_ceil_div(c, 64)), dim3(64), 0, st, moments, 1, c, cin, (const bf16_t*)w_packed, ld_w,
-                               1.0 / (double)count, unbias, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, invstd);
+                               inv, unbias, count_dev, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, invstd);
         RV_CHECK_LAUNCH("smallk_stats_kernel");
     }
     if (!h) return 0;

@@ -462,13 +462,49 @@ __global__ void sum_groups_f32_kernel(const double* red, int groups, int cols, f
     out[col] = (float)s;
 }
 
+// One launch: block = 16 columns x 16 row lanes, fp64 accumulation, four independent rows in flight per thread (the rows of a
+// SyncBN statistic are on the critical path of the step: conv -> totals -> all-reduce -> finalize -> next conv).
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* partial, int rows, int cols, float* out, float* out_copy,
+                                                          float count, int write_count) {
+    __shared__ double red[16][17];
+    const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int col = blockIdx.x * 16 + cx;
+    double s = 0.0;
+    if (col < cols) {
+        const float* p = partial + col;
+        int r = ry;
+        for (; r + 48 < rows; r += 64) {
+            const float a0 = p[(int64_t)r * cols], a1 = p[(int64_t)(r + 16) * cols], a2 = p[(int64_t)(r + 32) * cols], a3 = p[(int64_t)(r + 48) * cols];
+            s += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+        }
+        for (; r < rows; r += 16) s += (double)p[(int64_t)r * cols];
+    }
+    red[ry][cx] = s;
+    __syncthreads();
+    for (int half = 8; half > 0; half >>= 1) {
+        if (ry < half) red[ry][cx] += red[ry + half][cx];
+        __syncthreads();
+    }
+    if (ry == 0 && col < cols) {
+        const float v = (float)red[0][cx];
+        out[col] = v;
+        if (out_copy) out_copy[col] = v;
+    }
+    if (write_count && blockIdx.x == 0 && threadIdx.x == 0) out[cols] = count;
+}
+
 extern "C" int rv_reduce_rows(const float* partial, int32_t rows, int32_t cols, float* out, rvStream stream) {
     RV_REQUIRE(partial && out && rows > 0 && cols > 0, "rv_reduce_rows: bad argument");
-    double* scratch = (double*)(partial + (int64_t)rows * cols);
-    int groups;
-    if (rv_col_reduce(partial, rows, cols, scratch, &groups, (hipStream_t)stream)) return 1;
-    hipLaunchKernelGGL(sum_groups_f32_kernel, dim3(rv_ceil_div(cols, 256)), dim3(256), 0, (hipStream_t)stream, scratch, groups, cols, out);
-    RV_CHECK_LAUNCH("sum_groups_f32_kernel");
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(rv_ceil_div(cols, 16)), dim3(256), 0, (hipStream_t)stream, partial, rows, cols, out, (float*)nullptr, 0.f, 0);
+    RV_CHECK_LAUNCH("reduce_rows_kernel");
+    return 0;
+}
+
+extern "C" int rv_reduce_rows_count(const float* partial, int32_t rows, int32_t cols, float count, float* out, float* out_copy,
+                                    rvStream stream) {
+    RV_REQUIRE(partial && out && rows > 0 && cols > 0, "rv_reduce_rows_count: bad argument");
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(rv_ceil_div(cols, 16)), dim3(256), 0, (hipStream_t)stream, partial, rows, cols, out, out_copy, count, 1);
+    RV_CHECK_LAUNCH("reduce_rows_kernel");
     return 0;
 }
 
@@ -489,6 +525,7 @@ extern "C" int rv_bn_finalize(const float* partial, int32_t rows, int32_t c, int
         RV_CHECK_LAUNCH("bn_reduce_finalize_kernel");
         return 0;
     }
+    RV_REQUIRE(count > 0, "rv_bn_finalize: the two-stage path (RV3D_NO_FUSED_FINALIZE / > 1024 rows) takes a host-side count only");
     double* scratch = (double*)(partial + (int64_t)rows * 2 * c);
     int groups;
     if (rv_col_reduce(partial, rows, 2 * c, scratch, &groups, (hipStream_t)stream)) return 1;

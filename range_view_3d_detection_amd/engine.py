@@ -152,25 +152,66 @@ def tap_flops(geom, shape) -> float:
     return 2.0 * shape.N * shape.H * shape.Wu * geom.kh * geom.kw * geom.cu * geom.cv
 
 
-def allreduce_partial_rows(partial: Tensor, rows: int, count: int) -> Tensor:
-    """Column-sum ``rows`` partial-statistics rows on the device (``rv_reduce_rows``: fp64 accumulation, no ATen temporaries),
-    append this rank's element count, and all-reduce the (2*C + 1) totals in ONE collective over the default process group
-    (RCCL on the GPUs; gloo in the CPU tests).  Returns a (1 + scratch, 2, C) buffer whose row 0 holds the global totals,
-    ready for ``rv_bn_finalize`` / ``rv_bn_bwd_finalize`` with ``rows = 1, count = -1``: the global count sits in the slot
-    behind the totals and is read on the device (ranks may hold different numbers of pixels: an uneven last batch)."""
-    c2 = partial.shape[1] * partial.shape[2]
+def all_reduce_(t: Tensor) -> None:
+    """Sum ``t`` over the ranks of the default process group, in place.  Over RCCL the collective is enqueued on the current
+    compute stream through the direct binding (``rccl.py``: no second stream, no event round trip -- these are latency-bound
+    collectives on the critical path); other backends (gloo in the CPU tests) go through ``torch.distributed``."""
+    from . import rccl
+
+    if t.is_cuda and rccl.available():
+        rccl.all_reduce_(t)
+    else:
+        torch.distributed.all_reduce(t)
+
+
+def _totals_into(partial: Tensor, rows: int, count: int, region: Tensor, local_copy: Optional[Tensor] = None) -> None:
+    """region[: 2C] = column sums of ``rows`` partial rows, region[2C] = count (one launch: ``rv_reduce_rows_count``)."""
     if count >= 1 << 24:
         raise L.RvError("SyncBN: more than 2^24 elements per channel on one rank (the count travels as fp32)")
-    out = torch.empty((1 + L.STATS_SCRATCH_ROWS,) + tuple(partial.shape[1:]), dtype=torch.float32, device=partial.device)
-    flat = out.view(-1)
+    n = region.numel() - 1
     if partial.is_cuda:
-        L.call("rv_reduce_rows", L.ptr(partial), L.i32(rows), L.i32(c2), L.ptr(out), L.stream_ptr())
+        L.call("rv_reduce_rows_count", L.ptr(partial), L.i32(rows), L.i32(n), L.f32(float(count)), L.ptr(region), L.ptr(local_copy), L.stream_ptr())
     else:  # the gloo tests of the host logic run this function on CPU tensors
-        flat[:c2] = partial[:rows].double().sum(dim=0).float().view(-1)
-    flat[c2] = float(count)  # the scratch rows start here: one extra slot travels with the totals
-    COLLECTIVES.add(flat[: c2 + 1])
-    torch.distributed.all_reduce(flat[: c2 + 1])
-    return out
+        region[:n] = partial[:rows].double().sum(dim=0).float().view(-1)
+        region[n] = float(count)
+        if local_copy is not None:
+            local_copy.view(-1)[:n] = region[:n]
+
+
+def allreduce_partial_rows(partial: Tensor, rows: int, count: int, local_copy: Optional[Tensor] = None) -> Tensor:
+    """Column-sum ``rows`` partial-statistics rows on the device (fp64 accumulation), append this rank's element count, and
+    all-reduce the (2*C + 1) totals in ONE collective over the default process group (RCCL on the GPUs; gloo in the CPU
+    tests).  Returns a flat (2*C + 1) buffer, ready for ``rv_bn_finalize`` / ``rv_bn_bwd_finalize`` with ``rows = 1,
+    count = -1``: the global count sits in the slot behind the totals and is read on the device (ranks may hold different
+    numbers of pixels: an uneven last batch).  ``local_copy`` (2, C): receives this rank's own totals."""
+    c2 = partial.shape[1] * partial.shape[2]
+    flat = torch.empty(c2 + 1, dtype=torch.float32, device=partial.device)
+    _totals_into(partial, rows, count, flat, local_copy)
+    COLLECTIVES.add(flat)
+    all_reduce_(flat)
+    return flat
+
+
+def allreduce_partial_rows_many(items: Sequence[Tuple[Tensor, int, int, Optional[Tensor]]]) -> List[Tensor]:
+    """``allreduce_partial_rows`` for several BatchNorm layers at once: item = (partial rows, rows, this rank's count, local
+    copy or None).  The (2*C_i + 1) totals of every layer are packed back to back into ONE fp32 buffer and travel in ONE
+    collective -- layers whose statistics become available together (the two convs a BasicBlock applies to the same input,
+    layer i of the classification and the regression tower) share a latency-bound all-reduce instead of paying one each.
+    Returns one flat (2*C_i + 1) view per item."""
+    sizes = [p.shape[1] * p.shape[2] + 1 for p, _, _, _ in items]
+    offs, total = [], 0
+    for n in sizes:
+        offs.append(total)
+        total += (n + 3) // 4 * 4  # 16-byte aligned regions
+    flat = torch.empty(total, dtype=torch.float32, device=items[0][0].device)  # (the pad floats between regions are never read)
+    views = []
+    for (partial, rows, count, copy), o, n in zip(items, offs, sizes):
+        v = flat[o : o + n]
+        _totals_into(partial, rows, count, v, copy)
+        views.append(v)
+    COLLECTIVES.add(flat)
+    all_reduce_(flat)
+    return views
 
 
 class _CollectiveLog:
@@ -589,8 +630,24 @@ class Tape:
             self.param_grads[k] = g
 
     def backward(self) -> None:
+        from . import engine_bwd
+
+        # Consecutive BatchNorm backward ops (layers whose output gradients are all available: conv_bn_many puts their BnOps
+        # next to each other) are independent of one another; under SyncBN their (sum g, sum g*xhat) all-reduces travel as ONE
+        # collective: every op of the run forms its local sums first, then one all-reduce, then the finalize + apply passes.
+        pending: List[tuple] = []
         for op in reversed(self.ops):
+            if GROUP_SYNC_BN and isinstance(op, BnOp) and op.sync_world > 1:
+                rec = engine_bwd.bn_backward_begin(op, self)
+                if rec is not None:
+                    pending.append(rec)
+                continue
+            if pending:
+                engine_bwd.bn_backward_finish(pending, self)
+                pending = []
             op.backward(self)
+        if pending:
+            engine_bwd.bn_backward_finish(pending, self)
         if self.used_side_stream:  # parameter gradients (and the buffers the side stream read) are final after this
             torch.cuda.current_stream().wait_stream(side_stream(self.device))
 
@@ -700,7 +757,9 @@ class ConvOp(Op):
 class BnOp(Op):
     """Finalise batch statistics (train) or fold running statistics (eval) into scale/shift."""
 
-    def __init__(self, t: Tape, conv: ConvOp, bn: nn.BatchNorm2d, relu: bool = True) -> None:
+    def __init__(self, t: Tape, conv: ConvOp, bn: nn.BatchNorm2d, relu: bool = True, reduced: Optional[Tensor] = None) -> None:
+        """``reduced``: this layer's all-reduced (2*C + 1) totals when the caller grouped its collective with other layers'
+        (``conv_bn_many``); None: the op issues its own."""
         self.conv = conv
         self.sync_world = 1
         c = bn.num_features
@@ -717,7 +776,7 @@ class BnOp(Op):
             self.sync_world = bn_sync_world(bn, True)
             count_arg = conv.count
             if self.sync_world > 1:  # SyncBN: (sum, sum of squares, count) in one all-reduce; the kernel reads the global count
-                conv.partial = allreduce_partial_rows(conv.partial, conv.rows, conv.count)
+                conv.partial = reduced if reduced is not None else allreduce_partial_rows(conv.partial, conv.rows, conv.count)
                 conv.rows, count_arg = 1, -1
             L.call("rv_bn_finalize", L.ptr(conv.partial), L.i32(conv.rows), L.i32(cp), L.i64(count_arg), L.ptr(gamma),
                    L.ptr(beta), L.f32(bn.eps), L.f32(bn.momentum if bn.momentum is not None else 0.1), L.ptr(rm),
@@ -785,11 +844,14 @@ class SmallKOp(Op):
             moments = torch.empty(73, dtype=torch.float64, device=dev)
             L.call("rv_smallk_moments", x.ptr(), L.i32(x.ld), L.i64(x.pixels), L.i32(cin), L.ptr(moments), L.ptr(ws), L.stream_ptr())
             self.sync_world = bn_sync_world(bn, True)
-            if self.sync_world > 1:  # SyncBN: the moments are sums over pixels -> all-reduce them (and the pixel count,
-                moments[72] = float(x.pixels)  # last slot), then the closed form is global.  The closed form takes the count as
-                COLLECTIVES.add(moments)       # a host value: one device->host read per small-K layer (two per step).
-                torch.distributed.all_reduce(moments)
-                self.count = int(round(float(moments[72].item())))
+            if self.sync_world > 1:
+                # SyncBN: the moments are sums over pixels -> all-reduce them together with this rank's pixel count (the slot
+                # behind them); the closed form then reads the GLOBAL count on the device (count = -1): no host round trip
+                cin_pad = 4 if cin <= 4 else 8
+                moments[cin_pad + cin_pad * cin_pad] = float(x.pixels)
+                COLLECTIVES.add(moments)
+                all_reduce_(moments)
+                self.count = -1
             L.call("rv_smallk_forward", x.ptr(), L.i32(x.ld), L.i64(x.pixels), L.i32(cin), L.ptr(wp), L.i32(pad32(cin)), L.i32(cp),
                    L.ptr(moments), L.i64(self.count), L.ptr(self.gamma_p), L.ptr(self.beta_p), L.f32(bn.eps),
                    L.f32(bn.momentum if bn.momentum is not None else 0.1), L.ptr(rm), L.ptr(rv), L.ptr(scale), L.ptr(shift),
@@ -829,6 +891,25 @@ def conv_bn(t: Tape, layer: TapLayer, x: Operand, bn: nn.BatchNorm2d, relu: bool
         return SmallKOp(t, layer, x, bn).out
     conv = ConvOp(t, layer, x, stats=t.training, need_input_grad=need_input_grad)
     return BnOp(t, conv, bn, relu).lazy
+
+
+GROUP_SYNC_BN = os.environ.get("RV3D_NO_GROUP_SYNC_BN") is None
+
+
+def conv_bn_many(t: Tape, specs: Sequence[Tuple[TapLayer, Operand, nn.BatchNorm2d, bool, bool]]) -> List[Operand]:
+    """Several independent conv -> BatchNorm (-> ReLU) layers whose inputs are all available: every conv is launched first,
+    then every BatchNorm is finalised -- under SyncBN with ONE all-reduce for the whole group (``allreduce_partial_rows_many``)
+    instead of one per layer; the BnOps sit next to each other on the tape, so the backward pass groups their collectives
+    too (``Tape.backward``).  spec = (layer, input, bn, relu, need_input_grad).  Results in spec order."""
+    convs = [ConvOp(t, layer, x, stats=t.training, need_input_grad=nig) for layer, x, _, _, nig in specs]
+    reduced: List[Optional[Tensor]] = [None] * len(specs)
+    if t.training and GROUP_SYNC_BN and len(specs) > 1:
+        sync = [i for i, (_, _, bn, _, _) in enumerate(specs) if bn_sync_world(bn, True) > 1]
+        if len(sync) > 1:
+            views = allreduce_partial_rows_many([(convs[i].partial, convs[i].rows, convs[i].count, None) for i in sync])
+            for i, v in zip(sync, views):
+                reduced[i] = v
+    return [BnOp(t, conv, bn, relu, reduced=r).lazy for conv, (_, _, bn, relu, _), r in zip(convs, specs, reduced)]
 
 
 POS_FUSE = os.environ.get("RV3D_NO_POS_FUSE") is None

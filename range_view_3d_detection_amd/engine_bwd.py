@@ -187,9 +187,7 @@ def _pos_pair_backward(op: "E.ConvOp", t: Tape, dy2: Act) -> None:
     dw = torch.empty((cp, cin), dtype=torch.float32, device=dev)
     g01 = None
     if sk.sync_world > 1:  # SyncBN: the normalisation needs the GLOBAL (sum g, sum g*xhat); the other sums stay this rank's (as _smallk_grads)
-        g01 = sums[: 2 * cp].clone()
-        E.COLLECTIVES.add(g01)
-        torch.distributed.all_reduce(g01)
+        g01 = _global_s01(sums, cp, pixels)
     L.call("rv_bn_bwd_smallk_from_sums", L.i32(cp), L.i32(cin), L.ptr(sums), L.ptr(moms), L.ptr(g01), L.ptr(wp0), L.i32(E.pad32(cin)),
            L.ptr(sk.gamma_p), L.ptr(sk.mean), L.ptr(sk.invstd), L.i64(sk.count), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dw), L.stream_ptr())
     c = bn0.num_features
@@ -197,6 +195,17 @@ def _pos_pair_backward(op: "E.ConvOp", t: Tape, dy2: Act) -> None:
     t.add_param_grad(bn0.bias, dbeta[:c])
     t.add_param_grad(lay0.weight, lay0.unpermute_grad(dw[: lay0.c_out].reshape(lay0.c_out, cin, 1, 1).contiguous()))
     sk.grads_done = True
+
+
+def _global_s01(sums: Tensor, cp: int, pixels: int) -> Tensor:
+    """All-reduced (sum g, sum g*xhat) of a small-K layer with this rank's pixel count in the slot behind them: the finalize
+    kernel reads the GLOBAL count there (``count = -1``), so no value comes back to the host."""
+    g01 = torch.empty(2 * cp + 1, dtype=torch.float64, device=sums.device)
+    g01[: 2 * cp] = sums[: 2 * cp]
+    g01[2 * cp] = float(pixels)
+    E.COLLECTIVES.add(g01)
+    E.all_reduce_(g01)
+    return g01
 
 
 def _smallk_grads(t: Tape, pixels: int, cp: int, dout: Act, mask: Optional[Act], y: Optional[Act], scale, shift, mean, invstd, flags: int, v: Act,
@@ -218,11 +227,9 @@ def _smallk_grads(t: Tape, pixels: int, cp: int, dout: Act, mask: Optional[Act],
         sums = torch.empty((2 + cin_pad) * cp, dtype=torch.float64, device=dev)
         moms = torch.empty(cin_pad + cin_pad * cin_pad, dtype=torch.float64, device=dev)
         L.call("rv_bn_bwd_smallk_sums", *head, L.ptr(sums), L.ptr(moms), L.ptr(ws), L.stream_ptr())
-        g01 = sums[: 2 * cp].clone()
-        E.COLLECTIVES.add(g01)
-        torch.distributed.all_reduce(g01)  # SyncBN: global (sum g, sum g*xhat); the other sums stay this rank's
+        g01 = _global_s01(sums, cp, pixels)  # SyncBN: global (sum g, sum g*xhat, pixel count); the other sums stay this rank's
         L.call("rv_bn_bwd_smallk_from_sums", L.i32(cp), L.i32(cin), L.ptr(sums), L.ptr(moms), L.ptr(g01), L.ptr(wp), L.i32(E.pad32(cin)),
-               L.ptr(gamma_p), L.ptr(stat_mean), L.ptr(stat_invstd), L.i64(count), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dw), L.stream_ptr())
+               L.ptr(gamma_p), L.ptr(stat_mean), L.ptr(stat_invstd), L.i64(-1), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dw), L.stream_ptr())
     else:
         L.call("rv_bn_bwd_smallk", *head, L.ptr(gamma_p), L.ptr(stat_mean), L.ptr(stat_invstd), L.i64(count),
                L.ptr(dgamma), L.ptr(dbeta), L.ptr(dw), L.ptr(ws), L.stream_ptr())
@@ -233,13 +240,24 @@ SMALLK_FUSION = os.environ.get("RV3D_NO_SMALLK") is None
 
 
 def bn_backward(op: "E.BnOp", t: Tape) -> None:
+    rec = bn_backward_begin(op, t)
+    if rec is not None:
+        bn_backward_finish([rec], t)
+
+
+def bn_backward_begin(op: "E.BnOp", t: Tape):
+    """First half of a BatchNorm backward: this rank's (sum g, sum g*xhat) rows (from the backward-data epilogue that wrote the
+    gradient, or a reduce pass).  Returns a record for ``bn_backward_finish``, or None when the op was completed here (no
+    gradient arrived; the MetaKernel / small-K fused forms, which carry their own collectives)."""
     lazy = op.lazy
     meta = t.meta_in.pop(id(lazy), None)
     if meta is not None:
-        return _bn_backward_meta(op, t, meta)
+        assert id(lazy) not in t.lazy_in, "the positional Lazy behind the MetaKernel modulation has exactly one consumer"
+        _bn_backward_meta(op, t, meta)
+        return None
     entry = t.lazy_in.pop(id(lazy), None)
     if entry is None:
-        return
+        return None
     dout, mask, res = entry if len(entry) == 3 else (entry[0], entry[1], None)
     st, raw = lazy.bn, lazy.raw
     if st.mean is None:
@@ -259,7 +277,7 @@ def bn_backward(op: "E.BnOp", t: Tape) -> None:
         t.add_param_grad(st.module.weight, dgamma[:c])
         t.add_param_grad(st.module.bias, dbeta[:c])
         t.add_param_grad(lay.weight, lay.unpermute_grad(dw[: lay.c_out].reshape(lay.c_out, cin, 1, 1).contiguous()))
-        return
+        return None
     common = (L.i64(pixels), L.i32(cp), dout.ptr(), L.i32(dout.ld), mask.ptr() if mask is not None else None,
               L.i32(mask.ld if mask is not None else 0), raw.ptr(), L.i32(raw.ld), L.ptr(st.scale), L.ptr(st.shift),
               L.ptr(st.mean), L.ptr(st.invstd))
@@ -270,37 +288,57 @@ def bn_backward(op: "E.BnOp", t: Tape) -> None:
         rows = L.load().rv_bn_bwd_rows(L.i64(pixels))
         partial = torch.empty((rows + L.STATS_SCRATCH_ROWS, 2, cp), dtype=torch.float32, device=t.device)
         L.call("rv_bn_bwd_reduce", *common, L.i32(flags), L.ptr(partial), L.stream_ptr())
-    dgamma, dbeta, coef = _bn_finalize(op, t, partial, rows, pixels)
-    dy = raw.like()
-    if res is not None:
-        rg, racc = res
-        L.call("rv_bn_bwd_apply", *common, L.ptr(coef), L.i32(flags | (L.BNB_RES_ACCUM if racc else 0)), dy.ptr(), L.i32(dy.ld),
-               rg.ptr(), L.i32(rg.ld), L.stream_ptr())
-    else:
-        L.call("rv_bn_bwd_apply", *common, L.ptr(coef), L.i32(flags), dy.ptr(), L.i32(dy.ld), None, L.i32(0), L.stream_ptr())
-    t.raw_grad[id(raw)] = dy
-    c = st.module.num_features
-    t.add_param_grad(st.module.weight, dgamma[:c])
-    t.add_param_grad(st.module.bias, dbeta[:c])
+    return (op, common, partial, rows, pixels, flags, res, (dout, mask))  # (dout / mask referenced until the apply pass has been issued)
 
 
-def _bn_finalize(op: "E.BnOp", t: Tape, partial: Tensor, rows: int, pixels: int):
-    """(dgamma, dbeta, coef) from the partial (sum g, sum g*xhat) rows; SyncBN: the coefficients from the all-reduced totals."""
+def bn_backward_finish(recs, t: Tape) -> None:
+    """Second half for a run of independent BatchNorm layers: ONE all-reduce of all their sums under SyncBN, then per layer
+    the coefficients and the apply pass (gradient w.r.t. the raw conv output)."""
+    glob = [None] * len(recs)
+    local = [None] * len(recs)
+    sync = [i for i, r in enumerate(recs) if r[0].sync_world > 1]
+    if sync:
+        for i in sync:  # this rank's own (sum g, sum g*xhat) = (dbeta, dgamma): written by the same launch that fills the all-reduce buffer
+            local[i] = torch.empty((2, recs[i][0].lazy.raw.cp), dtype=torch.float32, device=t.device)
+        views = E.allreduce_partial_rows_many([(recs[i][2], recs[i][3], recs[i][4], local[i]) for i in sync])
+        for i, v in zip(sync, views):
+            glob[i] = v
+    for (op, common, partial, rows, pixels, flags, res, _keep), g, loc in zip(recs, glob, local):
+        lazy = op.lazy
+        st, raw = lazy.bn, lazy.raw
+        dgamma, dbeta, coef = _bn_finalize(op, t, partial, rows, pixels, glob=g, local=loc)
+        dy = raw.like()
+        if res is not None:
+            rg, racc = res
+            L.call("rv_bn_bwd_apply", *common, L.ptr(coef), L.i32(flags | (L.BNB_RES_ACCUM if racc else 0)), dy.ptr(), L.i32(dy.ld),
+                   rg.ptr(), L.i32(rg.ld), L.stream_ptr())
+        else:
+            L.call("rv_bn_bwd_apply", *common, L.ptr(coef), L.i32(flags), dy.ptr(), L.i32(dy.ld), None, L.i32(0), L.stream_ptr())
+        t.raw_grad[id(raw)] = dy
+        c = st.module.num_features
+        t.add_param_grad(st.module.weight, dgamma[:c])
+        t.add_param_grad(st.module.bias, dbeta[:c])
+
+
+def _bn_finalize(op: "E.BnOp", t: Tape, partial: Tensor, rows: int, pixels: int, glob: Optional[Tensor] = None, local: Optional[Tensor] = None):
+    """(dgamma, dbeta, coef) from the partial (sum g, sum g*xhat) rows; SyncBN: the coefficients from the all-reduced totals
+    (``glob`` / ``local``: already reduced in a group, else reduced here)."""
     st, cp = op.lazy.bn, op.lazy.raw.cp
-    dgamma = torch.empty(cp, dtype=torch.float32, device=t.device)
-    dbeta = torch.empty(cp, dtype=torch.float32, device=t.device)
     coef = torch.empty((3, cp), dtype=torch.float32, device=t.device)
     if op.sync_world > 1:
         # SyncBN backward: the normalisation coefficients need the GLOBAL (sum g, sum g*xhat) and count -> one RCCL
-        # all-reduce; dgamma / dbeta stay LOCAL sums (DDP averages parameter gradients over ranks, as under torch SyncBatchNorm).
-        glob = E.allreduce_partial_rows(partial, rows, pixels)  # (its rv_reduce_rows leaves `partial` untouched)
-        L.call("rv_bn_bwd_finalize", L.ptr(partial), L.i32(rows), L.i32(cp), L.i64(pixels), L.ptr(op.gamma_p), L.ptr(st.invstd),
-               L.ptr(dgamma), L.ptr(dbeta), L.i32(0), L.ptr(coef), L.stream_ptr())  # local dgamma / dbeta (coef overwritten below)
+        # all-reduce; dgamma / dbeta stay LOCAL sums (DDP averages parameter gradients over ranks, as under torch
+        # SyncBatchNorm): they are this rank's totals, copied out by the launch that filled the all-reduce buffer
+        if glob is None:
+            local = torch.empty((2, cp), dtype=torch.float32, device=t.device)
+            glob = E.allreduce_partial_rows(partial, rows, pixels, local)
         L.call("rv_bn_bwd_finalize", L.ptr(glob), L.i32(1), L.i32(cp), L.i64(-1), L.ptr(op.gamma_p), L.ptr(st.invstd),
                None, None, L.i32(0), L.ptr(coef), L.stream_ptr())
-    else:
-        L.call("rv_bn_bwd_finalize", L.ptr(partial), L.i32(rows), L.i32(cp), L.i64(st.count), L.ptr(op.gamma_p), L.ptr(st.invstd),
-               L.ptr(dgamma), L.ptr(dbeta), L.i32(0), L.ptr(coef), L.stream_ptr())
+        return local[1], local[0], coef
+    dgamma = torch.empty(cp, dtype=torch.float32, device=t.device)
+    dbeta = torch.empty(cp, dtype=torch.float32, device=t.device)
+    L.call("rv_bn_bwd_finalize", L.ptr(partial), L.i32(rows), L.i32(cp), L.i64(st.count), L.ptr(op.gamma_p), L.ptr(st.invstd),
+           L.ptr(dgamma), L.ptr(dbeta), L.i32(0), L.ptr(coef), L.stream_ptr())
     return dgamma, dbeta, coef
 
 

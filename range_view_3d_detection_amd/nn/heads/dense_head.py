@@ -57,7 +57,7 @@ def forward_pair(cls_head: DenseHead, reg_head: DenseHead, x: Tensor):
 
     def build(t, xin):
         a = Act.from_nchw(xin)
-        return [a], [program.dense_head_program(t, cls_head, a), program.dense_head_program(t, reg_head, a)]
+        return [a], list(program.dense_head_pair_program(t, cls_head, reg_head, a))
 
     params = [p for p in cls_head.parameters()] + [p for p in reg_head.parameters()]
     logits, regressands = program._ProgramFn.apply(build, cls_head.training, 1, x, *params)

@@ -25,7 +25,15 @@ from .engine import Act, Lazy, Operand, Tape
 def basic_block_program(t: Tape, m: nn.Module, x: Operand, out: Optional[Act] = None, need_input_grad: bool = True) -> Act:
     """``BasicBlock.forward`` (nn/blocks/__init__.py:68-81): relu_(net(x) + proj(x))."""
     c1, bn1, _, c2, bn2 = m.net
-    h1 = E.conv_bn(t, E.tap_layer(c1.conv), x, bn1, relu=True, need_input_grad=need_input_grad)
+    l1 = E.tap_layer(c1.conv)
+    if m.projection_block is not None and not E._smallk_eligible(l1, x, True, need_input_grad):
+        # net.0 and the projection conv read the same input: both convs first, then both BatchNorms (under SyncBN their
+        # statistics travel in ONE all-reduce, forward and backward -- engine.conv_bn_many)
+        pc, pbn = m.projection_block
+        h1, res = E.conv_bn_many(t, [(l1, x, bn1, True, need_input_grad), (E.tap_layer(pc.conv), x, pbn, False, need_input_grad)])
+        h2 = E.conv_bn(t, E.tap_layer(c2.conv), h1, bn2, relu=False)
+        return E.CombineOp(t, h2, res, relu_out=True, out=out).out
+    h1 = E.conv_bn(t, l1, x, bn1, relu=True, need_input_grad=need_input_grad)
     h2 = E.conv_bn(t, E.tap_layer(c2.conv), h1, bn2, relu=False)
     if m.projection_block is not None:
         pc, pbn = m.projection_block
@@ -123,6 +131,21 @@ def dense_head_program(t: Tape, m: nn.Module, x: Act) -> E.ConvOp:
     for blk in blocks[:-1]:
         h = E.conv_bn(t, E.tap_layer(blk[0]), h, blk[1], relu=True)
     return E.ConvOp(t, E.tap_layer(blocks[-1][0]), h, stats=False, out_f32=True)
+
+
+def dense_head_pair_program(t: Tape, cls_head: nn.Module, reg_head: nn.Module, x: Act) -> Tuple[E.ConvOp, E.ConvOp]:
+    """The classification and the regression tower of one (stride, task), layer by layer side by side: layer i of both towers
+    is launched before either BatchNorm is finalised, so that under SyncBN the two layers share one all-reduce in each
+    direction (``engine.conv_bn_many``).  Same arithmetic as two ``dense_head_program`` calls."""
+    ca, cb = list(cls_head.blocks), list(reg_head.blocks)
+    if len(ca) != len(cb):
+        return dense_head_program(t, cls_head, x), dense_head_program(t, reg_head, x)
+    ha: Operand = x
+    hb: Operand = x
+    for ba, bb in zip(ca[:-1], cb[:-1]):
+        ha, hb = E.conv_bn_many(t, [(E.tap_layer(ba[0]), ha, ba[1], True, True), (E.tap_layer(bb[0]), hb, bb[1], True, True)])
+    return (E.ConvOp(t, E.tap_layer(ca[-1][0]), ha, stats=False, out_f32=True),
+            E.ConvOp(t, E.tap_layer(cb[-1][0]), hb, stats=False, out_f32=True))
 
 
 # ---------------------------------------------------------------------------------------------

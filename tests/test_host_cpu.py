@@ -150,8 +150,17 @@ dist.all_gather(gathered, digest)
 g = torch.Generator().manual_seed(rank)
 partial = torch.randn(5 + 128, 2, 32, generator=g)
 E.COLLECTIVES.reset()
+local = torch.zeros(2, 32)
+glob = E.allreduce_partial_rows(partial, 5, 1000 + 7 * rank, local)   # flat (2C + 1): totals, then the global count
+tot = glob[:64].view(2, 32)
+local_ok = torch.allclose(local, partial[:5].sum(0), atol=1e-5)
+# several layers in ONE collective (conv_bn_many / the grouped backward): same totals, one call
+E.COLLECTIVES.reset()
+p2 = torch.randn(3 + 128, 2, 8, generator=g)
+views = E.allreduce_partial_rows_many([(partial, 5, 1000 + 7 * rank, None), (p2, 3, 10 + rank, None)])
+group_ok = E.COLLECTIVES.calls == 1 and torch.allclose(views[0][:64].view(2, 32), tot) and float(views[1][16]) == sum(10 + r for r in range(world))
+E.COLLECTIVES.reset()
 glob = E.allreduce_partial_rows(partial, 5, 1000 + 7 * rank)
-tot = glob[0]
 count_ok = float(glob.view(-1)[64]) == sum(1000 + 7 * r for r in range(world)) and E.COLLECTIVES.calls == 1 and E.COLLECTIVES.bytes == 65 * 4
 ref = torch.stack([torch.randn(5 + 128, 2, 32, generator=torch.Generator().manual_seed(r))[:5].sum(0) for r in range(world)]).sum(0)
 # (2b) which BatchNorm holders are synchronised (engine.SYNC_BN = None: decided per layer)
@@ -171,7 +180,7 @@ E.SYNC_BN = None
 t = torch.tensor([1.0 + rank], dtype=torch.float64)
 dist.all_reduce(t, op=dist.ReduceOp.MAX)
 out = {"rank": rank, "digests": [float(x) for x in gathered], "stats_err": float((tot - ref).abs().max()), "tmax": float(t),
-       "count_ok": bool(count_ok), "rules": rules}
+       "count_ok": bool(count_ok and local_ok and group_ok), "rules": rules}
 print("RESULT " + json.dumps(out), flush=True)
 dist.destroy_process_group()
 """
