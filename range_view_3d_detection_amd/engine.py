@@ -693,7 +693,7 @@ class ConvOp(Op):
             sc = sh = None
             flags = 0
         elif (isinstance(x, Lazy) and MATERIALIZE_FOR_DMA and not out_f32 and form == "gather" and g.stride_w > 1 and g.kh * g.kw > 1
-              and layer.fold_geom() is not None and src.ld == src.cp
+              and layer.fold_geom() is not None and src.ld == src.cp and src.W == g.stride_w * wu
               and _dma_eligible(layer.fold_geom(), src.N, src.H, wu, wu, g.stride_w * src.ld, pad32(layer.c_out), False)):
             # strided multi-tap conv fed by a folded BatchNorm+ReLU: written out once, the FOLDED stride-1 form (forward and
             # weight gradient) then runs on the LDS-DMA kernels instead of the generic strided ones
@@ -719,7 +719,8 @@ class ConvOp(Op):
         # a strided gather (stride-2 conv forward) runs on the stride-1 FOLDED view when the LDS-DMA kernels take that
         lg, lshape, wp = g, self.shape, None
         gf = layer.fold_geom() if (form == "gather" and g.stride_w > 1 and sc is None and flags & (L.IN_AFFINE | L.IN_RELU) == 0) else None
-        if gf is not None and src.ld == src.cp and _dma_eligible(gf, src.N, src.H, wu, wu, g.stride_w * src.ld, ld_dst, False):
+        # (the folded view reads row pitch wu * s * ld: only when the fine width is exactly s * wu -- an odd width keeps the generic kernel)
+        if gf is not None and src.ld == src.cp and src.W == g.stride_w * wu and _dma_eligible(gf, src.N, src.H, wu, wu, g.stride_w * src.ld, ld_dst, False):
             lg = gf
             lshape = L.TapShape(src.N, src.H, wu, wu, g.stride_w * src.ld, ld_dst, self.shape.flags)
             wp = layer.packed_folded()

@@ -80,7 +80,8 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
         shape = L.TapShape(sp.N, sp.H, sp.Wu, sp.Wv, dout.ld, dst.ld, L.OUT_ACCUM if accumulate else 0)
         bg, bshape = g, shape
         gf = layer.fold_geom() if (bwd == "gather" and g.stride_w > 1) else None
-        if gf is not None and dout.ld == dout.cp and E._dma_eligible(gf, sp.N, sp.H, sp.Wu, sp.Wu, g.stride_w * dout.ld, dst.ld, False):
+        if (gf is not None and dout.ld == dout.cp and dout.W == g.stride_w * sp.Wu
+                and E._dma_eligible(gf, sp.N, sp.H, sp.Wu, sp.Wu, g.stride_w * dout.ld, dst.ld, False)):
             # backward-data of a ConvTranspose2d = a strided gather over dOut: stride-1 on the folded view (engine.FOLD_STRIDED)
             bg = gf
             bshape = L.TapShape(sp.N, sp.H, sp.Wu, sp.Wu, g.stride_w * dout.ld, dst.ld, shape.flags)
@@ -125,7 +126,7 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
     # strided layers: the weight gradient on the stride-1 FOLDED view of the fine tensor (wgrad3 instead of the generic kernel),
     # then rv_unfold_weight_grad picks the kernel's own entries out of the folded gradient
     wg, wsh, ld_v = g, wshape, v.ld
-    gfw = layer.fold_geom() if (g.stride_w > 1 and sc is None and in_flags == 0 and v.ld == v.cp) else None
+    gfw = layer.fold_geom() if (g.stride_w > 1 and sc is None and in_flags == 0 and v.ld == v.cp and v.W == g.stride_w * sp.Wu) else None
     if gfw is not None:
         wg, wsh, ld_v = gfw, L.TapShape(sp.N, sp.H, sp.Wu, sp.Wu, 0, 0, L.WGRAD_TORCH_LAYOUT), g.stride_w * v.ld
 

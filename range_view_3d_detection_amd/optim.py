@@ -94,8 +94,15 @@ class AdamW(torch.optim.Optimizer):
             plan["table"].copy_(plan["host"], non_blocking=True)
             plan["copied"] = torch.cuda.Event()
             plan["copied"].record()
-            step_t = self.state[ps[0]]["step"]
-            step = int(step_t.item()) + 1
+            # torch.optim.AdamW bias-corrects every parameter with ITS OWN step count; one launch covers all parameters (and the
+            # clipping norm is over all of them), so the counts must agree -- they do unless a parameter had no gradient on
+            # earlier steps (an unused branch, frozen then unfrozen): refuse that rather than correct it with another's count
+            steps = {float(self.state[p]["step"]) for p in ps}  # host scalars: no device sync
+            if len(steps) != 1:
+                raise NotImplementedError(
+                    f"optim.AdamW: parameters with different step counts {sorted(steps)} in one step (some had no gradient earlier); "
+                    "the fused launch applies one bias correction -- use torch.optim.AdamW for such a schedule")
+            step = int(steps.pop()) + 1
             for p in ps:
                 self.state[p]["step"] += 1
             beta1, beta2 = group["betas"]
