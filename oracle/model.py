@@ -54,6 +54,7 @@ class Numerics:
     operand: Callable[[Tensor], Tensor] = _identity  # applied to conv inputs and weights
     store: Callable[[Tensor], Tensor] = _identity  # applied to every tensor written to HBM
     running: Optional[StateDict] = None  # receives updated running_mean/var when train
+    trace: Optional[List[dict]] = None  # teacher-forcing record: one dict per conv (+ BatchNorm) unit, see ``_trace``
 
     @staticmethod
     def bf16(train: bool = True) -> "Numerics":
@@ -61,6 +62,19 @@ class Numerics:
 
 
 FP32 = Numerics()
+
+
+def _trace(nm: Numerics, y: Tensor, **rec) -> None:
+    """Per-layer record for the teacher-forced parity tests: the unit's input ``x`` (as the layer receives it, before the
+    operand rounding), its weight key, geometry, BatchNorm prefix and raw fp32 output ``y``; ``dy`` (the gradient w.r.t. the
+    raw output) is filled in by a hook when the run is differentiated."""
+    if nm.trace is None:
+        return
+    rec["y"] = y.detach()
+    rec["x"] = rec["x"].detach()
+    if y.requires_grad:
+        y.register_hook(lambda g, d=rec: d.__setitem__("dy", g.detach()))
+    nm.trace.append(rec)
 
 
 # --------------------------------------------------------------------------------------
@@ -131,6 +145,7 @@ def _conv_bn(
     nm: Numerics,
 ) -> Tensor:
     y = conv2d_same(x, sd[conv_key], stride, nm=nm)
+    _trace(nm, y, kind="conv", x=x, w=conv_key, stride=stride, bn=bn_prefix)
     return batch_norm(y, sd, bn_prefix, nm, y_stored=nm.store(y))
 
 
@@ -188,6 +203,7 @@ def aggregation_block(
     """ConvTranspose2d-BN-ReLU on x2, add to x1, ResidualBlock (``nn/blocks/__init__.py:146-182``)."""
     w = sd[f"{prefix}.upscale.weight"]  # (Cin, Cout, kh, kw)
     up = F.conv_transpose2d(nm.operand(x2), nm.operand(w), stride=stride, padding=padding)
+    _trace(nm, up, kind="convT", x=x2, w=f"{prefix}.upscale.weight", stride=stride, padding=padding, bn=f"{prefix}.normalization")
     up = F.relu(batch_norm(up, sd, f"{prefix}.normalization", nm, y_stored=nm.store(up)))
     return residual_block(nm.store(x1 + up), sd, f"{prefix}.block", num_blocks, nm=nm)
 
@@ -198,6 +214,7 @@ def aggregation_block(
 def _conv_norm_act(x: Tensor, sd: StateDict, prefix: str, nm: Numerics) -> Tensor:
     """torchvision ``Conv2dNormActivation`` with k=1: conv(no bias) -> BN -> ReLU."""
     y = F.conv2d(nm.operand(x), nm.operand(sd[f"{prefix}.0.weight"]))
+    _trace(nm, y, kind="conv1x1", x=x, w=f"{prefix}.0.weight", stride=(1, 1), bn=f"{prefix}.1")
     return F.relu(batch_norm(y, sd, f"{prefix}.1", nm, y_stored=nm.store(y)))
 
 
@@ -300,10 +317,13 @@ def dense_head(x: Tensor, sd: StateDict, prefix: str, num_blocks: int = 4, nm: N
     for i in range(num_blocks):
         w = sd[f"{prefix}.blocks.{i}.0.weight"]
         y = conv2d_same(h, w, nm=nm)  # padding="same", odd k => symmetric
+        _trace(nm, y, kind="conv", x=h, w=f"{prefix}.blocks.{i}.0.weight", stride=(1, 1), bn=f"{prefix}.blocks.{i}.1")
         h = nm.store(F.relu(batch_norm(y, sd, f"{prefix}.blocks.{i}.1", nm, y_stored=nm.store(y))))
     w = sd[f"{prefix}.blocks.{num_blocks}.0.weight"]
     b = sd[f"{prefix}.blocks.{num_blocks}.0.bias"]
-    return conv2d_same(h, w, bias=b, nm=nm)
+    out = conv2d_same(h, w, bias=b, nm=nm)
+    _trace(nm, out, kind="conv", x=h, w=f"{prefix}.blocks.{num_blocks}.0.weight", stride=(1, 1), bn=None, bias=f"{prefix}.blocks.{num_blocks}.0.bias")
+    return out
 
 
 def detector_forward(
