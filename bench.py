@@ -249,7 +249,9 @@ def forward_only_leg(model, batch, n_cls: int, dev, warmup: int = 5, iters: int 
 
     times = {"backbone": [], "head": [], "decoder": []}
     boxes = 0
-    with torch.no_grad():
+    # fp16 autocast: what the reference's harness and validation_step run under (tools/benchmark.py:84-88, detector.py:329-333):
+    # the eval programs then run on the fp16-operand build of the library (librv3d_hip_f16.so)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
         for i in range(warmup + iters):
             feats, tb = stage(lambda: backbone(batch))
             (out, _), th = stage(lambda: head(feats, batch, return_loss=False))
@@ -279,7 +281,7 @@ def forward_only_leg(model, batch, n_cls: int, dev, warmup: int = 5, iters: int 
     return {"workload": f"rv-av2 eval forward + decode + weighted NMS, {B} synthetic 64x2048x5 sweeps (BASELINE configs[1]); stages synchronised as tools/benchmark.py:231-238",
             "batch": B, "ms_per_batch": {k: round(v, 3) for k, v in mean.items()}, "ms_per_batch_total": round(total, 3),
             "ms_per_sweep": round(total / B, 3), "sweeps_per_s": round(1e3 * B / total, 2), "ms_per_batch_pipelined": round(pipelined, 3),
-            "sweeps_per_s_pipelined": round(1e3 * B / pipelined, 2), "boxes_out_per_batch": boxes, "dtype": "bf16",
+            "sweeps_per_s_pipelined": round(1e3 * B / pipelined, 2), "boxes_out_per_batch": boxes, "dtype": "f16",
             "dominant_kernel": {k: roof.get(k) for k in ("kernel", "achieved", "peak", "unit", "frac", "launches", "avg_launch_us")}}
 
 

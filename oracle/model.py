@@ -61,6 +61,17 @@ class Numerics:
         return Numerics(train=train, operand=round_bf16, store=round_bf16, running={})
 
 
+def round_fp16(x: Tensor) -> Tensor:
+    """Round-to-nearest-even to fp16 and back (the storage points of the reference's evaluation under
+    ``torch.autocast(dtype=torch.float16)``, ``nn/arch/detector.py:329-340``, and of the fp16-operand HIP build)."""
+    return x.to(torch.float16).to(torch.float32)
+
+
+def _numerics_fp16(train: bool = False) -> "Numerics":
+    return Numerics(train=train, operand=round_fp16, store=round_fp16, running={})
+
+
+Numerics.fp16 = staticmethod(_numerics_fp16)
 FP32 = Numerics()
 
 

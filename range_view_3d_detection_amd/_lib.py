@@ -16,6 +16,8 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RV3D_LIB") or os.path.join(_HERE, "librv3d_hip.so")  # (RV3D_LIB: A/B of two builds in one gpurun call)
+# the same sources built with fp16 operands (csrc/common.h, RV_OPERAND_F16): inference under torch.autocast(dtype=float16)
+LIB_PATH_F16 = os.environ.get("RV3D_LIB_F16") or os.path.join(_HERE, "librv3d_hip_f16.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "rv3d.h")
 
 # flags (mirror include/rv3d.h)
@@ -46,6 +48,37 @@ class RvError(RuntimeError):
 
 
 _lib: Optional[ctypes.CDLL] = None
+_lib_f16: Optional[ctypes.CDLL] = None
+_OPERAND = "bf16"  # the operand type of the calls being issued: "bf16" (librv3d_hip.so) or "f16" (librv3d_hip_f16.so)
+
+
+class operand:
+    """``with operand("f16"):`` -- every ``call`` / ``load`` inside goes to the fp16-operand build of the library, and
+    ``act_dtype()`` is ``torch.float16``.  Set by ``program._ProgramFn`` for an eval-mode program under
+    ``torch.autocast(dtype=torch.float16)`` (the reference's ``eval_precision: 16``)."""
+
+    def __init__(self, tag: str) -> None:
+        if tag not in ("bf16", "f16"):
+            raise RvError(f"unknown operand type {tag!r}")
+        self.tag = tag
+
+    def __enter__(self):
+        global _OPERAND
+        self.old, _OPERAND = _OPERAND, self.tag
+        return self
+
+    def __exit__(self, *exc):
+        global _OPERAND
+        _OPERAND = self.old
+
+
+def operand_tag() -> str:
+    return _OPERAND
+
+
+def act_dtype() -> "torch.dtype":
+    """torch dtype of the 16-bit activation tensors of the current operand type."""
+    return torch.float16 if _OPERAND == "f16" else torch.bfloat16
 
 
 def declared_symbols() -> List[str]:
@@ -55,13 +88,22 @@ def declared_symbols() -> List[str]:
     return sorted(set(re.findall(r"\b(rv_[a-z0-9_]+)\s*\(", text)))
 
 
-def load() -> ctypes.CDLL:
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(tag: Optional[str] = None) -> ctypes.CDLL:
+    global _lib, _lib_f16
+    tag = tag or _OPERAND
+    if tag == "f16":
+        if _lib_f16 is None:
+            _lib_f16 = _dlopen(LIB_PATH_F16)
+        return _lib_f16
+    if _lib is None:
+        _lib = _dlopen(LIB_PATH)
+    return _lib
+
+
+def _dlopen(path: str) -> ctypes.CDLL:
+    if not os.path.exists(path):
         raise RvError(
-            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
         )
     # Load order matters on a GPU box: the library registers its code objects with the HIP runtime when it is loaded, and
@@ -70,12 +112,11 @@ def load() -> ctypes.CDLL:
     # touch the GPU, so CPU-only boxes (the build check) pass through.
     if torch.cuda.device_count() > 0 and torch.cuda.is_available():
         torch.cuda.init()
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     lib.rv_last_error.restype = ctypes.c_char_p
     for name in ("rv_packed_weight_bytes", "rv_decode_num_candidates", "rv_wnms_workspace_bytes", "rv_tap_wgrad_workspace_bytes", "rv_bn_bwd_smallk_workspace_bytes", "rv_smallk_forward_workspace_bytes", "rv_nms_sweeps_workspace_bytes", "rv_pack_batch_entry_bytes"):
         if hasattr(lib, name):
             getattr(lib, name).restype = ctypes.c_int64
-    _lib = lib
     return lib
 
 

@@ -7,8 +7,22 @@
 
 #include "../../include/rv3d.h"
 
-typedef uint16_t bf16_t;  // storage type of bf16 tensors
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+// 16-bit OPERAND type of the MFMA kernels.  The library is built twice from the same sources (csrc/Makefile):
+//   librv3d_hip.so      operands bf16 -- training (the reference trains in `precision: bf16-mixed`, conf/trainer/train.yaml:14)
+//   librv3d_hip_f16.so  operands fp16 (-DRV_OPERAND_F16) -- inference under `torch.autocast(dtype=torch.float16)`, which is what
+//                       the reference evaluates in (nn/arch/detector.py:329-340, conf/model/range_view.yaml:26 eval_precision: 16)
+// Same tiles, same staging, same schedules: only the element conversions below and the MFMA opcode differ
+// (v_mfma_f32_16x16x32_f16 issues at the bf16 rate).  The `bf16` in identifiers (bf16_t, f2bf, bf16x8 ...) reads "the
+// 16-bit operand type" in the fp16 build.
+typedef uint16_t bf16_t;  // storage type of the 16-bit tensors
+#ifdef RV_OPERAND_F16
+typedef _Float16 rv_elem_t;
+#define RV_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#else
+typedef __bf16 rv_elem_t;
+#define RV_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#endif
+typedef __attribute__((ext_vector_type(8))) rv_elem_t bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
@@ -39,6 +53,16 @@ static inline int rv_pad32(int c) { return (c + 31) & ~31; }
 // ---------------------------------------------------------------------------------------
 // bf16 <-> f32
 // ---------------------------------------------------------------------------------------
+#ifdef RV_OPERAND_F16
+__device__ __forceinline__ float bf2f(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+__device__ __forceinline__ float bf_lo(uint32_t packed) { return (float)__builtin_bit_cast(_Float16, (uint16_t)packed); }
+__device__ __forceinline__ float bf_hi(uint32_t packed) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(packed >> 16)); }
+// round-to-nearest-even (v_cvt_f16_f32); values beyond 65504 become infinities, as under torch.autocast(float16)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    _Float16 h = (_Float16)f;
+    return __builtin_bit_cast(bf16_t, h);
+}
+#else
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 __device__ __forceinline__ float bf_lo(uint32_t packed) { return __uint_as_float(packed << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t packed) { return __uint_as_float(packed & 0xffff0000u); }
@@ -47,6 +71,7 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     __bf16 b = (__bf16)f;
     return __builtin_bit_cast(bf16_t, b);
 }
+#endif
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
     return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
 }

@@ -47,7 +47,7 @@ struct PosFwdArgs {
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef rv_elem_t bf16x2_t __attribute__((ext_vector_type(2)));
 // two floats -> one dword of bf16 (round to nearest even): ONE v_cvt_pk_bf16_f32
 __device__ __forceinline__ uint32_t pack2(const f32x2 v) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t)); }
 __device__ __forceinline__ f32x2 max0(const f32x2 v) { return f32x2{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)}; }
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(512, 1) void pos_fwd_kernel(const PosFwdArgs a) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const f32x4 c0 = ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[i][j];
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j][ks], fa[ks & 3][i], c0, 0, 0, 0);
+                        acc[i][j] = RV_MFMA_16x16x32(fw[j][ks], fa[ks & 3][i], c0, 0, 0, 0);
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(512, 1) void pos_bwd_kernel(const PosBwdArgs a) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const f32x4 c0 = ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[i][j];
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks & 3][i], fw[j][ks], c0, 0, 0, 0);
+                        acc[i][j] = RV_MFMA_16x16x32(fa[ks & 3][i], fw[j][ks], c0, 0, 0, 0);
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void tapconv_kernel(const TapConvArgs a) {
                     const bf16x8 fa = *(const bf16x8*)(pa + i * 16 * S * kPix);
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = RV_MFMA_16x16x32(fa, fb[j], acc[i][j], 0, 0, 0);
                 }
             }
             write_b(buf ^ 1);

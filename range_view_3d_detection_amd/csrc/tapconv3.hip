@@ -209,7 +209,7 @@ __global__ __launch_bounds__(512, 2) void tapconv3_kernel(const TapConvArgs a) {
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = RV_MFMA_16x16x32(fa[i], fb[j], acc[i][j], 0, 0, 0);
                     __builtin_amdgcn_s_setprio(0);
                     __builtin_amdgcn_sched_barrier(0);
                 }

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(512, 2) void tapconv4_kernel(const TapConvArgs a) {
 #define RV_MFMA_HALF(MQ, NQ, FB, KS)                                                                               \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                 \
         acc[(MQ) * 4 + i][(NQ) * 2 + jj] =                                                                         \
-            __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][KS], FB[jj][KS], acc[(MQ) * 4 + i][(NQ) * 2 + jj], 0, 0, 0);
+            RV_MFMA_16x16x32(fa[i][KS], FB[jj][KS], acc[(MQ) * 4 + i][(NQ) * 2 + jj], 0, 0, 0);
 #define RV_PHASE_COMPUTE(MQ, NQ, FB, STAGE)                \
     __builtin_amdgcn_s_barrier();                          \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \

@@ -25,7 +25,7 @@
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) rv_elem_t bf16x4;
 
 struct WgradArgs {
     const bf16_t* U;
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
                 const bf16x8 fa = frag(&lds[buf][0][0], wm * 64 + i * 16);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = RV_MFMA_16x16x32(fa, fb[j], acc[i][j], 0, 0, 0);
             }
             if (has_next) store(buf ^ 1);
             __syncthreads();
@@ -389,7 +389,7 @@ __device__ __forceinline__ void wgrad2_body(const Wgrad2Args& a, bf16_t (*lds)[2
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int j = 0; j < 2; ++j)
-                            acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[t][i][j], 0, 0, 0);
+                            acc[t][i][j] = RV_MFMA_16x16x32(fa[i], fb[j], acc[t][i][j], 0, 0, 0);
                 }
             }
             if (has_next) store(buf ^ 1);
@@ -611,8 +611,8 @@ __device__ __forceinline__ void wgrad3_body(const Wgrad2Args& a, uint8_t* smem) 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bf16x8 ai = w3_join(fa[kk & 1][i]);
-            acc[t][i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ai, b0, acc[t][i][0], 0, 0, 0);
-            acc[t][i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ai, b1, acc[t][i][1], 0, 0, 0);
+            acc[t][i][0] = RV_MFMA_16x16x32(ai, b0, acc[t][i][0], 0, 0, 0);
+            acc[t][i][1] = RV_MFMA_16x16x32(ai, b1, acc[t][i][1], 0, 0, 0);
         }
     };
     // The two halves of the workgroup (waves w and w + 4 share a SIMD) issue their DMA at different points of the chunk -- half A

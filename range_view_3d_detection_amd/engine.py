@@ -252,7 +252,7 @@ class Act:
     __slots__ = ("data", "c", "parent", "c0", "_rv_owned")
 
     def __init__(self, data: Tensor, c: Optional[int] = None, parent: Optional["Act"] = None, c0: int = 0) -> None:
-        assert data.dtype == torch.bfloat16 and data.dim() == 4 and data.stride(3) == 1
+        assert data.dtype in (torch.bfloat16, torch.float16) and data.dim() == 4 and data.stride(3) == 1
         self.data = data
         self.c = data.shape[3] if c is None else c  # logical channels (<= stored, stored is a multiple of 32)
         self.parent = parent
@@ -262,7 +262,7 @@ class Act:
     @staticmethod
     def empty(n: int, h: int, w: int, c: int, device, zero: bool = False) -> "Act":
         cp = pad32(c)
-        data = (torch.zeros if zero else torch.empty)((n, h, w, cp), dtype=torch.bfloat16, device=device)
+        data = (torch.zeros if zero else torch.empty)((n, h, w, cp), dtype=L.act_dtype(), device=device)
         return Act(data, c)
 
     @property
@@ -305,10 +305,11 @@ class Act:
 
     @staticmethod
     def from_nchw(x: Tensor) -> "Act":
-        """Any (N,C,H,W) CUDA tensor -> Act (zero-copy when it already is bf16 channels_last with C % 32 == 0)."""
+        """Any (N,C,H,W) CUDA tensor -> Act (zero-copy when it already is channels_last with C % 32 == 0 in the operand type of
+        the program being built: bf16, or fp16 for an eval program under autocast(float16))."""
         n, c, h, w = x.shape
         nhwc = x.permute(0, 2, 3, 1)
-        if x.dtype == torch.bfloat16 and c % 32 == 0 and nhwc.is_contiguous():
+        if x.dtype == L.act_dtype() and c % 32 == 0 and nhwc.is_contiguous():
             return Act(nhwc, c)
         out = Act.empty(n, h, w, c, x.device, zero=(c % 32 != 0))
         out.data[..., :c].copy_(nhwc)
@@ -488,6 +489,15 @@ class TapLayer:
 
     def packed_folded(self) -> Tensor:
         """bf16 gather image of the folded form; re-packed with the other images when the parameter changed."""
+        if L.operand_tag() != "bf16":  # (eval under autocast(float16): its own image, re-made when the parameter changed)
+            ver = (self.weight._version, self.weight.data_ptr())
+            hit = self.__dict__.get("_fold_f16")
+            if hit is None or hit[0] != ver:
+                n = L.load().rv_packed_weight_bytes(ctypes.byref(self.fold_geom())) // 2
+                img = torch.empty(n, dtype=L.act_dtype(), device=self.weight.device)
+                L.call("rv_pack_weight_folded", ctypes.byref(self.geom), L.ptr(self.weight.detach().contiguous().float()), L.ptr(img), L.stream_ptr())
+                self.__dict__["_fold_f16"] = hit = (ver, img)
+            return hit[1]
         ver = (self.weight._version, self.weight.data_ptr())
         if ver != self._fold_version or self._fold_image is None:
             gf = self.fold_geom()
@@ -513,11 +523,20 @@ class TapLayer:
         if ver != self._version:
             self._packed.clear()
             self._version = ver
+        if L.operand_tag() != "bf16":  # fp16 images (inference under autocast(float16)): their own cache entries, packed by that build
+            key = form + ":" + L.operand_tag()
+            if key not in self._packed:
+                nbytes = L.load().rv_packed_weight_bytes(ctypes.byref(self.geom))
+                buf = torch.empty(nbytes // 2, dtype=L.act_dtype(), device=self.weight.device)
+                L.call("rv_pack_weight", ctypes.byref(self.geom), L.ptr(self._torch_weight()), L.ptr(buf if form == "gather" else None),
+                       L.ptr(buf if form == "scatter" else None), L.stream_ptr())
+                self._packed[key] = buf
+            return self._packed[key]
         if form not in self._packed:
             nbytes = L.load().rv_packed_weight_bytes(ctypes.byref(self.geom))
             w = self._torch_weight()
             # a training step needs both images (forward in one form, backward-data in the other): one launch writes both
-            forms = ("gather", "scatter") if (torch.is_grad_enabled() and self.weight.requires_grad and not self._packed) else (form,)
+            forms = ("gather", "scatter") if (torch.is_grad_enabled() and self.weight.requires_grad and "gather" not in self._packed and "scatter" not in self._packed) else (form,)
             bufs = {f: torch.empty(nbytes // 2, dtype=torch.bfloat16, device=self.weight.device) for f in forms}
             L.call("rv_pack_weight", ctypes.byref(self.geom), L.ptr(w), L.ptr(bufs.get("gather")), L.ptr(bufs.get("scatter")), L.stream_ptr())
             self._packed.update(bufs)

@@ -151,6 +151,26 @@ def dense_head_pair_program(t: Tape, cls_head: nn.Module, reg_head: nn.Module, x
 # ---------------------------------------------------------------------------------------------
 # autograd bridge
 # ---------------------------------------------------------------------------------------------
+# Operand type of an eval-mode program.  The reference evaluates under ``torch.autocast(device_type="cuda", dtype=torch.float16)``
+# (nn/arch/detector.py:329-340 with conf/model/range_view.yaml:26 ``eval_precision: 16``) and trains under bf16 autocast
+# (``precision: bf16-mixed``).  None: follow the caller's autocast state -- an eval program inside an fp16 autocast region runs
+# on the fp16-operand build of the library (librv3d_hip_f16.so: v_mfma_f32_16x16x32_f16, fp16 activations); anything else runs
+# bf16.  "f16" / "bf16": force it (bench.py's forward_only leg, tests).
+EVAL_OPERAND: Optional[str] = None
+
+
+def operand_for(training: bool) -> str:
+    fp16_autocast = torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.float16
+    if training:
+        if fp16_autocast:
+            raise NotImplementedError("training under torch.autocast(float16): the reference trains in bf16-mixed (conf/trainer/train.yaml:14); "
+                                      "fp16 operands are built for inference only (no loss scaling on this path)")
+        return "bf16"
+    if EVAL_OPERAND is not None:
+        return EVAL_OPERAND
+    return "f16" if fp16_autocast else "bf16"
+
+
 class _ProgramFn(torch.autograd.Function):
     """One autograd node for a whole fused program.
 
@@ -168,7 +188,8 @@ class _ProgramFn(torch.autograd.Function):
         tape = Tape(training, dev)
         if training:
             E.prepack_stale()  # weight images of every layer the optimiser touched, one launch
-        in_acts, outs = build(tape, *inputs)
+        with L.operand(operand_for(training)):
+            in_acts, outs = build(tape, *inputs)
         if tape.bn_counters:
             torch._foreach_add_(tape.bn_counters, 1)  # num_batches_tracked of every BatchNorm on the tape, one launch
             tape.bn_counters = []

@@ -1,0 +1,168 @@
+"""fp16 operand path for inference -- what the reference evaluates in.
+
+``Detector.validation_step`` runs the model under ``torch.autocast(device_type="cuda", dtype=torch.float16)``
+(``nn/arch/detector.py:329-340``, ``conf/model/range_view.yaml:26 eval_precision: 16``).  An eval-mode program called inside
+such a region runs on ``librv3d_hip_f16.so``: the same kernels built with fp16 operands (``v_mfma_f32_16x16x32_f16``, fp16
+activations, fp32 accumulation and BatchNorm folds).
+
+* kernel level: integer data -- every partial sum an integer below 2^11 in magnitude, so the fp16 output must equal the CPU
+  convolution bit for bit whatever the summation order -- on tapconv5 (3x3, 256- and 128-channel tiles), tapconv4 (1x1) and
+  the conv-transpose phases; fp16-representable random operands against fp32 ``F.conv2d`` at 2e-5 (fp32 output);
+* model level: the rv-av2 model at its real widths, ONE full 64 x 2048 sweep, eval mode under autocast(float16), against the
+  oracle with fp16 storage points (``oracle.model.Numerics.fp16``) and against the fp32 oracle.  Bounds (relative to the tensor
+  maximum): 4e-3 against either -- a fraction of what the bf16 path is allowed (3e-2 / 1.5 x yardstick + 1e-2,
+  test_gpu_realwidth.py); measured on an MI355X: logits 3.3e-4, regressands 1.3e-3 against the fp32 oracle, where the bf16
+  build of the same model is at 2.9e-3 (8.7x) -- the test also requires fp16 to be at least twice as close as bf16;
+* decode + weighted NMS from those logits against the oracle decoder on the same logits.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_gpu_forward import DEV, rel_err
+from test_gpu_tapconv4 import _ints
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _small_grids_allowed():
+    from range_view_3d_detection_amd import _lib as L
+
+    olds = {tag: L.load(tag).rv_set_option(b"tapconv4_min_blocks", ctypes.c_int32(1)) for tag in ("bf16", "f16")}
+    yield
+    for tag, old in olds.items():
+        L.load(tag).rv_set_option(b"tapconv4_min_blocks", ctypes.c_int32(old))
+
+
+def _run_f16(module, x, expect_kernel, stats=False, out_f32=False):
+    from range_view_3d_detection_amd import _lib as L
+    from range_view_3d_detection_amd import engine as E
+
+    with L.operand("f16"):
+        t = E.Tape(False, x.device)
+        layer = E.tap_layer(module)
+        a = E.Act.from_nchw(x)
+        assert a.data.dtype == torch.float16
+        op = E.ConvOp(t, layer, a, stats=stats, out_f32=out_f32)
+        info = (ctypes.c_int32 * 4)()
+        assert L.load().rv_tap_launch_info(ctypes.byref(layer.geom), ctypes.byref(op.shape), 1 if layer.fwd_form == "scatter" else 0, info) == 0
+        assert info[0] == expect_kernel, list(info)
+    if out_f32:
+        return op.out_t[..., : layer.c_out].permute(0, 3, 1, 2).float()
+    assert op.out.data.dtype == torch.float16
+    return op.out.data[..., : layer.c_out].permute(0, 3, 1, 2).float()
+
+
+@pytest.mark.parametrize("cin,cout,N,H,W,k,kernel", [(128, 512, 2, 64, 256, 3, 5), (320, 128, 3, 17, 1030, 3, 5), (64, 256, 4, 30, 520, 3, 5),
+                                                     (256, 256, 2, 32, 512, 1, 4), (128, 128, 2, 16, 1024, 1, 4)])
+def test_fp16_tap_conv_exact_on_integers(cin, cout, N, H, W, k, kernel):
+    g = torch.Generator().manual_seed(cin + W + k)
+    m = torch.nn.Conv2d(cin, cout, k, padding=k // 2, bias=False)
+    m.weight.data = _ints(m.weight.shape, g, -1, 2)  # {-1, 0, 1}
+    x = _ints((N, cin, H, W), g, -1, 2)
+    ref = F.conv2d(x, m.weight.data, padding=k // 2)
+    assert float(ref.abs().max()) < 2048  # every output (and partial sum) is an integer fp16 holds exactly
+    out = _run_f16(m.to(DEV), x.to(DEV), kernel)
+    assert torch.equal(out.cpu(), ref)
+
+
+def test_fp16_conv_transpose_phases_exact():
+    g = torch.Generator().manual_seed(7)
+    m = torch.nn.ConvTranspose2d(128, 256, kernel_size=(3, 8), stride=(1, 4), padding=(1, 2), bias=False)
+    m.weight.data = _ints(m.weight.shape, g, -1, 2)
+    x = _ints((4, 128, 16, 256), g, -1, 2)
+    ref = F.conv_transpose2d(x, m.weight.data, stride=(1, 4), padding=(1, 2))
+    out = _run_f16(m.to(DEV), x.to(DEV), 5)
+    assert torch.equal(out.cpu(), ref)
+
+
+def test_fp16_operands_fp32_output_vs_torch():
+    """fp16-representable random operands, fp32 result (the final head conv's form): 2e-5 of max against fp32 F.conv2d --
+    the products are exact in fp32, only the accumulation order differs."""
+    g = torch.Generator().manual_seed(3)
+    m = torch.nn.Conv2d(256, 32, 1, bias=True)
+    m.weight.data = (0.05 * torch.randn(m.weight.shape, generator=g)).half().float()
+    m.bias.data = torch.randn(32, generator=g)
+    x = torch.randn(2, 256, 16, 128, generator=g).half().float()
+    ref = F.conv2d(x, m.weight.data, m.bias.data)
+    # (kernel selection for this small-N layer is the library's business: only the numbers are checked)
+    from range_view_3d_detection_amd import _lib as L
+    from range_view_3d_detection_amd import engine as E
+
+    with L.operand("f16"):
+        t = E.Tape(False, DEV)
+        op = E.ConvOp(t, E.tap_layer(m.to(DEV)), E.Act.from_nchw(x.to(DEV)), out_f32=True)
+    out = op.out_t[..., :32].permute(0, 3, 1, 2).float().cpu()
+    assert rel_err(out, ref) < 2e-5, rel_err(out, ref)
+
+
+def test_training_under_fp16_autocast_is_refused():
+    from bench import build_model
+
+    backbone, _ = build_model("c32", 5)
+    backbone = backbone.to(DEV).train()
+    from bench import synthetic_batch
+
+    batch = synthetic_batch(1, 16, 64, seed=1, device=DEV, n_cls=5)
+    with torch.autocast("cuda", dtype=torch.float16), pytest.raises(NotImplementedError, match="bf16-mixed"):
+        backbone(batch)
+
+
+def test_full_size_eval_forward_fp16_vs_oracle_and_decode():
+    from oracle import decode as odec
+    from oracle import model as om
+    from range_view_3d_detection_amd import engine as E
+    from range_view_3d_detection_amd.nn.decoders.range_decoder import RangeDecoder
+    from test_gpu_realwidth import _prepare
+
+    backbone, head, sd, batch = _prepare("rv-av2", 5, 26, 2048, 0.5)
+    head.classification_head["1"]["0"].blocks[-1][0].bias.data.fill_(-1.5)  # some scores above min_confidence
+    sd["head.classification_head.1.0.blocks.4.0.bias"] = head.classification_head["1"]["0"].blocks[-1][0].bias.data.clone()
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    with torch.no_grad():
+        _, lg16, rg16 = om.detector_forward(batch["features"], batch["cart"], sd, nm=om.Numerics.fp16(train=False))
+        _, lg32, rg32 = om.detector_forward(batch["features"], batch["cart"], sd, nm=om.Numerics(train=False))
+    backbone, head = backbone.to(DEV).eval(), head.to(DEV).eval()
+    data = {k: (v.to(DEV) if k != "annotations" else v) for k, v in batch.items()}
+    E.PROFILE = E.KernelProfile()
+    try:
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):  # detector.py:329-333
+            feats = backbone(data)
+            outputs, _ = head(feats, data, return_loss=False)
+        torch.cuda.synchronize()
+        ran = set(name for name, *_ in E.PROFILE.records)
+    finally:
+        E.PROFILE = None
+    assert feats[1].dtype == torch.float16  # the activations really are fp16
+    assert {"tapconv5_kernel<256>", "tapconv4_kernel<256>", "tapconv4_kernel<128>"} <= ran, sorted(ran)
+    logits, reg = outputs[1][0]["logits"].float().cpu(), outputs[1][0]["regressands"].float().cpu()
+    m = {"logits~fp16": rel_err(logits, lg16), "logits~fp32": rel_err(logits, lg32), "emu~fp32": rel_err(lg16, lg32),
+         "reg~fp16": rel_err(reg, rg16), "reg~fp32": rel_err(reg, rg32), "reg emu~fp32": rel_err(rg16, rg32)}
+    print("[rv-av2 eval 1x64x2048, fp16 operands] " + "  ".join(f"{k} {v:.3e}" for k, v in m.items()))
+    for k in ("logits~fp16", "logits~fp32", "reg~fp16", "reg~fp32"):
+        assert m[k] < 4e-3, m
+    # the same model on the bf16 build: the fp16 path must be the tighter one
+    with torch.no_grad():
+        outputs_b, _ = head(backbone(data), data, return_loss=False)
+    mb = rel_err(outputs_b[1][0]["logits"].float().cpu(), lg32)
+    print(f"    bf16 operands, same model: logits~fp32 {mb:.3e}")
+    assert m["logits~fp32"] < 0.5 * mb, (m["logits~fp32"], mb)
+    # decode + weighted NMS from the fp16 logits, against the oracle decoder on the SAME logits
+    dec = RangeDecoder(True, True, [0, 15, 30], [15, 30, math.inf], [8, 2, 1])
+    post = {"num_pre_nms": 50000, "num_post_nms": 1000, "nms_threshold": 0.3, "min_confidence": 0.1, "nms_mode": "WEIGHTED"}
+    p, s, c, b = dec.decode(outputs, post, {0: [f"C{i}" for i in range(26)]}, use_nms=True)
+    po, so, co, bo = odec.range_decode(logits, reg, batch["cart"], batch["mask"], post, use_nms=True)
+    from test_gpu_nms_wrapper import _canonical  # rows with exactly equal (sweep, class, merged score): compared as a set
+
+    assert p.shape[0] > 20 and p.shape == po.shape, (p.shape, po.shape)
+    p, s, c, b = _canonical(p, s, c, b)
+    po, so, co, bo = _canonical(po, so, co, bo)
+    assert torch.equal(c, co) and torch.equal(b, bo)
+    assert rel_err(p, po) < 1e-5 and rel_err(s, so) < 1e-6, (rel_err(p, po), rel_err(s, so))

@@ -26,14 +26,20 @@ def lib():
     return _lib
 
 
-def test_library_exports_every_declared_symbol(lib):
-    handle = lib.load()
+@pytest.mark.parametrize("tag", ["bf16", "f16"])
+def test_library_exports_every_declared_symbol(lib, tag):
+    """Both builds of the C-ABI library (bf16 operands: training; fp16 operands: inference under autocast(float16)) load without
+    a GPU and export every symbol include/rv3d.h declares."""
+    handle = lib.load(tag)
     declared = lib.declared_symbols()
     assert len(declared) >= 30
     missing = [s for s in declared if not hasattr(handle, s)]
     assert not missing, missing
     assert handle.rv_version() >= 100
     assert handle.rv_pad_channels(5) == 32 and handle.rv_pad_channels(256) == 256
+    with lib.operand(tag):
+        assert lib.load() is handle and lib.act_dtype() == (torch.float16 if tag == "f16" else torch.bfloat16)
+    assert lib.operand_tag() == "bf16"
 
 
 def test_host_side_geometry(lib):
