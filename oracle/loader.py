@@ -54,7 +54,7 @@ def train_item_from_table(table: Mapping[str, np.ndarray], feature_column_names:
     """``__getitem__`` with ``split_name == "train"`` (``loader.py:594-697``): the ROI filter, then the augmentations on the
     UNPADDED table (``:598-603``; every column travels through flips / rolls, ``x y z range`` are rewritten), then the feature /
     cart / mask images (mask = AUGMENTED ``range`` > 0) and ``subsample_range_view``.  ``augmentations``: the chain with its
-    draws, e.g. ``[("flip",), ("rotate", theta), ("scale", s), ("translate", (tx, ty, tz))]``.  Pinned by
+    draws, e.g. ``[("dropout", keep), ("flip",), ("rotate", theta), ("scale", s), ("translate", (tx, ty, tz))]``.  Pinned by
     ``tests/golden/loader_train_item.npz``."""
     from . import augment as oaug
 
@@ -63,7 +63,9 @@ def train_item_from_table(table: Mapping[str, np.ndarray], feature_column_names:
     sweep = np.stack([np.asarray(table[n], dtype=np.float32) * roi for n in cols]).reshape(len(cols), height, width).astype(np.float64)
     ann = np.zeros((10, 0))
     for op in augmentations:
-        if op[0] == "flip":
+        if op[0] == "dropout":  # loader.py:506-512: every column times the keep mask
+            sweep = sweep * np.asarray(op[1], dtype=np.float64).reshape(1, height, width)
+        elif op[0] == "flip":
             sweep, _ = oaug.flip(sweep, cols, ann)
         elif op[0] == "rotate":
             sweep, _ = oaug.rotate(sweep, cols, ann, op[1])

@@ -50,12 +50,13 @@ def read_sweep_table(path) -> Dict[str, "np.ndarray"]:
 
 
 def range_view_from_table(table: Mapping[str, Any], range_view_config: Mapping[str, Any], dataset_name: str, x_stride: int = 1,
-                          padding_mode: str = "constant", device="cuda", pad: bool = True) -> Dict[str, Tensor]:
+                          padding_mode: str = "constant", device="cuda", pad: bool = True, keep=None) -> Dict[str, Tensor]:
     """``DataLoader.__getitem__`` from the sweep table on (``loader.py:594-690``): ``table`` maps column names to H*W-row
     arrays (numpy or tensors); returns ``features`` (F,H,W'), ``mask`` (1,H,W') bool, ``cart`` (3,H,W') on ``device`` with W'
     the padded width.  ``pad=False`` stops BEFORE ``subsample_range_view`` (``loader.py:684-691``): width = the configured width,
     ``features`` not yet multiplied by the mask -- the state the reference's augmentations see (``loader.py:598-603``); finish with
-    :func:`pad_batch`.  The needed columns cross PCIe once, as ONE (n_cols, H*W) fp32 block; ROI filter, tanh(intensity)
+    :func:`pad_batch`.  ``keep``: H*W booleans of a ``point_dropout`` (``loader.py:506-512``: every column times the keep mask) --
+    it multiplies the table exactly where the ROI flag does, so it rides on that column of the one kernel.  The needed columns cross PCIe once, as ONE (n_cols, H*W) fp32 block; ROI filter, tanh(intensity)
     (Waymo), the 1e-9 of ``timedelta_ns``, the (F,H,W) layout and the mask are one kernel (``rv_table_to_range_view``).
     The ``view`` feature (``loader.py:611-624``) is not selected by any shipped config and is not implemented."""
     import numpy as np
@@ -76,6 +77,16 @@ def range_view_from_table(table: Mapping[str, Any], range_view_config: Mapping[s
         if c.shape != (h * w,):
             raise L.RvError(f"column {n!r} has shape {c.shape}, expected ({h * w},) = height * width rows")
         cols.append(c.astype(np.float32, copy=False))
+    if keep is not None:
+        k = np.asarray(keep).reshape(-1)
+        if k.shape != (h * w,):
+            raise L.RvError(f"keep mask has {k.size} entries, expected {h * w}")
+        if roi:
+            cols[need.index("is_within_roi")] = (cols[need.index("is_within_roi")] != 0).astype(np.float32) * k.astype(np.float32)
+        else:
+            need.append("is_within_roi")
+            cols.append(k.astype(np.float32))
+            roi = True
     host = torch.from_numpy(np.stack(cols))
     dev = torch.device(device)
     if dev.type != "cuda":
@@ -214,7 +225,8 @@ def draw_sweep_transform(width: int, augmentations_config: Mapping[str, Mapping[
         elif k == "random_global_translation":
             tr.translate([rng.normalvariate(0, v["std_x"]), rng.normalvariate(0, v["std_y"]), rng.normalvariate(0, v["std_z"])])
         elif k == "point_dropout":
-            raise NotImplementedError("point_dropout draws H*W numbers from numpy's global generator per sweep; no shipped rv-* recipe enables it")
+            raise NotImplementedError("point_dropout inside a chain: supported at the HEAD of augmentations_config only (train_batch_from_tables folds its "
+                                      "keep mask into the table -> image kernel); no shipped rv-* recipe enables it")
         else:
             raise KeyError(f"unknown augmentation {k!r}")
     return tr
@@ -302,10 +314,20 @@ def train_batch_from_tables(tables: Sequence[Mapping[str, Any]], annotations: Op
     """The train-split item chain of ``DataLoader.__getitem__`` (``loader.py:594-705``) for a batch of sweep tables, in the
     reference's order: ROI filter + table -> image (unpadded) -> augmentations -> ``features *= mask`` + W padding.
     ``annotations``: (M, 13) fp64 rows in ``COLS`` order (``batch_index`` = position in ``tables``) or None."""
-    items = [range_view_from_table(t, range_view_config, dataset_name, x_stride, padding_mode, device, pad=False) for t in tables]
+    import numpy as np
+
+    aug = dict(augmentations_config) if augmentations_config else {}
+    keeps = [None] * len(tables)
+    if aug and next(iter(aug)) == "point_dropout":
+        # ``_point_dropout`` (loader.py:506-512): ``np.random.rand(rows, 1) <= p`` from numpy's GLOBAL generator, one draw per
+        # sweep, every column of the table times the mask -- i.e. dropped pixels become empty pixels before anything else
+        p = float(aug.pop("point_dropout")["p"])
+        hw = int(range_view_config["height"]) * int(range_view_config["width"])
+        keeps = [(np.random.rand(hw, 1) <= p).reshape(-1) for _ in tables]
+    items = [range_view_from_table(t, range_view_config, dataset_name, x_stride, padding_mode, device, pad=False, keep=k) for t, k in zip(tables, keeps)]
     batch: Dict[str, Any] = {k: torch.stack([it[k] for it in items]) for k in ("features", "mask", "cart")}
     if annotations is not None:
         batch["annotations"] = annotations
-    if augmentations_config:
-        batch = augment_batch(batch, range_view_config["feature_column_names"], augmentations_config, rng, width=int(range_view_config["width"]))
+    if aug:
+        batch = augment_batch(batch, range_view_config["feature_column_names"], aug, rng, width=int(range_view_config["width"]))
     return pad_batch(batch, dataset_name, x_stride, padding_mode)

@@ -706,8 +706,11 @@ def gen_loader_train_item() -> None:
           "random_global_scale": {"low": 0.95, "high": 1.05}, "random_global_translation": {"std_x": 0.5, "std_y": 0.5, "std_z": 0.2}}, 11),
         ("waymo", "waymo", ["elongation", "intensity", "range", "x", "y", "z"], False, "constant",
          {"random_rotation": {"low": 2.0, "high": 3.0, "p": 1.0}, "random_global_translation": {"std_x": 0.5, "std_y": 0.5, "std_z": 0.2},
-          "random_global_scale": {"low": 0.95, "high": 1.05}}, 12)):
-        rng = np.random.default_rng(51 if ds == "av2" else 52)
+          "random_global_scale": {"low": 0.95, "high": 1.05}}, 12),
+        # point_dropout (loader.py:506-512: EVERY column times a keep mask drawn from numpy's global generator) at the head of a chain
+        ("av2_dropout", "av2", ["intensity", "range", "x", "y", "z"], True, "circular",
+         {"point_dropout": {"p": 0.8}, "flip_azimuth": {"p": 1.0}, "random_global_scale": {"low": 0.95, "high": 1.05}}, 13)):
+        rng = np.random.default_rng({"av2": 51, "waymo": 52}.get(tag, 53))
         inc = np.linspace(0.2, -0.4, H)[:, None]
         az = np.linspace(math.pi, -math.pi, W)[None, :]
         r = (20.0 + 15.0 * np.sin(3 * az) + 10.0 * np.cos(7 * inc) + rng.random((H, W))).astype(np.float32)
@@ -740,7 +743,9 @@ def gen_loader_train_item() -> None:
             enable_database=False, db_config=None, x_stride=1, padding_mode=mode, targets_config=tcfg)
         me.apply_augmentations = types.MethodType(ref_loader.DataLoader.apply_augmentations, me)
         me.tasks_frame = ref_loader.DataLoader.tasks_frame.func(me)
+        me._point_dropout = types.MethodType(ref_loader.DataLoader._point_dropout, me)
         random.seed(seed)
+        np.random.seed(seed)
         datum = ref_loader.DataLoader.__getitem__(me, 0)
         # the same draws, in the reference's order (flip: random(); rotation: random(), uniform; scale: uniform; translation: 3 x normalvariate)
         random.seed(seed)
@@ -752,6 +757,9 @@ def gen_loader_train_item() -> None:
                 out[f"{tag}/theta"] = np.float64(random.uniform(v["low"], v["high"]))
             elif k == "random_global_scale":
                 out[f"{tag}/scale"] = np.float64(random.uniform(v["low"], v["high"]))
+            elif k == "point_dropout":
+                np.random.seed(seed)
+                out[f"{tag}/keep"] = (np.random.rand(H * W, 1) <= v["p"]).reshape(-1)
             else:
                 out[f"{tag}/t"] = np.array([random.normalvariate(0, v["std_x"]), random.normalvariate(0, v["std_y"]), random.normalvariate(0, v["std_z"])])
         for k, v in cols.items():

@@ -383,6 +383,9 @@ def _train_item_case(g, tag):
     ann_in = {k[len(f"{tag}/ann_in/"):]: g.np(k) for k in g.keys if k.startswith(f"{tag}/ann_in/")}
     chain = []
     for k in [str(n) for n in g.np(f"{tag}/augmentation_order")]:
+        if k == "point_dropout":
+            chain.append(("dropout", g.np(f"{tag}/keep")))
+            continue
         chain.append({"flip_azimuth": ("flip",), "random_rotation": ("rotate", float(g.np(f"{tag}/theta")) if f"{tag}/theta" in g else 0.0),
                       "random_global_scale": ("scale", float(g.np(f"{tag}/scale")) if f"{tag}/scale" in g else 1.0),
                       "random_global_translation": ("translate", tuple(g.np(f"{tag}/t").tolist()) if f"{tag}/t" in g else (0, 0, 0))}[k])
@@ -401,7 +404,7 @@ def test_loader_train_item_augments_before_padding(golden):
     from oracle import loader as old
 
     g = golden("loader_train_item")
-    for tag, ds in (("av2", "av2"), ("waymo", "waymo")):
+    for tag, ds in (("av2", "av2"), ("waymo", "waymo"), ("av2_dropout", "av2")):
         names, table, ann_in, chain, roi, mode = _train_item_case(g, tag)
         got = old.train_item_from_table(table, names, 8, 64, ds, roi, chain, 1, mode)
         assert np.array_equal(got["mask"], g.np(f"{tag}/mask")), tag
@@ -421,7 +424,7 @@ def test_loader_train_item_augments_before_padding(golden):
         cols = ("tx_m", "ty_m", "tz_m", "length_m", "width_m", "height_m", "qw", "qx", "qy", "qz")
         a = np.stack([np.asarray(ann_in[c], dtype=np.float64)[rows] for c in cols])
         s = np.zeros((6, 1, 1))
-        for op in chain:
+        for op in [o for o in chain if o[0] != "dropout"]:
             _, a = {"flip": lambda: oaug.flip(s, ["x", "y", "z", "range", "i", "e"], a), "rotate": lambda: oaug.rotate(s, ["x", "y", "z", "range", "i", "e"], a, op[1]),
                     "scale": lambda: oaug.scale(s, ["x", "y", "z", "range", "i", "e"], a, op[1]),
                     "translate": lambda: oaug.translate(s, ["x", "y", "z", "range", "i", "e"], a, op[1])}[op[0]]()
