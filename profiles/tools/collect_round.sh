@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 pass() {  # pass <dir> <rocprofv3 args...>
   d=/tmp/prof/${tag}_$1; shift
   mkdir -p $d
-  rocprofv3 "$@" -d $d -o p -- python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > $d/log.txt 2>&1
+  rocprofv3 "$@" -d $d -o p -- python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-extra > $d/log.txt 2>&1
   echo "$d rc=$? $(grep -c . $d/log.txt) log lines"
 }
 db() { find /tmp/prof/${tag}_$1 -name '*_results.db' | head -1; }
