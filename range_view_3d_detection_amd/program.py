@@ -22,42 +22,96 @@ from .engine import Act, Lazy, Operand, Tape
 # ---------------------------------------------------------------------------------------------
 # module programs
 # ---------------------------------------------------------------------------------------------
-def basic_block_program(t: Tape, m: nn.Module, x: Operand, out: Optional[Act] = None, need_input_grad: bool = True) -> Act:
+# Block programs are written as GENERATORS: wherever a conv -> BatchNorm group can be launched (its inputs exist), the program
+# yields the group's specs ``[(layer, input, bn, relu, need_input_grad), ...]`` and receives the results.  ``_drive`` runs ONE
+# program (each yielded group -> ``engine.conv_bn_many``); ``_drive_many`` runs several INDEPENDENT programs side by side and
+# merges the groups they yield at the same step into one ``conv_bn_many`` call -- under SyncBN the BatchNorm statistics of
+# every layer of a merged group travel in ONE all-reduce, forward and backward (the two convs a BasicBlock applies to its
+# input; layer i of the classification and regression towers; the layers of the backbone's independent agg1 / agg2 branches).
+def _drive(t: Tape, gen):
+    try:
+        specs = next(gen)
+        while True:
+            specs = gen.send(E.conv_bn_many(t, specs))
+    except StopIteration as stop:
+        return stop.value
+
+
+def _drive_many(t: Tape, gens):
+    gens = list(gens)
+    results = [None] * len(gens)
+    pending = {}
+    for i, g in enumerate(gens):
+        try:
+            pending[i] = next(g)
+        except StopIteration as stop:
+            results[i] = stop.value
+    while pending:
+        order = sorted(pending)
+        flat = [spec for i in order for spec in pending[i]]
+        outs = E.conv_bn_many(t, flat)
+        nxt, o = {}, 0
+        for i in order:
+            n = len(pending[i])
+            try:
+                nxt[i] = gens[i].send(outs[o : o + n])
+            except StopIteration as stop:
+                results[i] = stop.value
+            o += n
+        pending = nxt
+    return results
+
+
+def _basic_block_gen(t: Tape, m: nn.Module, x: Operand, out: Optional[Act] = None, need_input_grad: bool = True):
     """``BasicBlock.forward`` (nn/blocks/__init__.py:68-81): relu_(net(x) + proj(x))."""
     c1, bn1, _, c2, bn2 = m.net
     l1 = E.tap_layer(c1.conv)
-    if m.projection_block is not None and not E._smallk_eligible(l1, x, True, need_input_grad):
-        # net.0 and the projection conv read the same input: both convs first, then both BatchNorms (under SyncBN their
-        # statistics travel in ONE all-reduce, forward and backward -- engine.conv_bn_many)
-        pc, pbn = m.projection_block
-        h1, res = E.conv_bn_many(t, [(l1, x, bn1, True, need_input_grad), (E.tap_layer(pc.conv), x, pbn, False, need_input_grad)])
-        h2 = E.conv_bn(t, E.tap_layer(c2.conv), h1, bn2, relu=False)
+    if E._smallk_eligible(l1, x, True, need_input_grad):  # 5/6-channel stem projection: the small-K element-wise path
+        h1 = E.conv_bn(t, l1, x, bn1, relu=True, need_input_grad=need_input_grad)
+        (h2,) = yield [(E.tap_layer(c2.conv), h1, bn2, False, True)]
+        res: Operand = x
+        if m.projection_block is not None:
+            pc, pbn = m.projection_block
+            res = E.conv_bn(t, E.tap_layer(pc.conv), x, pbn, relu=False, need_input_grad=need_input_grad)
         return E.CombineOp(t, h2, res, relu_out=True, out=out).out
-    h1 = E.conv_bn(t, l1, x, bn1, relu=True, need_input_grad=need_input_grad)
-    h2 = E.conv_bn(t, E.tap_layer(c2.conv), h1, bn2, relu=False)
     if m.projection_block is not None:
+        # net.0 and the projection conv read the same input: both convs first, then both BatchNorms
         pc, pbn = m.projection_block
-        res: Operand = E.conv_bn(t, E.tap_layer(pc.conv), x, pbn, relu=False, need_input_grad=need_input_grad)
+        h1, res = yield [(l1, x, bn1, True, need_input_grad), (E.tap_layer(pc.conv), x, pbn, False, need_input_grad)]
     else:
+        (h1,) = yield [(l1, x, bn1, True, need_input_grad)]
         if isinstance(x, Lazy):
             x = E.CombineOp(t, x, None, relu_out=False).out
         res = x
+    (h2,) = yield [(E.tap_layer(c2.conv), h1, bn2, False, True)]
     return E.CombineOp(t, h2, res, relu_out=True, out=out).out
 
 
-def residual_block_program(t: Tape, m: nn.Module, x: Operand, out: Optional[Act] = None) -> Act:
+def _residual_block_gen(t: Tape, m: nn.Module, x: Operand, out: Optional[Act] = None):
     """``ResidualBlock.forward`` (nn/blocks/__init__.py:123-126)."""
     blocks = list(m.blocks)
     for i, b in enumerate(blocks):
-        x = basic_block_program(t, b, x, out=out if i == len(blocks) - 1 else None)
+        x = yield from _basic_block_gen(t, b, x, out=out if i == len(blocks) - 1 else None)
     return x
 
 
-def aggregation_block_program(t: Tape, m: nn.Module, x1: Act, x2: Act, out: Optional[Act] = None) -> Act:
+def _aggregation_block_gen(t: Tape, m: nn.Module, x1: Act, x2: Act, out: Optional[Act] = None):
     """``AggregationBlock.forward`` (nn/blocks/__init__.py:165-182): x1 + relu(bn(convT(x2))) -> ResidualBlock."""
-    up = E.conv_bn(t, E.tap_layer(m.upscale), x2, m.normalization, relu=True)
+    (up,) = yield [(E.tap_layer(m.upscale), x2, m.normalization, True, True)]
     s = E.CombineOp(t, x1, up, relu_out=False).out
-    return residual_block_program(t, m.block, s, out=out)
+    return (yield from _residual_block_gen(t, m.block, s, out=out))
+
+
+def basic_block_program(t: Tape, m: nn.Module, x: Operand, out: Optional[Act] = None, need_input_grad: bool = True) -> Act:
+    return _drive(t, _basic_block_gen(t, m, x, out, need_input_grad))
+
+
+def residual_block_program(t: Tape, m: nn.Module, x: Operand, out: Optional[Act] = None) -> Act:
+    return _drive(t, _residual_block_gen(t, m, x, out))
+
+
+def aggregation_block_program(t: Tape, m: nn.Module, x1: Act, x2: Act, out: Optional[Act] = None) -> Act:
+    return _drive(t, _aggregation_block_gen(t, m, x1, x2, out))
 
 
 def meta_kernel_program(t: Tape, m: nn.Module, features: Act, cart: Tensor, out: Optional[Act] = None) -> Act:
@@ -90,8 +144,8 @@ def range_backbone_program(t: Tape, m: nn.Module, stem: Act, feat1: Optional[Act
     res2 = residual_block_program(t, m.res2, res2a)
     res3a = residual_block_program(t, m.res3a, res2)
     res3 = residual_block_program(t, m.res3, res3a)
-    agg2 = aggregation_block_program(t, m.agg2, res2, res3)
-    agg1 = aggregation_block_program(t, m.agg1, res1, res2)
+    # agg2 (res2, res3) and agg1 (res1, res2) are independent branches: run side by side, their BatchNorm groups merged
+    agg2, agg1 = _drive_many(t, [_aggregation_block_gen(t, m.agg2, res2, res3), _aggregation_block_gen(t, m.agg1, res1, res2)])
     agg2a = aggregation_block_program(t, m.agg2a, res2a, agg2)
     c0 = stem.cp
     if feat1 is not None:  # concat written in place: stem already sits in channels [0, c0)
