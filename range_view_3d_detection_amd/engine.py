@@ -153,9 +153,10 @@ def tap_flops(geom, shape) -> float:
 
 
 def all_reduce_(t: Tensor) -> None:
-    """Sum ``t`` over the ranks of the default process group, in place.  Over RCCL the collective is enqueued on the current
-    compute stream through the direct binding (``rccl.py``: no second stream, no event round trip -- these are latency-bound
-    collectives on the critical path); other backends (gloo in the CPU tests) go through ``torch.distributed``."""
+    """Sum ``t`` over the ranks of the default process group, in place: ``torch.distributed.all_reduce`` (RCCL on the GPUs, gloo
+    in the CPU tests).  ``RV3D_DIRECT_RCCL=1`` opts in to the direct binding (``rccl.py``: ``ncclAllReduce`` enqueued on the
+    current compute stream, no second stream and no event round trip -- these are latency-bound collectives on the critical
+    path); opt-in because only a one-rank communicator of it could ever be tested on this one-GPU build."""
     from . import rccl
 
     if t.is_cuda and rccl.available():

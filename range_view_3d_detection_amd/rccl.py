@@ -10,6 +10,11 @@ compute stream of the calling thread: no second stream, no events, one C call.
 The communicator is bootstrapped over the existing ``torch.distributed`` process group (rank 0 creates the ``ncclUniqueId``
 and broadcasts it), uses the RCCL library PyTorch itself ships and has already loaded, and lives for the life of the
 process group.  Backends other than ``nccl`` (the gloo tests on CPU) keep using ``torch.distributed``.
+
+OPT-IN (``RV3D_DIRECT_RCCL=1``).  This build has only ever had ONE GPU: the binding is tested with a one-rank communicator
+(``tests/test_gpu_ddp.py``, ``profiles/tools/mb_collective.py``), its multi-rank bootstrap never ran.  The default therefore
+stays ``torch.distributed.all_reduce`` -- the path every multi-process test of this repository exercises -- and the direct
+binding is the A/B for a node (``profiles/r03_syncbn_collectives.md``: on one rank the two differ by ~1.5 % of a step).
 """
 
 from __future__ import annotations
@@ -35,7 +40,7 @@ class RcclError(RuntimeError):
 _lib: Optional[ctypes.CDLL] = None
 _comm: Optional[ctypes.c_void_p] = None
 _comm_key = None
-DISABLED = os.environ.get("RV3D_NO_DIRECT_RCCL") is not None
+DISABLED = os.environ.get("RV3D_DIRECT_RCCL") is None
 
 
 def _load() -> ctypes.CDLL:

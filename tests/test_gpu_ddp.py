@@ -139,6 +139,10 @@ def test_one_rank_rccl_sync_path_matches_the_local_run():
     assert calls > 100, calls
     assert rccl["config"]["collectives"]["per_step"]["gradient_all_reduce_bytes"] > 0
     assert abs(rccl["config"]["loss"] - local["config"]["loss"]) < 1e-2 * abs(local["config"]["loss"]), (rccl["config"]["loss"], local["config"]["loss"])
+    # the opt-in direct binding (rccl.py: ncclAllReduce on the compute stream, its own communicator): same arithmetic, same count
+    direct = run({"RV3D_FORCE_DIST": "1", "RV3D_SYNC_WORLD1": "1", "RV3D_DIST_BACKEND": "nccl", "RV3D_DIRECT_RCCL": "1"})
+    assert direct["config"]["collectives"]["per_step"]["sync_bn_all_reduce"]["calls"] == calls
+    assert abs(direct["config"]["loss"] - rccl["config"]["loss"]) < 1e-6 * abs(rccl["config"]["loss"]), (direct["config"]["loss"], rccl["config"]["loss"])
 
 
 def test_one_rank_rccl_sync_path_at_the_rv_av2_widths():
