@@ -10,7 +10,7 @@ TEST INFRASTRUCTURE (see ``oracle/__init__.py``).  numpy restatement of ``DataLo
                 circular, every ``x_stride``-th column
 
 Pinned by ``tests/golden/loader_item.npz`` (made by ``make_golden.py loader_item`` running the reference's own ``__getitem__``).
-The ``view`` feature (``:611-624``) is not restated: no shipped config selects it.
+* ``:605-624``  the ``view`` feature (``row_mapping_64`` = the dataset's ROW_MAPPING_64, an argument).
 """
 
 from __future__ import annotations
@@ -27,10 +27,19 @@ def _pad_w(x: np.ndarray, pad: int, mode: str) -> np.ndarray:
 
 
 def range_view_from_table(table: Mapping[str, np.ndarray], feature_column_names: Sequence[str], height: int, width: int, dataset_name: str,
-                          filter_roi: bool, x_stride: int = 1, padding_mode: str = "constant") -> Dict[str, np.ndarray]:
+                          filter_roi: bool, x_stride: int = 1, padding_mode: str = "constant", row_mapping_64=None) -> Dict[str, np.ndarray]:
     names = list(feature_column_names)
-    assert "view" not in names
     roi = np.asarray(table["is_within_roi"]).astype(np.float32) if filter_roi else np.float32(1.0)
+    if "view" in names:  # loader.py:605-624 (after the ROI filter): reverse ROW_MAPPING_64 on the laser rows, then the view id
+        assert row_mapping_64 is not None
+        rev = {int(v): i for i, v in enumerate(np.asarray(row_mapping_64).tolist())}
+        ln = np.asarray(table["laser_number"], dtype=np.float32) * roi
+        pos = ((np.asarray(table["range"], dtype=np.float32) * roi) > 0).astype(np.float32)
+        ln2 = ln.copy()
+        for k, v in rev.items():
+            ln2[ln == k] = v
+        ln2 = ln2 * pos
+        table = dict(table, laser_number=ln2, view=(2.0 * (ln2 <= 32).astype(np.float32) + (ln2 > 32).astype(np.float32)) * pos)
     col = lambda n: np.asarray(table[n], dtype=np.float32) * roi  # noqa: E731
     feats = []
     for n in names:

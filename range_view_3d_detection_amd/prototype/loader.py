@@ -58,14 +58,30 @@ def range_view_from_table(table: Mapping[str, Any], range_view_config: Mapping[s
     :func:`pad_batch`.  ``keep``: H*W booleans of a ``point_dropout`` (``loader.py:506-512``: every column times the keep mask) --
     it multiplies the table exactly where the ROI flag does, so it rides on that column of the one kernel.  The needed columns cross PCIe once, as ONE (n_cols, H*W) fp32 block; ROI filter, tanh(intensity)
     (Waymo), the 1e-9 of ``timedelta_ns``, the (F,H,W) layout and the mask are one kernel (``rv_table_to_range_view``).
-    The ``view`` feature (``loader.py:611-624``) is not selected by any shipped config and is not implemented."""
+    The ``view`` feature (``loader.py:605-624``: laser rows through the reverse ``ROW_MAPPING_64``, then 2 for rows <= 32 and 1
+    for the rest, both times ``range > 0``) is formed on the host from the ``laser_number`` and ``range`` columns before the
+    upload (two small integer maps over H*W rows); the dataset's row table is an argument, ``range_view_config["row_mapping_64"]``,
+    like the other id tables of this package (the reference imports it from ``datasets/argoverse/constants.py``)."""
     import numpy as np
 
     names = list(range_view_config["feature_column_names"])
-    if "view" in names:
-        raise NotImplementedError("the 'view' feature (loader.py:611-624) is not selected by any shipped rv-* config")
     h, w = int(range_view_config["height"]), int(range_view_config["width"])
     roi = bool(range_view_config.get("filter_roi", False))
+    if "view" in names:
+        if range_view_config.get("row_mapping_64") is None:
+            raise L.RvError("the 'view' feature needs range_view_config['row_mapping_64'] (ROW_MAPPING_64 of datasets/argoverse/constants.py)")
+        as_np = lambda c: c.detach().cpu().numpy() if isinstance(c, Tensor) else np.asarray(c)  # noqa: E731
+        flag = (as_np(table["is_within_roi"]) != 0).astype(np.float32) if roi else np.float32(1.0)  # the ROI filter comes first (loader.py:599-601)
+        ln = as_np(table["laser_number"]).astype(np.float32) * flag
+        pos = ((as_np(table["range"]).astype(np.float32) * flag) > 0).astype(np.float32)
+        rev = {int(v): i for i, v in enumerate(np.asarray(range_view_config["row_mapping_64"]).tolist())}
+        ln2 = ln.copy()
+        for k, v in rev.items():
+            ln2[ln == k] = v
+        ln2 = ln2 * pos
+        table = dict(table)
+        table["laser_number"] = ln2
+        table["view"] = (2.0 * (ln2 <= 32).astype(np.float32) + (ln2 > 32).astype(np.float32)) * pos
     need: List[str] = []
     for n in names + list(CART_COLUMNS) + ["range"] + (["is_within_roi"] if roi else []):
         if n not in need:

@@ -236,6 +236,20 @@ class _PlExpr:
     def __lt__(self, o):
         return self._bin(o, lambda a, b: a < b, keep_dtype=False)
 
+    def __le__(self, o):
+        return self._bin(o, lambda a, b: a <= b, keep_dtype=False)
+
+    def replace(self, mapping):
+        """``Expr.replace({old: new})``: values equal to a key become its value, everything else stays; the column keeps its dtype."""
+        def run(frame):
+            a = np.asarray(self.fn(frame))
+            out = a.copy()
+            for k, v in mapping.items():
+                out[a == k] = v
+            return out
+
+        return _PlExpr(run)
+
     def __and__(self, o):
         return self._bin(o, lambda a, b: a & b, keep_dtype=False)
 
@@ -252,6 +266,9 @@ class _PlExpr:
     def cast(self, dtype):
         npdt = {"Float32": np.float32, "Float64": np.float64, "Int64": np.int64}.get(dtype, dtype)
         return _PlExpr(lambda frame: np.asarray(self.fn(frame)).astype(npdt))
+
+    def __rmul__(self, o):
+        return self._bin(o, lambda a, b: a * b)
 
     __hash__ = None
 

@@ -457,8 +457,10 @@ def gen_loader_item() -> None:
     H, W = 8, 64
     out = {}
     for tag, ds, names, roi, mode in (("av2", "av2", ["intensity", "range", "x", "y", "z"], True, "circular"),
-                                      ("waymo", "waymo", ["elongation", "intensity", "range", "x", "y", "z"], False, "constant")):
-        rng = np.random.default_rng(31 if ds == "av2" else 32)
+                                      ("waymo", "waymo", ["elongation", "intensity", "range", "x", "y", "z"], False, "constant"),
+                                      # the `view` feature (loader.py:605-624): laser rows through the reverse ROW_MAPPING_64, upper / lower view id
+                                      ("av2_view", "av2", ["intensity", "laser_number", "view", "range", "x", "y", "z"], True, "circular")):
+        rng = np.random.default_rng({"av2": 31, "waymo": 32}.get(tag, 34))
         inc = np.linspace(0.2, -0.4, H)[:, None]
         az = np.linspace(math.pi, -math.pi, W)[None, :]
         r = (20.0 + 15.0 * np.sin(3 * az) + 10.0 * np.cos(7 * inc) + rng.random((H, W))).astype(np.float32)
@@ -470,6 +472,8 @@ def gen_loader_item() -> None:
                 "elongation": (rng.random((H, W)) * keep).astype(np.float32),
                 "laser_number": (np.arange(H)[:, None] * np.ones((1, W)) * keep).astype(np.float32),
                 "is_within_roi": rng.random((H, W)) >= 0.25}
+        if tag == "av2_view":  # laser ids over the whole 0..63 range, as the raw sweeps have them
+            cols["laser_number"] = (rng.integers(0, 64, (H, W)) * keep).astype(np.float32)
         tmp = Path(tempfile.mkdtemp())
         lidar = tmp / "sweep.feather"
         feather.write_feather(pa.table({k: v.reshape(-1) for k, v in cols.items()}), str(lidar), compression="uncompressed")
@@ -483,7 +487,7 @@ def gen_loader_item() -> None:
             split_name="val", augmentations_config=None, dataset_name=ds, enable_database=False, db_config=None, x_stride=1,
             padding_mode=mode, targets_config=None)
         datum = ref_loader.DataLoader.__getitem__(me, 0)
-        for k in ("intensity", "range", "x", "y", "z", "elongation", "is_within_roi"):
+        for k in ("intensity", "range", "x", "y", "z", "elongation", "is_within_roi") + (("laser_number",) if tag == "av2_view" else ()):
             out[f"{tag}/table/{k}"] = cols[k].reshape(-1)
         out[f"{tag}/feature_column_names"] = np.array(names)
         out[f"{tag}/padding_mode"] = np.array(mode)

@@ -327,9 +327,10 @@ def test_device_loader_item_matches_the_reference(golden, tmp_path):
     from test_oracle_golden import _loader_case
 
     g = golden("loader_item")
-    for tag, ds in (("av2", "av2"), ("waymo", "waymo")):
+    row_map = golden("raw_sweep").np("tables/ROW_MAPPING_64")
+    for tag, ds in (("av2", "av2"), ("waymo", "waymo"), ("av2_view", "av2")):  # av2_view: the `view` feature (loader.py:605-624)
         names, table, roi, mode = _loader_case(g, tag)
-        cfg = {"feature_column_names": names, "filter_roi": roi, "height": 8, "width": 64}
+        cfg = {"feature_column_names": names, "filter_roi": roi, "height": 8, "width": 64, "row_mapping_64": row_map}
         path = tmp_path / f"{tag}.feather"
         with pa.OSFile(str(path), "wb") as sink:
             t = pa.table(table)

@@ -290,7 +290,7 @@ def test_augmentations_match_the_reference(golden):
 
 def _loader_case(g, tag):
     names = [str(n) for n in g.np(f"{tag}/feature_column_names")]
-    table = {k: g.np(f"{tag}/table/{k}") for k in ("intensity", "range", "x", "y", "z", "elongation", "is_within_roi")}
+    table = {k: g.np(f"{tag}/table/{k}") for k in ("intensity", "range", "x", "y", "z", "elongation", "is_within_roi", "laser_number") if f"{tag}/table/{k}" in g}
     return names, table, bool(g.np(f"{tag}/filter_roi")), str(g.np(f"{tag}/padding_mode"))
 
 
@@ -301,14 +301,15 @@ def test_loader_item_matches_the_reference(golden):
     from oracle import loader as old
 
     g = golden("loader_item")
-    for tag, ds in (("av2", "av2"), ("waymo", "waymo")):
+    row_map = golden("raw_sweep").np("tables/ROW_MAPPING_64")  # (the dataset's id table, stored as data by the raw-sweep fixture)
+    for tag, ds in (("av2", "av2"), ("waymo", "waymo"), ("av2_view", "av2")):
         names, table, roi, mode = _loader_case(g, tag)
-        got = old.range_view_from_table(table, names, 8, 64, ds, roi, 1, mode)
+        got = old.range_view_from_table(table, names, 8, 64, ds, roi, 1, mode, row_mapping_64=row_map)
         for k in ("features", "cart", "mask"):
             ref = g.np(f"{tag}/{k}")
             assert got[k].shape == ref.shape and got[k].dtype == ref.dtype, (tag, k, got[k].shape, ref.shape, got[k].dtype, ref.dtype)
             assert np.array_equal(got[k], ref), (tag, k)
-        assert got["features"].shape[-1] == {"av2": 72, "waymo": 70}[tag]
+        assert got["features"].shape[-1] == {"av2": 72, "waymo": 70}[ds]
 
 
 def test_raw_sweep_path_matches_the_reference(golden):
