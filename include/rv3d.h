@@ -107,6 +107,9 @@ int rv_unpack_weight_grad(const rvTapGeom* g, const float* packed, float* dT, in
 #define RV_OUT_BIAS 8    /* dst += bias[c] */
 #define RV_OUT_STATS 16  /* write per-block partial sum / sum-of-squares of the fp32 result */
 #define RV_OUT_ACCUM 32  /* dst += result (gradient fan-in); bf16 dst only */
+#define RV_OUT_RELU 64   /* with RV_OUT_BIAS: dst = max(result + bias[c], 0) -- inference: an eval-mode BatchNorm folded into the
+                          * weights (w * gamma / sqrt(var + eps)) and the bias (beta - mean * scale), ReLU in the epilogue, so that
+                          * conv -> BatchNorm -> ReLU is ONE launch and one write (cuDNN conv + batch_norm + relu_ in the reference) */
 #define RV_WGRAD_TORCH_LAYOUT 128 /* rv_tap_wgrad only: dT_packed receives the torch layout dT[cu][cv][kh][kw] (cu*cv*kh*kw fp32,
                                   * no padding) straight from the split-K reduction -- no rv_unpack_weight_grad pass */
 

@@ -21,7 +21,7 @@ LIB_PATH_F16 = os.environ.get("RV3D_LIB_F16") or os.path.join(_HERE, "librv3d_hi
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "rv3d.h")
 
 # flags (mirror include/rv3d.h)
-IN_AFFINE, IN_RELU, OUT_F32, OUT_BIAS, OUT_STATS, OUT_ACCUM = 1, 2, 4, 8, 16, 32
+IN_AFFINE, IN_RELU, OUT_F32, OUT_BIAS, OUT_STATS, OUT_ACCUM, OUT_RELU = 1, 2, 4, 8, 16, 32, 64
 WGRAD_TORCH_LAYOUT = 128  # rv_tap_wgrad: result in dT[cu][cv][kh][kw] (no unpack pass)
 EW_RELU_A, EW_RELU_B, EW_RELU_OUT = 1, 2, 4
 BNB_RELU_Z, BNB_RES_ACCUM, BNB_Y_FROM_INPUT = 1, 2, 4

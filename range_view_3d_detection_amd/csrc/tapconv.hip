@@ -247,6 +247,7 @@ __global__ __launch_bounds__(256, 2) void tapconv_kernel(const TapConvArgs a) {
         }
     }
     if (a.flags & RV_OUT_BIAS) {
+        const bool relu_out = (a.flags & RV_OUT_RELU) != 0;  // eval: BatchNorm folded into weights + bias, ReLU on the way out
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int c = n0 + wn * NT * 16 + j * 16 + l15;
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void tapconv_kernel(const TapConvArgs a) {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][j][r] += b;
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = relu_out ? fmaxf(acc[i][j][r] + b, 0.f) : acc[i][j][r] + b;
         }
     }
     const int64_t dst_row = ((int64_t)(n * a.H + h) * a.W_dst) * a.ld_dst;

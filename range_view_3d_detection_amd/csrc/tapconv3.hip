@@ -269,6 +269,7 @@ __global__ __launch_bounds__(512, 2) void tapconv3_kernel(const TapConvArgs a) {
         }
     }
     if (a.flags & RV_OUT_BIAS) {
+        const bool relu_out = (a.flags & RV_OUT_RELU) != 0;  // eval: BatchNorm folded into weights + bias, ReLU on the way out
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int c = n0 + wn * 64 + j * 16 + l15;
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(512, 2) void tapconv3_kernel(const TapConvArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][j][r] += b;
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = relu_out ? fmaxf(acc[i][j][r] + b, 0.f) : acc[i][j][r] + b;
         }
     }
     if (a.flags & RV_OUT_F32) {

@@ -460,8 +460,12 @@ class TapLayer:
     def c_out(self) -> int:
         return self.cv if self.transposed else self.cu
 
-    def _torch_weight(self) -> Tensor:
+    def _torch_weight(self, out_scale: Optional[Tensor] = None) -> Tensor:
+        """fp32 weight in the layout the packers take; ``out_scale`` (c_out,) multiplies every OUTPUT channel first (an eval-mode
+        BatchNorm folded into the weights)."""
         w = self.weight.detach()
+        if out_scale is not None:
+            w = w.float() * (out_scale.view(1, -1, 1, 1) if self.transposed else out_scale.view(-1, 1, 1, 1))
         if self.in_perm is not None:
             c, taps = self.in_perm
             cu = w.shape[0]
@@ -508,6 +512,32 @@ class TapLayer:
             L.call("rv_pack_weight_folded", ctypes.byref(self.geom), L.ptr(self.weight.detach().contiguous().float()), L.ptr(self._fold_image), L.stream_ptr())
             self._fold_version = ver
         return self._fold_image
+
+    def packed_eval(self, form: str, bn: nn.Module) -> Tuple[Tensor, Tensor]:
+        """Inference image of conv -> eval-mode BatchNorm: (weight image with gamma / sqrt(var + eps) folded into every output
+        channel, padded bias beta - mean * scale), cached until the conv weight or any BatchNorm tensor changes.  The fold is
+        a handful of small fp32 torch ops once per checkpoint, not per forward."""
+        key = (self.weight._version, self.weight.data_ptr(), bn.weight._version, bn.bias._version,
+               bn.running_mean._version, bn.running_var._version, bn.running_mean.data_ptr())
+        cache = self.__dict__.setdefault("_eval_fold", {})
+        hit = cache.get((form, L.operand_tag()))
+        if hit is None or hit[0] != key:
+            c, cp = self.c_out, pad32(self.c_out)
+            scale = bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps)
+            shift = bn.bias.detach().double() - bn.running_mean.detach().double() * scale
+            w = self._torch_weight(out_scale=scale.float())
+            geom = self.fold_geom() if form == "folded" else self.geom
+            nbytes = L.load().rv_packed_weight_bytes(ctypes.byref(geom))
+            img = torch.empty(nbytes // 2, dtype=L.act_dtype(), device=self.weight.device)
+            if form == "folded":
+                L.call("rv_pack_weight_folded", ctypes.byref(self.geom), L.ptr(w.contiguous()), L.ptr(img), L.stream_ptr())
+            else:
+                L.call("rv_pack_weight", ctypes.byref(self.geom), L.ptr(w), L.ptr(img if form == "gather" else None),
+                       L.ptr(img if form == "scatter" else None), L.stream_ptr())
+            bias = torch.zeros(cp, dtype=torch.float32, device=self.weight.device)
+            bias[:c] = shift.float()
+            cache[(form, L.operand_tag())] = hit = (key, img, bias)
+        return hit[1], hit[2]
 
     def invalidate(self) -> None:
         """Drop the packed bf16 images.  They are re-packed automatically when ``weight._version`` or its storage changes
@@ -690,10 +720,13 @@ class ConvOp(Op):
     """``out = layer(x)``: tap-conv forward; optional batch statistics, bias, fp32 output."""
 
     def __init__(self, t: Tape, layer: TapLayer, x: Operand, stats: bool = False, out_f32: bool = False,
-                 out: Optional[Act] = None, need_input_grad: bool = True, precomputed: Optional[Tuple[Optional[Tensor], int]] = None) -> None:
+                 out: Optional[Act] = None, need_input_grad: bool = True, precomputed: Optional[Tuple[Optional[Tensor], int]] = None,
+                 eval_bn: Optional[nn.Module] = None, relu_out: bool = False) -> None:
         """``precomputed`` = (partial statistics rows, rows): ``out`` already holds the layer's output (a fused kernel wrote it);
-        the op only records what backward needs."""
+        the op only records what backward needs.  ``eval_bn`` (inference only): the eval-mode BatchNorm behind the conv is folded
+        into the weight image and the bias, ``relu_out`` applies the ReLU in the epilogue -- the output is the activation."""
         self.layer, self.x, self.need_input_grad = layer, x, need_input_grad
+        self.eval_bn = eval_bn
         self.pos_first: Optional["SmallKOp"] = None
         src, sc, sh, flags = _operand_parts(x)
         form = layer.fwd_form
@@ -730,7 +763,11 @@ class ConvOp(Op):
             self.out = out if out is not None else Act.empty(src.N, src.H, w_out, layer.c_out, t.device)
             dst_ptr, ld_dst = self.out.ptr(), self.out.ld
         bias = layer.bias
-        if bias is not None:
+        if eval_bn is not None:
+            assert bias is None and not stats and not t.training
+            flags |= L.OUT_BIAS | (L.OUT_RELU if relu_out else 0)
+            bias_p = None  # (filled below, with the folded weight image)
+        elif bias is not None:
             flags |= L.OUT_BIAS
             bias_p = torch.nn.functional.pad(bias.detach().float(), (0, pad32(layer.c_out) - layer.c_out))
         else:
@@ -743,7 +780,7 @@ class ConvOp(Op):
         if gf is not None and src.ld == src.cp and src.W == g.stride_w * wu and _dma_eligible(gf, src.N, src.H, wu, wu, g.stride_w * src.ld, ld_dst, False):
             lg = gf
             lshape = L.TapShape(src.N, src.H, wu, wu, g.stride_w * src.ld, ld_dst, self.shape.flags)
-            wp = layer.packed_folded()
+            wp = layer.packed_folded() if eval_bn is None else "folded"
         self.partial = None
         self.rows = 0
         if stats:
@@ -752,7 +789,9 @@ class ConvOp(Op):
                 raise L.RvError("rv_tap_stats_rows: " + L.load().rv_last_error().decode())
             self.partial = torch.empty((self.rows + L.STATS_SCRATCH_ROWS, 2, pad32(layer.c_out)), dtype=torch.float32,
                                        device=t.device)
-        if wp is None:
+        if eval_bn is not None:
+            wp, bias_p = layer.packed_eval("folded" if isinstance(wp, str) else form, eval_bn)
+        elif wp is None:
             wp = layer.packed(form)
         call = lambda: L.call("rv_tap_" + form, ctypes.byref(lg), ctypes.byref(lshape), src.ptr(), L.ptr(sc), L.ptr(sh),
                               L.ptr(wp), L.ptr(bias_p), dst_ptr, L.ptr(self.partial), L.stream_ptr())
@@ -769,6 +808,8 @@ class ConvOp(Op):
     def backward(self, t: Tape) -> None:
         from . import engine_bwd  # local import: backward kernels are a separate module
 
+        if self.eval_bn is not None:
+            raise L.RvError("this conv ran with an eval-mode BatchNorm folded into its weights (inference): there is no backward")
         engine_bwd.conv_backward(self, t)
 
 
@@ -904,12 +945,19 @@ def _smallk_eligible(layer: TapLayer, x: Operand, relu: bool, need_input_grad: b
             and g.kw == 1 and g.stride_w == 1 and layer.c_in <= 8 and layer.in_perm is None and layer.bias is None)
 
 
+EVAL_FOLD = os.environ.get("RV3D_NO_EVAL_FOLD") is None
+
+
 def conv_bn(t: Tape, layer: TapLayer, x: Operand, bn: nn.BatchNorm2d, relu: bool = True,
-            need_input_grad: bool = True, smallk: bool = True) -> Operand:
+            need_input_grad: bool = True, smallk: bool = True, fold_eval: bool = True) -> Operand:
     """conv -> BatchNorm (-> ReLU).  ``smallk=False`` keeps a small-K layer on the generic path (a Lazy result), for consumers
-    that fold the BatchNorm themselves (MetaModulateOp)."""
+    that fold the BatchNorm themselves (MetaModulateOp; ``fold_eval=False`` likewise keeps the Lazy form in eval mode)."""
     if smallk and _smallk_eligible(layer, x, relu, need_input_grad):
         return SmallKOp(t, layer, x, bn).out
+    if not t.training and EVAL_FOLD and fold_eval and layer.bias is None:
+        # inference: BatchNorm folded into the weight image and the bias, ReLU in the epilogue -- the conv writes the activation
+        # itself (no folded operand for the consumer to apply, no write-out pass for the LDS-DMA kernels)
+        return ConvOp(t, layer, x, need_input_grad=need_input_grad, eval_bn=bn, relu_out=relu).out
     conv = ConvOp(t, layer, x, stats=t.training, need_input_grad=need_input_grad)
     return BnOp(t, conv, bn, relu).lazy
 
@@ -922,6 +970,8 @@ def conv_bn_many(t: Tape, specs: Sequence[Tuple[TapLayer, Operand, nn.BatchNorm2
     then every BatchNorm is finalised -- under SyncBN with ONE all-reduce for the whole group (``allreduce_partial_rows_many``)
     instead of one per layer; the BnOps sit next to each other on the tape, so the backward pass groups their collectives
     too (``Tape.backward``).  spec = (layer, input, bn, relu, need_input_grad).  Results in spec order."""
+    if not t.training and EVAL_FOLD and all(layer.bias is None for layer, *_ in specs):
+        return [ConvOp(t, layer, x, need_input_grad=nig, eval_bn=bn, relu_out=relu).out for layer, x, bn, relu, nig in specs]
     convs = [ConvOp(t, layer, x, stats=t.training, need_input_grad=nig) for layer, x, _, _, nig in specs]
     reduced: List[Optional[Tensor]] = [None] * len(specs)
     if t.training and GROUP_SYNC_BN and len(specs) > 1:

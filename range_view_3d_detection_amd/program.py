@@ -128,7 +128,7 @@ def meta_kernel_program(t: Tape, m: nn.Module, features: Act, cart: Tensor, out:
     for i, blk in enumerate(blocks):
         # the LAST positional layer feeds MetaModulateOp, which folds its BatchNorm+ReLU itself and needs the Lazy form
         # (num_layers == 1: that is the 3 -> C layer, which would otherwise take the small-K fast path)
-        pos = E.conv_bn(t, E.tap_layer(blk[0]), pos, blk[1], relu=True, need_input_grad=(i > 0), smallk=(i + 1 < n_pos))
+        pos = E.conv_bn(t, E.tap_layer(blk[0]), pos, blk[1], relu=True, need_input_grad=(i > 0), smallk=(i + 1 < n_pos), fold_eval=(i + 1 < n_pos))
     geo: Operand = E.MetaModulateOp(t, pos, f).out
     c = m.out_channels
     for i, blk in enumerate(m.fusion_kernel):

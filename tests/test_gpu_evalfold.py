@@ -1,0 +1,108 @@
+"""Inference: eval-mode BatchNorm folded into the conv's weight image and bias, ReLU in the epilogue (RV_OUT_RELU).
+
+conv -> BatchNorm(eval) -> ReLU is ONE launch writing the activation (the reference: cuDNN conv + batch_norm + relu_).
+* exact: integer activations / weights, BatchNorm parameters chosen so that scale = gamma and shift are exactly representable:
+  the stored output must EQUAL relu(conv * gamma + shift) (rounded once to the operand type) on every kernel generation (tapconv5 3x3, tapconv4 1x1, the folded
+  stride-2 form, the conv-transpose phases), in the bf16 and in the fp16 build;
+* the same programs with the fold switched off (``engine.EVAL_FOLD = False``: BatchNorm applied as a folded operand of the
+  consumer, as in training) give the same block outputs within bf16 rounding (2e-2 of max).
+"""
+
+from __future__ import annotations
+
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_gpu_forward import DEV, rel_err
+from test_gpu_tapconv4 import _ints
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _small_grids_allowed():
+    from range_view_3d_detection_amd import _lib as L
+
+    olds = {tag: L.load(tag).rv_set_option(b"tapconv4_min_blocks", ctypes.c_int32(1)) for tag in ("bf16", "f16")}
+    yield
+    for tag, old in olds.items():
+        L.load(tag).rv_set_option(b"tapconv4_min_blocks", ctypes.c_int32(old))
+
+
+def _exact_bn(c, g):
+    bn = torch.nn.BatchNorm2d(c, eps=0.0)
+    bn.weight.data = torch.tensor([0.5, 1.0, 2.0])[torch.randint(0, 3, (c,), generator=g)]
+    bn.bias.data = _ints((c,), g, -4, 5)
+    bn.running_mean.data = _ints((c,), g, -2, 3)
+    bn.running_var.data = torch.ones(c)  # eps = 0, var = 1: scale = gamma and shift = beta - mean * gamma exactly
+    return bn.eval()
+
+
+@pytest.mark.parametrize("tag", ["bf16", "f16"])
+@pytest.mark.parametrize("kind", ["3x3", "1x1", "3x3s2", "convT"])
+def test_eval_fold_exact(kind, tag):
+    from range_view_3d_detection_amd import _lib as L
+    from range_view_3d_detection_amd import engine as E
+    from range_view_3d_detection_amd.nn.modules.conv import Conv2dSame
+
+    g = torch.Generator().manual_seed(hash(kind) % 1000)
+    cin, cout = 128, 256
+    x = _ints((2, cin, 16, 256), g, -1, 2)
+    if kind == "convT":
+        m = torch.nn.ConvTranspose2d(cin, cout, kernel_size=(3, 4), stride=(1, 2), padding=(1, 1), bias=False)
+        m.weight.data = _ints(m.weight.shape, g, -1, 2)
+        ref = F.conv_transpose2d(x, m.weight.data, stride=(1, 2), padding=(1, 1))
+        conv = m
+    else:
+        k, s = (1, (1, 1)) if kind == "1x1" else (3, (1, 2) if kind == "3x3s2" else (1, 1))
+        m = Conv2dSame(cin, cout, k, stride=s, bias=False)
+        m.conv.weight.data = _ints(m.conv.weight.shape, g, -1, 2)
+        t_ = k - 1
+        ref = F.conv2d(F.pad(x, [t_ // 2, t_ - t_ // 2, t_ // 2, t_ - t_ // 2]), m.conv.weight.data, stride=s)
+        conv = m.conv
+    bn = _exact_bn(cout, g)
+    scale = bn.weight.data
+    want = F.relu(ref * scale.view(1, -1, 1, 1) + (bn.bias.data - bn.running_mean.data * scale).view(1, -1, 1, 1))
+    assert float(want.abs().max()) < 2048
+    conv, bn = conv.to(DEV), bn.to(DEV)
+    with L.operand(tag):
+        t = E.Tape(False, DEV)
+        out = E.conv_bn(t, E.tap_layer(conv), E.Act.from_nchw(x.to(DEV)), bn, relu=True)
+    assert isinstance(out, E.Act) and len(t.ops) == 1  # one launch, a plain activation
+    # every partial sum is exact in fp32: the stored value is relu(conv * gamma + shift) rounded ONCE to the operand type
+    got, exp = out.nchw().float().cpu(), want.to(torch.float16 if tag == "f16" else torch.bfloat16).float()
+    assert torch.equal(got, exp), (float((got - exp).abs().max()), int((got != exp).sum()), got.numel())
+
+
+def test_eval_fold_equals_the_unfolded_programs(golden):
+    """Block programs and the tiny detector in eval mode: folded (inference default) against unfolded (BatchNorm as a folded
+    operand of the consumer) and against the reference's eval outputs."""
+    from range_view_3d_detection_amd import engine as E
+    from test_gpu_model import load_tiny
+
+    g = golden("tiny_model")
+    backbone, head = load_tiny(g)
+    backbone.eval()
+    head.eval()
+    data = {"features": g["features"].to(DEV), "cart": g["cart"].to(DEV), "mask": g["mask"].to(DEV)}
+
+    def run():
+        with torch.no_grad():
+            out, _ = head(backbone(data), data, return_loss=False)
+        return out[1][0]["logits"].float().cpu(), out[1][0]["regressands"].float().cpu()
+
+    lf, rf = run()
+    old = E.EVAL_FOLD
+    E.EVAL_FOLD = False
+    try:
+        lu, ru = run()
+    finally:
+        E.EVAL_FOLD = old
+    assert rel_err(lf, lu) < 2e-2 and rel_err(rf, ru) < 2e-2, (rel_err(lf, lu), rel_err(rf, ru))
+    # and no further from the reference's fp32 eval outputs than the unfolded form is (+ 20 %)
+    ef, eu = rel_err(lf, g["eval/logits"]), rel_err(lu, g["eval/logits"])
+    print(f"tiny model eval logits vs the reference: folded {ef:.3e}, unfolded {eu:.3e}")
+    assert ef < 4e-2 and ef < 1.2 * eu + 1e-3

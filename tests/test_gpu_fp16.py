@@ -154,15 +154,25 @@ def test_full_size_eval_forward_fp16_vs_oracle_and_decode():
     mb = rel_err(outputs_b[1][0]["logits"].float().cpu(), lg32)
     print(f"    bf16 operands, same model: logits~fp32 {mb:.3e}")
     assert m["logits~fp32"] < 0.5 * mb, (m["logits~fp32"], mb)
-    # decode + weighted NMS from the fp16 logits, against the oracle decoder on the SAME logits
-    dec = RangeDecoder(True, True, [0, 15, 30], [15, 30, math.inf], [8, 2, 1])
-    post = {"num_pre_nms": 50000, "num_post_nms": 1000, "nms_threshold": 0.3, "min_confidence": 0.1, "nms_mode": "WEIGHTED"}
-    p, s, c, b = dec.decode(outputs, post, {0: [f"C{i}" for i in range(26)]}, use_nms=True)
-    po, so, co, bo = odec.range_decode(logits, reg, batch["cart"], batch["mask"], post, use_nms=True)
+    # decode + weighted NMS from the fp16 logits.  Two layers, so that a last-bit difference between the device's and the CPU's
+    # sigmoid cannot flip the order of two nearly equal scores and with it a cluster head: (1) the decoded candidates against the
+    # oracle decoder on the same logits; (2) the NMS rows against the oracle NMS fed the DEVICE's own candidates.
+    from oracle import nms as onms
+    from range_view_3d_detection_amd.nn.decoders.range_decoder import decode_candidates
     from test_gpu_nms_wrapper import _canonical  # rows with exactly equal (sweep, class, merged score): compared as a set
 
+    dec = RangeDecoder(True, True, [0, 15, 30], [15, 30, math.inf], [8, 2, 1])
+    post = {"num_pre_nms": 50000, "num_post_nms": 1000, "nms_threshold": 0.3, "min_confidence": 0.1, "nms_mode": "WEIGHTED"}
+    o = outputs[1][0]
+    sc, ct, bx = decode_candidates(o["logits"], o["regressands"], data["cart"], data["mask"], True, [0, 15, 30], [15, 30, math.inf], [8, 2, 1])
+    sco, cto, bxo = odec.dense_candidates(logits, reg, batch["cart"], batch["mask"])
+    assert rel_err(sc, sco) < 1e-6 and rel_err(bx, bxo) < 1e-5
+    assert float((ct.cpu() != cto).float().mean()) < 1e-4  # (fp32-sigmoid collisions of saturated logits: test_gpu_fullsize.py)
+    p, s, c, b = dec.decode(outputs, post, {0: [f"C{i}" for i in range(26)]}, use_nms=True)
+    bo_, so, co, io = onms.batched_multiclass_nms(bx.cpu(), sc.cpu(), ct.cpu(), 50000, 1000, 0.3, 0.1)
+    po = torch.cat([bo_[:, :-1], odec.yaw_to_quat(bo_[:, -1:])], dim=-1)
     assert p.shape[0] > 20 and p.shape == po.shape, (p.shape, po.shape)
     p, s, c, b = _canonical(p, s, c, b)
-    po, so, co, bo = _canonical(po, so, co, bo)
-    assert torch.equal(c, co) and torch.equal(b, bo)
+    po, so, co, io = _canonical(po, so, co, io)
+    assert torch.equal(c, co) and torch.equal(b, io)
     assert rel_err(p, po) < 1e-5 and rel_err(s, so) < 1e-6, (rel_err(p, po), rel_err(s, so))
