@@ -396,9 +396,16 @@ def main() -> None:
     model = Detector(backbone, head).to(dev).train()
     E.SYNC_BN = dist_on and not args.no_sync_bn  # explicit: sync every BatchNorm (what Lightning's sync_batchnorm: true does) / local
     step_model = model
-    if dist_on:
-        step_model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], gradient_as_bucket_view=True, static_graph=True)
     params = [p for p in model.parameters()]
+    use_ddp = os.environ.get("RV3D_DDP") is not None  # A/B: torch's DistributedDataParallel instead of engine.GradSync
+    if dist_on and use_ddp:
+        step_model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], gradient_as_bucket_view=True, static_graph=True)
+    elif dist_on:
+        # the model's backward is three autograd nodes: one flat gradient buffer, one multi-tensor copy + one asynchronous RCCL
+        # all-reduce per finished node, instead of DDP's per-parameter hooks / bucket copies / divisions (engine.GradSync)
+        E.GRAD_SYNC = E.GradSync(params, world)
+        if world > 1:
+            E.GRAD_SYNC.broadcast_parameters(model)
     # the reference's recipe (nn/meta/arch.py:48-75): AdamW(1e-3) + OneCycleLR(max_lr = 0.00075 * sqrt(devices * batch)), per step
     from range_view_3d_detection_amd.nn.meta.arch import configure_optimizers
 
@@ -411,6 +418,8 @@ def main() -> None:
         opt.zero_grad(set_to_none=True)
         loss = step_model(batch)
         loss.backward()
+        if E.GRAD_SYNC is not None:
+            E.GRAD_SYNC.finish()  # gradients averaged over the ranks, p.grad = views of the flat buffer
         if not fused_opt:
             torch.nn.utils.clip_grad_norm_(params, 35.0)
         opt.step()  # fused: gradient clipping at 35.0 + AdamW in two launches (rv_adamw_step)
@@ -466,7 +475,8 @@ def main() -> None:
                        "sync_bn": bool(E.SYNC_BN), "loss": float(loss.detach().item()),
                        "collectives": {"per_step": {"sync_bn_all_reduce": {"calls": sync_calls, "bytes": sync_bytes},
                                                     "gradient_all_reduce_bytes": 4 * sum(p.numel() for p in params) if dist_on else 0},
-                                       "note": "SyncBN: one all-reduce of (2C+1) fp32 per BatchNorm layer and direction; gradients: DDP buckets"},
+                                       "gradient_sync": ("DistributedDataParallel" if use_ddp else "engine.GradSync (flat buffer, one all-reduce per autograd node)") if dist_on else None,
+                                       "note": "SyncBN: (2C+1) fp32 per BatchNorm layer and direction, layers that become available together share one all-reduce"},
                        "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 2)},
             "roofline": roofline(prof, iso),
             "kernels": prof.summary(),

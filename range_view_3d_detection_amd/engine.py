@@ -215,6 +215,73 @@ def allreduce_partial_rows_many(items: Sequence[Tuple[Tensor, int, int, Optional
     return views
 
 
+class GradSync:
+    """Data-parallel gradient averaging for the fused programs, without ``DistributedDataParallel``.
+
+    The model's backward is THREE autograd nodes (backbone + stem, the tower pair, the loss): per-parameter hooks, bucket copies
+    and per-bucket divisions -- DDP's machinery for graphs of thousands of nodes -- cost ~380 tiny kernels per step here
+    (+3.4 ms on one rank, profiles/r03_syncbn_collectives.md).  Instead: ONE flat fp32 buffer holds every parameter's gradient;
+    when a program node's backward has finished (``program._ProgramFn.backward``) its gradients are copied into their views of
+    that buffer by one multi-tensor copy and the node's contiguous range is all-reduced asynchronously (RCCL through
+    ``torch.distributed``: the towers' 75 MB travel while the backbone's backward runs, the backbone's 63 MB are exposed at the
+    end, as under DDP); ``finish()`` waits, divides by the world size and points ``p.grad`` at the views.  No gradient
+    accumulation over several backward passes (the flat buffer is overwritten per step) -- the recipe has none."""
+
+    def __init__(self, params: Sequence[nn.Parameter], world: Optional[int] = None) -> None:
+        self.params = [p for p in params if p.requires_grad]
+        self.world = world if world is not None else _dist_world()
+        self.offsets: Dict[int, Tuple[int, int]] = {}
+        total = 0
+        for p in self.params:
+            self.offsets[id(p)] = (total, p.numel())
+            total += (p.numel() + 63) // 64 * 64  # 256-byte aligned views
+        dev = self.params[0].device
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.works: List[tuple] = []
+        self.bytes = 4 * sum(p.numel() for p in self.params)
+
+    def view(self, p: nn.Parameter) -> Tensor:
+        o, n = self.offsets[id(p)]
+        return self.flat[o : o + n].view_as(p)  # (a fresh tensor object each time: autograd may keep it as p.grad without a copy)
+
+    def broadcast_parameters(self, module: nn.Module) -> None:
+        """Rank 0's parameters and buffers to every rank, once (what DDP does at construction)."""
+        for t in list(module.parameters()) + list(module.buffers()):
+            torch.distributed.broadcast(t.data, src=0)
+
+    def reduce_node(self, params: Sequence[nn.Parameter], grads: Sequence[Optional[Tensor]]) -> List[Optional[Tensor]]:
+        """Gradients of the parameters of ONE finished autograd node -> their flat views, all-reduce started; returns the list
+        with the views in place of the node's own gradient tensors."""
+        out = list(grads)
+        idx = [i for i, (p, g) in enumerate(zip(params, grads)) if g is not None and id(p) in self.offsets]
+        if not idx:
+            return out
+        dst = [self.view(params[i]) for i in idx]
+        torch._foreach_copy_(dst, [grads[i].to(torch.float32) for i in idx])
+        lo = min(self.offsets[id(params[i])][0] for i in idx)
+        hi = max(self.offsets[id(params[i])][0] + (self.offsets[id(params[i])][1] + 63) // 64 * 64 for i in idx)
+        seg = self.flat[lo:hi]
+        if torch.distributed.is_available() and torch.distributed.is_initialized():  # (also with ONE rank: the one-GPU test of the path)
+            self.works.append((torch.distributed.all_reduce(seg, async_op=True), seg))
+        for i, d in zip(idx, dst):
+            out[i] = d
+        return out
+
+    def finish(self) -> None:
+        """Before the optimizer step: wait for the collectives, average, and make every ``p.grad`` its view of the flat buffer."""
+        for work, seg in self.works:
+            work.wait()
+            if self.world > 1:
+                seg.mul_(1.0 / self.world)
+        self.works.clear()
+        for p in self.params:
+            if p.grad is not None:
+                p.grad = self.view(p)
+
+
+GRAD_SYNC: Optional[GradSync] = None
+
+
 class _CollectiveLog:
     """Per-step census of the collectives the engine itself issues (bench.py reports it in ``config.collectives``)."""
 

@@ -278,6 +278,8 @@ class _ProgramFn(torch.autograd.Function):
             else:
                 gin.append(tape.grads[id(a)].nchw().to(meta[0]))
         gparams = [tape.param_grads.get(id(p)) for p in ctx.params]
+        if E.GRAD_SYNC is not None:  # data parallel: this node's gradients into the flat buffer, its all-reduce under way
+            gparams = E.GRAD_SYNC.reduce_node(ctx.params, gparams)
         ctx.tape = None  # free activations
         return (None, None, None, *gin, *gparams)
 

@@ -182,11 +182,24 @@ rules.append(E.bn_sync_world(bn, True) == world)
 E.SYNC_BN = False
 rules.append(E.bn_sync_world(sbn, True) == 1 and E.bn_sync_world(bn, True) == 1)
 E.SYNC_BN = None
+# (2c) gradient averaging without DistributedDataParallel: flat buffer, one all-reduce per finished node
+torch.manual_seed(0)
+pa, pb, pc = (torch.nn.Parameter(torch.zeros(s)) for s in ((3, 5), (7,), (2, 2, 2)))
+gs = E.GradSync([pa, pb, pc], world)
+ga, gb, gc = (torch.full_like(p, float(rank + 1) * (i + 1)) for i, p in enumerate((pa, pb, pc)))
+node1 = gs.reduce_node([pc], [gc])            # the node that finishes first (the towers) ...
+node2 = gs.reduce_node([pa, pb], [ga, None])  # ... then the rest; pb got no gradient
+for p_, g_ in zip((pc, pa, pb), (node1[0], node2[0], node2[1])):
+    p_.grad = g_
+gs.finish()
+mean = sum(r + 1 for r in range(world)) / world
+grad_ok = (torch.allclose(pa.grad, torch.full((3, 5), mean * 1)) and pb.grad is None and torch.allclose(pc.grad, torch.full((2, 2, 2), mean * 3))
+           and pa.grad.data_ptr() == gs.view(pa).data_ptr() and not gs.works)
 # (3) step time = MAX over ranks (bench.py contract)
 t = torch.tensor([1.0 + rank], dtype=torch.float64)
 dist.all_reduce(t, op=dist.ReduceOp.MAX)
 out = {"rank": rank, "digests": [float(x) for x in gathered], "stats_err": float((tot - ref).abs().max()), "tmax": float(t),
-       "count_ok": bool(count_ok and local_ok and group_ok), "rules": rules}
+       "count_ok": bool(count_ok and local_ok and group_ok and grad_ok), "rules": rules}
 print("RESULT " + json.dumps(out), flush=True)
 dist.destroy_process_group()
 """
