@@ -10,9 +10,9 @@ DLA backbone + cls/reg towers (forward), device target assignment + varifocal/L1
 through every layer, gradient clipping (35.0) and the AdamW update -- the work of one
 ``Detector.training_step`` (nn/arch/detector.py:238-247) with ``conf/experiment/rv-av2.yaml``.
 Inputs are resident in HBM before the timed region.  N > 1: one process per GPU, sweeps sharded
-across ranks (weak scaling, 4 sweeps per GPU), gradient all-reduce through DDP over RCCL overlapped
-with the backward of the earlier stage, BatchNorm statistics all-reduced (SyncBN as in
-conf/trainer/train.yaml:15).
+across ranks (weak scaling, 4 sweeps per GPU), gradient all-reduce over RCCL per finished program node
+(engine.GradSync: the towers' gradients travel under the backbone's backward; RV3D_DDP=1: torch DDP),
+BatchNorm statistics all-reduced (SyncBN as in conf/trainer/train.yaml:15).
 
 Rank 0 prints ONE JSON line (contract in the task statement) including
   "roofline":     the dominant kernel (tapconv5: 256 x 256-tile bf16 MFMA tap-conv with the input halo resident in LDS)
