@@ -333,7 +333,7 @@ int rv_meta_modulate_bwd_apply(const void* dgeo, const void* pos_raw, const floa
                                int32_t ld_feat, int32_t N, int32_t H, int32_t W, int32_t C, void* dy, rvStream stream);
 
 /* The two positional layers of the MetaKernel stem (nn/stems/__init__.py:41-49, 80: Conv2dNormActivation(3, C, 1) ->
- * Conv2dNormActivation(C, C, 1) on the 9x neighbour grid) as ONE persistent streaming GEMM, C = 256:
+ * Conv2dNormActivation(C, C, 1) on the 9x neighbour grid) as ONE persistent streaming GEMM, C = 256 (rv-av2) or 128 (rv-waymo):
  *   h1 = relu(scale1 * (W1 rel) + shift1)   generated in the K-operand staging from `rel` (bf16 [pixels][ld_rel], cin <= 3
  *                                           channels used) and written once (the second layer's weight gradient reads it),
  *   y2 = W2 h1                              raw bf16, with fp32 (sum, sum of squares) rows of the accumulators in

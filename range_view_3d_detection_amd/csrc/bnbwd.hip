@@ -730,7 +730,7 @@ extern "C" int rv_bn_bwd_smallk_sums(int64_t pixels, int32_t c, const void* dout
 // dOut = dy2 W2 is formed on the fly by pos_bwd_kernel (posconv.hip), which writes the per-workgroup rows of the planes.
 int rv_pos_bwd_launch(int64_t pixels, const void* dy2, const void* w2_scatter, const void* rel, int32_t ld_rel, int32_t cin,
                       const void* w1_packed, int32_t ld_w1, const float* scale1, const float* shift1, const float* mean1,
-                      const float* invstd1, float* partial, int32_t planes, int32_t max_rows, int32_t* rows, hipStream_t stream);
+                      const float* invstd1, float* partial, int32_t planes, int32_t max_rows, int32_t* rows, int32_t c, hipStream_t stream);
 
 extern "C" int rv_pos_backward_sums(int64_t pixels, int32_t c, const void* dy2, const void* w2_scatter, const void* rel, int32_t ld_rel,
                                     int32_t cin, const void* w1_packed, int32_t ld_w1, const float* scale1, const float* shift1,
@@ -738,7 +738,8 @@ extern "C" int rv_pos_backward_sums(int64_t pixels, int32_t c, const void* dy2, 
                                     rvStream stream) {
     RV_REQUIRE(dy2 && w2_scatter && rel && w1_packed && scale1 && shift1 && mean1 && invstd1 && sums && moms && workspace,
                "rv_pos_backward_sums: null argument");
-    RV_REQUIRE(c == 256 && cin >= 1 && cin <= 3 && ld_rel % 8 == 0 && ld_rel >= 8 && pixels > 0, "rv_pos_backward_sums: built for 256 channels, cin <= 3");
+    RV_REQUIRE((c == 256 || c == 128) && cin >= 1 && cin <= 3 && ld_rel % 8 == 0 && ld_rel >= 8 && pixels > 0,
+               "rv_pos_backward_sums: built for 256 or 128 channels, cin <= 3");
     const int CIN = 4, planes = 2 + CIN, mcols = CIN + CIN * CIN;
     const int rows_max = rv_bn_bwd_rows(pixels);  // the workspace layout of rv_bn_bwd_smallk_workspace_bytes
     float* part_g = (float*)workspace;
@@ -749,7 +750,7 @@ extern "C" int rv_pos_backward_sums(int64_t pixels, int32_t c, const void* dy2, 
     hipStream_t st = (hipStream_t)stream;
     int rows = 0;
     if (rv_pos_bwd_launch(pixels, dy2, w2_scatter, rel, ld_rel, cin, w1_packed, ld_w1, scale1, shift1, mean1, invstd1, part_g, planes, rows_max,
-                          &rows, st))
+                          &rows, c, st))
         return 1;
     hipLaunchKernelGGL(smallk_moments_kernel<4>, dim3(mblocks), dim3(256), 0, st, (const bf16_t*)rel, ld_rel, pixels, part_m);
     RV_CHECK_LAUNCH("smallk_moments_kernel");

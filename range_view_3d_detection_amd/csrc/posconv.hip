@@ -30,9 +30,24 @@
 
 namespace {
 
-constexpr int kC = 256;                 // channels of both layers
-constexpr int kTM = 128;                // pixels per step
-constexpr int kBuf = kTM * kC * 2;      // 64 KB per LDS image
+// Geometry per channel count C (256: rv-av2's stem, 128: rv-waymo's).  An LDS image is 64 KB either way, so a step is 128 pixels at
+// C = 256 and 256 pixels at C = 128; a wave owns 32 output channels, and at C = 128 the eight waves are 4 channel slices x 2 pixel halves.
+template <int C>
+struct Pos {
+    static_assert(C == 256 || C == 128, "positional pair: 256 or 128 channels");
+    static constexpr int kC = C;                 // channels of both layers
+    static constexpr int kTM = 128 * 256 / C;    // pixels per step
+    static constexpr int kRow = C * 2;           // bytes of one pixel of an image
+    static constexpr int kBuf = kTM * kRow;      // 64 KB per LDS image
+    static constexpr int kOct = C / 8;           // 16-byte octets per pixel
+    static constexpr int kPass = 512 / kOct;     // pixels the workgroup generates (or a DMA round moves) per pass
+    static constexpr int kSel = 64 / kOct;       // pixels of one wave per pass
+    static constexpr int kKS = C / 32;           // MFMA K-steps
+    static constexpr int kWC = C / 32;           // waves along the channels ...
+    static constexpr int kWP = 8 / kWC;          // ... and along the pixels of a step
+    static constexpr int kGroups = kTM / 32 / kWP;  // 32-pixel groups a wave multiplies per step (4)
+};
+constexpr int kTMmin = 128;  // the row count of the partial buffers is sized for 128-pixel steps (rv_pos_forward_rows): surplus rows are zeros
 
 struct PosFwdArgs {
     const bf16_t* rel;  // [P][ld_rel] bf16, channels 0..cin-1 used
@@ -52,24 +67,28 @@ typedef rv_elem_t bf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack2(const f32x2 v) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t)); }
 __device__ __forceinline__ f32x2 max0(const f32x2 v) { return f32x2{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)}; }
 
+template <int C>
 __global__ __launch_bounds__(512, 1) void pos_fwd_kernel(const PosFwdArgs a) {
+    using G = Pos<C>;
+    constexpr int kC = G::kC, kTM = G::kTM, kBuf = G::kBuf, kRow = G::kRow, kKS = G::kKS;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave = 32-channel slice of the output, all 128 pixels of a step
+    const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wn % G::kWC, wp = wn / G::kWC;  // wave = 32-channel slice of the output x pixel half of a step (C = 256: all 128 pixels)
     const int l15_ = lane & 15, lg_ = lane >> 4;
     const int l15 = l15_, lg = lg_;
 
     // ---- second-layer weights of this wave: A operand, row m = l15 of tile j is channel 32 wn + 8 (m >> 2) + 4 j + (m & 3),
     // so that a lane of the result (rows 4 lg + r of both tiles) holds the 8 consecutive channels 32 wn + 8 lg + 0..7
-    bf16x8 fw[2][8];
+    bf16x8 fw[2][kKS];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int ch = wn * 32 + (l15 >> 2) * 8 + j * 4 + (l15 & 3);
+        const int ch = wc * 32 + (l15 >> 2) * 8 + j * 4 + (l15 & 3);
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) fw[j][ks] = *(const bf16x8*)(a.w2 + (int64_t)ch * kC + ks * 32 + lg * 8);
+        for (int ks = 0; ks < kKS; ++ks) fw[j][ks] = *(const bf16x8*)(a.w2 + (int64_t)ch * kC + ks * 32 + lg * 8);
     }
-    // ---- first layer: this thread generates octet `oct` of pixels pxl, pxl + 16, ... of a step
-    const int oct_ = tid & 31, pxl_ = tid >> 5;
+    // ---- first layer: this thread generates octet `oct` of pixels pxl, pxl + kPass, ... of a step
+    const int oct_ = tid % G::kOct, pxl_ = tid / G::kOct;
     const int oct = oct_;
     // (channel PAIRS -> v_pk_fma_f32; the arithmetic order is rv_smallk_forward's: relu(s (w . rel) + t))
     f32x2 gw[4][3], gs[4], gh[4];
@@ -84,8 +103,8 @@ __global__ __launch_bounds__(512, 1) void pos_fwd_kernel(const PosFwdArgs a) {
             gh[j][q] = a.shift1[c];
         }
     }
-    // `rel` reaches the lanes through SCALAR loads (s_load_dwordx2: a wave generates two pixels per call, lanes 0-31 one,
-    // lanes 32-63 the other).  The step loop then contains NO vector-memory load: on gfx9 loads and stores share vmcnt and
+    // `rel` reaches the lanes through SCALAR loads (s_load_dwordx2: a wave generates kSel pixels per pass -- C = 256: lanes 0-31 one,
+    // lanes 32-63 the other; C = 128: four groups of 16 lanes).  The step loop then contains NO vector-memory load: on gfx9 loads and stores share vmcnt and
     // return out of order with respect to each other, so a wait for any load inside the loop drains every outstanding h1 / y2
     // store first (measured: waves 74 % of their cycles in s_waitcnt, 1.6 ms instead of 0.9).
     const uint64_t* relq = (const uint64_t*)a.rel;
@@ -93,34 +112,41 @@ __global__ __launch_bounds__(512, 1) void pos_fwd_kernel(const PosFwdArgs a) {
     auto generate8 = [&](int64_t step, int buf) __attribute__((always_inline)) {  // this thread's 8 pixels of `step` -> LDS image `buf`, h1
         // (inline asm: hipcc turns these into VECTOR loads because the h1 / y2 stores might alias `rel`; indices are clamped
         //  instead of guarded -- pixels past the end are masked in the epilogue and never stored)
-        uint64_t q0[8], q1[8];
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int64_t pu = step * kTM + it * 16 + 2 * wn;  // wave-uniform
-            const int64_t p0 = pu < a.P ? pu : a.P - 1, p1 = pu + 1 < a.P ? pu + 1 : a.P - 1;
-            asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=s"(q0[it]) : "s"(relq + p0 * ldq));
-            asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=s"(q1[it]) : "s"(relq + p1 * ldq));
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+s"(q0[0]), "+s"(q0[1]), "+s"(q0[2]), "+s"(q0[3]), "+s"(q0[4]), "+s"(q0[5]), "+s"(q0[6]), "+s"(q0[7]), "+s"(q1[0]),
-                       "+s"(q1[1]), "+s"(q1[2]), "+s"(q1[3]), "+s"(q1[4]), "+s"(q1[5]), "+s"(q1[6]), "+s"(q1[7]));
+        constexpr int kSel = G::kSel, kIt = 16 / kSel;  // sixteen scalar loads in flight: 8 passes x 2 pixels, or 4 passes x 4 pixels twice
         int oct = oct_, pxl = pxl_;
         asm volatile("" : "+v"(oct), "+v"(pxl));  // (see multiply: no hoisting of the eight pixels' offsets)
         bf16_t* const h1_step = a.h1 + step * (int64_t)(kTM * kC);  // wave-uniform base: the lane part stays a 32-bit offset
         const int64_t left = a.P - step * kTM;                      // pixels of this step that exist
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int pl = it * 16 + pxl;
-            const uint64_t q = lane < 32 ? q0[it] : q1[it];
+        for (int it0 = 0; it0 < 8; it0 += kIt) {
+        uint64_t qs[16];
+#pragma unroll
+        for (int it = 0; it < kIt; ++it)
+#pragma unroll
+            for (int e = 0; e < kSel; ++e) {
+                const int64_t pu = step * kTM + (it0 + it) * G::kPass + kSel * wn + e;  // wave-uniform
+                const int64_t p0 = pu < a.P ? pu : a.P - 1;
+                asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=s"(qs[it * kSel + e]) : "s"(relq + p0 * ldq));
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+s"(qs[0]), "+s"(qs[1]), "+s"(qs[2]), "+s"(qs[3]), "+s"(qs[4]), "+s"(qs[5]), "+s"(qs[6]), "+s"(qs[7]), "+s"(qs[8]),
+                       "+s"(qs[9]), "+s"(qs[10]), "+s"(qs[11]), "+s"(qs[12]), "+s"(qs[13]), "+s"(qs[14]), "+s"(qs[15]));
+#pragma unroll
+        for (int it = 0; it < kIt; ++it) {
+            const int pl = (it0 + it) * G::kPass + pxl;
+            uint64_t q = qs[it * kSel];
+#pragma unroll
+            for (int e = 1; e < kSel; ++e) q = lane >= e * G::kOct ? qs[it * kSel + e] : q;
             const uint32_t lo = (uint32_t)q, hi = (uint32_t)(q >> 32);
             const float x = bf_lo(lo), y = bf_hi(lo), z = bf_lo(hi);
             const f32x2 xx = {x, x}, yy = {y, y}, zz = {z, z};
             u32x4 hv;
 #pragma unroll
             for (int j = 0; j < 4; ++j) hv[j] = pack2(max0((gw[j][0] * xx + gw[j][1] * yy + gw[j][2] * zz) * gs[j] + gh[j]));
-            *(u32x4*)(smem + buf * kBuf + pl * 512 + ((oct ^ (pl & 15)) * 16)) = hv;
+            *(u32x4*)(smem + buf * kBuf + pl * kRow + ((oct ^ (pl & 15)) * 16)) = hv;
             if (pl < left) *(u32x4*)(h1_step + pl * kC + oct * 8) = hv;
             __builtin_amdgcn_sched_barrier(0);  // one pixel at a time: eight interleaved would need 32 more registers
+        }
         }
     };
 
@@ -138,20 +164,21 @@ __global__ __launch_bounds__(512, 1) void pos_fwd_kernel(const PosFwdArgs a) {
         const uint8_t* img = smem + cur * kBuf;
         bf16_t* const y2_step = a.y2 + s * (int64_t)(kTM * kC);
 #pragma unroll
-        for (int half = 0; half < 4; ++half) {  // 32 pixels at a time: 16 accumulator + 16 fragment registers
+        for (int hq = 0; hq < G::kGroups; ++hq) {  // 32 pixels at a time: 16 accumulator + 16 fragment registers
+            const int half = wp * G::kGroups + hq;
             f32x4 acc[2][2];
             bf16x8 fa[4][2];
             auto read_fa = [&](int ks, bf16x8 (&f)[2]) __attribute__((always_inline)) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
-                    f[i] = *(const bf16x8*)(img + ((half * 2 + i) * 16 + l15) * 512 + (((ks * 4 + lg) ^ l15) * 16));
+                    f[i] = *(const bf16x8*)(img + ((half * 2 + i) * 16 + l15) * kRow + (((ks * 4 + lg) ^ l15) * 16));
             };
             read_fa(0, fa[0]);
             read_fa(1, fa[1]);
             read_fa(2, fa[2]);
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                if (ks + 3 < 8) read_fa(ks + 3, fa[(ks + 3) & 3]);  // three K-steps ahead (4 MFMAs = 64 cycles per K-step against ~200 of LDS latency), and no further (sched_barrier below):
+            for (int ks = 0; ks < kKS; ++ks) {
+                if (ks + 3 < kKS) read_fa(ks + 3, fa[(ks + 3) & 3]);  // three K-steps ahead (4 MFMAs = 64 cycles per K-step against ~200 of LDS latency), and no further (sched_barrier below):
 #pragma unroll                                                       // hoisting all the fragment reads costs 128 registers -> spills,
                 for (int i = 0; i < 2; ++i)                          // and a scratch reload is a VMEM load: vmcnt(0) in the loop
 #pragma unroll
@@ -161,7 +188,7 @@ __global__ __launch_bounds__(512, 1) void pos_fwd_kernel(const PosFwdArgs a) {
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // lane (pixel l15 of tile i, lane group lg) holds channels 32 wn + 8 lg + 4 j + r
+            // lane (pixel l15 of tile i, lane group lg) holds channels 32 wc + 8 lg + 4 j + r
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int pl = (half * 2 + i) * 16 + l15;
@@ -177,7 +204,7 @@ __global__ __launch_bounds__(512, 1) void pos_fwd_kernel(const PosFwdArgs a) {
                         ssq[j * 2 + r2] += x * x;
                         out[j * 2 + r2] = pack2(x);
                     }
-                if (ok) *(u32x4*)(y2_step + pl * kC + wn * 32 + lg * 8) = out;
+                if (ok) *(u32x4*)(y2_step + pl * kC + wc * 32 + lg * 8) = out;
             }
         }
     };
@@ -207,19 +234,36 @@ __global__ __launch_bounds__(512, 1) void pos_fwd_kernel(const PosFwdArgs a) {
         cur ^= 1;
     }
     if (a.partial) {
-        // per-channel totals of this workgroup: sum over the 16 pixel lanes (l15), then one row per workgroup
+        // per-channel totals of this workgroup: sum over the 16 pixel lanes (l15), then (C = 128) over the two waves of a channel slice
+        // through LDS (the images are dead: the loop ends on a barrier), then one row per workgroup
+        float* const red = (float*)smem;  // [2][C]
+        float sv[8], qv[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            float sv = ssum[q >> 1][q & 1], qv = ssq[q >> 1][q & 1];
+            sv[q] = ssum[q >> 1][q & 1], qv[q] = ssq[q >> 1][q & 1];
 #pragma unroll
             for (int d = 1; d < 16; d <<= 1) {
-                sv += __shfl_xor(sv, d, 64);
-                qv += __shfl_xor(qv, d, 64);
+                sv[q] += __shfl_xor(sv[q], d, 64);
+                qv[q] += __shfl_xor(qv[q], d, 64);
             }
-            if (l15 == 0) {
-                const int ch = wn * 32 + lg * 8 + q;
-                a.partial[((int64_t)blockIdx.x * 2) * kC + ch] = sv;
-                a.partial[((int64_t)blockIdx.x * 2 + 1) * kC + ch] = qv;
+        }
+        if (G::kWP > 1) {
+            if (wp == 1 && l15 == 0) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    red[wc * 32 + lg * 8 + q] = sv[q];
+                    red[kC + wc * 32 + lg * 8 + q] = qv[q];
+                }
+            }
+            __syncthreads();
+        }
+        if (wp == 0 && l15 == 0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int ch = wc * 32 + lg * 8 + q;
+                const float s2 = G::kWP > 1 ? red[ch] : 0.f, q2 = G::kWP > 1 ? red[kC + ch] : 0.f;
+                a.partial[((int64_t)blockIdx.x * 2) * kC + ch] = sv[q] + s2;
+                a.partial[((int64_t)blockIdx.x * 2 + 1) * kC + ch] = qv[q] + q2;
             }
         }
     }
@@ -250,22 +294,26 @@ struct PosBwdArgs {
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
+template <int C>
 __global__ __launch_bounds__(512, 1) void pos_bwd_kernel(const PosBwdArgs a) {
+    using G = Pos<C>;
+    constexpr int kC = G::kC, kTM = G::kTM, kBuf = G::kBuf, kRow = G::kRow, kKS = G::kKS;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wn % G::kWC, wp = wn / G::kWC;
     const int l15_ = lane & 15, lg_ = lane >> 4;
     const int l15 = l15_, lg = lg_;
-    uint8_t* const relbuf = smem + 2 * kBuf;  // [2][128 pixels][8 bytes]
+    uint8_t* const relbuf = smem + 2 * kBuf;  // [2][kTM pixels][8 bytes]
 
-    // B operand: row n = l15 of tile j is input channel ci = 32 wn + 16 j + l15
-    bf16x8 fw[2][8];
+    // B operand: row n = l15 of tile j is input channel ci = 32 wc + 16 j + l15
+    bf16x8 fw[2][kKS];
     f32x2 w1c[3], sc, sh, mu, is;  // the lane's two channels (j = 0, 1) side by side: v_pk_* arithmetic in the epilogue
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int ci = wn * 32 + j * 16 + l15;
+        const int ci = wc * 32 + j * 16 + l15;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) fw[j][ks] = *(const bf16x8*)(a.w2s + (int64_t)ci * kC + ks * 32 + lg * 8);
+        for (int ks = 0; ks < kKS; ++ks) fw[j][ks] = *(const bf16x8*)(a.w2s + (int64_t)ci * kC + ks * 32 + lg * 8);
 #pragma unroll
         for (int e = 0; e < 3; ++e) w1c[e][j] = e < a.cin ? bf2f(a.w1[(int64_t)ci * a.ld_w1 + e]) : 0.f;
         sc[j] = a.scale1[ci];
@@ -276,14 +324,14 @@ __global__ __launch_bounds__(512, 1) void pos_bwd_kernel(const PosBwdArgs a) {
     f32x2 s0 = {0.f, 0.f}, s1 = {0.f, 0.f}, rx = {0.f, 0.f}, ry = {0.f, 0.f}, rz = {0.f, 0.f};
 
     const int64_t steps = (a.P + kTM - 1) / kTM;
-    // image fill: DMA instruction q (0..63) of a step moves pixels 2q, 2q+1 (lane = pixel-in-pair x 32 slots); wave w issues
+    // image fill: DMA instruction q (0..63) of a step moves 1 KB = kSel pixels (lane = pixel x kOct slots); wave w issues
     // q = w, w + 8, ...  The LDS side is lane-linear, so slot s of pixel p receives source octet s ^ (p & 15).
     __device__ __attribute__((aligned(256))) static uint32_t zero_page[64];
     auto fill = [&](int64_t step, int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int q = wn + 8 * i;
-            const int pl = 2 * q + (lane >> 5), slot = lane & 31;
+            const int pl = G::kSel * q + lane / G::kOct, slot = lane % G::kOct;
             const int64_t px = step * kTM + pl;
             const bf16_t* src = px < a.P ? a.dy2 + px * kC + ((slot ^ (pl & 15)) * 8) : (const bf16_t*)zero_page + (lane & 7) * 8;
             __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(smem + buf * kBuf + q * 1024), 16, 0, 0);
@@ -317,20 +365,21 @@ __global__ __launch_bounds__(512, 1) void pos_bwd_kernel(const PosBwdArgs a) {
         int l15 = l15_, lg = lg_;
         asm volatile("" : "+v"(l15), "+v"(lg));  // (no hoisting of the per-position LDS offsets out of the step loop: registers)
 #pragma unroll 1  // (rolled: unrolled x4 the allocator spilled the weight fragments)
-        for (int quarter = 0; quarter < 4; ++quarter) {  // 32 pixels at a time
+        for (int qq = 0; qq < G::kGroups; ++qq) {  // 32 pixels at a time
+            const int quarter = wp * G::kGroups + qq;
             f32x4 acc[2][2];
             bf16x8 fa[4][2];
             auto read_fa = [&](int ks, bf16x8 (&f)[2]) __attribute__((always_inline)) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
-                    f[i] = *(const bf16x8*)(img + ((quarter * 2 + i) * 16 + l15) * 512 + (((ks * 4 + lg) ^ l15) * 16));
+                    f[i] = *(const bf16x8*)(img + ((quarter * 2 + i) * 16 + l15) * kRow + (((ks * 4 + lg) ^ l15) * 16));
             };
             read_fa(0, fa[0]);
             read_fa(1, fa[1]);
             read_fa(2, fa[2]);
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                if (ks + 3 < 8) read_fa(ks + 3, fa[(ks + 3) & 3]);
+            for (int ks = 0; ks < kKS; ++ks) {
+                if (ks + 3 < kKS) read_fa(ks + 3, fa[(ks + 3) & 3]);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -340,7 +389,7 @@ __global__ __launch_bounds__(512, 1) void pos_bwd_kernel(const PosBwdArgs a) {
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // lane: channel ci(j) = 32 wn + 16 j + l15, pixels (quarter*2 + i)*16 + 4 lg + r
+            // lane: channel ci(j) = 32 wc + 16 j + l15, pixels (quarter*2 + i)*16 + 4 lg + r
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -368,20 +417,35 @@ __global__ __launch_bounds__(512, 1) void pos_bwd_kernel(const PosBwdArgs a) {
         __syncthreads();
         cur ^= 1;
     }
-    // lanes lg = 0..3 of a channel hold disjoint pixels: sum them, then one row of `planes` x C per workgroup
+    // lanes lg = 0..3 of a channel hold disjoint pixels: sum them (C = 128: and the two waves of a channel slice, through LDS -- the
+    // images are dead, the loop ends on a barrier), then one row of `planes` x C per workgroup
+    float* const red = (float*)smem;  // [5][C]
+    float v[2][5];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        float v[5] = {s0[j], s1[j], rx[j], ry[j], rz[j]};
+        v[j][0] = s0[j], v[j][1] = s1[j], v[j][2] = rx[j], v[j][3] = ry[j], v[j][4] = rz[j];
 #pragma unroll
         for (int q = 0; q < 5; ++q) {
-            v[q] += __shfl_xor(v[q], 16, 64);
-            v[q] += __shfl_xor(v[q], 32, 64);
+            v[j][q] += __shfl_xor(v[j][q], 16, 64);
+            v[j][q] += __shfl_xor(v[j][q], 32, 64);
         }
-        if (lg == 0) {
-            const int ci = wn * 32 + j * 16 + l15;
+    }
+    if (G::kWP > 1) {
+        if (wp == 1 && lg == 0) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 5; ++q) red[q * kC + wc * 32 + j * 16 + l15] = v[j][q];
+        }
+        __syncthreads();
+    }
+    if (wp == 0 && lg == 0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ci = wc * 32 + j * 16 + l15;
             float* row = a.partial + (int64_t)blockIdx.x * a.planes * kC + ci;
 #pragma unroll
-            for (int q = 0; q < 5; ++q) row[(int64_t)q * kC] = v[q];
+            for (int q = 0; q < 5; ++q) row[(int64_t)q * kC] = v[j][q] + (G::kWP > 1 ? red[q * kC + ci] : 0.f);
             for (int q = 5; q < a.planes; ++q) row[(int64_t)q * kC] = 0.f;
         }
     }
@@ -392,27 +456,31 @@ __global__ __launch_bounds__(512, 1) void pos_bwd_kernel(const PosBwdArgs a) {
 // launcher used by rv_pos_backward_sums (bnbwd.hip, which owns the small-K reduction workspace layout)
 int rv_pos_bwd_launch(int64_t pixels, const void* dy2, const void* w2_scatter, const void* rel, int32_t ld_rel, int32_t cin,
                       const void* w1_packed, int32_t ld_w1, const float* scale1, const float* shift1, const float* mean1,
-                      const float* invstd1, float* partial, int32_t planes, int32_t max_rows, int32_t* rows, hipStream_t stream) {
+                      const float* invstd1, float* partial, int32_t planes, int32_t max_rows, int32_t* rows, int32_t c, hipStream_t stream) {
+    RV_REQUIRE(c == 256 || c == 128, "rv_pos_backward_sums: built for 256 or 128 channels (got %d)", c);
+    const int lds = c == 256 ? 2 * Pos<256>::kBuf + 2 * Pos<256>::kTM * 8 : 2 * Pos<128>::kBuf + 2 * Pos<128>::kTM * 8;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)pos_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kBuf + 2 * kTM * 8);
+        (void)hipFuncSetAttribute((const void*)pos_bwd_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Pos<256>::kBuf + 2 * Pos<256>::kTM * 8);
+        (void)hipFuncSetAttribute((const void*)pos_bwd_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Pos<128>::kBuf + 2 * Pos<128>::kTM * 8);
         attr_set = true;
     }
     PosBwdArgs a{};
     a.dy2 = (const bf16_t*)dy2, a.w2s = (const bf16_t*)w2_scatter, a.rel = (const bf16_t*)rel, a.w1 = (const bf16_t*)w1_packed;
     a.scale1 = scale1, a.shift1 = shift1, a.mean1 = mean1, a.invstd1 = invstd1;
     a.partial = partial, a.P = pixels, a.ld_rel = ld_rel, a.ld_w1 = ld_w1, a.cin = cin, a.planes = planes;
-    const int64_t steps = (pixels + kTM - 1) / kTM;
+    const int64_t steps = (pixels + kTMmin - 1) / kTMmin;
     int grid = (int)(steps < 256 ? steps : 256);
     if (grid > max_rows) grid = max_rows;  // (the caller's partial-row buffer; a persistent workgroup takes any number of steps)
     *rows = grid;
-    hipLaunchKernelGGL(pos_bwd_kernel, dim3(*rows), dim3(512), 2 * kBuf + 2 * kTM * 8, stream, a);
+    if (c == 256) hipLaunchKernelGGL(pos_bwd_kernel<256>, dim3(*rows), dim3(512), lds, stream, a);
+    else hipLaunchKernelGGL(pos_bwd_kernel<128>, dim3(*rows), dim3(512), lds, stream, a);
     RV_CHECK_LAUNCH("pos_bwd_kernel");
     return 0;
 }
 
 extern "C" int32_t rv_pos_forward_rows(int64_t pixels) {
-    const int64_t steps = (pixels + kTM - 1) / kTM;
+    const int64_t steps = (pixels + kTMmin - 1) / kTMmin;
     return (int32_t)(steps < 256 ? steps : 256);
 }
 
@@ -420,11 +488,12 @@ extern "C" int rv_pos_forward(const void* rel, int32_t ld_rel, int32_t cin, int6
                               const float* scale1, const float* shift1, const void* w2_packed, int32_t c, void* h1, void* y2,
                               float* stats_partial, rvStream stream) {
     RV_REQUIRE(rel && w1_packed && scale1 && shift1 && w2_packed && h1 && y2, "rv_pos_forward: null argument");
-    RV_REQUIRE(c == kC, "rv_pos_forward: built for %d channels (got %d)", kC, c);
+    RV_REQUIRE(c == 256 || c == 128, "rv_pos_forward: built for 256 or 128 channels (got %d)", c);
     RV_REQUIRE(cin >= 1 && cin <= 3 && ld_rel >= 4 && ld_rel % 4 == 0 && pixels > 0, "rv_pos_forward: bad shape");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)pos_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kBuf);
+        (void)hipFuncSetAttribute((const void*)pos_fwd_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Pos<256>::kBuf);
+        (void)hipFuncSetAttribute((const void*)pos_fwd_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Pos<128>::kBuf);
         attr_set = true;
     }
     PosFwdArgs a{};
@@ -432,7 +501,8 @@ extern "C" int rv_pos_forward(const void* rel, int32_t ld_rel, int32_t cin, int6
     a.scale1 = scale1, a.shift1 = shift1;
     a.h1 = (bf16_t*)h1, a.y2 = (bf16_t*)y2, a.partial = stats_partial;
     a.P = pixels, a.ld_rel = ld_rel, a.ld_w1 = ld_w1, a.cin = cin;
-    hipLaunchKernelGGL(pos_fwd_kernel, dim3(rv_pos_forward_rows(pixels)), dim3(512), 2 * kBuf, (hipStream_t)stream, a);
+    if (c == 256) hipLaunchKernelGGL(pos_fwd_kernel<256>, dim3(rv_pos_forward_rows(pixels)), dim3(512), 2 * Pos<256>::kBuf, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(pos_fwd_kernel<128>, dim3(rv_pos_forward_rows(pixels)), dim3(512), 2 * Pos<128>::kBuf, (hipStream_t)stream, a);
     RV_CHECK_LAUNCH("pos_fwd_kernel");
     return 0;
 }

@@ -1054,10 +1054,11 @@ POS_FUSE = os.environ.get("RV3D_NO_POS_FUSE") is None
 
 
 def pos_pair_eligible(l0: TapLayer, l1: TapLayer, x: Operand) -> bool:
-    """3 -> 256 -> 256 positional pair of the MetaKernel stem on a plain 9x-grid input: the pair runs as rv_pos_forward."""
+    """3 -> C -> C positional pair of the MetaKernel stem (C = 256: rv-av2, C = 128: rv-waymo) on a plain 9x-grid input: the pair runs
+    as rv_pos_forward."""
     g0, g1 = l0.geom, l1.geom
-    return (POS_FUSE and SMALLK_FORWARD and isinstance(x, Act) and _smallk_eligible(l0, x, True, False) and l0.c_in <= 3 and l0.c_out == 256
-            and l1.fwd_form == "gather" and g1.kh == 1 and g1.kw == 1 and g1.stride_w == 1 and l1.c_in == 256 and l1.c_out == 256
+    return (POS_FUSE and SMALLK_FORWARD and isinstance(x, Act) and _smallk_eligible(l0, x, True, False) and l0.c_in <= 3 and l0.c_out in (256, 128)
+            and l1.fwd_form == "gather" and g1.kh == 1 and g1.kw == 1 and g1.stride_w == 1 and l1.c_in == l0.c_out and l1.c_out == l0.c_out
             and l1.bias is None and l1.in_perm is None and x.ld >= 4)
 
 
@@ -1073,7 +1074,7 @@ def pos_pair(t: Tape, l0: TapLayer, bn0: nn.BatchNorm2d, l1: TapLayer, bn1: nn.B
     call = lambda: L.call("rv_pos_forward", x.ptr(), L.i32(x.ld), L.i32(l0.c_in), L.i64(x.pixels), L.ptr(l0.packed("gather")), L.i32(pad32(l0.c_in)),
                           L.ptr(sk.scale), L.ptr(sk.shift), L.ptr(l1.packed("gather")), L.i32(y2.cp), h1.ptr(), y2.ptr(), L.ptr(partial), L.stream_ptr())
     if PROFILE is not None:
-        _launch("pos_fwd_kernel", 2.0 * x.pixels * 256 * 256, call)
+        _launch("pos_fwd_kernel", 2.0 * x.pixels * l1.c_in * l1.c_out, call)
     else:
         call()
     conv = ConvOp(t, l1, h1, stats=t.training, out=y2, precomputed=(partial, rows))

@@ -180,7 +180,7 @@ def _pos_pair_backward(op: "E.ConvOp", t: Tape, dy2: Act) -> None:
                           L.ptr(wp0), L.i32(E.pad32(cin)), L.ptr(sk.scale), L.ptr(sk.shift), L.ptr(sk.mean), L.ptr(sk.invstd), L.ptr(sums),
                           L.ptr(moms), L.ptr(ws), L.stream_ptr())
     if E.PROFILE is not None:
-        E._launch("pos_bwd_kernel", 2.0 * pixels * 256 * 256, call)
+        E._launch("pos_bwd_kernel", 2.0 * pixels * cp * cp, call)
     else:
         call()
     dgamma = torch.empty(cp, dtype=torch.float32, device=dev)

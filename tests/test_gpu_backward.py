@@ -412,8 +412,9 @@ def test_meta_kernel_backward_fused_matches_unfused():
         assert _cos(a[k], b[k]) > 0.999 and rel_err(a[k], b[k]) < 2e-2, (k, _cos(a[k], b[k]), rel_err(a[k], b[k]))
 
 
+@pytest.mark.parametrize("C", [256, 128])
 @pytest.mark.parametrize("P", [999, 41472])
-def test_pos_backward_sums_kernel_vs_fp64(P):
+def test_pos_backward_sums_kernel_vs_fp64(P, C):
     """rv_pos_backward_sums (second positional layer's backward-data GEMM fused with the first layer's small-K BatchNorm
     backward sums: dh1 = dy2 W2 never written) against the same sums in fp64 torch ops on the bf16 inputs:
     S0 = sum g, S1 = sum g xhat, R[d] = sum g rel[d] with g = dh1 [s1 y1 + t1 > 0], y1 = W1 rel -- 2e-4 of each plane's scale
@@ -421,7 +422,6 @@ def test_pos_backward_sums_kernel_vs_fp64(P):
     from range_view_3d_detection_amd import _lib as L
 
     gen = torch.Generator().manual_seed(P + 1)
-    C = 256
     rel = torch.zeros(P, 32, dtype=torch.bfloat16)
     rel[:, :3] = (torch.randn(P, 3, generator=gen) * 2).to(torch.bfloat16)
     w1 = torch.zeros(C, 32, dtype=torch.bfloat16)
@@ -454,8 +454,9 @@ def test_pos_backward_sums_kernel_vs_fp64(P):
     assert float((moms[:4] - m1).abs().max()) < 1e-6 * float(r3.abs().sum())
 
 
-def test_meta_kernel_positional_pair_backward_fused_matches_unfused():
-    """MetaKernel at the rv-av2 stem width with the fused positional-pair backward against the chain it replaces
+@pytest.mark.parametrize("C", [256, 128])
+def test_meta_kernel_positional_pair_backward_fused_matches_unfused(C):
+    """MetaKernel at the rv-av2 (256) and rv-waymo (128) stem widths with the fused positional-pair backward against the chain it replaces
     (rv_tap_scatter of the second layer -> rv_bn_bwd_smallk of the first): the first layer's conv / BatchNorm gradients within
     the bf16 rounding of the input gradient the unfused chain stores (cosine 0.9999, 2e-2 of max); every other gradient
     bit-identical (same kernels, same inputs)."""
@@ -463,11 +464,11 @@ def test_meta_kernel_positional_pair_backward_fused_matches_unfused():
     from range_view_3d_detection_amd.nn.stems import MetaKernel
 
     gen = torch.Generator().manual_seed(23)
-    m = MetaKernel(5, 256, 3, 2).to(DEV).train()
+    m = MetaKernel(5, C, 3, 2).to(DEV).train()
     sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
     feats = torch.randn(1, 5, 16, 160, generator=gen).to(DEV)
     cart = (torch.randn(1, 3, 16, 160, generator=gen) * 5).to(DEV)
-    probe = torch.randn(1, 256, 16, 160, generator=gen).to(DEV)
+    probe = torch.randn(1, C, 16, 160, generator=gen).to(DEV)
 
     def run(fused: bool):
         engine_bwd.POS_BWD_FUSE = fused

@@ -461,17 +461,18 @@ def test_raw_sweep_path_on_device(golden):
         assert np.array_equal(got, want), int((got != want).sum())
 
 
+@pytest.mark.parametrize("C", [256, 128])
 @pytest.mark.parametrize("P", [999, 41472])
-def test_pos_forward_kernel_vs_fp32(P):
+def test_pos_forward_kernel_vs_fp32(P, C):
     """rv_pos_forward (both positional layers of the MetaKernel stem in one persistent streaming GEMM: the first layer is
     generated in the second one's operand staging) against fp32 torch ops: h1 one bf16 rounding of relu(s1 (W1 rel) + t1)
     (4e-3 of max), y2 = W2 h1 from the kernel's own bf16 h1 one bf16 rounding (4e-3), the (sum, sum of squares) rows of the
     fp32 accumulators 1e-4 of their scale.  P = 999: one partial step per workgroup; 41472: 324 steps over 256 persistent
-    workgroups (both LDS images, the generate-next-while-multiplying path)."""
+    workgroups (both LDS images, the generate-next-while-multiplying path).  C = 256 is rv-av2's stem, C = 128 rv-waymo's (256-pixel
+    steps, two waves per channel slice: 162 steps, so some workgroups take one step and the rest none)."""
     from range_view_3d_detection_amd import _lib as L
 
     gen = torch.Generator().manual_seed(P)
-    C = 256
     rel = torch.zeros(P, 32, dtype=torch.bfloat16)
     rel[:, :3] = (torch.randn(P, 3, generator=gen) * 2).to(torch.bfloat16)
     w1 = torch.zeros(C, 32, dtype=torch.bfloat16)
@@ -496,19 +497,20 @@ def test_pos_forward_kernel_vs_fp32(P):
     assert float((got[1] - (want_y2.double() ** 2).sum(0)).abs().max()) < 1e-4 * float((want_y2.double() ** 2).sum(0).max())
 
 
-def test_meta_kernel_positional_pair_fused_matches_unfused():
-    """MetaKernel at the rv-av2 stem width (C = 256): rv_pos_forward against the SmallKOp + 1x1 tap-conv pair it replaces --
+@pytest.mark.parametrize("C", [256, 128])
+def test_meta_kernel_positional_pair_fused_matches_unfused(C):
+    """MetaKernel at the rv-av2 (C = 256) and rv-waymo (C = 128) stem widths: rv_pos_forward against the SmallKOp + 1x1 tap-conv pair it replaces --
     output and running statistics within bf16 rounding (2e-2 / 2e-3 of max), every parameter gradient (backward is shared; bf16
     roundings of h1 / y2 differ in the last place and flip a few ReLU gates) cosine 0.9999, 4e-2 of max."""
     from range_view_3d_detection_amd import engine as E
     from range_view_3d_detection_amd.nn.stems import MetaKernel
 
     gen = torch.Generator().manual_seed(21)
-    m = MetaKernel(5, 256, 3, 2).to(DEV).train()
+    m = MetaKernel(5, C, 3, 2).to(DEV).train()
     sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
     feats = torch.randn(1, 5, 16, 160, generator=gen).to(DEV)
     cart = (torch.randn(1, 3, 16, 160, generator=gen) * 5).to(DEV)
-    probe = torch.randn(1, 256, 16, 160, generator=gen).to(DEV)
+    probe = torch.randn(1, C, 16, 160, generator=gen).to(DEV)
 
     def run(fused: bool):
         E.POS_FUSE = fused
