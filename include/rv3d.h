@@ -110,6 +110,7 @@ int rv_unpack_weight_grad(const rvTapGeom* g, const float* packed, float* dT, in
 #define RV_OUT_RELU 64   /* with RV_OUT_BIAS: dst = max(result + bias[c], 0) -- inference: an eval-mode BatchNorm folded into the
                           * weights (w * gamma / sqrt(var + eps)) and the bias (beta - mean * scale), ReLU in the epilogue, so that
                           * conv -> BatchNorm -> ReLU is ONE launch and one write (cuDNN conv + batch_norm + relu_ in the reference) */
+#define RV_OUT_RES_RELU 256 /* rv_tap_residual only: ReLU AFTER the residual has been added (RV_OUT_RELU: before) */
 #define RV_WGRAD_TORCH_LAYOUT 128 /* rv_tap_wgrad only: dT_packed receives the torch layout dT[cu][cv][kh][kw] (cu*cv*kh*kw fp32,
                                   * no padding) straight from the split-K reduction -- no rv_unpack_weight_grad pass */
 
@@ -152,6 +153,16 @@ int rv_tap_gather(const rvTapGeom* g, const rvTapShape* s, const void* V, const 
 int rv_tap_scatter(const rvTapGeom* g, const rvTapShape* s, const void* U, const float* in_scale,
                    const float* in_shift, const void* scatter_w, const float* bias, void* V,
                    float* stats_partial, rvStream stream);
+
+/* Inference: a tap op (scatter != 0: the SCATTER form) whose epilogue adds a residual tensor of the output's pixels,
+ *   dst = [relu]( [relu]( op(src) + bias ) + res ),   s->flags: RV_OUT_BIAS, RV_OUT_RELU (inner), RV_OUT_RES_RELU (outer),
+ * with the eval-mode BatchNorm folded into w / bias: the block outputs relu_(net(x) + proj(x)) of BasicBlock.forward
+ * (nn/blocks/__init__.py:68-81) and x1 + relu(bn(convT(x2))) of AggregationBlock.forward (:165-182) leave the conv's own
+ * launch -- no separate element-wise pass (ATen add + relu_ in the reference).  The result is the one the separate pass
+ * produces, bit for bit: the conv result is rounded to the storage type before the residual is added, as a stored tensor
+ * would have been.  res: bf16/fp16 [pixels of dst][ld_res]; plain operands only (no RV_IN_*, RV_OUT_STATS, RV_OUT_F32). */
+int rv_tap_residual(const rvTapGeom* g, const rvTapShape* s, int32_t scatter, const void* src, const void* w, const float* bias,
+                    const void* res, int32_t ld_res, void* dst, rvStream stream);
 
 /* Backward-data launch that ALSO forms the BatchNorm-backward sums of the layer whose output gradient it writes
  * (conv -> BatchNorm(+ReLU) -> THIS conv: autograd's native_batch_norm_backward reduce over (dOut, y), fused into the

@@ -22,6 +22,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "rv3d.h")
 
 # flags (mirror include/rv3d.h)
 IN_AFFINE, IN_RELU, OUT_F32, OUT_BIAS, OUT_STATS, OUT_ACCUM, OUT_RELU = 1, 2, 4, 8, 16, 32, 64
+OUT_RES_RELU = 256
 WGRAD_TORCH_LAYOUT = 128  # rv_tap_wgrad: result in dT[cu][cv][kh][kw] (no unpack pass)
 EW_RELU_A, EW_RELU_B, EW_RELU_OUT = 1, 2, 4
 BNB_RELU_Z, BNB_RES_ACCUM, BNB_Y_FROM_INPUT = 1, 2, 4

@@ -41,6 +41,9 @@ struct TapConvArgs {
     const float *bnb_scale, *bnb_shift, *bnb_mean, *bnb_invstd;
     float* bnb_partial;  // [tiles][2][C_dst]
     int32_t ld_bnb_y, bnb_flags;
+    // RV_OUT_ACCUM: the tensor added to the result -- dst itself (gradient fan-in) or a residual (rv_tap_residual), same pixels as dst
+    const bf16_t* res;
+    int32_t ld_res;
     TapTable tt;
 };
 

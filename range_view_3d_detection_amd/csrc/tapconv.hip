@@ -292,6 +292,7 @@ __global__ __launch_bounds__(256, 2) void tapconv_kernel(const TapConvArgs a) {
             }
     __syncthreads();
     bf16_t* dst = (bf16_t*)a.dst + dst_row;
+    const int64_t res_row = ((int64_t)(n * a.H + h) * a.W_dst) * a.ld_res;
     constexpr int kChunks = BN / 8;
     const bool accum = a.flags & RV_OUT_ACCUM;
     for (int q = tid; q < BM * kChunks; q += 256) {
@@ -301,9 +302,13 @@ __global__ __launch_bounds__(256, 2) void tapconv_kernel(const TapConvArgs a) {
         u32x4 v = *(const u32x4*)(epi + pm * kEpi + c8 * 8);
         bf16_t* p = dst + (int64_t)(a.phases * m + ph) * a.ld_dst + c;
         if (accum) {
-            const u32x4 o = *(const u32x4*)p;
+            const u32x4 o = *(const u32x4*)(a.res + res_row + (int64_t)(a.phases * m + ph) * a.ld_res + c);
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = pack_bf2(bf_lo(v[j]) + bf_lo(o[j]), bf_hi(v[j]) + bf_hi(o[j]));
+            if (a.flags & RV_OUT_RES_RELU) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = pack_bf2(fmaxf(bf_lo(v[j]), 0.f), fmaxf(bf_hi(v[j]), 0.f));
+            }
         }
         *(u32x4*)p = v;
     }
@@ -392,7 +397,7 @@ static int g_tapconv5_enable = 1;  // rv_set_option("tapconv5_enable", 0): multi
 static int tap_launch(const rvTapGeom* g, const rvTapShape* s, bool scatter, const void* src, const float* in_scale,
                       const float* in_shift, const void* w, const float* bias, void* dst, float* stats,
                       rvStream stream, bool dry_run, int* stats_rows, int* info = nullptr, const rvBnbEpilogue* bnb = nullptr,
-                      int* bnb_rows = nullptr) {
+                      int* bnb_rows = nullptr, const void* residual = nullptr, int32_t ld_res = 0) {
     TapConvArgs a;
     memset(&a, 0, sizeof(a));
     int phases, step;
@@ -414,6 +419,17 @@ static int tap_launch(const rvTapGeom* g, const rvTapShape* s, bool scatter, con
     a.phases = phases;
     a.step = step;
     a.flags = s->flags;
+    a.res = (const bf16_t*)dst;  // RV_OUT_ACCUM adds into dst ...
+    a.ld_res = a.ld_dst;
+    if (residual) {  // ... rv_tap_residual adds another tensor of the same pixels
+        RV_REQUIRE(!(a.flags & (RV_OUT_ACCUM | RV_OUT_STATS)), "rv_tap_residual: not together with RV_OUT_ACCUM / RV_OUT_STATS");
+        RV_REQUIRE(ld_res >= a.C_dst && ld_res % 8 == 0, "rv_tap_residual: bad channel stride of the residual (%d)", ld_res);
+        a.flags |= RV_OUT_ACCUM;
+        a.res = (const bf16_t*)residual;
+        a.ld_res = ld_res;
+    } else {
+        RV_REQUIRE(dry_run || !(a.flags & RV_OUT_RES_RELU), "RV_OUT_RES_RELU belongs to rv_tap_residual");
+    }
     RV_REQUIRE(!((a.flags & RV_OUT_F32) && (a.flags & RV_OUT_ACCUM)), "RV_OUT_ACCUM needs a bf16 destination");
     RV_REQUIRE(dry_run || !(a.flags & RV_IN_AFFINE) || (in_scale && in_shift), "RV_IN_AFFINE without scale/shift");
     RV_REQUIRE(dry_run || !(a.flags & RV_OUT_BIAS) || bias, "RV_OUT_BIAS without bias");
@@ -600,6 +616,13 @@ int rv_tap_data_grad_bnb(const rvTapGeom* g, const rvTapShape* s, int32_t scatte
                          const rvBnbEpilogue* e, rvStream stream) {
     RV_REQUIRE(g && s && dout && w && dx && e, "rv_tap_data_grad_bnb: null argument");
     return tap_launch(g, s, scatter != 0, dout, nullptr, nullptr, w, nullptr, dx, nullptr, stream, false, nullptr, nullptr, e);
+}
+
+int rv_tap_residual(const rvTapGeom* g, const rvTapShape* s, int32_t scatter, const void* src, const void* w, const float* bias,
+                    const void* res, int32_t ld_res, void* dst, rvStream stream) {
+    RV_REQUIRE(g && s && src && w && res && dst, "rv_tap_residual: null argument");
+    return tap_launch(g, s, scatter != 0, src, nullptr, nullptr, w, bias, dst, nullptr, stream, false, nullptr, nullptr, nullptr, nullptr, res,
+                      ld_res);
 }
 
 int rv_tap_gather(const rvTapGeom* g, const rvTapShape* s, const void* V, const float* in_scale, const float* in_shift,

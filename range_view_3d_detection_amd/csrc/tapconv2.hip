@@ -329,9 +329,13 @@ __global__ __launch_bounds__(256, 2) void tapconv2_kernel(const TapConvArgs a) {
         u32x4 v = *(const u32x4*)(epi + pm * kEpi + c8 * 8);
         bf16_t* p = (bf16_t*)a.dst + (((int64_t)(n * a.H + hh) * a.W_dst) + (a.phases * m + ph)) * a.ld_dst + c;
         if (accum) {
-            const u32x4 o = *(const u32x4*)p;
+            const u32x4 o = *(const u32x4*)(a.res + (((int64_t)(n * a.H + hh) * a.W_dst) + (a.phases * m + ph)) * a.ld_res + c);
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = pack_bf2(bf_lo(v[j]) + bf_lo(o[j]), bf_hi(v[j]) + bf_hi(o[j]));
+            if (a.flags & RV_OUT_RES_RELU) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = pack_bf2(fmaxf(bf_lo(v[j]), 0.f), fmaxf(bf_hi(v[j]), 0.f));
+            }
         }
         *(u32x4*)p = v;
     }

@@ -461,7 +461,7 @@ __global__ __launch_bounds__(512, 2) void tapconv5_kernel(const TapConvArgs a) {
             const int rr = pm / kTC, mm = pm - rr * kTC;
             const int m = m0 + mm, c = n0 + c8 * 8, hh = h0 + rr;
             yv[it] = u32x4{0u, 0u, 0u, 0u};
-            if (m < Wm && hh < a.H) yv[it] = *(const u32x4*)((const bf16_t*)a.dst + (((int64_t)(n * a.H + hh) * a.W_dst) + (a.phases * m + ph)) * a.ld_dst + c);
+            if (m < Wm && hh < a.H) yv[it] = *(const u32x4*)(a.res + (((int64_t)(n * a.H + hh) * a.W_dst) + (a.phases * m + ph)) * a.ld_res + c);
         }
     }
     __syncthreads();
@@ -479,6 +479,10 @@ __global__ __launch_bounds__(512, 2) void tapconv5_kernel(const TapConvArgs a) {
             const u32x4 o = yv[it];
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = pack_bf2(bf_lo(v[j]) + bf_lo(o[j]), bf_hi(v[j]) + bf_hi(o[j]));
+            if (a.flags & RV_OUT_RES_RELU) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = pack_bf2(fmaxf(bf_lo(v[j]), 0.f), fmaxf(bf_hi(v[j]), 0.f));
+            }
         }
         *(u32x4*)p = v;
         if (bnb) {

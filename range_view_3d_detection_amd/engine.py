@@ -788,12 +788,15 @@ class ConvOp(Op):
 
     def __init__(self, t: Tape, layer: TapLayer, x: Operand, stats: bool = False, out_f32: bool = False,
                  out: Optional[Act] = None, need_input_grad: bool = True, precomputed: Optional[Tuple[Optional[Tensor], int]] = None,
-                 eval_bn: Optional[nn.Module] = None, relu_out: bool = False) -> None:
+                 eval_bn: Optional[nn.Module] = None, relu_out: bool = False, residual: Optional[Act] = None,
+                 res_relu: bool = False) -> None:
         """``precomputed`` = (partial statistics rows, rows): ``out`` already holds the layer's output (a fused kernel wrote it);
         the op only records what backward needs.  ``eval_bn`` (inference only): the eval-mode BatchNorm behind the conv is folded
-        into the weight image and the bias, ``relu_out`` applies the ReLU in the epilogue -- the output is the activation."""
+        into the weight image and the bias, ``relu_out`` applies the ReLU in the epilogue -- the output is the activation;
+        ``residual`` is added to that activation in the same epilogue (``res_relu``: ReLU after the sum) -- rv_tap_residual."""
         self.layer, self.x, self.need_input_grad = layer, x, need_input_grad
         self.eval_bn = eval_bn
+        assert residual is None or (eval_bn is not None and not out_f32 and not stats)
         self.pos_first: Optional["SmallKOp"] = None
         src, sc, sh, flags = _operand_parts(x)
         form = layer.fwd_form
@@ -832,7 +835,7 @@ class ConvOp(Op):
         bias = layer.bias
         if eval_bn is not None:
             assert bias is None and not stats and not t.training
-            flags |= L.OUT_BIAS | (L.OUT_RELU if relu_out else 0)
+            flags |= L.OUT_BIAS | (L.OUT_RELU if relu_out else 0) | (L.OUT_RES_RELU if residual is not None and res_relu else 0)
             bias_p = None  # (filled below, with the folded weight image)
         elif bias is not None:
             flags |= L.OUT_BIAS
@@ -862,6 +865,10 @@ class ConvOp(Op):
             wp = layer.packed(form)
         call = lambda: L.call("rv_tap_" + form, ctypes.byref(lg), ctypes.byref(lshape), src.ptr(), L.ptr(sc), L.ptr(sh),
                               L.ptr(wp), L.ptr(bias_p), dst_ptr, L.ptr(self.partial), L.stream_ptr())
+        if residual is not None:
+            assert sc is None and flags & (L.IN_AFFINE | L.IN_RELU) == 0 and residual.cp == self.out.cp and residual.pixels == self.out.pixels
+            call = lambda: L.call("rv_tap_residual", ctypes.byref(lg), ctypes.byref(lshape), L.i32(1 if form == "scatter" else 0), src.ptr(),
+                                  L.ptr(wp), L.ptr(bias_p), residual.ptr(), L.i32(residual.ld), dst_ptr, L.stream_ptr())
         if precomputed is not None:
             assert out is not None and not out_f32 and bias is None
             self.partial, self.rows = precomputed
@@ -1029,6 +1036,20 @@ def conv_bn(t: Tape, layer: TapLayer, x: Operand, bn: nn.BatchNorm2d, relu: bool
     return BnOp(t, conv, bn, relu).lazy
 
 
+EVAL_RES_FUSE = os.environ.get("RV3D_NO_EVAL_RES_FUSE") is None
+
+
+def conv_bn_residual(t: Tape, layer: TapLayer, x: Operand, bn: nn.BatchNorm2d, res: Operand, relu_conv: bool, relu_out: bool,
+                     out: Optional[Act] = None) -> Optional[Act]:
+    """Inference: ``relu_out?( relu_conv?(bn(conv(x))) + res )`` in the conv's own launch (BatchNorm folded, residual added in the
+    epilogue: rv_tap_residual).  None when the fusion does not apply (training; folded operands) -- the caller then takes
+    ``conv_bn`` + ``CombineOp``, whose result is the same bit for bit."""
+    if (t.training or not (EVAL_FOLD and EVAL_RES_FUSE) or layer.bias is not None or not isinstance(x, Act) or not isinstance(res, Act)
+            or res.cp != pad32(layer.c_out)):
+        return None
+    return ConvOp(t, layer, x, eval_bn=bn, relu_out=relu_conv, residual=res, res_relu=relu_out, out=out).out
+
+
 GROUP_SYNC_BN = os.environ.get("RV3D_NO_GROUP_SYNC_BN") is None
 
 
@@ -1085,10 +1106,15 @@ def pos_pair(t: Tape, l0: TapLayer, bn0: nn.BatchNorm2d, l1: TapLayer, bn1: nn.B
 # ---------------------------------------------------------------------------------------------
 # element-wise combine
 # ---------------------------------------------------------------------------------------------
+COMBINE_LAUNCHES = 0  # element-wise combine passes issued so far (tests: the inference epilogues remove them)
+
+
 class CombineOp(Op):
     """``out = relu?( fa(a) + fb(b) )`` with Lazy operands folded in; materialises a block output."""
 
     def __init__(self, t: Tape, a: Operand, b: Optional[Operand], relu_out: bool, out: Optional[Act] = None) -> None:
+        global COMBINE_LAUNCHES
+        COMBINE_LAUNCHES += 1
         self.a, self.b, self.relu_out = a, b, relu_out
         ra, sa, ta, fa = _operand_parts(a)
         flags = (L.EW_RELU_A if fa & L.IN_RELU else 0) | (L.EW_RELU_OUT if relu_out else 0)

@@ -68,11 +68,14 @@ def _basic_block_gen(t: Tape, m: nn.Module, x: Operand, out: Optional[Act] = Non
     l1 = E.tap_layer(c1.conv)
     if E._smallk_eligible(l1, x, True, need_input_grad):  # 5/6-channel stem projection: the small-K element-wise path
         h1 = E.conv_bn(t, l1, x, bn1, relu=True, need_input_grad=need_input_grad)
-        (h2,) = yield [(E.tap_layer(c2.conv), h1, bn2, False, True)]
         res: Operand = x
         if m.projection_block is not None:
             pc, pbn = m.projection_block
             res = E.conv_bn(t, E.tap_layer(pc.conv), x, pbn, relu=False, need_input_grad=need_input_grad)
+        fused = E.conv_bn_residual(t, E.tap_layer(c2.conv), h1, bn2, res, False, True, out=out)
+        if fused is not None:
+            return fused
+        (h2,) = yield [(E.tap_layer(c2.conv), h1, bn2, False, True)]
         return E.CombineOp(t, h2, res, relu_out=True, out=out).out
     if m.projection_block is not None:
         # net.0 and the projection conv read the same input: both convs first, then both BatchNorms
@@ -83,6 +86,10 @@ def _basic_block_gen(t: Tape, m: nn.Module, x: Operand, out: Optional[Act] = Non
         if isinstance(x, Lazy):
             x = E.CombineOp(t, x, None, relu_out=False).out
         res = x
+    # inference: the block's sum and ReLU leave the second conv's own launch (rv_tap_residual)
+    fused = E.conv_bn_residual(t, E.tap_layer(c2.conv), h1, bn2, res, False, True, out=out)
+    if fused is not None:
+        return fused
     (h2,) = yield [(E.tap_layer(c2.conv), h1, bn2, False, True)]
     return E.CombineOp(t, h2, res, relu_out=True, out=out).out
 
@@ -97,8 +104,10 @@ def _residual_block_gen(t: Tape, m: nn.Module, x: Operand, out: Optional[Act] = 
 
 def _aggregation_block_gen(t: Tape, m: nn.Module, x1: Act, x2: Act, out: Optional[Act] = None):
     """``AggregationBlock.forward`` (nn/blocks/__init__.py:165-182): x1 + relu(bn(convT(x2))) -> ResidualBlock."""
-    (up,) = yield [(E.tap_layer(m.upscale), x2, m.normalization, True, True)]
-    s = E.CombineOp(t, x1, up, relu_out=False).out
+    s = E.conv_bn_residual(t, E.tap_layer(m.upscale), x2, m.normalization, x1, True, False)  # (inference)
+    if s is None:
+        (up,) = yield [(E.tap_layer(m.upscale), x2, m.normalization, True, True)]
+        s = E.CombineOp(t, x1, up, relu_out=False).out
     return (yield from _residual_block_gen(t, m.block, s, out=out))
 
 

@@ -106,3 +106,74 @@ def test_eval_fold_equals_the_unfolded_programs(golden):
     ef, eu = rel_err(lf, g["eval/logits"]), rel_err(lu, g["eval/logits"])
     print(f"tiny model eval logits vs the reference: folded {ef:.3e}, unfolded {eu:.3e}")
     assert ef < 4e-2 and ef < 1.2 * eu + 1e-3
+
+
+@pytest.mark.parametrize("tag", ["bf16", "f16"])
+@pytest.mark.parametrize("kind,hw", [("3x3", (16, 256)), ("1x1", (16, 256)), ("3x3s2", (16, 256)), ("convT", (16, 256)), ("3x3", (4, 32)), ("1x1", (4, 32))])
+def test_residual_epilogue_equals_the_separate_pass(kind, hw, tag):
+    """rv_tap_residual -- relu(bn(conv(x)) + res) and res + relu(bn(convT(x))) leaving the conv's own launch -- against the
+    folded conv followed by the element-wise pass it replaces: EQUAL bit for bit on random (non-integer) data, because the
+    conv result is rounded to the storage type before the residual is added, exactly as the stored intermediate was.  Shapes
+    pick every kernel generation: tapconv5 (3x3), tapconv4 (1x1), the folded stride-2 form, the conv-transpose phases on the
+    16 x 256 images; the register-staged generic kernels on the 4 x 32 ones."""
+    from range_view_3d_detection_amd import _lib as L
+    from range_view_3d_detection_amd import engine as E
+    from range_view_3d_detection_amd.nn.modules.conv import Conv2dSame
+
+    g = torch.Generator().manual_seed(7 + sum(map(ord, kind)) + hw[0])
+    cin, cout = 128, 256
+    h, w = hw
+    x = torch.randn(2, cin, h, w, generator=g)
+    if kind == "convT":
+        conv = torch.nn.ConvTranspose2d(cin, cout, kernel_size=(3, 4), stride=(1, 2), padding=(1, 1), bias=False)
+        wo = 2 * w
+    else:
+        k, s = (1, (1, 1)) if kind == "1x1" else (3, (1, 2) if kind == "3x3s2" else (1, 1))
+        conv = Conv2dSame(cin, cout, k, stride=s, bias=False).conv
+        wo = w // s[1]
+    bn = torch.nn.BatchNorm2d(cout)
+    bn.weight.data = 0.5 + torch.rand(cout, generator=g)
+    bn.bias.data = 0.2 * torch.randn(cout, generator=g)
+    bn.running_mean.data = 0.1 * torch.randn(cout, generator=g)
+    bn.running_var.data = 0.5 + torch.rand(cout, generator=g)
+    conv, bn = conv.to(DEV), bn.eval().to(DEV)
+    res = torch.randn(2, cout, h, wo, generator=g)
+    for relu_conv, relu_out in ((False, True), (True, False)):
+        with L.operand(tag):
+            t = E.Tape(False, DEV)
+            xa, ra = E.Act.from_nchw(x.to(DEV)), E.Act.from_nchw(res.to(DEV))
+            fused = E.conv_bn_residual(t, E.tap_layer(conv), xa, bn, ra, relu_conv, relu_out)
+            assert fused is not None and len(t.ops) == 1
+            y = E.conv_bn(t, E.tap_layer(conv), xa, bn, relu=relu_conv)
+            sep = E.CombineOp(t, y, ra, relu_out=relu_out).out
+            a, b = fused.nchw().float().cpu(), sep.nchw().float().cpu()
+        assert torch.equal(a, b), (kind, relu_conv, relu_out, float((a - b).abs().max()), int((a != b).sum()))
+
+
+@pytest.mark.parametrize("precision", ["bf16", "f16"])
+def test_residual_epilogue_in_the_tiny_detector(golden, precision):
+    """The tiny detector in eval mode with the block sums in the conv epilogues (default) against the separate passes
+    (``engine.EVAL_RES_FUSE = False``): every output EQUAL, and fewer element-wise launches on the tape."""
+    from range_view_3d_detection_amd import engine as E
+    from test_gpu_model import load_tiny
+
+    g = golden("tiny_model")
+    backbone, head = load_tiny(g)
+    backbone.eval()
+    head.eval()
+    data = {"features": g["features"].to(DEV), "cart": g["cart"].to(DEV), "mask": g["mask"].to(DEV)}
+
+    def run():
+        n0 = E.COMBINE_LAUNCHES
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=precision == "f16"):
+            out, _ = head(backbone(data), data, return_loss=False)
+        return out[1][0]["logits"].float().cpu(), out[1][0]["regressands"].float().cpu(), E.COMBINE_LAUNCHES - n0
+
+    lf, rf, nf = run()
+    E.EVAL_RES_FUSE = False
+    try:
+        lu, ru, nu = run()
+    finally:
+        E.EVAL_RES_FUSE = True
+    assert torch.equal(lf, lu) and torch.equal(rf, ru)
+    assert nf < nu, (nf, nu)
