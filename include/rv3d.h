@@ -356,6 +356,17 @@ int rv_pos_forward(const void* rel, int32_t ld_rel, int32_t cin, int64_t pixels,
                    const float* scale1, const float* shift1, const void* w2_packed, int32_t c, void* h1, void* y2,
                    float* stats_partial, rvStream stream);
 
+/* Inference form of the same kernel with the modulation of MetaKernel.forward (nn/stems/__init__.py:80-83: positional
+ * weights times the unfolded neighbour features) in its epilogue: row 9 p + k of the 9x grid is neighbour k of pixel p, and
+ *   geo[p][k*c + ch] = relu(scale2[ch] * y2[9 p + k][ch] + shift2[ch]) * feat[neighbour k of p][ch]   (0 outside the image)
+ * is what the kernel stores -- neither h1 nor y2 reaches memory (2 x 2.4 GB at 4 x 64 x 2048 x 256), and the separate
+ * rv_meta_modulate pass (read 2.4 GB, write 2.4 GB) disappears.  y2 is rounded to the storage type before the BatchNorm, as the
+ * stored tensor was: the result equals rv_pos_forward + rv_meta_modulate bit for bit.  scale2 / shift2: the second layer's
+ * eval-mode BatchNorm (rv_bn_fold_eval); feat: bf16/fp16 [N*H*W][ld_feat]; geo: [N*H*W][9*c].  W >= 32, 9 N H W < 2^31. */
+int rv_pos_modulate_forward(const void* rel, int32_t ld_rel, int32_t cin, const void* w1_packed, int32_t ld_w1, const float* scale1,
+                            const float* shift1, const void* w2_packed, int32_t c, const float* scale2, const float* shift2,
+                            const void* feat, int32_t ld_feat, int32_t N, int32_t H, int32_t W, void* geo, rvStream stream);
+
 /* Backward of the same pair: the second layer's backward-data GEMM dh1 = dy2 W2 fused with phase (A) of the first layer's
  * small-K BatchNorm backward (rv_bn_bwd_smallk_sums with RV_BNB_Y_FROM_INPUT): dh1 is consumed in registers and never
  * written -- 2.4 GB less to store and 2.4 GB less to read back at 4 x 64 x 2048.  w2_scatter = the second layer's packed

@@ -59,6 +59,10 @@ struct PosFwdArgs {
     float* partial;     // [gridDim.x][2][C] fp32 (sum, sum of squares) or NULL
     int64_t P;
     int ld_rel, ld_w1, cin;
+    // inference form (EVAL): y2 is not stored -- geo = relu(scale2 * y2 + shift2) * feat[neighbour] goes to `y2`'s place, h1 nowhere
+    const float *scale2, *shift2;
+    const bf16_t* feat;  // [N*H*W][ld_feat]
+    int ld_feat, H, W;
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -67,7 +71,7 @@ typedef rv_elem_t bf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack2(const f32x2 v) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t)); }
 __device__ __forceinline__ f32x2 max0(const f32x2 v) { return f32x2{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)}; }
 
-template <int C>
+template <int C, bool EVAL>
 __global__ __launch_bounds__(512, 1) void pos_fwd_kernel(const PosFwdArgs a) {
     using G = Pos<C>;
     constexpr int kC = G::kC, kTM = G::kTM, kBuf = G::kBuf, kRow = G::kRow, kKS = G::kKS;
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(512, 1) void pos_fwd_kernel(const PosFwdArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) hv[j] = pack2(max0((gw[j][0] * xx + gw[j][1] * yy + gw[j][2] * zz) * gs[j] + gh[j]));
             *(u32x4*)(smem + buf * kBuf + pl * kRow + ((oct ^ (pl & 15)) * 16)) = hv;
-            if (pl < left) *(u32x4*)(h1_step + pl * kC + oct * 8) = hv;
+            if (!EVAL && pl < left) *(u32x4*)(h1_step + pl * kC + oct * 8) = hv;
             __builtin_amdgcn_sched_barrier(0);  // one pixel at a time: eight interleaved would need 32 more registers
         }
         }
@@ -154,8 +158,48 @@ __global__ __launch_bounds__(512, 1) void pos_fwd_kernel(const PosFwdArgs a) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) ssum[q] = ssq[q] = f32x2{0.f, 0.f};
 
+    // ---- inference: the modulation of MetaKernel.forward (nn/stems/__init__.py:80-83) in the epilogue.  Row pk = 9 p + k of the
+    // 9x grid is neighbour k of pixel p; a lane owns 8 channels of 8 rows per step and fetches the neighbour's 8 feature
+    // channels (16 bytes, zero outside the image) with ordinary vector loads issued a WHOLE STEP before their use, right after
+    // the epilogue that consumed the previous contents of the same registers: the shared vmcnt (see the note on `rel` above) then
+    // only asks for stores that are a step old when a wave waits for its features.  Measured at 4 x 64 x 2048 x 256: 1.34 ms (one
+    // generate phase ahead: 1.40) against 1.36 + 1.04 for the two kernels; with neither loads nor stores the step loop itself takes
+    // 1.21 ms (generate + multiply + barrier per 128 pixels), which is what bounds this form -- the write bound would be 0.7.
+    f32x2 sc2[4], sh2[4];
+    u32x4 fv[G::kGroups][2];
+    if (EVAL) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            sc2[q] = f32x2{a.scale2[wc * 32 + lg * 8 + 2 * q], a.scale2[wc * 32 + lg * 8 + 2 * q + 1]};
+            sh2[q] = f32x2{a.shift2[wc * 32 + lg * 8 + 2 * q], a.shift2[wc * 32 + lg * 8 + 2 * q + 1]};
+        }
+    }
+    auto load_feat = [&](int64_t step, int hq) __attribute__((always_inline)) {  // fv[hq][:] of `step`
+        const int pk0 = (int)(step * kTM);  // (the launcher checks 9 N H W < 2^31 and W >= 32)
+        const int p0 = pk0 / 9, k0 = pk0 - 9 * p0;
+        const int r0 = p0 / a.W, w0 = p0 - r0 * a.W, h0 = r0 % a.H;
+        int l15 = l15_, lg = lg_;
+        asm volatile("" : "+v"(l15), "+v"(lg));
+        {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int pl = ((wp * G::kGroups + hq) * 2 + i) * 16 + l15;
+                const int d = pl + k0, q9 = (d * 7282) >> 16, k = d - 9 * q9;  // d < 265: exact d / 9
+                int w = w0 + q9, h = h0;
+                if (w >= a.W) w -= a.W, h += 1;
+                if (h >= a.H) h = 0;
+                const int dy = ((k * 11) >> 5) - 1, dx = k - 3 * (dy + 1) - 1;  // k / 3 - 1, k % 3 - 1
+                const int hn = h + dy, wn = w + dx;
+                const bool in = pk0 + pl < a.P && hn >= 0 && hn < a.H && wn >= 0 && wn < a.W;
+                const int64_t nbr = (int64_t)(p0 + q9) + dy * a.W + dx;
+                fv[hq][i] = u32x4{0u, 0u, 0u, 0u};
+                if (in) fv[hq][i] = *(const u32x4*)(a.feat + nbr * a.ld_feat + wc * 32 + lg * 8);
+            }
+        }
+    };
+
     // multiply the image of step `s` (LDS image `cur`) by this wave's weights, store y2, accumulate the statistics
-    auto multiply = [&](int64_t s, int cur) __attribute__((always_inline)) {
+    auto multiply = [&](int64_t s, int cur, int64_t nxt, bool has_next) __attribute__((always_inline)) {
         const bool full = (s + 1) * kTM <= a.P;  // every pixel of the step exists
         // (opaque copies of the lane coordinates: derived LDS / store offsets are recomputed per step instead of being hoisted
         //  out of the step loop for every unrolled position, which cost ~40 registers and spilled)
@@ -199,6 +243,13 @@ __global__ __launch_bounds__(512, 1) void pos_fwd_kernel(const PosFwdArgs a) {
 #pragma unroll
                     for (int r2 = 0; r2 < 2; ++r2) {
                         f32x2 x = {acc[i][j][2 * r2], acc[i][j][2 * r2 + 1]};
+                        if (EVAL) {
+                            // y2 rounded to the storage type first (what the separate modulation pass read), then its arithmetic
+                            const uint32_t y16 = pack2(x), f16 = fv[hq][i][j * 2 + r2];
+                            const f32x2 y = {bf_lo(y16), bf_hi(y16)}, f = {bf_lo(f16), bf_hi(f16)};
+                            out[j * 2 + r2] = pack2(max0(y * sc2[j * 2 + r2] + sh2[j * 2 + r2]) * f);
+                            continue;
+                        }
                         x = ok ? x : f32x2{0.f, 0.f};
                         ssum[j * 2 + r2] += x;
                         ssq[j * 2 + r2] += x * x;
@@ -206,25 +257,32 @@ __global__ __launch_bounds__(512, 1) void pos_fwd_kernel(const PosFwdArgs a) {
                     }
                 if (ok) *(u32x4*)(y2_step + pl * kC + wc * 32 + lg * 8) = out;
             }
+            if (EVAL && has_next) load_feat(nxt, hq);
         }
     };
 
     const int64_t steps = (a.P + kTM - 1) / kTM;
-    if ((int64_t)blockIdx.x < steps) generate8(blockIdx.x, 0);
+    const bool gen_first = wn < 4;
+    if ((int64_t)blockIdx.x < steps) {
+        if (EVAL) {
+#pragma unroll
+            for (int hq = 0; hq < G::kGroups; ++hq) load_feat(blockIdx.x, hq);
+        }
+        generate8(blockIdx.x, 0);
+    }
     __syncthreads();
     // The two waves of a SIMD (w and w + 4) walk a step in OPPOSITE order -- generate-then-multiply against
     // multiply-then-generate (the image being generated and the one being multiplied are different buffers) -- so that one
     // issues VALU work while the other keeps the matrix pipe busy.
-    const bool gen_first = wn < 4;
     int cur = 0;  // k & 1 of the step being multiplied
     for (int64_t s = blockIdx.x; s < steps; s += gridDim.x) {
         const int64_t nxt = s + gridDim.x;
         const bool has_next = nxt < steps;
         if (gen_first) {
             if (has_next) generate8(nxt, cur ^ 1);
-            multiply(s, cur);
+            multiply(s, cur, nxt, has_next);
         } else {
-            multiply(s, cur);
+            multiply(s, cur, nxt, has_next);
             if (has_next) generate8(nxt, cur ^ 1);
         }
         // image cur^1 is complete and everyone is done reading image cur: LDS traffic only -- NOT __syncthreads(), whose
@@ -233,7 +291,7 @@ __global__ __launch_bounds__(512, 1) void pos_fwd_kernel(const PosFwdArgs a) {
         __builtin_amdgcn_s_barrier();
         cur ^= 1;
     }
-    if (a.partial) {
+    if (!EVAL && a.partial) {
         // per-channel totals of this workgroup: sum over the 16 pixel lanes (l15), then (C = 128) over the two waves of a channel slice
         // through LDS (the images are dead: the loop ends on a barrier), then one row per workgroup
         float* const red = (float*)smem;  // [2][C]
@@ -492,8 +550,8 @@ extern "C" int rv_pos_forward(const void* rel, int32_t ld_rel, int32_t cin, int6
     RV_REQUIRE(cin >= 1 && cin <= 3 && ld_rel >= 4 && ld_rel % 4 == 0 && pixels > 0, "rv_pos_forward: bad shape");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)pos_fwd_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Pos<256>::kBuf);
-        (void)hipFuncSetAttribute((const void*)pos_fwd_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Pos<128>::kBuf);
+        (void)hipFuncSetAttribute((const void*)pos_fwd_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Pos<256>::kBuf);
+        (void)hipFuncSetAttribute((const void*)pos_fwd_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Pos<128>::kBuf);
         attr_set = true;
     }
     PosFwdArgs a{};
@@ -501,8 +559,35 @@ extern "C" int rv_pos_forward(const void* rel, int32_t ld_rel, int32_t cin, int6
     a.scale1 = scale1, a.shift1 = shift1;
     a.h1 = (bf16_t*)h1, a.y2 = (bf16_t*)y2, a.partial = stats_partial;
     a.P = pixels, a.ld_rel = ld_rel, a.ld_w1 = ld_w1, a.cin = cin;
-    if (c == 256) hipLaunchKernelGGL(pos_fwd_kernel<256>, dim3(rv_pos_forward_rows(pixels)), dim3(512), 2 * Pos<256>::kBuf, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(pos_fwd_kernel<128>, dim3(rv_pos_forward_rows(pixels)), dim3(512), 2 * Pos<128>::kBuf, (hipStream_t)stream, a);
+    if (c == 256) hipLaunchKernelGGL((pos_fwd_kernel<256, false>), dim3(rv_pos_forward_rows(pixels)), dim3(512), 2 * Pos<256>::kBuf, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((pos_fwd_kernel<128, false>), dim3(rv_pos_forward_rows(pixels)), dim3(512), 2 * Pos<128>::kBuf, (hipStream_t)stream, a);
     RV_CHECK_LAUNCH("pos_fwd_kernel");
+    return 0;
+}
+
+extern "C" int rv_pos_modulate_forward(const void* rel, int32_t ld_rel, int32_t cin, const void* w1_packed, int32_t ld_w1, const float* scale1,
+                                       const float* shift1, const void* w2_packed, int32_t c, const float* scale2, const float* shift2,
+                                       const void* feat, int32_t ld_feat, int32_t N, int32_t H, int32_t W, void* geo, rvStream stream) {
+    RV_REQUIRE(rel && w1_packed && scale1 && shift1 && w2_packed && scale2 && shift2 && feat && geo, "rv_pos_modulate_forward: null argument");
+    RV_REQUIRE(c == 256 || c == 128, "rv_pos_modulate_forward: built for 256 or 128 channels (got %d)", c);
+    RV_REQUIRE(cin >= 1 && cin <= 3 && ld_rel >= 4 && ld_rel % 4 == 0, "rv_pos_modulate_forward: bad shape");
+    RV_REQUIRE(N > 0 && H > 0 && W >= 32 && ld_feat >= c && ld_feat % 8 == 0, "rv_pos_modulate_forward: W >= 32, feature rows of at least c channels");
+    const int64_t pixels = (int64_t)N * H * W * 9;
+    RV_REQUIRE(pixels < ((int64_t)1 << 31) - 512, "rv_pos_modulate_forward: 9 N H W must stay below 2^31");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)pos_fwd_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Pos<256>::kBuf);
+        (void)hipFuncSetAttribute((const void*)pos_fwd_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Pos<128>::kBuf);
+        attr_set = true;
+    }
+    PosFwdArgs a{};
+    a.rel = (const bf16_t*)rel, a.w1 = (const bf16_t*)w1_packed, a.w2 = (const bf16_t*)w2_packed;
+    a.scale1 = scale1, a.shift1 = shift1, a.scale2 = scale2, a.shift2 = shift2;
+    a.feat = (const bf16_t*)feat, a.ld_feat = ld_feat, a.H = H, a.W = W;
+    a.h1 = nullptr, a.y2 = (bf16_t*)geo, a.partial = nullptr;
+    a.P = pixels, a.ld_rel = ld_rel, a.ld_w1 = ld_w1, a.cin = cin;
+    if (c == 256) hipLaunchKernelGGL((pos_fwd_kernel<256, true>), dim3(rv_pos_forward_rows(pixels)), dim3(512), 2 * Pos<256>::kBuf, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((pos_fwd_kernel<128, true>), dim3(rv_pos_forward_rows(pixels)), dim3(512), 2 * Pos<128>::kBuf, (hipStream_t)stream, a);
+    RV_CHECK_LAUNCH("pos_fwd_kernel<eval>");
     return 0;
 }

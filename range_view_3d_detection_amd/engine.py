@@ -1023,7 +1023,7 @@ EVAL_FOLD = os.environ.get("RV3D_NO_EVAL_FOLD") is None
 
 
 def conv_bn(t: Tape, layer: TapLayer, x: Operand, bn: nn.BatchNorm2d, relu: bool = True,
-            need_input_grad: bool = True, smallk: bool = True, fold_eval: bool = True) -> Operand:
+            need_input_grad: bool = True, smallk: bool = True, fold_eval: bool = True, out: Optional[Act] = None) -> Operand:
     """conv -> BatchNorm (-> ReLU).  ``smallk=False`` keeps a small-K layer on the generic path (a Lazy result), for consumers
     that fold the BatchNorm themselves (MetaModulateOp; ``fold_eval=False`` likewise keeps the Lazy form in eval mode)."""
     if smallk and _smallk_eligible(layer, x, relu, need_input_grad):
@@ -1031,7 +1031,8 @@ def conv_bn(t: Tape, layer: TapLayer, x: Operand, bn: nn.BatchNorm2d, relu: bool
     if not t.training and EVAL_FOLD and fold_eval and layer.bias is None:
         # inference: BatchNorm folded into the weight image and the bias, ReLU in the epilogue -- the conv writes the activation
         # itself (no folded operand for the consumer to apply, no write-out pass for the LDS-DMA kernels)
-        return ConvOp(t, layer, x, need_input_grad=need_input_grad, eval_bn=bn, relu_out=relu).out
+        # (``out``: where the activation goes -- honoured on this path only, the caller checks ``result is out``)
+        return ConvOp(t, layer, x, need_input_grad=need_input_grad, eval_bn=bn, relu_out=relu, out=out).out
     conv = ConvOp(t, layer, x, stats=t.training, need_input_grad=need_input_grad)
     return BnOp(t, conv, bn, relu).lazy
 
@@ -1101,6 +1102,47 @@ def pos_pair(t: Tape, l0: TapLayer, bn0: nn.BatchNorm2d, l1: TapLayer, bn1: nn.B
     conv = ConvOp(t, l1, h1, stats=t.training, out=y2, precomputed=(partial, rows))
     conv.pos_first = sk  # backward: this conv's input gradient is consumed by `sk`'s BatchNorm backward inside one kernel
     return BnOp(t, conv, bn1, True).lazy
+
+
+POS_MOD_FUSE = os.environ.get("RV3D_NO_POS_MOD_FUSE") is None
+
+
+def _eval_scale_shift(bn: nn.BatchNorm2d, cp: int, dev) -> Tuple[Tensor, Tensor]:
+    """Eval-mode BatchNorm as (scale, shift) over the padded channels."""
+    scale = torch.empty(cp, dtype=torch.float32, device=dev)
+    shift = torch.empty(cp, dtype=torch.float32, device=dev)
+    L.call("rv_bn_fold_eval", L.i32(cp), L.ptr(_padded(bn.weight, cp)), L.ptr(_padded(bn.bias, cp)), L.ptr(_padded(bn.running_mean, cp)),
+           L.ptr(_padded(bn.running_var, cp, 1.0)), L.f32(bn.eps), L.ptr(scale), L.ptr(shift), L.stream_ptr())
+    return scale, shift
+
+
+def pos_modulate_eligible(t: Tape, l0: TapLayer, l1: TapLayer, x: Operand, feat: Operand) -> bool:
+    """Inference: the positional pair AND the modulation in one kernel (rv_pos_modulate_forward)."""
+    return (not t.training and POS_MOD_FUSE and pos_pair_eligible(l0, l1, x) and isinstance(feat, Act) and feat.cp == pad32(l1.c_out)
+            and feat.cp == l1.c_out and feat.W >= 32 and x.pixels == 9 * feat.pixels and x.pixels < 2**31 - 512)
+
+
+class PosModulateOp(Op):
+    """Inference only: ``geo = relu(bn1(conv1(relu(bn0(conv0(rel)))))) * unfold(feat)`` of MetaKernel.forward
+    (nn/stems/__init__.py:76-83) from ONE persistent kernel -- the two positional tensors of the 9x grid never reach memory."""
+
+    def __init__(self, t: Tape, l0: TapLayer, bn0: nn.BatchNorm2d, l1: TapLayer, bn1: nn.BatchNorm2d, x: Act, feat: Act) -> None:
+        assert not t.training
+        cp = feat.cp
+        s1, t1 = _eval_scale_shift(bn0, cp, t.device)
+        s2, t2 = _eval_scale_shift(bn1, cp, t.device)
+        self.out = Act.empty(feat.N, feat.H, feat.W, 9 * cp, t.device)
+        call = lambda: L.call("rv_pos_modulate_forward", x.ptr(), L.i32(x.ld), L.i32(l0.c_in), L.ptr(l0.packed("gather")), L.i32(pad32(l0.c_in)),
+                              L.ptr(s1), L.ptr(t1), L.ptr(l1.packed("gather")), L.i32(cp), L.ptr(s2), L.ptr(t2), feat.ptr(), L.i32(feat.ld),
+                              L.i32(feat.N), L.i32(feat.H), L.i32(feat.W), self.out.ptr(), L.stream_ptr())
+        if PROFILE is not None:
+            _launch("pos_fwd_kernel<eval>", 2.0 * x.pixels * l1.c_in * l1.c_out, call)
+        else:
+            call()
+        t.ops.append(self)
+
+    def backward(self, t: Tape) -> None:
+        raise L.RvError("the fused positional pair + modulation is an inference kernel: there is no backward")
 
 
 # ---------------------------------------------------------------------------------------------

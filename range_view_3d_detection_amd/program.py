@@ -130,7 +130,12 @@ def meta_kernel_program(t: Tape, m: nn.Module, features: Act, cart: Tensor, out:
     pos: Operand = rel
     n_pos = len(m.positional_kernel)
     blocks = list(m.positional_kernel)
-    if n_pos == 2 and E.pos_pair_eligible(E.tap_layer(blocks[0][0]), E.tap_layer(blocks[1][0]), rel):
+    geo: Optional[Operand] = None
+    if n_pos == 2 and E.pos_modulate_eligible(t, E.tap_layer(blocks[0][0]), E.tap_layer(blocks[1][0]), rel, f):
+        # inference: positional pair and modulation in one kernel, nothing of the 9x grid but `geo` itself is stored
+        geo = E.PosModulateOp(t, E.tap_layer(blocks[0][0]), blocks[0][1], E.tap_layer(blocks[1][0]), blocks[1][1], rel, f).out
+        blocks = []
+    elif n_pos == 2 and E.pos_pair_eligible(E.tap_layer(blocks[0][0]), E.tap_layer(blocks[1][0]), rel):
         # 3 -> 256 -> 256: both layers in one persistent streaming kernel (csrc/posconv.hip)
         pos = E.pos_pair(t, E.tap_layer(blocks[0][0]), blocks[0][1], E.tap_layer(blocks[1][0]), blocks[1][1], rel)
         blocks = []
@@ -138,11 +143,15 @@ def meta_kernel_program(t: Tape, m: nn.Module, features: Act, cart: Tensor, out:
         # the LAST positional layer feeds MetaModulateOp, which folds its BatchNorm+ReLU itself and needs the Lazy form
         # (num_layers == 1: that is the 3 -> C layer, which would otherwise take the small-K fast path)
         pos = E.conv_bn(t, E.tap_layer(blk[0]), pos, blk[1], relu=True, need_input_grad=(i > 0), smallk=(i + 1 < n_pos), fold_eval=(i + 1 < n_pos))
-    geo: Operand = E.MetaModulateOp(t, pos, f).out
+    if geo is None:
+        geo = E.MetaModulateOp(t, pos, f).out
     c = m.out_channels
+    last = len(m.fusion_kernel) - 1
     for i, blk in enumerate(m.fusion_kernel):
         kw = {"in_perm": (c, m.num_neighbors**2)} if i == 0 else {}
-        geo = E.conv_bn(t, E.tap_layer(blk[0], **kw), geo, blk[1], relu=True)
+        geo = E.conv_bn(t, E.tap_layer(blk[0], **kw), geo, blk[1], relu=True, out=out if i == last else None)
+    if out is not None and geo is out:  # (inference: the last fusion conv wrote the activation into its place)
+        return out
     return E.CombineOp(t, geo, None, relu_out=False, out=out).out
 
 

@@ -177,3 +177,72 @@ def test_residual_epilogue_in_the_tiny_detector(golden, precision):
         E.EVAL_RES_FUSE = True
     assert torch.equal(lf, lu) and torch.equal(rf, ru)
     assert nf < nu, (nf, nu)
+
+
+@pytest.mark.parametrize("tag", ["bf16", "f16"])
+@pytest.mark.parametrize("C", [256, 128])
+@pytest.mark.parametrize("N,H,W", [(2, 5, 37), (3, 16, 160)])
+def test_pos_modulate_forward_equals_the_two_kernels(N, H, W, C, tag):
+    """rv_pos_modulate_forward (inference: positional pair + modulation in one persistent kernel, neither h1 nor y2 stored)
+    against rv_pos_forward followed by rv_meta_modulate: EQUAL bit for bit (y2 is rounded to the storage type before the
+    BatchNorm, as the stored tensor was).  2 x 5 x 37: rows that wrap image rows and images inside a step, a partial last
+    step, every border neighbour; 3 x 16 x 160: 540 (C = 256) / 270 (C = 128) steps over 256 persistent workgroups."""
+    from range_view_3d_detection_amd import _lib as L
+
+    dt = torch.float16 if tag == "f16" else torch.bfloat16
+    gen = torch.Generator().manual_seed(N * 1000 + W + C)
+    P = N * H * W * 9
+    rel = torch.zeros(P, 32, dtype=dt)
+    rel[:, :3] = (torch.randn(P, 3, generator=gen) * 2).to(dt)
+    w1 = torch.zeros(C, 32, dtype=dt)
+    w1[:, :3] = torch.randn(C, 3, generator=gen).to(dt)
+    w2 = (torch.randn(C, C, generator=gen) / 16).to(dt)
+    s1, t1 = 0.5 + torch.rand(C, generator=gen), 0.3 * torch.randn(C, generator=gen)
+    s2, t2 = 0.5 + torch.rand(C, generator=gen), 0.3 * torch.randn(C, generator=gen)
+    feat = torch.randn(N * H * W, C, generator=gen).to(dt)
+    rel, w1, w2, s1, t1, s2, t2, feat = (x.to(DEV) for x in (rel, w1, w2, s1, t1, s2, t2, feat))
+    with L.operand(tag):
+        h1 = torch.empty((P, C), dtype=dt, device=DEV)
+        y2 = torch.empty((P, C), dtype=dt, device=DEV)
+        L.call("rv_pos_forward", L.ptr(rel), L.i32(32), L.i32(3), L.i64(P), L.ptr(w1), L.i32(32), L.ptr(s1), L.ptr(t1), L.ptr(w2), L.i32(C),
+               L.ptr(h1), L.ptr(y2), None, L.stream_ptr())
+        want = torch.full((N * H * W, 9 * C), float("nan"), dtype=dt, device=DEV)
+        L.call("rv_meta_modulate", L.ptr(y2), L.ptr(s2), L.ptr(t2), L.ptr(feat), L.i32(C), L.i32(N), L.i32(H), L.i32(W), L.i32(C), L.ptr(want),
+               L.stream_ptr())
+        got = torch.full((N * H * W, 9 * C), float("nan"), dtype=dt, device=DEV)
+        L.call("rv_pos_modulate_forward", L.ptr(rel), L.i32(32), L.i32(3), L.ptr(w1), L.i32(32), L.ptr(s1), L.ptr(t1), L.ptr(w2), L.i32(C),
+               L.ptr(s2), L.ptr(t2), L.ptr(feat), L.i32(C), L.i32(N), L.i32(H), L.i32(W), L.ptr(got), L.stream_ptr())
+        torch.cuda.synchronize()
+    assert not bool(torch.isnan(want.float()).any()) and float(want.float().abs().max()) > 0
+    a, b = got.float().cpu(), want.float().cpu()
+    assert torch.equal(a, b), (float((a - b).abs().max()), int((a != b).sum()), a.numel())
+
+
+@pytest.mark.parametrize("precision", ["bf16", "f16"])
+@pytest.mark.parametrize("C", [256, 128])
+def test_meta_kernel_eval_with_the_fused_stem_kernel(C, precision):
+    """MetaKernel in eval mode at the rv-av2 / rv-waymo stem widths: the fused inference kernel (default) against the
+    positional pair + separate modulation (``engine.POS_MOD_FUSE = False``): outputs EQUAL."""
+    from range_view_3d_detection_amd import engine as E
+    from range_view_3d_detection_amd.nn.stems import MetaKernel
+
+    gen = torch.Generator().manual_seed(31)
+    m = MetaKernel(5, C, 3, 2).to(DEV).eval()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.data = 0.1 * torch.randn(mod.num_features, generator=gen).to(DEV)
+            mod.running_var.data = (0.5 + torch.rand(mod.num_features, generator=gen)).to(DEV)
+    feats = torch.randn(2, 5, 16, 160, generator=gen).to(DEV)
+    cart = (torch.randn(2, 3, 16, 160, generator=gen) * 5).to(DEV)
+
+    def run():
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=precision == "f16"):
+            return m(feats, cart).float().cpu()
+
+    a = run()
+    E.POS_MOD_FUSE = False
+    try:
+        b = run()
+    finally:
+        E.POS_MOD_FUSE = True
+    assert float(a.abs().max()) > 0 and torch.equal(a, b), float((a - b).abs().max())
