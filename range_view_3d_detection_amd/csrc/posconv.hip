@@ -94,6 +94,17 @@ __global__ __launch_bounds__(512, 1) void pos_fwd_kernel(const PosFwdArgs a) {
     // ---- first layer: this thread generates octet `oct` of pixels pxl, pxl + kPass, ... of a step
     const int oct_ = tid % G::kOct, pxl_ = tid / G::kOct;
     const int oct = oct_;
+    // Per-lane address parts, formed ONCE and kept opaque (the step loop adds wave-uniform and immediate parts only: recomputing
+    // them per position cost ~200 of the ~830 VALU instructions a wave issued per step, and this kernel is VALU-issue bound):
+    //   wb       LDS byte offset of this thread's octet in row pxl of an image (the XOR uses pxl & 15 = pl & 15: kPass % 16 == 0)
+    //   rb[x]    LDS byte offset of the fragment read of row l15, K-step ks with (ks & 3) == x: slot ((ks*4 + lg) ^ l15) --
+    //            the XOR reaches the low four slot bits only, so (ks >> 2), the 16-row tile and the group are immediates
+    //   hoff / yoff   element offsets of this thread's h1 octet / y2 octet inside a step
+    uint32_t wb = pxl_ * kRow + ((oct_ ^ (pxl_ & 15)) * 16), rb[4];
+    int hoff = pxl_ * kC + oct_ * 8, yoff = (wp * G::kGroups * 32 + l15_) * kC + wc * 32 + lg_ * 8;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) rb[x] = (wp * G::kGroups * 32 + l15_) * kRow + (((((x << 2) | lg_) ^ l15_) & 15) * 16);
+    asm volatile("" : "+v"(wb), "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(hoff), "+v"(yoff));
     // (channel PAIRS -> v_pk_fma_f32; the arithmetic order is rv_smallk_forward's: relu(s (w . rel) + t))
     f32x2 gw[4][3], gs[4], gh[4];
 #pragma unroll
@@ -117,10 +128,10 @@ __global__ __launch_bounds__(512, 1) void pos_fwd_kernel(const PosFwdArgs a) {
         // (inline asm: hipcc turns these into VECTOR loads because the h1 / y2 stores might alias `rel`; indices are clamped
         //  instead of guarded -- pixels past the end are masked in the epilogue and never stored)
         constexpr int kSel = G::kSel, kIt = 16 / kSel;  // sixteen scalar loads in flight: 8 passes x 2 pixels, or 4 passes x 4 pixels twice
-        int oct = oct_, pxl = pxl_;
-        asm volatile("" : "+v"(oct), "+v"(pxl));  // (see multiply: no hoisting of the eight pixels' offsets)
         bf16_t* const h1_step = a.h1 + step * (int64_t)(kTM * kC);  // wave-uniform base: the lane part stays a 32-bit offset
-        const int64_t left = a.P - step * kTM;                      // pixels of this step that exist
+        const int64_t left64 = a.P - step * kTM;                    // pixels of this step that exist
+        const int left = left64 < kTM ? (int)left64 : kTM;
+        const uint32_t wbuf = wb + buf * kBuf;
 #pragma unroll
         for (int it0 = 0; it0 < 8; it0 += kIt) {
         uint64_t qs[16];
@@ -137,7 +148,7 @@ __global__ __launch_bounds__(512, 1) void pos_fwd_kernel(const PosFwdArgs a) {
                        "+s"(qs[9]), "+s"(qs[10]), "+s"(qs[11]), "+s"(qs[12]), "+s"(qs[13]), "+s"(qs[14]), "+s"(qs[15]));
 #pragma unroll
         for (int it = 0; it < kIt; ++it) {
-            const int pl = (it0 + it) * G::kPass + pxl;
+            const int pl0 = (it0 + it) * G::kPass;  // (+ pxl_)
             uint64_t q = qs[it * kSel];
 #pragma unroll
             for (int e = 1; e < kSel; ++e) q = lane >= e * G::kOct ? qs[it * kSel + e] : q;
@@ -147,8 +158,8 @@ __global__ __launch_bounds__(512, 1) void pos_fwd_kernel(const PosFwdArgs a) {
             u32x4 hv;
 #pragma unroll
             for (int j = 0; j < 4; ++j) hv[j] = pack2(max0((gw[j][0] * xx + gw[j][1] * yy + gw[j][2] * zz) * gs[j] + gh[j]));
-            *(u32x4*)(smem + buf * kBuf + pl * kRow + ((oct ^ (pl & 15)) * 16)) = hv;
-            if (!EVAL && pl < left) *(u32x4*)(h1_step + pl * kC + oct * 8) = hv;
+            *(u32x4*)(smem + wbuf + pl0 * kRow) = hv;
+            if (!EVAL && pl0 + pxl_ < left) *(u32x4*)(h1_step + pl0 * kC + hoff) = hv;
             __builtin_amdgcn_sched_barrier(0);  // one pixel at a time: eight interleaved would need 32 more registers
         }
         }
@@ -200,22 +211,18 @@ __global__ __launch_bounds__(512, 1) void pos_fwd_kernel(const PosFwdArgs a) {
 
     // multiply the image of step `s` (LDS image `cur`) by this wave's weights, store y2, accumulate the statistics
     auto multiply = [&](int64_t s, int cur, int64_t nxt, bool has_next) __attribute__((always_inline)) {
-        const bool full = (s + 1) * kTM <= a.P;  // every pixel of the step exists
-        // (opaque copies of the lane coordinates: derived LDS / store offsets are recomputed per step instead of being hoisted
-        //  out of the step loop for every unrolled position, which cost ~40 registers and spilled)
-        int l15 = l15_, lg = lg_;
-        asm volatile("" : "+v"(l15), "+v"(lg));
-        const uint8_t* img = smem + cur * kBuf;
+        const int64_t left64 = a.P - s * kTM;
+        const int left = left64 < kTM ? (int)left64 : kTM;
+        const bool full = left == kTM;  // every pixel of the step exists
+        const uint32_t rbc[4] = {rb[0] + cur * kBuf, rb[1] + cur * kBuf, rb[2] + cur * kBuf, rb[3] + cur * kBuf};
         bf16_t* const y2_step = a.y2 + s * (int64_t)(kTM * kC);
 #pragma unroll
         for (int hq = 0; hq < G::kGroups; ++hq) {  // 32 pixels at a time: 16 accumulator + 16 fragment registers
-            const int half = wp * G::kGroups + hq;
             f32x4 acc[2][2];
             bf16x8 fa[4][2];
             auto read_fa = [&](int ks, bf16x8 (&f)[2]) __attribute__((always_inline)) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    f[i] = *(const bf16x8*)(img + ((half * 2 + i) * 16 + l15) * kRow + (((ks * 4 + lg) ^ l15) * 16));
+                for (int i = 0; i < 2; ++i) f[i] = *(const bf16x8*)(smem + rbc[ks & 3] + ((hq * 2 + i) * 16 * kRow + (ks >> 2) * 256));
             };
             read_fa(0, fa[0]);
             read_fa(1, fa[1]);
@@ -235,8 +242,8 @@ __global__ __launch_bounds__(512, 1) void pos_fwd_kernel(const PosFwdArgs a) {
             // lane (pixel l15 of tile i, lane group lg) holds channels 32 wc + 8 lg + 4 j + r
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int pl = (half * 2 + i) * 16 + l15;
-                const bool ok = full || pl < a.P - s * kTM;
+                const int pl0 = (hq * 2 + i) * 16;  // (+ wp's groups + l15: the row inside the step)
+                const bool ok = full || (wp * G::kGroups * 32 + pl0 + l15_) < left;
                 u32x4 out;
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
@@ -250,12 +257,12 @@ __global__ __launch_bounds__(512, 1) void pos_fwd_kernel(const PosFwdArgs a) {
                             out[j * 2 + r2] = pack2(max0(y * sc2[j * 2 + r2] + sh2[j * 2 + r2]) * f);
                             continue;
                         }
-                        x = ok ? x : f32x2{0.f, 0.f};
+                        if (!full) x = ok ? x : f32x2{0.f, 0.f};
                         ssum[j * 2 + r2] += x;
                         ssq[j * 2 + r2] += x * x;
                         out[j * 2 + r2] = pack2(x);
                     }
-                if (ok) *(u32x4*)(y2_step + pl * kC + wc * 32 + lg * 8) = out;
+                if (ok) *(u32x4*)(y2_step + pl0 * kC + yoff) = out;
             }
             if (EVAL && has_next) load_feat(nxt, hq);
         }
