@@ -9,6 +9,8 @@ the tap tables, the channel concat is written in place.  ``run`` wraps a program
 
 from __future__ import annotations
 
+import os
+
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -243,6 +245,9 @@ def operand_for(training: bool) -> str:
     return "f16" if fp16_autocast else "bf16"
 
 
+_MATERIALIZE_GRADS = os.environ.get("RV3D_MATERIALIZE_GRADS") is not None  # (A/B switch: autograd's default zero-filled gradients)
+
+
 class _ProgramFn(torch.autograd.Function):
     """One autograd node for a whole fused program.
 
@@ -265,6 +270,9 @@ class _ProgramFn(torch.autograd.Function):
         if tape.bn_counters:
             torch._foreach_add_(tape.bn_counters, 1)  # num_batches_tracked of every BatchNorm on the tape, one launch
             tape.bn_counters = []
+        # an output nobody differentiates (the backbone's stride-2/4/16 maps when the head reads stride 1 only) gets NO gradient
+        # instead of a materialised zero tensor, which would be converted, copied and then accumulated into by every real writer
+        ctx.set_materialize_grads(_MATERIALIZE_GRADS)
         ctx.tape, ctx.in_acts, ctx.outs, ctx.n_in = tape, in_acts, outs, n_in
         ctx.params = args[n_in:]
         ctx.in_meta = [(x.dtype, x.shape) if isinstance(x, Tensor) else None for x in inputs]
