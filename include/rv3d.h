@@ -170,7 +170,10 @@ int rv_tap_residual(const rvTapGeom* g, const rvTapShape* s, int32_t scatter, co
  * rv_tap_gather / rv_tap_scatter (scatter != 0: the SCATTER form) without RV_OUT_ACCUM; from the bf16 values it stores,
  *   g = dx * [scale*y+shift > 0 if flags & RV_BNB_RELU_Z],   partial[row][0][c] = sum g,  partial[row][1][c] = sum g * (y-mean)*invstd
  * over the row's pixels -- the layout rv_bn_bwd_finalize takes (rv_bn_bwd_reduce then is not needed).
- * rv_tap_bnb_rows: partial rows such a launch writes; 0 = the kernel (g, s) selects has no such epilogue (only the
+ * With RV_BNB_MASK (and RV_OUT_ACCUM in s->flags) the launch is the LAST of several writers of dx -- the gradient of a block
+ * output relu(bn(y) + x) whose other consumers have already written their share: dx += result, g = dx * [e->mask > 0] with the
+ * block output itself as the mask, sums as above: bn_bwd_reduce's pass over (gradient, output, y) disappears for that layer.
+ * rv_tap_bnb_rows: partial rows such a launch writes (s->flags with RV_OUT_ACCUM asks about the masked form); 0 = the kernel (g, s) selects has no such epilogue (only the
  * fifth-generation tap-conv has): use rv_tap_gather/scatter + rv_bn_bwd_reduce. */
 typedef struct rvBnbEpilogue {
     const void* y;      /* bf16 NHWC pre-BatchNorm conv output of the destination layer, same pixels as dx */
@@ -181,6 +184,8 @@ typedef struct rvBnbEpilogue {
     const float* mean;
     const float* invstd;
     float* partial;     /* [rows + RV_STATS_SCRATCH_ROWS][2][c_pad] fp32 */
+    const void* mask;   /* RV_BNB_MASK: bf16 NHWC tensor of dx's pixels, g = dx * [mask > 0] -- the block output relu(bn(y) + x) itself */
+    int32_t ld_mask;
 } rvBnbEpilogue;
 int32_t rv_tap_bnb_rows(const rvTapGeom* g, const rvTapShape* s, int32_t scatter);
 int rv_tap_data_grad_bnb(const rvTapGeom* g, const rvTapShape* s, int32_t scatter, const void* dout, const void* w, void* dx,
@@ -243,6 +248,8 @@ int rv_ew_combine(int64_t pixels, int32_t c, const void* a, int32_t ld_a, const 
  * Replaces cuDNN BatchNorm backward + ReLU backward + the add's gradient fan-out. */
 #define RV_BNB_RELU_Z 1
 #define RV_BNB_RES_ACCUM 2
+#define RV_BNB_MASK 8 /* rvBnbEpilogue only: the sums take their ReLU mask from e->mask and the launch ACCUMULATES into dx (s->flags has
+                       * RV_OUT_ACCUM): the last writer of a block output's gradient forms the sums of the COMPLETE gradient */
 #define RV_BNB_Y_FROM_INPUT 4 /* rv_bn_bwd_smallk*: y (may be NULL) is recomputed as W v from the conv input and w_packed */
 int32_t rv_bn_bwd_rows(int64_t pixels);
 int rv_bn_bwd_reduce(int64_t pixels, int32_t c, const void* dout, int32_t ld_dout, const void* out, int32_t ld_out,

@@ -25,7 +25,7 @@ IN_AFFINE, IN_RELU, OUT_F32, OUT_BIAS, OUT_STATS, OUT_ACCUM, OUT_RELU = 1, 2, 4,
 OUT_RES_RELU = 256
 WGRAD_TORCH_LAYOUT = 128  # rv_tap_wgrad: result in dT[cu][cv][kh][kw] (no unpack pass)
 EW_RELU_A, EW_RELU_B, EW_RELU_OUT = 1, 2, 4
-BNB_RELU_Z, BNB_RES_ACCUM, BNB_Y_FROM_INPUT = 1, 2, 4
+BNB_RELU_Z, BNB_RES_ACCUM, BNB_Y_FROM_INPUT, BNB_MASK = 1, 2, 4, 8
 STATS_SCRATCH_ROWS = 128
 
 
@@ -41,7 +41,7 @@ class BnbEpilogue(ctypes.Structure):
     """``rvBnbEpilogue`` of include/rv3d.h (rv_tap_data_grad_bnb)."""
 
     _fields_ = [("y", ctypes.c_void_p), ("ld_y", ctypes.c_int32), ("flags", ctypes.c_int32), ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p),
-                ("mean", ctypes.c_void_p), ("invstd", ctypes.c_void_p), ("partial", ctypes.c_void_p)]
+                ("mean", ctypes.c_void_p), ("invstd", ctypes.c_void_p), ("partial", ctypes.c_void_p), ("mask", ctypes.c_void_p), ("ld_mask", ctypes.c_int32)]
 
 
 class RvError(RuntimeError):

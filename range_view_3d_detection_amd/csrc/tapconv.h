@@ -41,6 +41,8 @@ struct TapConvArgs {
     const float *bnb_scale, *bnb_shift, *bnb_mean, *bnb_invstd;
     float* bnb_partial;  // [tiles][2][C_dst]
     int32_t ld_bnb_y, bnb_flags;
+    const bf16_t* bnb_mask;  // RV_BNB_MASK: g = dOut * [mask > 0] (the block output itself), together with RV_OUT_ACCUM
+    int32_t ld_bnb_mask;
     // RV_OUT_ACCUM: the tensor added to the result -- dst itself (gradient fan-in) or a residual (rv_tap_residual), same pixels as dst
     const bf16_t* res;
     int32_t ld_res;

@@ -444,6 +444,8 @@ static int tap_launch(const rvTapGeom* g, const rvTapShape* s, bool scatter, con
     if (bnb_rows) *bnb_rows = 0;
     if (bnb || bnb_rows) {  // backward-data launch that also forms the BatchNorm-backward sums of its destination layer
         a.flags |= RV_OUT_BNB;
+        // (row query for an ACCUMULATING launch = the masked last-writer form: a dry run, the pointer is never followed)
+        if (!bnb && (a.flags & RV_OUT_ACCUM)) a.bnb_mask = (const bf16_t*)(uintptr_t)16;
         if (bnb) {
             RV_REQUIRE(bnb->y && bnb->scale && bnb->shift && bnb->mean && bnb->invstd && bnb->partial, "rv_tap_data_grad_bnb: null epilogue pointer");
             RV_REQUIRE(bnb->ld_y >= a.C_dst && bnb->ld_y % 8 == 0, "rv_tap_data_grad_bnb: bad channel stride of y (%d)", bnb->ld_y);
@@ -455,6 +457,12 @@ static int tap_launch(const rvTapGeom* g, const rvTapShape* s, bool scatter, con
             a.bnb_mean = bnb->mean;
             a.bnb_invstd = bnb->invstd;
             a.bnb_partial = bnb->partial;
+            if (bnb->flags & RV_BNB_MASK) {
+                RV_REQUIRE(bnb->mask && bnb->ld_mask >= a.C_dst && bnb->ld_mask % 8 == 0, "rv_tap_data_grad_bnb: RV_BNB_MASK without a mask tensor");
+                RV_REQUIRE(a.flags & RV_OUT_ACCUM, "rv_tap_data_grad_bnb: RV_BNB_MASK is the accumulating (last-writer) form");
+                a.bnb_mask = (const bf16_t*)bnb->mask;
+                a.ld_bnb_mask = bnb->ld_mask;
+            }
         }
     }
 

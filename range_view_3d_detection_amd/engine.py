@@ -424,6 +424,9 @@ Operand = Union[Act, Lazy]
 MATERIALIZE_FOR_DMA = os.environ.get("RV3D_NO_MATERIALIZE") is None
 # conv -> BatchNorm(+ReLU) -> conv: the second conv's backward-data launch also forms the BatchNorm-backward sums (rv_tap_data_grad_bnb)
 BNB_FUSE = os.environ.get("RV3D_NO_BNB_FUSE") is None
+# ... and where the gradient of a block output relu(bn(y) + x) has several writers, its LAST writer (the accumulating
+# backward-data launch of the next block's first conv) forms them over the complete gradient (RV_BNB_MASK)
+BNB_LAST_WRITER = os.environ.get("RV3D_NO_BNB_LAST_WRITER") is None
 
 
 def _dma_eligible(geom, n: int, h: int, wu: int, wv: int, ld_src: int, ld_dst: int, scatter: bool) -> bool:
@@ -657,6 +660,9 @@ class Tape:
         self.lazy_in: Dict[int, Tuple[Act, Optional[Act]]] = {}  # id(Lazy) -> (dOut, OUT mask source)
         self.lazy_sums: Dict[int, Tuple[Tensor, int]] = {}  # id(Lazy) -> BatchNorm-backward partial sums its ONE writer formed, rows
         self.meta_in: Dict[int, tuple] = {}      # id(Lazy) -> (dgeo, feat, partial sums, rows): MetaKernel modulation fused into the BatchNorm backward
+        self.producers: Dict[int, "Op"] = {}     # id(block-output Act) -> the CombineOp that made it
+        self.grad_version: Dict[int, int] = {}   # id(root Act) -> bumped whenever somebody asks for / writes its gradient buffer
+        self.acc_sums: Dict[int, tuple] = {}     # id(root Act) -> (partial, rows, gradient Act, version): BatchNorm-backward sums the last writer formed
         self.raw_grad: Dict[int, Act] = {}       # id(raw Act) -> gradient w.r.t. the raw conv output
         self.param_grads: Dict[int, Tensor] = {}  # id(param) -> fp32 gradient
         self.params: Dict[int, nn.Parameter] = {}
@@ -671,6 +677,7 @@ class Tape:
             chain.append(root)
             root = root.parent
         key = id(root)
+        self.grad_version[key] = self.grad_version.get(key, 0) + 1
         if key not in self.grads:
             self.grads[key] = root.like(zero=bool(chain))  # partial (view) writers need a defined background
             if chain:
@@ -686,6 +693,19 @@ class Tape:
         while root.parent is not None:
             root = root.parent
         self.written.add(id(root))
+        self.grad_version[id(root)] = self.grad_version.get(id(root), 0) + 1
+
+    def touch_grad(self, g: Act) -> None:
+        """``g`` (a gradient Act handed out by ``grad_buffer``, or a view of one) has just been written outside ``grad_buffer``'s
+        own callers: invalidate what depends on its contents."""
+        root = g
+        while root.parent is not None:
+            root = root.parent
+        for key, buf in self.grads.items():
+            if buf is root:
+                self.grad_version[key] = self.grad_version.get(key, 0) + 1
+                self.acc_sums.pop(key, None)
+                return
 
     def set_grad(self, a: Act, g: Act) -> None:
         assert a.parent is None
@@ -724,6 +744,7 @@ class Tape:
             self._masked_into(dout, mask, res[0], res[1])
 
     def _masked_into(self, dout: Act, mask: Optional[Act], dst: Act, accumulate: bool) -> None:
+        self.touch_grad(dst)
         L.call("rv_ew_mask_grad", L.i64(dout.pixels), L.i32(dout.cp), dout.ptr(), L.i32(dout.ld), mask.ptr() if mask is not None else None,
                L.i32(mask.ld if mask is not None else 0), dst.ptr(), L.i32(dst.ld), L.i32(1 if accumulate else 0), L.stream_ptr())
 
@@ -1169,6 +1190,7 @@ class CombineOp(Op):
         L.call("rv_ew_combine", L.i64(ra.pixels), L.i32(ra.cp), ra.ptr(), L.i32(ra.ld), L.ptr(sa), L.ptr(ta),
                rb.ptr() if rb is not None else None, L.i32(rb.ld if rb is not None else 0), L.ptr(sb), L.ptr(tb),
                self.out.ptr(), L.i32(self.out.ld), L.i32(flags), L.stream_ptr())
+        t.producers[id(self.out)] = self
         t.ops.append(self)
 
     def backward(self, t: Tape) -> None:

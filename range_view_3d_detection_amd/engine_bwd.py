@@ -100,6 +100,22 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
             wp = layer.packed(bwd)
         call = lambda: L.call("rv_tap_" + bwd, ctypes.byref(bg), ctypes.byref(bshape), dout.ptr(), None, None, L.ptr(wp), None,
                               dst.ptr(), None, L.stream_ptr())
+        acc_sums = None
+        lw = _last_writer_target(op, t) if (E.BNB_FUSE and E.BNB_LAST_WRITER and bg is g and accumulate and not isinstance(op.x, Lazy)) else None
+        if lw is not None:
+            # op.x = relu(bn(y) + x'), its gradient already holds the other consumers' shares and this launch adds the last one:
+            # the sums of that BatchNorm's backward over the COMPLETE gradient leave with it (mask = op.x itself)
+            rows = L.load().rv_tap_bnb_rows(ctypes.byref(g), ctypes.byref(shape), L.i32(1 if bwd == "scatter" else 0))
+            if rows > 0:
+                st = lw.bn
+                partial = torch.empty((rows + L.STATS_SCRATCH_ROWS, 2, dst.cp), dtype=torch.float32, device=t.device)
+                epi = L.BnbEpilogue(lw.raw.ptr().value, lw.raw.ld, L.BNB_MASK, L.ptr(st.scale).value, L.ptr(st.shift).value,
+                                    L.ptr(st.mean).value, L.ptr(st.invstd).value, L.ptr(partial).value, op.x.ptr().value, op.x.ld)
+                call = lambda: L.call("rv_tap_data_grad_bnb", ctypes.byref(g), ctypes.byref(shape), L.i32(1 if bwd == "scatter" else 0), dout.ptr(),
+                                      L.ptr(wp), dst.ptr(), ctypes.byref(epi), L.stream_ptr())
+                acc_sums = (partial, rows, dst)
+                global LAST_WRITER_LAUNCHES
+                LAST_WRITER_LAUNCHES += 1
         if E.BNB_FUSE and bg is g and isinstance(op.x, Lazy) and not accumulate and op.x.bn.mean is not None:
             # first (often only) consumer of relu(bn(y)): this launch can form that BatchNorm's backward sums on the way out
             rows = L.load().rv_tap_bnb_rows(ctypes.byref(g), ctypes.byref(shape), L.i32(1 if bwd == "scatter" else 0))
@@ -117,6 +133,8 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
             call()
         if not isinstance(op.x, Lazy):
             t.mark_written(op.x)
+            if acc_sums is not None:  # valid as long as nobody else touches this gradient buffer (checked by version in combine_backward)
+                t.acc_sums[id(op.x)] = acc_sums + (t.grad_version[id(op.x)],)
     # ---- weight gradient ---------------------------------------------------------------------------
     if fwd == "gather":
         u, v, v_affine = dout, src, 1
@@ -160,6 +178,26 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
         t.used_side_stream = True
     else:
         run_wgrad()
+
+
+LAST_WRITER_LAUNCHES = 0  # backward-data launches that formed a block output's BatchNorm-backward sums (tests)
+
+
+def _last_writer_target(op: "E.ConvOp", t: Tape) -> Optional[Lazy]:
+    """The Lazy ``bn(y)`` behind ``op.x = relu(bn(y) + x')`` when ``op.x`` is a whole block output of exactly that form (what
+    ``combine_backward`` hands to ONE BatchNorm with ``op.x`` as the mask), else None."""
+    x = op.x
+    prod = t.producers.get(id(x))
+    if prod is None or x.parent is not None or not isinstance(prod, E.CombineOp) or not prod.relu_out or not t.training:
+        return None
+    lazies = [v for v in (prod.a, prod.b) if isinstance(v, Lazy)]
+    plains = [v for v in (prod.a, prod.b) if v is not None and not isinstance(v, Lazy)]
+    if len(lazies) != 1 or len(plains) != 1 or lazies[0].relu or lazies[0].bn.mean is None:
+        return None
+    lz = lazies[0]
+    if lz.raw.cp != x.cp or lz.raw.pixels != x.pixels:
+        return None
+    return lz
 
 
 POS_BWD_FUSE = os.environ.get("RV3D_NO_POS_BWD_FUSE") is None
@@ -283,7 +321,7 @@ def bn_backward_begin(op: "E.BnOp", t: Tape):
               L.i32(mask.ld if mask is not None else 0), raw.ptr(), L.i32(raw.ld), L.ptr(st.scale), L.ptr(st.shift),
               L.ptr(st.mean), L.ptr(st.invstd))
     sums = t.lazy_sums.pop(id(lazy), None)
-    if sums is not None and sums[2] is dout and mask is None and res is None:
+    if sums is not None and sums[2] is dout and ((len(sums) == 3 and mask is None and res is None) or (len(sums) == 4 and mask is not None)):
         partial, rows = sums[0], sums[1]  # formed by the backward-data launch that wrote dout (rv_tap_data_grad_bnb)
     else:
         rows = L.load().rv_bn_bwd_rows(L.i64(pixels))
@@ -313,6 +351,7 @@ def bn_backward_finish(recs, t: Tape) -> None:
             rg, racc = res
             L.call("rv_bn_bwd_apply", *common, L.ptr(coef), L.i32(flags | (L.BNB_RES_ACCUM if racc else 0)), dy.ptr(), L.i32(dy.ld),
                    rg.ptr(), L.i32(rg.ld), L.stream_ptr())
+            t.touch_grad(rg)  # (a write into another tensor's gradient buffer: sums formed over it earlier are stale)
         else:
             L.call("rv_bn_bwd_apply", *common, L.ptr(coef), L.i32(flags), dy.ptr(), L.i32(dy.ld), None, L.i32(0), L.stream_ptr())
         t.raw_grad[id(raw)] = dy
@@ -359,6 +398,10 @@ def _bn_backward_meta(op: "E.BnOp", t: Tape, meta) -> None:
 
 
 def combine_backward(op: "E.CombineOp", t: Tape) -> None:
+    # sums the last writer of this output's gradient formed in its epilogue: good if nobody has touched the buffer since
+    acc = t.acc_sums.pop(id(op.out), None)
+    if acc is not None and acc[3] != t.grad_version.get(id(op.out)):
+        acc = None
     gout, have = t.grad_buffer(op.out)
     if not have:
         return
@@ -374,7 +417,10 @@ def combine_backward(op: "E.CombineOp", t: Tape) -> None:
             g, have_x = t.grad_buffer(plains[0])
             res = (g, have_x)
             t.mark_written(plains[0])
+        first = id(x) not in t.lazy_in
         t.add_lazy_grad(x, gout, mask, res)
+        if acc is not None and fuse_res and first and acc[2] is gout and mask is not None:
+            t.lazy_sums[id(x)] = (acc[0], acc[1], gout, True)  # (masked sums: bn_backward_begin skips its reduce pass)
     if fuse_res:
         return
     for x in plains:

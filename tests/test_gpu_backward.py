@@ -11,6 +11,8 @@ Tolerances:
 
 from __future__ import annotations
 
+import ctypes
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -553,3 +555,48 @@ def test_strided_layers_on_the_folded_view(kind, cin, cout, kernel, stride, pad,
         assert rel_err(got_dx, bf16r(x.grad)) < 8e-3
         assert rel_err(got_dw, w.grad) < 2e-5
     assert rel_err(dw_f, dw_u) < 2e-5 and rel_err(y_f, y_u) < 8e-3 and rel_err(dx_f, dx_u) < 8e-3
+
+
+@pytest.mark.parametrize("C,W", [(128, 256), (256, 256)])
+def test_last_writer_forms_the_block_output_batchnorm_sums(C, W):
+    """A ResidualBlock of four BasicBlocks (the first with a projection, three identity blocks): the gradient of a block output has two writers (the next block's residual
+    and its first conv); the accumulating backward-data launch of that conv -- the last writer -- forms the BatchNorm-backward
+    sums of the block's second BatchNorm over the complete gradient (RV_BNB_MASK, tapconv5 EPI 3) instead of a separate
+    bn_bwd_reduce pass.  Against the same run with the switch off; the launches are counted."""
+    from range_view_3d_detection_amd import _lib as L
+    from range_view_3d_detection_amd import engine as E
+    from range_view_3d_detection_amd import engine_bwd
+    from range_view_3d_detection_amd.nn.blocks import ResidualBlock
+
+    old = L.load().rv_set_option(b"tapconv4_min_blocks", ctypes.c_int32(1))
+    try:
+        gen = torch.Generator().manual_seed(C + 5)
+        m = ResidualBlock(C, C, 4).to(DEV).train()
+        x = torch.randn(2, C, 16, W, generator=gen).to(DEV)
+        probe = torch.randn(2, C, 16, W, generator=gen).to(DEV)
+
+        def run(on: bool):
+            E.BNB_LAST_WRITER = on
+            n0 = engine_bwd.LAST_WRITER_LAUNCHES
+            try:
+                m.zero_grad(set_to_none=True)
+                xi = x.clone().requires_grad_(True)
+                (m(xi).float() * probe).sum().backward()
+                return ({k: p.grad.detach().float().cpu() for k, p in m.named_parameters()}, xi.grad.detach().float().cpu(),
+                        engine_bwd.LAST_WRITER_LAUNCHES - n0)
+            finally:
+                E.BNB_LAST_WRITER = True
+
+        ga, dxa, na = run(True)
+        gb, dxb, nb = run(False)
+        assert na == 2 and nb == 0, (na, nb)  # identity blocks 1 and 2: their outputs feed the next block's conv + residual
+        # blocks.2's second BatchNorm: everything upstream of it is identical in both runs, and (dbeta, dgamma) ARE the sums --
+        # the same bf16 gradient values added in a different order
+        for k in ("blocks.2.net.4.weight", "blocks.2.net.4.bias"):
+            assert rel_err(ga[k], gb[k]) < 2e-5, (k, rel_err(ga[k], gb[k]))
+        # downstream of it the last-place differences of the coefficients flip bf16 roundings of dy: bf16-level agreement
+        assert rel_err(dxa, dxb) < 2e-2 and _cos(dxa, dxb) > 0.9999, (rel_err(dxa, dxb), _cos(dxa, dxb))
+        for k in ga:
+            assert rel_err(ga[k], gb[k]) < 2e-2 and _cos(ga[k], gb[k]) > 0.9999, (k, rel_err(ga[k], gb[k]), _cos(ga[k], gb[k]))
+    finally:
+        L.load().rv_set_option(b"tapconv4_min_blocks", ctypes.c_int32(old))
