@@ -255,6 +255,13 @@ int32_t rv_bn_bwd_rows(int64_t pixels);
 int rv_bn_bwd_reduce(int64_t pixels, int32_t c, const void* dout, int32_t ld_dout, const void* out, int32_t ld_out,
                      const void* y, int32_t ld_y, const float* scale, const float* shift, const float* mean,
                      const float* invstd, int32_t flags, float* partial, rvStream stream);
+/* The reduce pass for the TWO BatchNorms under one block sum out = relu(bn_a(ya) + bn_b(yb)) -- a BasicBlock with a projection
+ * (nn/blocks/__init__.py:68-81: net(x) + projection_block(x)) -- in one launch: both take g = dOut * [out > 0]; partial_a /
+ * partial_b receive (sum g, sum g * xhat_a) and (sum g, sum g * xhat_b) in rv_bn_bwd_reduce's layout ([rv_bn_bwd_rows(pixels) +
+ * RV_STATS_SCRATCH_ROWS][2][c]).  Four tensor reads where two rv_bn_bwd_reduce launches take six. */
+int rv_bn_bwd_reduce_pair(int64_t pixels, int32_t c, const void* dout, int32_t ld_dout, const void* out, int32_t ld_out,
+                          const void* ya, int32_t ld_ya, const float* mean_a, const float* invstd_a, const void* yb, int32_t ld_yb,
+                          const float* mean_b, const float* invstd_b, float* partial_a, float* partial_b, rvStream stream);
 int rv_bn_bwd_finalize(const float* partial, int32_t rows, int32_t c, int64_t count, const float* gamma,
                        const float* invstd, float* dgamma, float* dbeta, int32_t accumulate, float* coef,
                        rvStream stream);

@@ -138,6 +138,90 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnbArgs a) {
     }
 }
 
+// The same reduce pass for the TWO BatchNorms under one block sum out = relu(bn_a(ya) + bn_b(yb)) (BasicBlock with a projection,
+// nn/blocks/__init__.py:68-81): both take g = dOut * [out > 0]; one pass over (dOut, out, ya, yb) forms sum g (shared) and
+// sum g * xhat for each -- four reads where two separate passes take six.
+struct Bnb2Args {
+    const bf16_t *dout, *out, *ya, *yb;
+    const float *mean_a, *invstd_a, *mean_b, *invstd_b;
+    int64_t pixels;
+    int c, c8, ld_dout, ld_out, ld_ya, ld_yb;
+    float *partial_a, *partial_b;
+};
+__global__ __launch_bounds__(256) void bn_bwd_reduce2_kernel(const Bnb2Args a) {
+    __shared__ float red[256][25];
+    const int tid = threadIdx.x;
+    const int lanes_px = 256 / a.c8;
+    const int oct = tid % a.c8, pl = tid / a.c8;
+    const bool active = pl < lanes_px;
+    const int c0 = oct * 8;
+    float mua[8], isa[8], mub[8], isb[8], s0[8], sa[8], sb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        mua[j] = a.mean_a[c0 + j];
+        isa[j] = a.invstd_a[c0 + j];
+        mub[j] = a.mean_b[c0 + j];
+        isb[j] = a.invstd_b[c0 + j];
+        s0[j] = sa[j] = sb[j] = 0.f;
+    }
+    const int64_t p0 = (int64_t)blockIdx.x * kPixPerBlock;
+    const int64_t p1 = p0 + kPixPerBlock < a.pixels ? p0 + kPixPerBlock : a.pixels;
+    if (active) {
+        auto add = [&](const u32x4 dv, const u32x4 ov, const u32x4 av, const u32x4 bv) {
+            float d[8], o[8], ya[8], yb[8];
+            unpack8(dv, d);
+            unpack8(ov, o);
+            unpack8(av, ya);
+            unpack8(bv, yb);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float g = o[j] > 0.f ? d[j] : 0.f;
+                s0[j] += g;
+                sa[j] += g * ((ya[j] - mua[j]) * isa[j]);
+                sb[j] += g * ((yb[j] - mub[j]) * isb[j]);
+            }
+        };
+        int64_t px = p0 + pl;
+        for (; px + lanes_px < p1; px += 2 * lanes_px) {  // two pixels (eight 16-byte loads) in flight per thread
+            u32x4 v[2][4];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int64_t q = px + u * lanes_px;
+                v[u][0] = *(const u32x4*)(a.dout + q * a.ld_dout + c0);
+                v[u][1] = *(const u32x4*)(a.out + q * a.ld_out + c0);
+                v[u][2] = *(const u32x4*)(a.ya + q * a.ld_ya + c0);
+                v[u][3] = *(const u32x4*)(a.yb + q * a.ld_yb + c0);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) add(v[u][0], v[u][1], v[u][2], v[u][3]);
+        }
+        for (; px < p1; px += lanes_px)
+            add(*(const u32x4*)(a.dout + px * a.ld_dout + c0), *(const u32x4*)(a.out + px * a.ld_out + c0),
+                *(const u32x4*)(a.ya + px * a.ld_ya + c0), *(const u32x4*)(a.yb + px * a.ld_yb + c0));
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        red[tid][j] = s0[j];
+        red[tid][8 + j] = sa[j];
+        red[tid][16 + j] = sb[j];
+    }
+    __syncthreads();
+    for (int i = tid; i < a.c8 * 24; i += 256) {
+        const int o = i / 24, j = i - o * 24;
+        float s = 0.f;
+        for (int l = 0; l < lanes_px; ++l) s += red[l * a.c8 + o][j];
+        const int ch = o * 8 + (j & 7);
+        if (j < 8) {
+            a.partial_a[((int64_t)blockIdx.x * 2) * a.c + ch] = s;
+            a.partial_b[((int64_t)blockIdx.x * 2) * a.c + ch] = s;
+        } else if (j < 16) {
+            a.partial_a[((int64_t)blockIdx.x * 2 + 1) * a.c + ch] = s;
+        } else {
+            a.partial_b[((int64_t)blockIdx.x * 2 + 1) * a.c + ch] = s;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* red, int groups, int c, double inv_count, const float* gamma,
                                        const float* invstd, float* dgamma, float* dbeta, int accumulate, float* coef) {
     __shared__ double part[2][4][64];
@@ -618,6 +702,23 @@ extern "C" int rv_bn_bwd_reduce(int64_t pixels, int32_t c, const void* dout, int
     a.partial = partial;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rv_bn_bwd_rows(pixels)), dim3(256), 0, (hipStream_t)stream, a);
     RV_CHECK_LAUNCH("bn_bwd_reduce_kernel");
+    return 0;
+}
+
+extern "C" int rv_bn_bwd_reduce_pair(int64_t pixels, int32_t c, const void* dout, int32_t ld_dout, const void* out, int32_t ld_out,
+                                     const void* ya, int32_t ld_ya, const float* mean_a, const float* invstd_a, const void* yb, int32_t ld_yb,
+                                     const float* mean_b, const float* invstd_b, float* partial_a, float* partial_b, rvStream stream) {
+    RV_REQUIRE(dout && out && ya && yb && mean_a && invstd_a && mean_b && invstd_b && partial_a && partial_b, "rv_bn_bwd_reduce_pair: null argument");
+    RV_REQUIRE(pixels > 0 && c > 0 && c % 8 == 0 && c <= 2048 && ld_dout % 8 == 0 && ld_out % 8 == 0 && ld_ya % 8 == 0 && ld_yb % 8 == 0 &&
+                   ld_dout >= c && ld_out >= c && ld_ya >= c && ld_yb >= c,
+               "rv_bn_bwd_reduce_pair: channels / strides must be multiples of 8 (at most 2048 channels)");
+    Bnb2Args a{};
+    a.dout = (const bf16_t*)dout, a.out = (const bf16_t*)out, a.ya = (const bf16_t*)ya, a.yb = (const bf16_t*)yb;
+    a.mean_a = mean_a, a.invstd_a = invstd_a, a.mean_b = mean_b, a.invstd_b = invstd_b;
+    a.pixels = pixels, a.c = c, a.c8 = c / 8, a.ld_dout = ld_dout, a.ld_out = ld_out, a.ld_ya = ld_ya, a.ld_yb = ld_yb;
+    a.partial_a = partial_a, a.partial_b = partial_b;
+    hipLaunchKernelGGL(bn_bwd_reduce2_kernel, dim3(rv_bn_bwd_rows(pixels)), dim3(256), 0, (hipStream_t)stream, a);
+    RV_CHECK_LAUNCH("bn_bwd_reduce2_kernel");
     return 0;
 }
 

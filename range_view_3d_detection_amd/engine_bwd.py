@@ -411,6 +411,22 @@ def combine_backward(op: "E.CombineOp", t: Tape) -> None:
     # out = relu(bn(y) + x): the residual gradient dOut*[out>0] is exactly the `g` the BatchNorm-backward apply pass
     # already forms, so that pass also writes it (rv_bn_bwd_apply's dres output) instead of a separate masking pass.
     fuse_res = len(lazies) == 1 and len(plains) == 1 and not lazies[0].relu and t.training
+    if (BNB_PAIR and len(lazies) == 2 and not plains and mask is not None and t.training and all(not x.relu and x.bn.mean is not None for x in lazies)
+            and all(id(x) not in t.lazy_in for x in lazies) and lazies[0].raw.cp == lazies[1].raw.cp == gout.cp
+            and lazies[0].raw.pixels == lazies[1].raw.pixels == gout.pixels):
+        # out = relu(bn_a(ya) + bn_b(yb)) (a block with a projection): the sums of BOTH BatchNorm backwards from one pass
+        # over (dOut, out, ya, yb); each bn_backward_begin then finds its rows and skips its own reduce pass
+        la, lb = lazies
+        rows = L.load().rv_bn_bwd_rows(L.i64(gout.pixels))
+        pa = torch.empty((rows + L.STATS_SCRATCH_ROWS, 2, gout.cp), dtype=torch.float32, device=t.device)
+        pb = torch.empty((rows + L.STATS_SCRATCH_ROWS, 2, gout.cp), dtype=torch.float32, device=t.device)
+        L.call("rv_bn_bwd_reduce_pair", L.i64(gout.pixels), L.i32(gout.cp), gout.ptr(), L.i32(gout.ld), mask.ptr(), L.i32(mask.ld),
+               la.raw.ptr(), L.i32(la.raw.ld), L.ptr(la.bn.mean), L.ptr(la.bn.invstd), lb.raw.ptr(), L.i32(lb.raw.ld), L.ptr(lb.bn.mean),
+               L.ptr(lb.bn.invstd), L.ptr(pa), L.ptr(pb), L.stream_ptr())
+        for x, part in ((la, pa), (lb, pb)):
+            t.add_lazy_grad(x, gout, mask, None)
+            t.lazy_sums[id(x)] = (part, rows, gout, True)
+        return
     for x in lazies:
         res = None
         if fuse_res:
@@ -431,6 +447,7 @@ def combine_backward(op: "E.CombineOp", t: Tape) -> None:
         t.mark_written(x)
 
 
+BNB_PAIR = os.environ.get("RV3D_NO_BNB_PAIR") is None
 META_BWD_FUSE = os.environ.get("RV3D_NO_META_FUSE") is None
 
 

@@ -600,3 +600,33 @@ def test_last_writer_forms_the_block_output_batchnorm_sums(C, W):
             assert rel_err(ga[k], gb[k]) < 2e-2 and _cos(ga[k], gb[k]) > 0.9999, (k, rel_err(ga[k], gb[k]), _cos(ga[k], gb[k]))
     finally:
         L.load().rv_set_option(b"tapconv4_min_blocks", ctypes.c_int32(old))
+
+
+@pytest.mark.parametrize("C,W", [(128, 256), (256, 128)])
+def test_projection_block_sums_from_one_pass(C, W):
+    """BasicBlock with a projection: out = relu(bn2(y2) + bn_p(yp)) puts two BatchNorms on one gradient; rv_bn_bwd_reduce_pair
+    forms both sets of backward sums in one pass over (dOut, out, y2, yp).  Against two rv_bn_bwd_reduce passes
+    (``engine_bwd.BNB_PAIR = False``): every gradient equal to 1e-6 of its max (the same values added in the same order)."""
+    from range_view_3d_detection_amd import engine_bwd
+    from range_view_3d_detection_amd.nn.blocks import BasicBlock
+
+    gen = torch.Generator().manual_seed(C + W)
+    m = BasicBlock(C // 2, C, project=True).to(DEV).train()
+    x = torch.randn(2, C // 2, 16, W, generator=gen).to(DEV)
+    probe = torch.randn(2, C, 16, W, generator=gen).to(DEV)
+
+    def run(on: bool):
+        engine_bwd.BNB_PAIR = on
+        try:
+            m.zero_grad(set_to_none=True)
+            xi = x.clone().requires_grad_(True)
+            (m(xi).float() * probe).sum().backward()
+            return {k: p.grad.detach().float().cpu() for k, p in m.named_parameters()}, xi.grad.detach().float().cpu()
+        finally:
+            engine_bwd.BNB_PAIR = True
+
+    ga, dxa = run(True)
+    gb, dxb = run(False)
+    assert rel_err(dxa, dxb) < 1e-6, rel_err(dxa, dxb)
+    for k in ga:
+        assert rel_err(ga[k], gb[k]) < 1e-6, (k, rel_err(ga[k], gb[k]))
