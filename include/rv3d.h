@@ -262,6 +262,12 @@ int rv_bn_bwd_reduce(int64_t pixels, int32_t c, const void* dout, int32_t ld_dou
 int rv_bn_bwd_reduce_pair(int64_t pixels, int32_t c, const void* dout, int32_t ld_dout, const void* out, int32_t ld_out,
                           const void* ya, int32_t ld_ya, const float* mean_a, const float* invstd_a, const void* yb, int32_t ld_yb,
                           const float* mean_b, const float* invstd_b, float* partial_a, float* partial_b, rvStream stream);
+/* ... and their apply pass: dYa = coef_a0 * (g - coef_a1 - xhat_a * coef_a2), dYb likewise, g formed once (coef_* from
+ * rv_bn_bwd_finalize over partial_a / partial_b).  Four reads and two writes where two rv_bn_bwd_apply launches take six and two. */
+int rv_bn_bwd_apply_pair(int64_t pixels, int32_t c, const void* dout, int32_t ld_dout, const void* out, int32_t ld_out,
+                         const void* ya, int32_t ld_ya, const float* mean_a, const float* invstd_a, const float* coef_a, void* dya,
+                         int32_t ld_dya, const void* yb, int32_t ld_yb, const float* mean_b, const float* invstd_b,
+                         const float* coef_b, void* dyb, int32_t ld_dyb, rvStream stream);
 int rv_bn_bwd_finalize(const float* partial, int32_t rows, int32_t c, int64_t count, const float* gamma,
                        const float* invstd, float* dgamma, float* dbeta, int32_t accumulate, float* coef,
                        rvStream stream);

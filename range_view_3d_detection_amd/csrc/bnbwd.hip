@@ -373,6 +373,50 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnbArgs a) {
     }
 }
 
+// The apply pass for the two BatchNorms under one block sum (see bn_bwd_reduce2_kernel): g = dOut * [out > 0] is formed once,
+// dYa / dYb leave together -- four reads and two writes where two apply passes take six and two.
+struct Bnb2Apply {
+    const bf16_t *dout, *out, *ya, *yb;
+    const float *mean_a, *invstd_a, *coef_a, *mean_b, *invstd_b, *coef_b;
+    bf16_t *dya, *dyb;
+    int64_t pixels;
+    int c, c8, ld_dout, ld_out, ld_ya, ld_yb, ld_dya, ld_dyb;
+};
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_bwd_apply2_kernel(const Bnb2Apply a) {
+    const int tid = threadIdx.x;
+    const int lanes_px = 256 / a.c8;
+    const int oct = tid % a.c8, pl = tid / a.c8;
+    if (pl >= lanes_px) return;
+    const int c0 = oct * 8;
+    float mua[8], isa[8], ka0[8], ka1[8], ka2[8], mub[8], isb[8], kb0[8], kb1[8], kb2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        mua[j] = a.mean_a[c0 + j], isa[j] = a.invstd_a[c0 + j];
+        ka0[j] = a.coef_a[c0 + j], ka1[j] = a.coef_a[a.c + c0 + j], ka2[j] = a.coef_a[2 * a.c + c0 + j];
+        mub[j] = a.mean_b[c0 + j], isb[j] = a.invstd_b[c0 + j];
+        kb0[j] = a.coef_b[c0 + j], kb1[j] = a.coef_b[a.c + c0 + j], kb2[j] = a.coef_b[2 * a.c + c0 + j];
+    }
+    const int64_t per = ((a.pixels + gridDim.x - 1) / gridDim.x + lanes_px - 1) / lanes_px * lanes_px;
+    const int64_t end = (int64_t)(blockIdx.x + 1) * per < a.pixels ? (int64_t)(blockIdx.x + 1) * per : a.pixels;
+    for (int64_t px = (int64_t)blockIdx.x * per + pl; px < end; px += lanes_px) {
+        float d[8], o[8], ya[8], yb[8], ra[8], rb[8];
+        unpack8(ld16<MODE>(a.dout + px * a.ld_dout + c0), d);
+        unpack8(ld16<MODE>(a.out + px * a.ld_out + c0), o);
+        unpack8(ld16<MODE>(a.ya + px * a.ld_ya + c0), ya);
+        unpack8(ld16<MODE>(a.yb + px * a.ld_yb + c0), yb);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float g = o[j] > 0.f ? d[j] : 0.f;
+            const float xa = (ya[j] - mua[j]) * isa[j], xb = (yb[j] - mub[j]) * isb[j];
+            ra[j] = ka0[j] * (g - ka1[j] - xa * ka2[j]);
+            rb[j] = kb0[j] * (g - kb1[j] - xb * kb2[j]);
+        }
+        st16<MODE>(a.dya + px * a.ld_dya + c0, pack8(ra));
+        st16<MODE>(a.dyb + px * a.ld_dyb + c0, pack8(rb));
+    }
+}
+
 __global__ __launch_bounds__(256) void ew_mask_grad_kernel(int64_t pixels, int c8, const bf16_t* dout, int ld_dout,
                                                            const bf16_t* out, int ld_out, bf16_t* d, int ld_d,
                                                            int accumulate) {
@@ -764,6 +808,31 @@ extern "C" int rv_bn_bwd_apply(int64_t pixels, int32_t c, const void* dout, int3
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel<0>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, a);
     RV_CHECK_LAUNCH("bn_bwd_apply_kernel");
+    return 0;
+}
+
+extern "C" int rv_bn_bwd_apply_pair(int64_t pixels, int32_t c, const void* dout, int32_t ld_dout, const void* out, int32_t ld_out,
+                                    const void* ya, int32_t ld_ya, const float* mean_a, const float* invstd_a, const float* coef_a, void* dya,
+                                    int32_t ld_dya, const void* yb, int32_t ld_yb, const float* mean_b, const float* invstd_b,
+                                    const float* coef_b, void* dyb, int32_t ld_dyb, rvStream stream) {
+    RV_REQUIRE(dout && out && ya && yb && mean_a && invstd_a && coef_a && dya && mean_b && invstd_b && coef_b && dyb, "rv_bn_bwd_apply_pair: null argument");
+    RV_REQUIRE(pixels > 0 && c > 0 && c % 8 == 0 && c <= 2048 && ld_dout % 8 == 0 && ld_out % 8 == 0 && ld_ya % 8 == 0 && ld_yb % 8 == 0 &&
+                   ld_dya % 8 == 0 && ld_dyb % 8 == 0 && ld_dout >= c && ld_out >= c && ld_ya >= c && ld_yb >= c && ld_dya >= c && ld_dyb >= c,
+               "rv_bn_bwd_apply_pair: channels / strides must be multiples of 8 (at most 2048 channels)");
+    Bnb2Apply a{};
+    a.dout = (const bf16_t*)dout, a.out = (const bf16_t*)out, a.ya = (const bf16_t*)ya, a.yb = (const bf16_t*)yb;
+    a.mean_a = mean_a, a.invstd_a = invstd_a, a.coef_a = coef_a, a.mean_b = mean_b, a.invstd_b = invstd_b, a.coef_b = coef_b;
+    a.dya = (bf16_t*)dya, a.dyb = (bf16_t*)dyb;
+    a.pixels = pixels, a.c = c, a.c8 = c / 8;
+    a.ld_dout = ld_dout, a.ld_out = ld_out, a.ld_ya = ld_ya, a.ld_yb = ld_yb, a.ld_dya = ld_dya, a.ld_dyb = ld_dyb;
+    const int lanes_px = 256 / a.c8;
+    int64_t blocks = (pixels + lanes_px - 1) / lanes_px;
+    if (blocks > 4096) blocks = 4096;
+    if ((int64_t)pixels * c * 2 >= ((int64_t)256 << 20))
+        hipLaunchKernelGGL(bn_bwd_apply2_kernel<1>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply2_kernel<0>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    RV_CHECK_LAUNCH("bn_bwd_apply2_kernel");
     return 0;
 }
 

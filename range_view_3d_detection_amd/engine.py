@@ -661,6 +661,7 @@ class Tape:
         self.lazy_sums: Dict[int, Tuple[Tensor, int]] = {}  # id(Lazy) -> BatchNorm-backward partial sums its ONE writer formed, rows
         self.meta_in: Dict[int, tuple] = {}      # id(Lazy) -> (dgeo, feat, partial sums, rows): MetaKernel modulation fused into the BatchNorm backward
         self.producers: Dict[int, "Op"] = {}     # id(block-output Act) -> the CombineOp that made it
+        self.bn_of: Dict[int, "Op"] = {}         # id(Lazy) -> its BnOp
         self.grad_version: Dict[int, int] = {}   # id(root Act) -> bumped whenever somebody asks for / writes its gradient buffer
         self.acc_sums: Dict[int, tuple] = {}     # id(root Act) -> (partial, rows, gradient Act, version): BatchNorm-backward sums the last writer formed
         self.raw_grad: Dict[int, Act] = {}       # id(raw Act) -> gradient w.r.t. the raw conv output
@@ -950,6 +951,7 @@ class BnOp(Op):
                    L.ptr(scale), L.ptr(shift), L.stream_ptr())
             self.state = BnState(bn, scale, shift)
         self.lazy = Lazy(conv.out, self.state, relu)
+        t.bn_of[id(self.lazy)] = self  # (backward: the BatchNorm op behind a Lazy operand -- on the tape, not on the Lazy: no reference cycle)
         t.ops.append(self)
 
     def backward(self, t: Tape) -> None:

@@ -423,6 +423,24 @@ def combine_backward(op: "E.CombineOp", t: Tape) -> None:
         L.call("rv_bn_bwd_reduce_pair", L.i64(gout.pixels), L.i32(gout.cp), gout.ptr(), L.i32(gout.ld), mask.ptr(), L.i32(mask.ld),
                la.raw.ptr(), L.i32(la.raw.ld), L.ptr(la.bn.mean), L.ptr(la.bn.invstd), lb.raw.ptr(), L.i32(lb.raw.ld), L.ptr(lb.bn.mean),
                L.ptr(lb.bn.invstd), L.ptr(pa), L.ptr(pb), L.stream_ptr())
+        ops = [t.bn_of.get(id(x)) for x in lazies]
+        if all(o is not None and o.sync_world == 1 for o in ops):
+            # ... and both apply passes as one (no collective between the sums and the coefficients): the gradients w.r.t. both raw
+            # conv outputs leave now; the two BatchNorm ops find nothing pending when the tape reaches them
+            coefs = []
+            for o, part in zip(ops, (pa, pb)):
+                dgamma, dbeta, coef = _bn_finalize(o, t, part, rows, gout.pixels)
+                c = o.lazy.bn.module.num_features
+                t.add_param_grad(o.lazy.bn.module.weight, dgamma[:c])
+                t.add_param_grad(o.lazy.bn.module.bias, dbeta[:c])
+                coefs.append(coef)
+            dya, dyb = la.raw.like(), lb.raw.like()
+            L.call("rv_bn_bwd_apply_pair", L.i64(gout.pixels), L.i32(gout.cp), gout.ptr(), L.i32(gout.ld), mask.ptr(), L.i32(mask.ld),
+                   la.raw.ptr(), L.i32(la.raw.ld), L.ptr(la.bn.mean), L.ptr(la.bn.invstd), L.ptr(coefs[0]), dya.ptr(), L.i32(dya.ld),
+                   lb.raw.ptr(), L.i32(lb.raw.ld), L.ptr(lb.bn.mean), L.ptr(lb.bn.invstd), L.ptr(coefs[1]), dyb.ptr(), L.i32(dyb.ld), L.stream_ptr())
+            t.raw_grad[id(la.raw)] = dya
+            t.raw_grad[id(lb.raw)] = dyb
+            return
         for x, part in ((la, pa), (lb, pb)):
             t.add_lazy_grad(x, gout, mask, None)
             t.lazy_sums[id(x)] = (part, rows, gout, True)
