@@ -557,3 +557,33 @@ def test_fused_adamw_matches_torch_adamw_with_clipping():
         assert float(oa.state[p]["step"]) == float(ob.state[q]["step"]) == 5.0
     sd = oa.state_dict()  # the state keys / layout torch.optim.AdamW checkpoints carry
     assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and sd["param_groups"][0]["weight_decay"] == 1e-2
+
+
+def test_training_step_on_sweeps_without_annotations(golden):
+    """Edge case of real data: no cuboid in any sweep of the batch (or in one of them).  The reference normalises by
+    ``total_objects.clamp(1.0)`` and ``total_fg + additive_smoothing`` (nn/heads/detection_head.py:391-400), so the step is
+    well defined: every target is background, the loss finite.  Asserted: what a training loop needs -- finite loss, finite
+    gradients, all-background labels / no instance ids where no cuboid exists."""
+    g = golden("tiny_model")
+    backbone, head = load_tiny(g)
+    backbone.train()
+    head.train()
+    ann = g["annotations"]
+    for keep in (ann[:0], ann[ann[:, -1] == 0]):  # nothing at all; only the first sweep's cuboids
+        backbone.zero_grad(set_to_none=True)
+        head.zero_grad(set_to_none=True)
+        data = {"features": g["features"].to(DEV), "cart": g["cart"].to(DEV), "mask": g["mask"].to(DEV), "annotations": keep}
+        outputs, losses = head(backbone(data), data, return_loss=True)
+        loss = losses["loss"]
+        assert torch.isfinite(loss).all(), loss
+        loss.backward()
+        for mod in (backbone, head):
+            for k, p in mod.named_parameters():
+                assert p.grad is None or torch.isfinite(p.grad).all(), k
+        labels = data[1][0]["classification_labels"]
+        n_cls = outputs[1][0]["logits"].shape[1]  # (the background label is the class count)
+        if keep.shape[0] == 0:
+            assert int((labels != n_cls).sum()) == 0 and int((data[1][0]["panoptics"] != 0).sum()) == 0
+        else:
+            pan = data[1][0]["panoptics"]
+            assert int((pan[1:] != 0).sum()) == 0 and int((pan[0] != 0).sum()) > 0  # sweep 1 has no cuboid, sweep 0 kept its own
