@@ -392,6 +392,8 @@ int rv_build_tap_table(const rvTapGeom* g, bool scatter, TapTable* tt, int* phas
 }
 
 extern int g_tapconv5_persist;
+static int g_tapconv6_enable = 1;  // rv_set_option("tapconv6_enable", 0): tests of the fifth generation
+extern int g_tapconv6_min_blocks;
 static int g_tapconv5_enable = 1;  // rv_set_option("tapconv5_enable", 0): multi-tap layers stay on tapconv4 (tests of that kernel)
 
 static int tap_launch(const rvTapGeom* g, const rvTapShape* s, bool scatter, const void* src, const float* in_scale,
@@ -437,6 +439,7 @@ static int tap_launch(const rvTapGeom* g, const rvTapShape* s, bool scatter, con
     a.src = (const bf16_t*)src;
     a.dst = dst;
     a.w = (const bf16_t*)w;
+    a.w_tile6 = rv_weight_has_tile6(g, a.C_dst) ? (int64_t)g->kh * g->kw * a.C_dst * a.C_src : 0;
     a.in_scale = in_scale;
     a.in_shift = in_shift;
     a.bias = bias;
@@ -466,6 +469,24 @@ static int tap_launch(const rvTapGeom* g, const rvTapShape* s, bool scatter, con
         }
     }
 
+    // multi-tap layers with at least one round of 512-pixel x 128-channel tiles (tapconv6.hip)
+    if (g_tapconv6_enable && g_tapconv5_enable && getenv("RV3D_NO_TAPCONV6") == nullptr) {
+        int tiles;
+        size_t lds6;
+        TapConvArgs a6 = a;
+        if (rv_tapconv6_plan(&a6, &tiles, &lds6)) {
+            if (stats_rows) *stats_rows = tiles * 4;
+            if (bnb_rows) *bnb_rows = tiles;
+            if (info) {
+                info[0] = 6;
+                info[1] = 128;
+                info[2] = tiles;
+                info[3] = a6.n_tiles;
+            }
+            if (dry_run) return 0;
+            return rv_tapconv6_launch(a6, lds6, (hipStream_t)stream);
+        }
+    }
     // multi-tap layers with 256-channel output tiles: input halo resident in LDS across the taps (tapconv5.hip)
     if (g_tapconv5_enable && getenv("RV3D_NO_TAPCONV5") == nullptr) {
         int tiles, bn5;
@@ -590,6 +611,16 @@ int32_t rv_set_option(const char* key, int32_t value) {
     if (key && strcmp(key, "tapconv5_enable") == 0) {
         const int32_t old = g_tapconv5_enable;
         if (value >= 0) g_tapconv5_enable = value ? 1 : 0;
+        return old;
+    }
+    if (key && strcmp(key, "tapconv6_enable") == 0) {
+        const int32_t old = g_tapconv6_enable;
+        if (value >= 0) g_tapconv6_enable = value ? 1 : 0;
+        return old;
+    }
+    if (key && strcmp(key, "tapconv6_min_blocks") == 0) {
+        const int32_t old = g_tapconv6_min_blocks;
+        if (value >= 0) g_tapconv6_min_blocks = value;
         return old;
     }
     if (key && strcmp(key, "tapconv5_persist_blocks") == 0) {

@@ -137,7 +137,7 @@ def _launch(name: str, flops: float, fn) -> None:
 def tap_kernel_name(geom, shape, scatter: bool) -> str:
     info = (ctypes.c_int32 * 4)()
     L.call("rv_tap_launch_info", ctypes.byref(geom), ctypes.byref(shape), L.i32(1 if scatter else 0), info)
-    if info[0] in (4, 5):
+    if info[0] in (4, 5, 6):
         name = f"tapconv{info[0]}_kernel<{info[1]}>"
     elif info[0] in (2, 3):
         name = f"tapconv{info[0]}_kernel<{info[1]}>"
@@ -432,7 +432,7 @@ BNB_LAST_WRITER = os.environ.get("RV3D_NO_BNB_LAST_WRITER") is None
 def _dma_eligible(geom, n: int, h: int, wu: int, wv: int, ld_src: int, ld_dst: int, scatter: bool) -> bool:
     info = (ctypes.c_int32 * 4)()
     shape = L.TapShape(n, h, wu, wv, ld_src, ld_dst, 0)
-    return L.load().rv_tap_launch_info(ctypes.byref(geom), ctypes.byref(shape), 1 if scatter else 0, info) == 0 and info[0] in (4, 5)
+    return L.load().rv_tap_launch_info(ctypes.byref(geom), ctypes.byref(shape), 1 if scatter else 0, info) == 0 and info[0] in (4, 5, 6)
 
 
 # ---------------------------------------------------------------------------------------------

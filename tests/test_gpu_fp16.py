@@ -60,7 +60,7 @@ def _run_f16(module, x, expect_kernel, stats=False, out_f32=False):
     return op.out.data[..., : layer.c_out].permute(0, 3, 1, 2).float()
 
 
-@pytest.mark.parametrize("cin,cout,N,H,W,k,kernel", [(128, 512, 2, 64, 256, 3, 5), (320, 128, 3, 17, 1030, 3, 5), (64, 256, 4, 30, 520, 3, 5),
+@pytest.mark.parametrize("cin,cout,N,H,W,k,kernel", [(128, 512, 2, 64, 256, 3, 6), (320, 128, 3, 17, 1030, 3, 5), (64, 256, 4, 30, 520, 3, 6),
                                                      (256, 256, 2, 32, 512, 1, 4), (128, 128, 2, 16, 1024, 1, 4)])
 def test_fp16_tap_conv_exact_on_integers(cin, cout, N, H, W, k, kernel):
     g = torch.Generator().manual_seed(cin + W + k)
@@ -79,7 +79,7 @@ def test_fp16_conv_transpose_phases_exact():
     m.weight.data = _ints(m.weight.shape, g, -1, 2)
     x = _ints((4, 128, 16, 256), g, -1, 2)
     ref = F.conv_transpose2d(x, m.weight.data, stride=(1, 4), padding=(1, 2))
-    out = _run_f16(m.to(DEV), x.to(DEV), 5)
+    out = _run_f16(m.to(DEV), x.to(DEV), 6)
     assert torch.equal(out.cpu(), ref)
 
 
@@ -141,7 +141,7 @@ def test_full_size_eval_forward_fp16_vs_oracle_and_decode():
     finally:
         E.PROFILE = None
     assert feats[1].dtype == torch.float16  # the activations really are fp16
-    assert {"tapconv5_kernel<256>", "tapconv4_kernel<256>", "tapconv4_kernel<128>"} <= ran, sorted(ran)
+    assert {"tapconv4_kernel<256>", "tapconv4_kernel<128>"} <= ran and any(n.startswith(("tapconv5_kernel<", "tapconv6_kernel<")) for n in ran), sorted(ran)
     logits, reg = outputs[1][0]["logits"].float().cpu(), outputs[1][0]["regressands"].float().cpu()
     m = {"logits~fp16": rel_err(logits, lg16), "logits~fp32": rel_err(logits, lg32), "emu~fp32": rel_err(lg16, lg32),
          "reg~fp16": rel_err(reg, rg16), "reg~fp32": rel_err(reg, rg32), "reg emu~fp32": rel_err(rg16, rg32)}

@@ -203,4 +203,4 @@ def test_rv_waymo_training_step_at_its_stated_size():
     assert out.returncode == 0, out.stderr[-3000:]
     j = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
     assert j["config"]["sweep"] == [64, 2656, 6] and 0.0 < j["config"]["loss"] < 100.0 and j["value"] > 0
-    assert any(k.startswith("tapconv5_kernel") for k in j["kernels"]) and any(k.startswith("wgrad3_kernel") for k in j["kernels"]), list(j["kernels"])
+    assert any(k.startswith("tapconv6_kernel") for k in j["kernels"]) and any(k.startswith("wgrad3_kernel") for k in j["kernels"]), list(j["kernels"])

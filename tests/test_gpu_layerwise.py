@@ -141,8 +141,8 @@ def test_every_layer_teacher_forced(widths, n_feat, n_cls, W):
         finally:
             E.PROFILE = None
     print(f"[{widths}] {len(trace)} units; worst " + "  ".join(f"{k} {v[0]:.2e} ({v[1].split('.weight')[0][-40:]})" for k, v in worst.items()))
-    need = {"tapconv5_kernel<256>", "tapconv4_kernel<128>", "wgrad3_kernel(+reduce)"}
-    assert need <= ran, (need - ran, sorted(ran))
+    need = {"tapconv4_kernel<128>", "wgrad3_kernel(+reduce)"}
+    assert need <= ran and any(n.startswith(("tapconv5_kernel<", "tapconv6_kernel<")) for n in ran), (need - ran, sorted(ran))
 
 
 def test_rv_waymo_full_size_eval_forward_vs_oracle():
@@ -167,7 +167,7 @@ def test_rv_waymo_full_size_eval_forward_vs_oracle():
         ran = set(name for name, *_ in E.PROFILE.records)
     finally:
         E.PROFILE = None
-    assert {"tapconv5_kernel<256>", "tapconv5_kernel<128>"} <= ran, sorted(ran)
+    assert "tapconv6_kernel<128>" in ran, sorted(ran)  # (full size: every 3x3 layer has at least one round of 512 x 128 tiles)
     logits, reg = outputs[1][0]["logits"].float().cpu(), outputs[1][0]["regressands"].float().cpu()
     m = {"logits~bf16": rel_err(logits, lg16), "logits~fp32": rel_err(logits, lg32), "emu~fp32": rel_err(lg16, lg32),
          "reg~bf16": rel_err(reg, rg16), "reg~fp32": rel_err(reg, rg32), "reg emu~fp32": rel_err(rg16, rg32)}

@@ -1,10 +1,11 @@
-"""tapconv5 (256 x 256 tiles, input halo of a channel chunk resident in LDS across the taps): exact checks with integer data.
+"""tapconv6 (512-pixel x 128-channel tiles, 32-channel chunks, input halo resident in LDS across the taps): exact checks.
 
-Same method as test_gpu_tapconv4.py: small-integer activations and weights make every partial sum an integer below 2^24, so
+Same method as test_gpu_tapconv4/5.py: small-integer activations and weights make every partial sum an integer below 2^24, so
 the bf16 output must equal the CPU convolution rounded once to bf16, bit for bit, whatever the summation order.  Every case
-asserts (``rv_tap_launch_info``) that generation 5 runs.  Shapes cover ragged tile rows (H % 8 != 0) and columns
-(W % 32 != 0), one and several channel chunks (halo double-buffering), two channel tiles, bias, batch statistics, the
-conv-transpose phases (2 x 3 taps per phase, short chunks) and the accumulate epilogue.
+asserts (``rv_tap_launch_info``) that generation 6 runs.  Shapes cover ragged tile rows (H % 16 != 0) and columns
+(W % 32 != 0), one / two / many 32-channel chunks (halo double-buffering, every position of the counted waits), one to four
+channel tiles, bias, batch statistics (four partial rows per tile), the conv-transpose phases (2 x 3 taps), 3 x 2 kernels,
+the accumulate epilogue, the BatchNorm-backward-sum epilogue and a race screen on random data.
 """
 
 from __future__ import annotations
@@ -23,14 +24,14 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True)
 def _small_grids_allowed():
-    """The library keeps grids below one round of CUs on the register-staged kernels (speed heuristic); lift that here."""
+    """The library keeps grids below one round of CUs on the smaller tiles (speed heuristic); lift that here."""
     from range_view_3d_detection_amd import _lib as L
 
-    old = L.load().rv_set_option(b"tapconv4_min_blocks", ctypes.c_int32(1))
-    old6 = L.load().rv_set_option(b"tapconv6_enable", ctypes.c_int32(0))  # (these tests pin generation 5)
+    old4 = L.load().rv_set_option(b"tapconv4_min_blocks", ctypes.c_int32(1))
+    old6 = L.load().rv_set_option(b"tapconv6_min_blocks", ctypes.c_int32(1))
     yield
-    L.load().rv_set_option(b"tapconv4_min_blocks", ctypes.c_int32(old))
-    L.load().rv_set_option(b"tapconv6_enable", ctypes.c_int32(old6))
+    L.load().rv_set_option(b"tapconv4_min_blocks", ctypes.c_int32(old4))
+    L.load().rv_set_option(b"tapconv6_min_blocks", ctypes.c_int32(old6))
 
 
 def _run(module, x, stats=False):
@@ -42,20 +43,17 @@ def _run(module, x, stats=False):
     op = E.ConvOp(t, layer, E.Act.from_nchw(x), stats=stats)
     info = (ctypes.c_int32 * 4)()
     assert L.load().rv_tap_launch_info(ctypes.byref(layer.geom), ctypes.byref(op.shape), 1 if layer.fwd_form == "scatter" else 0, info) == 0
-    assert info[0] == 5, list(info)
+    assert info[0] == 6, list(info)
     return op.out.data[..., : layer.c_out].permute(0, 3, 1, 2).float(), op
 
 
-@pytest.mark.parametrize("cin,cout,N,H,W,bias", [(64, 256, 4, 30, 520, False),    # ragged rows / columns, ONE chunk (no halo refill)
-                                                 (128, 512, 2, 64, 256, True),    # two channel tiles, two chunks, bias
-                                                 (192, 256, 4, 17, 1030, False),  # three chunks, one-row last tile row
-                                                 (512, 256, 1, 64, 288, False),   # eight chunks
-                                                 (64, 256, 8, 8, 32, False),      # a single tile per image
-                                                 # 128-channel tiles (one weight piece per K tile, two phases, its own wait counts)
-                                                 (64, 128, 4, 30, 520, False),    # one chunk
-                                                 (128, 128, 2, 64, 256, True),    # two chunks, bias
-                                                 (320, 128, 3, 17, 1030, False),  # five chunks, ragged
-                                                 (128, 384, 1, 16, 96, False)])   # three channel tiles of 128
+@pytest.mark.parametrize("cin,cout,N,H,W,bias", [(32, 128, 4, 30, 520, False),    # ONE chunk (no halo refill), ragged rows / columns
+                                                 (64, 256, 2, 64, 256, True),     # two chunks, two channel tiles, bias
+                                                 (96, 128, 4, 17, 1030, False),   # three chunks, one-row last tile row
+                                                 (512, 512, 1, 64, 288, False),   # sixteen chunks, four channel tiles
+                                                 (64, 128, 8, 16, 32, False),     # a single tile per image
+                                                 (320, 128, 3, 33, 1030, False),  # ten chunks, ragged
+                                                 (128, 384, 1, 16, 96, True)])    # three channel tiles
 def test_gather_3x3_exact(cin, cout, N, H, W, bias):
     g = torch.Generator().manual_seed(cin + W)
     m = torch.nn.Conv2d(cin, cout, 3, padding=1, bias=bias)
@@ -72,17 +70,15 @@ def test_gather_3x3_exact(cin, cout, N, H, W, bias):
         assert torch.allclose(rows[1, :cout], (ref.double() ** 2).sum(dim=(0, 2, 3)), rtol=1e-5)
 
 
-@pytest.mark.parametrize("kh,kw", [(3, 1), (1, 3), (3, 2)])
-def test_gather_other_kernels_exact(kh, kw):
-    """Column-only / row-only / even-width kernels through Conv2dSame's asymmetric padding rule."""
+def test_gather_3x2_exact():
+    """Even-width kernel through Conv2dSame's asymmetric padding rule (six taps: the shortest chunk the kernel takes)."""
     from range_view_3d_detection_amd.nn.modules.conv import Conv2dSame
 
-    g = torch.Generator().manual_seed(kh * 10 + kw)
-    m = Conv2dSame(128, 256, (kh, kw), bias=False)
+    g = torch.Generator().manual_seed(32)
+    m = Conv2dSame(128, 256, (3, 2), bias=False)
     m.conv.weight.data = _ints(m.conv.weight.shape, g, -2, 3)
     x = _ints((2, 128, 24, 200), g)
-    th, tw = kh - 1, kw - 1
-    ref = F.conv2d(F.pad(x, [tw // 2, tw - tw // 2, th // 2, th - th // 2]), m.conv.weight.data)
+    ref = F.conv2d(F.pad(x, [0, 1, 1, 1]), m.conv.weight.data)
     out, _ = _run(m.conv.to(DEV), x.to(DEV))
     assert torch.equal(out.cpu(), ref.bfloat16().float())
 
@@ -117,7 +113,7 @@ def test_input_gradient_and_accumulate_exact():
         dst = E.Act.from_nchw(old.to(DEV)) if accumulate else E.Act.empty(N, H, W, cin, DEV)
         shape = L.TapShape(N, H, W, W, gact.ld, dst.ld, L.OUT_ACCUM if accumulate else 0)
         info = (ctypes.c_int32 * 4)()
-        assert L.load().rv_tap_launch_info(ctypes.byref(layer.geom), ctypes.byref(shape), 1, info) == 0 and info[0] == 5, list(info)
+        assert L.load().rv_tap_launch_info(ctypes.byref(layer.geom), ctypes.byref(shape), 1, info) == 0 and info[0] == 6, list(info)
         L.call("rv_tap_scatter", ctypes.byref(layer.geom), ctypes.byref(shape), gact.ptr(), None, None, L.ptr(layer.packed("scatter")), None,
                dst.ptr(), None, L.stream_ptr())
         got = dst.data[..., :cin].permute(0, 3, 1, 2).float().cpu()
@@ -127,15 +123,15 @@ def test_input_gradient_and_accumulate_exact():
         assert torch.equal(got, want)
 
 
-@pytest.mark.parametrize("cout", [512, 128])
-def test_repeatable_on_random_data(cout):
+@pytest.mark.parametrize("cin,cout", [(512, 512), (128, 128)])
+def test_repeatable_on_random_data(cin, cout):
     """Race screen (see test_gpu_tapconv4.py): fixed summation order => repeated launches on random data agree bit for bit;
     a halo or weight piece read before its DMA landed, or overwritten while still being read, shows up as a difference."""
     g = torch.Generator().manual_seed(9)
-    m = torch.nn.Conv2d(512, cout, 3, padding=1, bias=False)
+    m = torch.nn.Conv2d(cin, cout, 3, padding=1, bias=False)
     m.weight.data = torch.randn(m.weight.shape, generator=g) * 0.05
     m = m.to(DEV)
-    x = torch.randn(4, 512, 64, 1024, generator=g).bfloat16().float().to(DEV)
+    x = torch.randn(4, cin, 64, 1024, generator=g).bfloat16().float().to(DEV)
     first, _ = _run(m, x)
     ref = F.conv2d(x[:1, :, :6, :96], m.weight.data.bfloat16().float(), padding=1)[:, :, 1:5, 1:95]
     assert float((first[:1, :, 1:5, 1:95] - ref).abs().max()) / float(ref.abs().max()) < 1e-2  # bf16 output rounding
@@ -144,13 +140,35 @@ def test_repeatable_on_random_data(cout):
         assert torch.equal(first, again)
 
 
-@pytest.mark.parametrize("cin,c,N,H,W,relu", [(64, 256, 2, 24, 200, True), (64, 512, 1, 17, 96, True), (128, 256, 2, 16, 64, False),
-                                              (64, 128, 2, 24, 200, True)])
+def test_matches_generation_5_on_random_data():
+    """Both generations accumulate in fp32 (in different orders): outputs equal to one bf16 ulp, statistics to 1e-5."""
+    from range_view_3d_detection_amd import _lib as L
+
+    g = torch.Generator().manual_seed(11)
+    m = torch.nn.Conv2d(256, 256, 3, padding=1, bias=False)
+    m.weight.data = torch.randn(m.weight.shape, generator=g) * 0.03
+    m = m.to(DEV)
+    x = torch.randn(2, 256, 64, 512, generator=g).bfloat16().float().to(DEV)
+    out6, op6 = _run(m, x, stats=True)
+    L.load().rv_set_option(b"tapconv6_enable", ctypes.c_int32(0))
+    try:
+        from range_view_3d_detection_amd import engine as E
+
+        t = E.Tape(True, x.device)
+        op5 = E.ConvOp(t, E.tap_layer(m), E.Act.from_nchw(x), stats=True)
+        out5 = op5.out.data[..., :256].permute(0, 3, 1, 2).float()
+    finally:
+        L.load().rv_set_option(b"tapconv6_enable", ctypes.c_int32(1))
+    assert float((out6 - out5).abs().max()) <= 2 ** -7 * float(out5.abs().max())
+    s6 = op6.partial[: op6.rows].double().sum(dim=0)
+    s5 = op5.partial[: op5.rows].double().sum(dim=0)
+    assert torch.allclose(s6, s5, rtol=1e-5, atol=1e-3 * float(s5.abs().max()))
+
+
+@pytest.mark.parametrize("cin,c,N,H,W,relu", [(64, 256, 2, 24, 200, True), (64, 512, 1, 17, 96, True), (128, 128, 2, 16, 64, False)])
 def test_data_grad_launch_forms_the_batchnorm_backward_sums(cin, c, N, H, W, relu, monkeypatch):
-    """conv -> BatchNorm(+ReLU) -> conv: the second conv's backward-data launch (``rv_tap_data_grad_bnb``) also emits
-    sum(g), sum(g*xhat) of the BatchNorm between them, so ``rv_bn_bwd_reduce`` is not launched.  Same tape run both ways:
-    the input gradient of the second conv is bit-identical (same kernel, same values), dgamma / dbeta agree to 1e-5
-    relative (fp32 sums in another order), the first conv's output gradient to bf16 rounding of those coefficients."""
+    """conv -> BatchNorm(+ReLU) -> conv: the second conv's backward-data launch (``rv_tap_data_grad_bnb``, now generation 6)
+    also emits sum(g), sum(g*xhat) of the BatchNorm between them -- same checks as the generation-5 test."""
     from range_view_3d_detection_amd import _lib as L
     from range_view_3d_detection_amd import engine as E
     from range_view_3d_detection_amd import engine_bwd
@@ -176,7 +194,6 @@ def test_data_grad_launch_forms_the_batchnorm_backward_sums(cin, c, N, H, W, rel
         t.backward()
         torch.cuda.synchronize()
         monkeypatch.setattr(L, "call", real)
-        raw = h.raw if isinstance(h, E.Lazy) else None
         return calls, t.param_grads[id(bn.weight)].float().cpu(), t.param_grads[id(bn.bias)].float().cpu(), t.param_grads[id(c1.weight)].float().cpu()
 
     calls_f, dg_f, db_f, dw_f = run(True)
@@ -185,7 +202,6 @@ def test_data_grad_launch_forms_the_batchnorm_backward_sums(cin, c, N, H, W, rel
     assert "rv_bn_bwd_reduce" in calls_s and "rv_tap_data_grad_bnb" not in calls_s
     assert torch.allclose(dg_f, dg_s, rtol=1e-4, atol=1e-3 * float(dg_s.abs().max()))
     assert torch.allclose(db_f, db_s, rtol=1e-4, atol=1e-3 * float(db_s.abs().max()))
-    # the first conv's weight gradient sees the BatchNorm-backward output: equal up to bf16 roundings that the coefficients' last bits flip
     assert float((dw_f - dw_s).abs().max()) <= 2e-2 * float(dw_s.abs().max())
     cos = float((dw_f * dw_s).sum() / (dw_f.norm() * dw_s.norm()))
     assert cos > 0.99999, cos

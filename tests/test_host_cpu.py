@@ -45,12 +45,20 @@ def test_library_exports_every_declared_symbol(lib, tag):
 def test_host_side_geometry(lib):
     h = lib.load()
     g = lib.TapGeom(3, 3, 1, 1, 1, 256, 256)
-    assert h.rv_packed_weight_bytes(ctypes.byref(g)) == 9 * 256 * 256 * 2
+    # (a geometry with >= 6 taps and 128-aligned output channels carries the tiled copy for tapconv6 behind the row-major image)
+    assert h.rv_packed_weight_bytes(ctypes.byref(g)) == 2 * 9 * 256 * 256 * 2
+    assert h.rv_packed_weight_bytes(ctypes.byref(lib.TapGeom(1, 1, 1, 0, 0, 256, 256))) == 256 * 256 * 2
+    assert h.rv_packed_weight_bytes(ctypes.byref(lib.TapGeom(3, 3, 1, 1, 1, 64, 5))) == 9 * 64 * 32 * 2
     s = lib.TapShape(4, 64, 2048, 2048, 256, 256, lib.OUT_STATS)
     info = (ctypes.c_int32 * 4)()
     assert h.rv_tap_launch_info(ctypes.byref(g), ctypes.byref(s), 0, info) == 0
+    assert list(info) == [6, 128, 64 * 4 * 4, 2]  # tapconv6: (16 rows x 32 cols) pixel tiles x two 128-channel tiles
+    assert h.rv_tap_stats_rows(ctypes.byref(g), ctypes.byref(s), 0) == 4 * 64 * 4 * 4
+    assert h.rv_set_option(b"tapconv6_enable", 0) == 1
+    assert h.rv_tap_launch_info(ctypes.byref(g), ctypes.byref(s), 0, info) == 0
     assert list(info) == [5, 256, 64 * 8 * 4, 1]  # tapconv5<256>: (8 rows x 32 cols) pixel tiles x one 256-channel tile
     assert h.rv_tap_stats_rows(ctypes.byref(g), ctypes.byref(s), 0) == 2 * 64 * 8 * 4
+    assert h.rv_set_option(b"tapconv6_enable", 1) == 0
     # the same layer with generation 5 switched off, and a pointwise layer: tapconv4<256>, (4 rows x 64 cols) pixel tiles
     assert h.rv_set_option(b"tapconv5_enable", 0) == 1
     assert h.rv_tap_launch_info(ctypes.byref(g), ctypes.byref(s), 0, info) == 0 and list(info) == [4, 256, 32 * 16 * 4, 1]
@@ -70,7 +78,7 @@ def test_host_side_geometry(lib):
     # transposed conv (3,8)/s4: four phases
     g3 = lib.TapGeom(3, 8, 4, 1, 2, 128, 256)
     s3 = lib.TapShape(4, 64, 512, 2048, 128, 256, 0)
-    assert h.rv_tap_launch_info(ctypes.byref(g3), ctypes.byref(s3), 1, info) == 0 and list(info)[:3] == [5, 256, 4 * 16 * 8 * 4]
+    assert h.rv_tap_launch_info(ctypes.byref(g3), ctypes.byref(s3), 1, info) == 0 and list(info) == [6, 128, 4 * 16 * 4 * 4, 2]
     rates = (ctypes.c_int32 * 3)(8, 2, 1)
     assert h.rv_decode_num_candidates(64, 2048, 3, rates) == 64 * (256 + 1024 + 2048)  # 212 992
     assert h.rv_decode_num_candidates(64, 2048, 0, rates) == 64 * 2048
