@@ -42,6 +42,8 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 (MI355X_MICROARCH.md: ~2.5 PF dense
 HBM_PEAK_GBS = 8000.0
 
 AV2_CLASSES = 26
+# forward FLOPs per sweep (forward hooks on the reference's own modules); fwd + bwd = 3x
+FWD_TFLOP_PER_SWEEP = {("rv-av2", 2048): 7.736, ("rv-waymo", 2656): 2.905}
 
 
 def synthetic_batch(B: int, H: int, W: int, seed: int, device, n_feat: int = 5, boxes_per_sweep: int = 16, n_cls: int = AV2_CLASSES):
@@ -305,17 +307,45 @@ def rv_waymo_leg(dev, batch_size: int = 4, warmup: int = 3, steps: int = 10) -> 
         sched.step()
         return loss
 
+    from range_view_3d_detection_amd import engine as E
+
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
+    E.PROFILE = prof = E.KernelProfile()  # events around each tap-conv / wgrad launch, as in the headline's timed region
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    E.PROFILE = None
+    summ = prof.summary()
+    dom = max((k for k in summ if not k.startswith("wgrad")), key=lambda k: summ[k]["ms"])  # the dominant tap-conv kernel of this model
+    roof = prof.roofline(MFMA_BF16_PEAK_TFLOPS, dom)
     return {"workload": f"rv-waymo full model, fwd+bwd+AdamW, {batch_size} synthetic 64x2656x6 sweeps (single-GPU shard of BASELINE configs[4])",
             "sweeps_per_s": round(batch_size * steps / dt, 2), "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps, "warmup": warmup,
-            "loss": float(loss.detach().item()), "dtype": "bf16"}
+            "loss": float(loss.detach().item()), "dtype": "bf16",
+            "roofline": roof, "whole_step": whole_step("rv-waymo", 2656, batch_size, dt / steps),
+            "kernels": {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "tflops": round(v["tflops"], 1)} for k, v in summ.items()}}
+
+
+def whole_step(widths: str, width: int, sweeps: int, seconds: float) -> dict:
+    """The whole training step against the dense bf16 MFMA peak: 3 x the model's forward FLOPs per sweep."""
+    tflop = 3.0 * FWD_TFLOP_PER_SWEEP[(widths, width)] * sweeps
+    return {"tflop": round(tflop, 2), "achieved": round(tflop / seconds, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tflop / seconds / MFMA_BF16_PEAK_TFLOPS, 4)}
+
+
+def first_step_loss(dev, widths: str = "rv-av2", n_cls: int = AV2_CLASSES, n_feat: int = 5, width: int = 2048) -> float:
+    """ONE reproducible number of the benchmarked model: the loss of the freshly initialised (seed 0) model in train mode on the
+    first sweep of the benchmark's own synthetic data (seed 1234, B = 1), before any update.  tests/test_gpu_fullsize_train.py
+    compares it with the oracle's fp32 value of the same quantity (1e-2)."""
+    torch.manual_seed(0)
+    backbone, head = build_model(widths, n_cls, n_feat)
+    model = Detector(backbone, head).to(dev).train()
+    batch = synthetic_batch(1, 64, width, seed=1234, device=dev, n_feat=n_feat, n_cls=n_cls)
+    with torch.no_grad():
+        return float(model(batch).item())
 
 
 def roofline(prof, iso) -> dict:
@@ -480,8 +510,17 @@ def main() -> None:
                        "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 2)},
             "roofline": roofline(prof, iso),
             "kernels": prof.summary(),
+            # the same launches with nothing else on the GPU (side stream off, two steps outside the timed region): with the small
+            # layers' weight gradients on the side stream the live event-to-event times of overlapping kernels include their neighbour
+            "kernels_isolated": iso.summary(),
         }
+        if (args.widths, args.width) in FWD_TFLOP_PER_SWEEP and args.height == 64:
+            out["whole_step"] = whole_step(args.widths, args.width, args.batch * world, elapsed / args.steps)
         headline = (args.widths, args.width, args.height, args.features) == ("rv-av2", 2048, 64, 5)
+        if world == 1 and headline:
+            # (the model of the timed region has taken optimizer steps; this is a fresh one: 0.3 s)
+            out["loss_first_step"] = {"value": first_step_loss(dev), "what": "train-mode loss of the seed-0 model on sweep 0 of the seed-1234 batch, B = 1, "
+                                      "before any update; the fp32 oracle's value of the same quantity is asserted in tests/test_gpu_fullsize_train.py (1e-2)"}
         if world == 1 and not args.no_extra and headline:
             # extra keys, outside the timed region: BASELINE configs[1] (forward only + decode + NMS) and the one-GPU shard of configs[4]
             _progress("forward_only leg (eval forward + decode + weighted NMS)")

@@ -39,18 +39,7 @@ struct PackArgs {
     // T[cu][c][ky][kx], kx = s (j' + jmin) + r + pad_w (zero where kx falls outside the kernel).  kh, kw, cv, cv_pad above then
     // describe the folded image; fold_cv / fold_kw are the original channel count and kernel width.
     int fold_s, fold_pw, fold_jmin, fold_cvp, fold_cv, fold_kw;
-    // second copy of the image for tapconv6 (rv_weight_has_tile6): behind the row-major one, every [128 rows][32 k] piece of a tap
-    // image contiguous (8 KB = what one K tile of that kernel streams: whole lines per DMA instruction), its 16-byte k-chunks
-    // already in the swizzled order the kernel's LDS image has
-    int tile6;
 };
-
-// element offset of (tap image img, output-channel row, input-channel k) in the tiled copy; rows / kdim: padded channel counts
-__device__ __forceinline__ int64_t tile6_index(int64_t n_img, int64_t pairs, int img, int row, int k, int kdim) {
-    const int rho = row & 127, kk = k & 31;
-    const int chunk = (kk >> 3) ^ (((rho >> 2) & 1) << 1);
-    return (n_img + img) * pairs + (int64_t)(row >> 7) * (128 * kdim) + (k >> 5) * 4096 + rho * 32 + chunk * 8 + (kk & 7);
-}
 
 struct PackArgs2 {  // both forms in one launch: blockIdx.y selects
     PackArgs f[2];
@@ -77,28 +66,19 @@ __device__ __forceinline__ void pack_one(const PackArgs& a, int64_t first, int64
             for (int t = 0; t < taps; ++t) {
                 const int ky = t / a.kw, jp = t - ky * a.kw;
                 const int kx = a.fold_s * (jp + a.fold_jmin) + r + a.fold_pw;
-                const bf16_t val = f2bf(in && kx >= 0 && kx < a.fold_kw ? src[ky * a.fold_kw + kx] : 0.f);
-                a.out[(int64_t)t * pairs + pair] = val;
-                if (a.tile6) a.out[tile6_index(taps, pairs, t, u, v, a.cv_pad)] = val;
+                a.out[(int64_t)t * pairs + pair] = f2bf(in && kx >= 0 && kx < a.fold_kw ? src[ky * a.fold_kw + kx] : 0.f);
             }
             continue;
         }
         const bool in = u < a.cu && v < a.cv;
         const float* src = a.T + ((int64_t)u * a.cv + v) * taps;
         if (!a.scatter) {
-            for (int t = 0; t < taps; ++t) {
-                const bf16_t val = f2bf(in ? src[t] : 0.f);
-                a.out[(int64_t)t * pairs + pair] = val;
-                if (a.tile6) a.out[tile6_index(taps, pairs, t, u, v, a.cv_pad)] = val;
-            }
+            for (int t = 0; t < taps; ++t) a.out[(int64_t)t * pairs + pair] = f2bf(in ? src[t] : 0.f);
         } else {
             int img = 0;
             for (int r = 0; r < a.phases; ++r)
-                for (int idx = 0; idx < a.tt.ntaps[r]; ++idx, ++img) {
-                    const bf16_t val = f2bf(in ? src[a.tt.ky[r][idx] * a.kw + a.tt.kx[r][idx]] : 0.f);
-                    a.out[(int64_t)img * pairs + pair] = val;
-                    if (a.tile6) a.out[tile6_index(taps, pairs, img, v, u, a.cu_pad)] = val;
-                }
+                for (int idx = 0; idx < a.tt.ntaps[r]; ++idx, ++img)
+                    a.out[(int64_t)img * pairs + pair] = f2bf(in ? src[a.tt.ky[r][idx] * a.kw + a.tt.kx[r][idx]] : 0.f);
         }
     }
 }
@@ -131,11 +111,7 @@ __device__ __forceinline__ void pack_scatter_tiles(const PackArgs& a, float (*ti
             }
             __syncthreads();
             for (int vv = ly; vv < kPackTile; vv += 8)
-                for (int t = 0; t < nt; ++t) {
-                    const bf16_t val = f2bf(tile[t][lx][vv]);
-                    a.out[(int64_t)(t0 + t) * pairs + (int64_t)(v0 + vv) * a.cu_pad + u0 + lx] = val;
-                    if (a.tile6) a.out[tile6_index(taps, pairs, t0 + t, v0 + vv, u0 + lx, a.cu_pad)] = val;
-                }
+                for (int t = 0; t < nt; ++t) a.out[(int64_t)(t0 + t) * pairs + (int64_t)(v0 + vv) * a.cu_pad + u0 + lx] = f2bf(tile[t][lx][vv]);
         }
     }
 }
@@ -173,13 +149,8 @@ __global__ void unpack_wgrad_kernel(const float* packed, float* dT, int cu, int 
 
 }  // namespace
 
-// Does the packed image of this geometry carry the tiled copy (for output channels c_dst: cu of the gather form, cv of the
-// scatter form)?  Geometry only -- every packer and every launch of a layer must agree on it.
-bool rv_weight_has_tile6(const rvTapGeom* g, int c_dst_pad) { return g->kh * g->kw >= 6 && c_dst_pad % 128 == 0; }
-
 extern "C" int64_t rv_packed_weight_bytes(const rvTapGeom* g) {
-    const int64_t one = (int64_t)g->kh * g->kw * rv_pad32(g->cu) * rv_pad32(g->cv) * (int64_t)sizeof(bf16_t);
-    return rv_weight_has_tile6(g, rv_pad32(g->cu)) || rv_weight_has_tile6(g, rv_pad32(g->cv)) ? 2 * one : one;  // (one size for both forms)
+    return (int64_t)g->kh * g->kw * rv_pad32(g->cu) * rv_pad32(g->cv) * (int64_t)sizeof(bf16_t);
 }
 
 extern "C" int rv_pack_weight(const rvTapGeom* g, const float* T, void* gather_w, void* scatter_w, rvStream stream) {
@@ -202,7 +173,6 @@ extern "C" int rv_pack_weight(const rvTapGeom* g, const float* T, void* gather_w
         a.kh = g->kh;
         a.kw = g->kw;
         a.scatter = form;
-        a.tile6 = rv_weight_has_tile6(g, form ? a.cv_pad : a.cu_pad);
     }
     if (n == 0) return 0;
     const int64_t total = (int64_t)rv_pad32(g->cu) * rv_pad32(g->cv);  // one thread per channel pair
@@ -225,7 +195,6 @@ static int fill_pack_args(const rvTapGeom* g, const float* T, void* out, int for
     a->kh = g->kh;
     a->kw = g->kw;
     a->scatter = form;
-    a->tile6 = rv_weight_has_tile6(g, form ? a->cv_pad : a->cu_pad);
     return 0;
 }
 
@@ -264,7 +233,6 @@ static int fill_pack_args_folded(const rvTapGeom* g, const float* T, void* out, 
     a->fold_cvp = rv_pad32(g->cv);
     a->fold_cv = g->cv;
     a->fold_kw = g->kw;
-    a->tile6 = rv_weight_has_tile6(&gf, a->cu_pad);
     return 0;
 }
 

@@ -46,7 +46,6 @@ struct TapConvArgs {
     // RV_OUT_ACCUM: the tensor added to the result -- dst itself (gradient fan-in) or a residual (rv_tap_residual), same pixels as dst
     const bf16_t* res;
     int32_t ld_res;
-    int64_t w_tile6;  // element offset of the tiled copy of the weight image behind `w` (0: this geometry has none), see misc.hip
     TapTable tt;
 };
 
@@ -74,5 +73,3 @@ int rv_tapconv5_launch(const TapConvArgs& a, size_t lds, int bn, hipStream_t str
 // the taps; stats rows = 4 * tiles, BatchNorm-backward rows = tiles
 bool rv_tapconv6_plan(TapConvArgs* a, int* tiles, size_t* lds);
 int rv_tapconv6_launch(const TapConvArgs& a, size_t lds, hipStream_t stream);
-// the packed weight image of this geometry carries a second, tiled copy for tapconv6 (misc.hip)
-bool rv_weight_has_tile6(const rvTapGeom* g, int c_dst_pad);

@@ -439,7 +439,6 @@ static int tap_launch(const rvTapGeom* g, const rvTapShape* s, bool scatter, con
     a.src = (const bf16_t*)src;
     a.dst = dst;
     a.w = (const bf16_t*)w;
-    a.w_tile6 = rv_weight_has_tile6(g, a.C_dst) ? (int64_t)g->kh * g->kw * a.C_dst * a.C_src : 0;
     a.in_scale = in_scale;
     a.in_shift = in_shift;
     a.bias = bias;

@@ -25,7 +25,7 @@
 // swizzle bit flips, so ONE address computation per K tile serves all four rows a wave reads (a_b1 = a_b0 ^ 32).
 //
 // Eligible: stride-1 phases with 6..16 taps on a rows x columns grid whose halo fits (<= 18 rows x 34 columns), C_src % 32 == 0,
-// C_dst % 128 == 0 (the geometries whose packed image carries the tiled copy), plain bf16 input, bf16 output (+ statistics / bias / accumulate / BatchNorm-backward sums), H >= 16 and
+// C_dst % 128 == 0, plain bf16 input, bf16 output (+ statistics / bias / accumulate / BatchNorm-backward sums), H >= 16 and
 // at least one round of workgroups.  Everything else stays on tapconv5 / tapconv4.
 #include <stdlib.h>
 
@@ -125,12 +125,13 @@ __global__ __launch_bounds__(512, 2) void tapconv6_kernel(const TapConvArgs a) {
     const int s_row = lane >> 2, s_slot = lane & 3;
     const int kq8 = (s_slot ^ (((s_row >> 2) & 1) << 1)) * 8;
     const bf16_t* zero = (const bf16_t*)g_zero_page6 + s_slot * 8;
-    // Weights: piece j = K tile j = [128 channels][32 k], CONTIGUOUS (and already swizzled) in the tiled copy of the packed image
-    // (misc.hip, tile6_index): wave w's instruction is the w-th KB of the piece, lane-linear -- eight whole lines per instruction.
-    // (From the row-major image the same piece is 128 half-lines: measured, the fill stream then runs at half its byte rate.)
+    // Weights: piece j = K tile j = [128 channels][32 k] of the row-major image: wave w's instruction covers channels 16 w + s_row.
+    // (Measured and dropped: a tiled copy of the image with every 8 KB piece contiguous and pre-swizzled, i.e. eight whole lines
+    //  per instruction instead of sixteen half-lines -- the same kernel time, profiles/r04_tapconv6_ablation.md: all CUs of an XCD
+    //  then pull the same 8 KB from one or two L2 channels at the same moment.)
     const int64_t w_img = (int64_t)a.C_dst * a.C_src;
-    const bf16_t* w_ph = a.w + a.w_tile6 + (int64_t)a.tt.w_first[ph] * w_img;
-    const int b_voff = (n0 >> 7) * (128 * a.C_src) + wave * 512 + lane * 8;
+    const bf16_t* w_ph = a.w + (int64_t)a.tt.w_first[ph] * w_img;
+    const int b_voff = (n0 + wave * 16 + s_row) * a.C_src + kq8;
     int bq = 0, bt = 0;  // K tile / tap of the piece being issued
     int b_so = 0;        // element offset of its (tap image, chunk) in the packed weight -- kept scalar
     auto stage_b = [&](int j) {
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(512, 2) void tapconv6_kernel(const TapConvArgs a) {
         const bool go = bq + 1 < nkt;  // pieces past the last K tile re-fetch it (never read; keeps the wait counts uniform)
         const bool wrap = bt + 1 == T;
         bq += go ? 1 : 0;
-        b_so += go ? (wrap ? kPiece / 2 - (T - 1) * (int)w_img : (int)w_img) : 0;
+        b_so += go ? (wrap ? kBK - (T - 1) * (int)w_img : (int)w_img) : 0;
         bt = go ? (wrap ? 0 : bt + 1) : bt;
     };
     // Halo: instruction q (0..40) covers pixel slots 16 q + s_row of the [18 rows][36 slots] image; wave w issues q = w, w + 8,
@@ -464,7 +465,7 @@ bool rv_tapconv6_plan(TapConvArgs* a, int* tiles, size_t* lds) {
     if (a->flags & (RV_IN_AFFINE | RV_IN_RELU | RV_OUT_F32)) return false;  // the DMA path has no register prologue
     if ((a->flags & RV_OUT_BNB) && (a->flags & RV_OUT_ACCUM) && !a->bnb_mask) return false;  // (accumulating sums: the masked last-writer form only)
     if ((a->flags & RV_OUT_BNB) && a->bnb_mask && !(a->flags & RV_OUT_ACCUM)) return false;
-    if (a->C_src % kBK != 0 || a->C_dst % kBN != 0 || a->w_tile6 == 0) return false;
+    if (a->C_src % kBK != 0 || a->C_dst % kBN != 0) return false;
     const int wm_total = a->W_dst / a->phases;
     if (wm_total < kTC || a->H < kTR) return false;
     if (kTR + a->tt.rows - 1 > kHaloRows) return false;

@@ -65,23 +65,24 @@ class KernelProfile:
     """Event pairs around individual kernel launches (bench.py: live per-kernel timing inside the timed region)."""
 
     def __init__(self) -> None:
-        self.records: List[Tuple[str, float, torch.cuda.Event, torch.cuda.Event]] = []
+        self.records: List[tuple] = []  # (name, flops, start event, end event, algorithmic bytes)
 
-    def launch(self, name: str, flops: float, fn) -> None:
+    def launch(self, name: str, flops: float, fn, nbytes: float = 0.0) -> None:
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         fn()
         b.record()
-        self.records.append((name, flops, a, b))
+        self.records.append((name, flops, a, b, nbytes))
 
     def summary(self) -> Dict[str, Dict[str, float]]:
         torch.cuda.synchronize()
         agg: Dict[str, Dict[str, float]] = {}
-        for name, flops, a, b in self.records:
-            d = agg.setdefault(name, {"launches": 0, "ms": 0.0, "tflop": 0.0})
+        for name, flops, a, b, nbytes in self.records:
+            d = agg.setdefault(name, {"launches": 0, "ms": 0.0, "tflop": 0.0, "gbyte": 0.0})
             d["launches"] += 1
             d["ms"] += a.elapsed_time(b)
             d["tflop"] += flops / 1e12
+            d["gbyte"] += nbytes / 1e9
         for d in agg.values():
             d["avg_us"] = 1e3 * d["ms"] / max(d["launches"], 1)
             d["tflops"] = d["tflop"] / max(d["ms"] * 1e-3, 1e-12)
@@ -96,7 +97,9 @@ class KernelProfile:
         d = agg[name]
         return {"kernel": name, "bound": "mfma", "achieved": d["tflops"], "peak": peak_tflops, "unit": "TFLOP/s",
                 "frac": d["tflops"] / peak_tflops, "traffic": None, "launches": d["launches"], "avg_launch_us": d["avg_us"],
-                "flops_per_launch": 1e12 * d["tflop"] / max(d["launches"], 1)}
+                "flops_per_launch": 1e12 * d["tflop"] / max(d["launches"], 1),
+                # every operand tensor once in, the result once out, bf16 (fp32 for a weight gradient's result)
+                "algorithmic_bytes": 1e9 * d["gbyte"] / max(d["launches"], 1)}
 
 
 PROFILE: Optional[KernelProfile] = None
@@ -127,9 +130,9 @@ def side_stream(device) -> "torch.cuda.Stream":
     return _SIDE_STREAMS[idx]
 
 
-def _launch(name: str, flops: float, fn) -> None:
+def _launch(name: str, flops: float, fn, nbytes: float = 0.0) -> None:
     if PROFILE is not None:
-        PROFILE.launch(name, flops, fn)
+        PROFILE.launch(name, flops, fn, nbytes)
     else:
         fn()
 
@@ -150,6 +153,14 @@ def tap_kernel_name(geom, shape, scatter: bool) -> str:
 
 def tap_flops(geom, shape) -> float:
     return 2.0 * shape.N * shape.H * shape.Wu * geom.kh * geom.kw * geom.cu * geom.cv
+
+
+def tap_bytes(geom, shape, wgrad: bool = False) -> float:
+    """Algorithmic bytes of one tap-conv launch (SURVEY 8d): the coarse and the fine tensor once each (bf16, padded channels);
+    a weight gradient reads both and writes the fp32 parameter gradient."""
+    px = float(shape.N) * shape.H
+    act = 2.0 * px * (shape.Wu * pad32(geom.cu) + shape.Wv * pad32(geom.cv))
+    return act + (4.0 * geom.kh * geom.kw * geom.cu * geom.cv if wgrad else 2.0 * geom.kh * geom.kw * pad32(geom.cu) * pad32(geom.cv))
 
 
 def all_reduce_(t: Tensor) -> None:
@@ -238,6 +249,7 @@ class GradSync:
         dev = self.params[0].device
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.works: List[tuple] = []
+        self.pending: List[nn.Parameter] = []  # parameters whose gradient sits in the flat buffer since the last finish()
         self.bytes = 4 * sum(p.numel() for p in self.params)
 
     def view(self, p: nn.Parameter) -> Tensor:
@@ -250,33 +262,53 @@ class GradSync:
             torch.distributed.broadcast(t.data, src=0)
 
     def reduce_node(self, params: Sequence[nn.Parameter], grads: Sequence[Optional[Tensor]]) -> List[Optional[Tensor]]:
-        """Gradients of the parameters of ONE finished autograd node -> their flat views, all-reduce started; returns the list
-        with the views in place of the node's own gradient tensors."""
+        """Gradients of the parameters of ONE finished autograd node -> their flat views, all-reduce started.  Returns the list
+        with ``None`` in place of the gradients it took over: ``finish()`` installs the views as ``p.grad`` (handing the views to
+        autograd here would make AccumulateGrad clone every one of them -- they are referenced from this object -- or, with a
+        view already installed from the previous step, add the buffer to itself).
+        The node's parameters need not be contiguous in ``model.parameters()`` order (a DetectionHead with several strides or
+        tasks registers all classification towers before the regression towers): the flat range is cut into maximal runs of
+        parameters that all belong to THIS node and each run travels in its own all-reduce, so no region is reduced while it
+        still holds another node's stale values, and every region is scaled exactly once."""
         out = list(grads)
         idx = [i for i, (p, g) in enumerate(zip(params, grads)) if g is not None and id(p) in self.offsets]
         if not idx:
             return out
+        for i in idx:
+            g = params[i].grad
+            if g is not None and g.data_ptr() == self.flat.data_ptr() + 4 * self.offsets[id(params[i])][0]:
+                raise L.RvError("GradSync: p.grad still is last step's view of the flat buffer -- call zero_grad(set_to_none=True) "
+                                "before backward (gradient accumulation over several backward passes is not supported)")
         dst = [self.view(params[i]) for i in idx]
         torch._foreach_copy_(dst, [grads[i].to(torch.float32) for i in idx])
-        lo = min(self.offsets[id(params[i])][0] for i in idx)
-        hi = max(self.offsets[id(params[i])][0] + (self.offsets[id(params[i])][1] + 63) // 64 * 64 for i in idx)
-        seg = self.flat[lo:hi]
-        if torch.distributed.is_available() and torch.distributed.is_initialized():  # (also with ONE rank: the one-GPU test of the path)
-            self.works.append((torch.distributed.all_reduce(seg, async_op=True), seg))
-        for i, d in zip(idx, dst):
-            out[i] = d
+        spans = sorted((self.offsets[id(params[i])][0], (self.offsets[id(params[i])][1] + 63) // 64 * 64) for i in idx)
+        runs: List[List[int]] = []
+        for o, n in spans:  # (views are 256-byte aligned and laid out back to back: adjacent parameters touch exactly)
+            if runs and runs[-1][1] == o:
+                runs[-1][1] = o + n
+            else:
+                runs.append([o, o + n])
+        live = torch.distributed.is_available() and torch.distributed.is_initialized()  # (also with ONE rank: the one-GPU test of the path)
+        for lo, hi in runs:
+            seg = self.flat[lo:hi]
+            self.works.append((torch.distributed.all_reduce(seg, async_op=True) if live else None, seg))
+        for i in idx:
+            self.pending.append(params[i])
+            out[i] = None
         return out
 
     def finish(self) -> None:
-        """Before the optimizer step: wait for the collectives, average, and make every ``p.grad`` its view of the flat buffer."""
+        """Before the optimizer step: wait for the collectives, average, and make ``p.grad`` of every parameter reduced this
+        step its view of the flat buffer."""
         for work, seg in self.works:
-            work.wait()
+            if work is not None:
+                work.wait()
             if self.world > 1:
                 seg.mul_(1.0 / self.world)
         self.works.clear()
-        for p in self.params:
-            if p.grad is not None:
-                p.grad = self.view(p)
+        for p in self.pending:
+            p.grad = self.view(p)
+        self.pending.clear()
 
 
 GRAD_SYNC: Optional[GradSync] = None
@@ -653,6 +685,12 @@ class Tape:
     def __init__(self, training: bool, device) -> None:
         self.training = training
         self.device = device
+        # eval-mode programs take the inference forms (BatchNorm folded into the weights, block sums and the stem's modulation in
+        # conv epilogues).  They are INFERENCE-ONLY: BatchNorm backward is built on batch statistics, so a backward pass through
+        # an eval-mode program raises RvError (fine-tuning with frozen statistics is not on the reference's path: its trainer
+        # always runs training_step in train mode, nn/arch/detector.py:238-247).  Not switched on "does anything require grad":
+        # an eval forward outside torch.no_grad() would silently lose the fused forms.
+        self.inference = not training
         self.ops: List["Op"] = []
         # backward state
         self.grads: Dict[int, Act] = {}          # id(root Act) -> gradient Act (same padded shape)
@@ -895,7 +933,7 @@ class ConvOp(Op):
             assert out is not None and not out_f32 and bias is None
             self.partial, self.rows = precomputed
         elif PROFILE is not None:
-            _launch(tap_kernel_name(lg, lshape, form == "scatter"), tap_flops(g, self.shape), call)
+            _launch(tap_kernel_name(lg, lshape, form == "scatter"), tap_flops(g, self.shape), call, tap_bytes(g, self.shape))
         else:
             call()
         self.count = src.N * src.H * w_out
@@ -1051,7 +1089,7 @@ def conv_bn(t: Tape, layer: TapLayer, x: Operand, bn: nn.BatchNorm2d, relu: bool
     that fold the BatchNorm themselves (MetaModulateOp; ``fold_eval=False`` likewise keeps the Lazy form in eval mode)."""
     if smallk and _smallk_eligible(layer, x, relu, need_input_grad):
         return SmallKOp(t, layer, x, bn).out
-    if not t.training and EVAL_FOLD and fold_eval and layer.bias is None:
+    if t.inference and EVAL_FOLD and fold_eval and layer.bias is None:
         # inference: BatchNorm folded into the weight image and the bias, ReLU in the epilogue -- the conv writes the activation
         # itself (no folded operand for the consumer to apply, no write-out pass for the LDS-DMA kernels)
         # (``out``: where the activation goes -- honoured on this path only, the caller checks ``result is out``)
@@ -1068,7 +1106,7 @@ def conv_bn_residual(t: Tape, layer: TapLayer, x: Operand, bn: nn.BatchNorm2d, r
     """Inference: ``relu_out?( relu_conv?(bn(conv(x))) + res )`` in the conv's own launch (BatchNorm folded, residual added in the
     epilogue: rv_tap_residual).  None when the fusion does not apply (training; folded operands) -- the caller then takes
     ``conv_bn`` + ``CombineOp``, whose result is the same bit for bit."""
-    if (t.training or not (EVAL_FOLD and EVAL_RES_FUSE) or layer.bias is not None or not isinstance(x, Act) or not isinstance(res, Act)
+    if (not t.inference or not (EVAL_FOLD and EVAL_RES_FUSE) or layer.bias is not None or not isinstance(x, Act) or not isinstance(res, Act)
             or res.cp != pad32(layer.c_out)):
         return None
     return ConvOp(t, layer, x, eval_bn=bn, relu_out=relu_conv, residual=res, res_relu=relu_out, out=out).out
@@ -1082,7 +1120,7 @@ def conv_bn_many(t: Tape, specs: Sequence[Tuple[TapLayer, Operand, nn.BatchNorm2
     then every BatchNorm is finalised -- under SyncBN with ONE all-reduce for the whole group (``allreduce_partial_rows_many``)
     instead of one per layer; the BnOps sit next to each other on the tape, so the backward pass groups their collectives
     too (``Tape.backward``).  spec = (layer, input, bn, relu, need_input_grad).  Results in spec order."""
-    if not t.training and EVAL_FOLD and all(layer.bias is None for layer, *_ in specs):
+    if t.inference and EVAL_FOLD and all(layer.bias is None for layer, *_ in specs):
         return [ConvOp(t, layer, x, need_input_grad=nig, eval_bn=bn, relu_out=relu).out for layer, x, bn, relu, nig in specs]
     convs = [ConvOp(t, layer, x, stats=t.training, need_input_grad=nig) for layer, x, _, _, nig in specs]
     reduced: List[Optional[Tensor]] = [None] * len(specs)
@@ -1141,7 +1179,7 @@ def _eval_scale_shift(bn: nn.BatchNorm2d, cp: int, dev) -> Tuple[Tensor, Tensor]
 
 def pos_modulate_eligible(t: Tape, l0: TapLayer, l1: TapLayer, x: Operand, feat: Operand) -> bool:
     """Inference: the positional pair AND the modulation in one kernel (rv_pos_modulate_forward)."""
-    return (not t.training and POS_MOD_FUSE and pos_pair_eligible(l0, l1, x) and isinstance(feat, Act) and feat.cp == pad32(l1.c_out)
+    return (t.inference and POS_MOD_FUSE and pos_pair_eligible(l0, l1, x) and isinstance(feat, Act) and feat.cp == pad32(l1.c_out)
             and feat.cp == l1.c_out and feat.W >= 32 and x.pixels == 9 * feat.pixels and x.pixels < 2**31 - 512)
 
 

@@ -133,7 +133,7 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
                                       L.ptr(wp), dst.ptr(), ctypes.byref(epi), L.stream_ptr())
                 t.lazy_sums[id(lz)] = (partial, rows, dst)
         if E.PROFILE is not None:
-            E._launch(E.tap_kernel_name(bg, bshape, bwd == "scatter"), E.tap_flops(g, shape), call)
+            E._launch(E.tap_kernel_name(bg, bshape, bwd == "scatter"), E.tap_flops(g, shape), call, E.tap_bytes(g, shape))
         else:
             call()
         if not isinstance(op.x, Lazy):
@@ -167,7 +167,8 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
         # the split-K reduction writes the torch layout dT[cu][cv][kh][kw] itself (RV_WGRAD_TORCH_LAYOUT): no unpack pass
         E._launch(wname, E.tap_flops(g, wshape),
                   lambda: L.call("rv_tap_wgrad", ctypes.byref(wg), ctypes.byref(wsh), u.ptr(), L.i32(u.ld), v.ptr(), L.i32(ld_v),
-                                 L.ptr(sc), L.ptr(sh), L.i32(v_affine), L.ptr(grad), L.ptr(ws), L.stream_ptr()))
+                                 L.ptr(sc), L.ptr(sh), L.i32(v_affine), L.ptr(grad), L.ptr(ws), L.stream_ptr()),
+                  E.tap_bytes(g, wshape, wgrad=True))
         if wg is not g:
             folded, grad = grad, torch.empty((g.cu, g.cv, g.kh, g.kw), dtype=torch.float32, device=t.device)
             L.call("rv_unfold_weight_grad", ctypes.byref(g), L.ptr(folded), L.ptr(grad), L.i32(0), L.stream_ptr())

@@ -246,3 +246,24 @@ def test_meta_kernel_eval_with_the_fused_stem_kernel(C, precision):
     finally:
         E.POS_MOD_FUSE = True
     assert float(a.abs().max()) > 0 and torch.equal(a, b), float((a - b).abs().max())
+
+
+def test_eval_mode_backward_fails_loudly(golden):
+    """Eval-mode programs are inference-only (BatchNorm backward is built on batch statistics): the forward outside
+    ``torch.no_grad()`` still takes the fused inference forms and equals the no-grad run bit for bit; asking for gradients
+    raises ``RvError`` instead of returning something silently wrong (round-3 ADVICE, documented limitation)."""
+    from range_view_3d_detection_amd import _lib as L
+    from test_gpu_model import load_tiny
+
+    g = golden("tiny_model")
+    backbone, head = load_tiny(g)
+    backbone.eval()
+    head.eval()
+    data = {"features": g["features"].to(DEV), "cart": g["cart"].to(DEV), "mask": g["mask"].to(DEV)}
+    with torch.no_grad():
+        ref, _ = head(backbone(data), data, return_loss=False)
+    out, _ = head(backbone(data), data, return_loss=False)
+    logits = out[1][0]["logits"]
+    assert torch.equal(logits.detach(), ref[1][0]["logits"])
+    with pytest.raises(L.RvError):
+        logits.float().square().mean().backward()
