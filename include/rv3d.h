@@ -204,6 +204,22 @@ int rv_tap_wgrad(const rvTapGeom* g, const rvTapShape* s, const void* U, int32_t
                  const float* in_scale, const float* in_shift, int32_t v_affine, float* dT_packed,
                  void* workspace, rvStream stream);
 
+/* Deferred split-K reduction.  With RV_WGRAD_DEFER_REDUCE in s->flags rv_tap_wgrad only fills the slabs; the sums of MANY layers
+ * are then formed by ONE launch per 64 layers (rv_wgrad_reduce_batch) instead of one latency-bound reduce launch behind every
+ * weight-gradient kernel (78 per training step of the rv-av2 model).  rv_wgrad_reduce_entry describes one layer's reduction
+ * (same plan as rv_tap_wgrad: call it with the same g, s, workspace, dT); the batch takes a HOST array of entries (passed to
+ * the kernel by value, no device table).  Same slab order per element as the immediate reduction: bit-identical results.
+ * The workspaces must stay alive, and all rv_tap_wgrad launches must precede the batch in stream order. */
+#define RV_WGRAD_DEFER_REDUCE 512
+typedef struct {
+    const void* slabs;
+    float* out;
+    int64_t elems;
+    int32_t ksplit, torch_layout, cu, cv, cu_pad, cv_pad, taps, reserved;
+} rvWgradReduceEntry;
+int rv_wgrad_reduce_entry(const rvTapGeom* g, const rvTapShape* s, const void* workspace, float* dT_packed, rvWgradReduceEntry* entry);
+int rv_wgrad_reduce_batch(const rvWgradReduceEntry* host_entries, int32_t n_entries, rvStream stream);
+
 /* ---------------------------------------------------------------------------------------
  * BatchNorm2d (nn.BatchNorm2d train/eval; nn/blocks/__init__.py:41,51,63,158; torchvision
  * Conv2dNormActivation norm layer).  eps / momentum are torch defaults passed by the host.

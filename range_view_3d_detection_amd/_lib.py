@@ -24,6 +24,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "rv3d.h")
 IN_AFFINE, IN_RELU, OUT_F32, OUT_BIAS, OUT_STATS, OUT_ACCUM, OUT_RELU = 1, 2, 4, 8, 16, 32, 64
 OUT_RES_RELU = 256
 WGRAD_TORCH_LAYOUT = 128  # rv_tap_wgrad: result in dT[cu][cv][kh][kw] (no unpack pass)
+WGRAD_DEFER_REDUCE = 512  # rv_tap_wgrad: slabs only, the sums later in one batched launch (rv_wgrad_reduce_batch)
 EW_RELU_A, EW_RELU_B, EW_RELU_OUT = 1, 2, 4
 BNB_RELU_Z, BNB_RES_ACCUM, BNB_Y_FROM_INPUT, BNB_MASK = 1, 2, 4, 8
 STATS_SCRATCH_ROWS = 128
@@ -42,6 +43,13 @@ class BnbEpilogue(ctypes.Structure):
 
     _fields_ = [("y", ctypes.c_void_p), ("ld_y", ctypes.c_int32), ("flags", ctypes.c_int32), ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p),
                 ("mean", ctypes.c_void_p), ("invstd", ctypes.c_void_p), ("partial", ctypes.c_void_p), ("mask", ctypes.c_void_p), ("ld_mask", ctypes.c_int32)]
+
+
+class WgradReduceEntry(ctypes.Structure):
+    """``rvWgradReduceEntry`` of include/rv3d.h (rv_wgrad_reduce_entry / rv_wgrad_reduce_batch)."""
+
+    _fields_ = [("slabs", ctypes.c_void_p), ("out", ctypes.c_void_p), ("elems", ctypes.c_int64)] + [
+        (n, ctypes.c_int32) for n in ("ksplit", "torch_layout", "cu", "cv", "cu_pad", "cv_pad", "taps", "reserved")]
 
 
 class RvError(RuntimeError):

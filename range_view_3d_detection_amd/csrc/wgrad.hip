@@ -221,10 +221,11 @@ struct UnpackTo {
 };
 
 // sum of the split-K slabs in slab order (bitwise reproducible); elems is a multiple of 1024 (padded channel counts)
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, int ksplit, int64_t elems, float* out, const UnpackTo up) {
+__device__ __forceinline__ void wgrad_reduce_body(const float* slabs, int ksplit, int64_t elems, float* out, const UnpackTo& up, int64_t first,
+                                                  int64_t stride) {
     const int64_t n4 = elems >> 2;
     const f32x4* in = (const f32x4*)slabs;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = first; i < n4; i += stride) {
         f32x4 s = in[i];
         int k = 1;
         for (; k + 3 < ksplit; k += 4) {
@@ -247,6 +248,28 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, i
         for (int j = 0; j < 4; ++j)
             if (v0 + j < up.cv) out[((int64_t)u * up.cv + v0 + j) * up.taps + tap] = s[j];
     }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, int ksplit, int64_t elems, float* out, const UnpackTo up) {
+    wgrad_reduce_body(slabs, ksplit, elems, out, up, blockIdx.x * (int64_t)blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
+}
+
+// the reductions of up to 64 layers in one launch (rv_wgrad_reduce_batch): blockIdx.y = layer, the table travels as kernel arguments
+constexpr int kReduceBatch = 64;
+struct ReduceBatch {
+    rvWgradReduceEntry e[kReduceBatch];
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const ReduceBatch b) {
+    const rvWgradReduceEntry& e = b.e[blockIdx.y];
+    UnpackTo up;
+    up.on = e.torch_layout;
+    up.cu = e.cu;
+    up.cv = e.cv;
+    up.cu_pad = e.cu_pad;
+    up.cv_pad = e.cv_pad;
+    up.taps = e.taps;
+    wgrad_reduce_body((const float*)e.slabs, e.ksplit, e.elems, e.out, up, blockIdx.x * (int64_t)blockDim.x + threadIdx.x,
+                      (int64_t)gridDim.x * blockDim.x);
 }
 
 
@@ -818,7 +841,7 @@ extern "C" int rv_tap_wgrad(const rvTapGeom* g, const rvTapShape* s, const void*
         b.chunks = p.chunks;
         b.tiles_u = p.tiles_u;
         b.tiles_v = p.tiles_v;
-        b.flags = s->flags & ~RV_WGRAD_TORCH_LAYOUT;
+        b.flags = s->flags & ~(RV_WGRAD_TORCH_LAYOUT | RV_WGRAD_DEFER_REDUCE);
         b.v_affine = v_affine;
         b.xcd_remap = 1;
         int gi = 0;
@@ -847,6 +870,7 @@ extern "C" int rv_tap_wgrad(const rvTapGeom* g, const rvTapShape* s, const void*
             hipLaunchKernelGGL(wgrad2_kernel, dim3(grid2), dim3(512), 0, st2, b);
             RV_CHECK_LAUNCH("wgrad2_kernel");
         }
+        if (s->flags & RV_WGRAD_DEFER_REDUCE) return 0;  // (the caller sums the slabs later: rv_wgrad_reduce_batch)
         const int rb2 = (int)((p.elems / 4 + 255) / 256 < 4096 ? (p.elems / 4 + 255) / 256 : 4096);
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb2), dim3(256), 0, st2, (const float*)workspace, p.ksplit, p.elems, dT_packed, up);
         RV_CHECK_LAUNCH("wgrad_reduce_kernel");
@@ -874,7 +898,7 @@ extern "C" int rv_tap_wgrad(const rvTapGeom* g, const rvTapShape* s, const void*
     a.k_per_split = p.k_per_split;
     a.tiles_u = p.tiles_u;
     a.tiles_v = p.tiles_v;
-    a.flags = s->flags & ~RV_WGRAD_TORCH_LAYOUT;
+    a.flags = s->flags & ~(RV_WGRAD_TORCH_LAYOUT | RV_WGRAD_DEFER_REDUCE);
     a.v_affine = v_affine;
     for (int ky = 0; ky < g->kh; ++ky)
         for (int kx = 0; kx < g->kw; ++kx) {
@@ -885,8 +909,49 @@ extern "C" int rv_tap_wgrad(const rvTapGeom* g, const rvTapShape* s, const void*
     const int grid = p.tiles_v * p.tiles_u * p.taps * p.ksplit;
     hipLaunchKernelGGL(wgrad_kernel, dim3(grid), dim3(256), 0, st, a);
     RV_CHECK_LAUNCH("wgrad_kernel");
+    if (s->flags & RV_WGRAD_DEFER_REDUCE) return 0;
     const int rb = (int)((p.elems / 4 + 255) / 256 < 4096 ? (p.elems / 4 + 255) / 256 : 4096);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, st, (const float*)workspace, p.ksplit, p.elems, dT_packed, up);
     RV_CHECK_LAUNCH("wgrad_reduce_kernel");
+    return 0;
+}
+
+extern "C" int rv_wgrad_reduce_entry(const rvTapGeom* g, const rvTapShape* s, const void* workspace, float* dT_packed, rvWgradReduceEntry* entry) {
+    RV_REQUIRE(g && s && workspace && dT_packed && entry, "rv_wgrad_reduce_entry: null argument");
+    WgradPlan p;
+    plan(g, s, &p);
+    memset(entry, 0, sizeof(*entry));
+    entry->slabs = workspace;
+    entry->out = dT_packed;
+    entry->elems = p.elems;
+    entry->ksplit = p.ksplit;
+    entry->torch_layout = (s->flags & RV_WGRAD_TORCH_LAYOUT) ? 1 : 0;
+    entry->cu = g->cu;
+    entry->cv = g->cv;
+    entry->cu_pad = rv_pad32(g->cu);
+    entry->cv_pad = rv_pad32(g->cv);
+    entry->taps = g->kh * g->kw;
+    return 0;
+}
+
+extern "C" int rv_wgrad_reduce_batch(const rvWgradReduceEntry* host_entries, int32_t n_entries, rvStream stream) {
+    RV_REQUIRE(host_entries && n_entries > 0, "rv_wgrad_reduce_batch: empty batch");
+    for (int first = 0; first < n_entries; first += kReduceBatch) {
+        const int n = n_entries - first < kReduceBatch ? n_entries - first : kReduceBatch;
+        ReduceBatch b;
+        memset(&b, 0, sizeof(b));
+        int64_t most = 0;
+        for (int i = 0; i < n; ++i) {
+            b.e[i] = host_entries[first + i];
+            RV_REQUIRE(b.e[i].slabs && b.e[i].out && b.e[i].ksplit > 0 && b.e[i].elems > 0, "rv_wgrad_reduce_batch: bad entry %d", first + i);
+            most = most > b.e[i].elems ? most : b.e[i].elems;
+        }
+        // blocks per layer: enough for the largest one to have one 16-byte element per thread, at most 128 (x up to 64 layers: the
+        // launch has thousands of workgroups either way; the small layers' surplus blocks exit at once)
+        int gx = (int)((most / 4 + 255) / 256);
+        gx = gx < 1 ? 1 : (gx > 128 ? 128 : gx);
+        hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, b);
+        RV_CHECK_LAUNCH("wgrad_reduce_batch_kernel");
+    }
     return 0;
 }

@@ -454,6 +454,12 @@ Operand = Union[Act, Lazy]
 # register-staged kernels (3x3 512 -> 512: 1330 vs 980 TFLOP/s, one box) to pay for writing the operand out once
 # (one HBM-bound pass); forward conv, and the weight gradient in backward, then both read the plain tensor.
 MATERIALIZE_FOR_DMA = os.environ.get("RV3D_NO_MATERIALIZE") is None
+# split-K sums of the weight gradients in one batched launch at the end of a program's backward (Tape.flush_wgrad_reduces) instead
+# of one reduce launch behind every weight-gradient kernel.  OPT-IN (RV3D_DEFER_WGRAD_REDUCE=1): bit-identical gradients and 76
+# launches fewer per step, but measured 1.0-1.6 ms per step SLOWER on rv-av2 (99.5 / 100.2 against 98.55 / 98.56 ms, same box):
+# the immediate reduction reads slabs that are still in the 256 MB Infinity Cache and every layer reuses one workspace block; the
+# deferred one keeps ~4 GB of slabs alive and reads them back from HBM.
+DEFER_WGRAD_REDUCE = os.environ.get("RV3D_DEFER_WGRAD_REDUCE") is not None
 # conv -> BatchNorm(+ReLU) -> conv: the second conv's backward-data launch also forms the BatchNorm-backward sums (rv_tap_data_grad_bnb)
 BNB_FUSE = os.environ.get("RV3D_NO_BNB_FUSE") is None
 # ... and where the gradient of a block output relu(bn(y) + x) has several writers, its LAST writer (the accumulating
@@ -703,7 +709,10 @@ class Tape:
         self.grad_version: Dict[int, int] = {}   # id(root Act) -> bumped whenever somebody asks for / writes its gradient buffer
         self.acc_sums: Dict[int, tuple] = {}     # id(root Act) -> (partial, rows, gradient Act, version): BatchNorm-backward sums the last writer formed
         self.raw_grad: Dict[int, Act] = {}       # id(raw Act) -> gradient w.r.t. the raw conv output
-        self.param_grads: Dict[int, Tensor] = {}  # id(param) -> fp32 gradient
+        self._param_grads: Dict[int, Tensor] = {}  # id(param) -> fp32 gradient (read through `param_grads`)
+        # split-K reductions of weight gradients deferred to ONE batched launch (rv_wgrad_reduce_batch): (entry, workspace, gradient)
+        self.deferred_wgrad: List[tuple] = []
+        self.deferred_params: set = set()
         self.params: Dict[int, nn.Parameter] = {}
         self.used_side_stream = False
         self.bn_counters: List[Tensor] = []
@@ -798,13 +807,39 @@ class Tape:
             self._masked_into(dout, mask, res[0], res[1])
         self.lazy_in[key] = (buf, None, None)
 
-    def add_param_grad(self, p: nn.Parameter, g: Tensor) -> None:
+    @property
+    def param_grads(self) -> Dict[int, Tensor]:
+        """Parameter gradients; reading them first completes the deferred split-K reductions."""
+        self.flush_wgrad_reduces()
+        return self._param_grads
+
+    def add_param_grad(self, p: nn.Parameter, g: Tensor, deferred: bool = False) -> None:
+        """``deferred``: ``g`` is the destination of a weight-gradient reduction still queued in ``deferred_wgrad``."""
         k = id(p)
         self.params[k] = p
-        if k in self.param_grads:
-            self.param_grads[k] = self.param_grads[k] + g
+        if k in self._param_grads:
+            if deferred or k in self.deferred_params:  # (a parameter used by two layers: the sum needs both values now)
+                self.flush_wgrad_reduces()
+            self._param_grads[k] = self._param_grads[k] + g
         else:
-            self.param_grads[k] = g
+            self._param_grads[k] = g
+            if deferred:
+                self.deferred_params.add(k)
+
+    def flush_wgrad_reduces(self) -> None:
+        """Sum the split-K slabs of every weight gradient queued since the last flush: one launch per 64 layers
+        (78 latency-bound reduce launches per training step of the rv-av2 model otherwise)."""
+        if not self.deferred_wgrad:
+            return
+        if self.used_side_stream:  # slabs written on the side stream
+            torch.cuda.current_stream().wait_stream(side_stream(self.device))
+        n = len(self.deferred_wgrad)
+        table = (L.WgradReduceEntry * n)(*[e for e, _, _ in self.deferred_wgrad])
+        L.call("rv_wgrad_reduce_batch", table, L.i32(n), L.stream_ptr())
+        for _, ws, _ in self.deferred_wgrad:
+            ws.record_stream(torch.cuda.current_stream())  # (allocated under the side stream's context in some cases)
+        self.deferred_wgrad = []
+        self.deferred_params = set()
 
     def backward(self) -> None:
         from . import engine_bwd
@@ -827,6 +862,7 @@ class Tape:
             engine_bwd.bn_backward_finish(pending, self)
         if self.used_side_stream:  # parameter gradients (and the buffers the side stream read) are final after this
             torch.cuda.current_stream().wait_stream(side_stream(self.device))
+        self.flush_wgrad_reduces()
 
 
 class Op:

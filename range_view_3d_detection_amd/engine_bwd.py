@@ -164,11 +164,21 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
             wname = ("wgrad_kernel", "wgrad_kernel", "wgrad2_kernel", "wgrad3_kernel")[winfo[0]] + "(+reduce)"
         if os.environ.get("RV3D_PROFILE_SHAPES"):
             wname += f" k{g.kh}x{g.kw}s{g.stride_w} {g.cu}<->{g.cv} {wshape.N}x{wshape.H}x{wshape.Wu}"
-        # the split-K reduction writes the torch layout dT[cu][cv][kh][kw] itself (RV_WGRAD_TORCH_LAYOUT): no unpack pass
+        # the split-K reduction writes the torch layout dT[cu][cv][kh][kw] itself (RV_WGRAD_TORCH_LAYOUT): no unpack pass.
+        # Its launch is deferred to one batched launch at the end of the program's backward (Tape.flush_wgrad_reduces) unless
+        # something reads the sum right away (the folded form's unfold pass, a permuted parameter layout).
+        defer = E.DEFER_WGRAD_REDUCE and wg is g and layer.in_perm is None
+        wsh_run = L.TapShape(wsh.N, wsh.H, wsh.Wu, wsh.Wv, wsh.ld_src, wsh.ld_dst, wsh.flags | (L.WGRAD_DEFER_REDUCE if defer else 0))
         E._launch(wname, E.tap_flops(g, wshape),
-                  lambda: L.call("rv_tap_wgrad", ctypes.byref(wg), ctypes.byref(wsh), u.ptr(), L.i32(u.ld), v.ptr(), L.i32(ld_v),
+                  lambda: L.call("rv_tap_wgrad", ctypes.byref(wg), ctypes.byref(wsh_run), u.ptr(), L.i32(u.ld), v.ptr(), L.i32(ld_v),
                                  L.ptr(sc), L.ptr(sh), L.i32(v_affine), L.ptr(grad), L.ptr(ws), L.stream_ptr()),
                   E.tap_bytes(g, wshape, wgrad=True))
+        if defer:
+            entry = L.WgradReduceEntry()
+            L.call("rv_wgrad_reduce_entry", ctypes.byref(wg), ctypes.byref(wsh), L.ptr(ws), L.ptr(grad), ctypes.byref(entry))
+            t.deferred_wgrad.append((entry, ws, grad))
+            t.add_param_grad(layer.weight, grad, deferred=True)
+            return
         if wg is not g:
             folded, grad = grad, torch.empty((g.cu, g.cv, g.kh, g.kw), dtype=torch.float32, device=t.device)
             L.call("rv_unfold_weight_grad", ctypes.byref(g), L.ptr(folded), L.ptr(grad), L.i32(0), L.stream_ptr())

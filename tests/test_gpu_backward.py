@@ -661,3 +661,40 @@ def test_a_training_step_frees_its_activations_without_the_cycle_collector():
     finally:
         gc.enable()
     assert grown < (1 << 20), f"{grown / 2**20:.1f} MiB still allocated after three steps with the cycle collector off"
+
+
+def test_deferred_weight_gradient_reductions_equal_the_immediate_ones(golden, monkeypatch):
+    """The split-K sums of a program's weight gradients leave in ONE batched launch at the end of its backward
+    (``Tape.flush_wgrad_reduces`` / ``rv_wgrad_reduce_batch``) instead of one reduce launch behind every weight-gradient kernel:
+    same slab order per element, so every parameter gradient of the tiny detector is bit-identical to the immediate form, and
+    the number of reduce launches drops to one per program."""
+    from range_view_3d_detection_amd import _lib as L
+    from range_view_3d_detection_amd import engine as E
+    from test_gpu_model import load_tiny
+
+    g = golden("tiny_model")
+
+    def run(defer):
+        monkeypatch.setattr(E, "DEFER_WGRAD_REDUCE", defer)
+        calls = []
+        real = L.call
+        monkeypatch.setattr(L, "call", lambda name, *a: (calls.append(name), real(name, *a))[1])
+        torch.manual_seed(0)
+        backbone, head = load_tiny(g)
+        backbone.train()
+        head.train()
+        d = {"features": g["features"].to(DEV), "cart": g["cart"].to(DEV), "mask": g["mask"].to(DEV)}
+        out, _ = head(backbone(d), d, return_loss=False)
+        (out[1][0]["logits"].float().square().mean() + out[1][0]["regressands"].float().abs().mean()).backward()
+        torch.cuda.synchronize()
+        monkeypatch.setattr(L, "call", real)
+        grads = {n: p.grad.clone() for n, p in list(backbone.named_parameters()) + list(head.named_parameters()) if p.grad is not None}
+        return calls, grads
+
+    calls_d, grads_d = run(True)
+    calls_i, grads_i = run(False)
+    assert calls_d.count("rv_wgrad_reduce_batch") >= 1 and calls_i.count("rv_wgrad_reduce_batch") == 0
+    assert calls_d.count("rv_wgrad_reduce_batch") <= 3  # one per program (backbone + stem, the towers)
+    assert grads_d.keys() == grads_i.keys() and len(grads_d) > 20
+    for k in grads_d:
+        assert torch.equal(grads_d[k], grads_i[k]), k
