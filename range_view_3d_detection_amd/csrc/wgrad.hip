@@ -758,20 +758,20 @@ int plan(const rvTapGeom* g, const rvTapShape* s, WgradPlan* p) {
         p->groups = g->kh * ((g->kw + 2) / 3);
         p->chunks = s->N * s->H * ((s->Wu + 63) / 64);
         const int base2 = p->groups * p->tiles_u * p->tiles_v;
-        // split-K factor: whole rounds of 256 CUs (a 2.06-round grid ran 30 % slower than a 3-round one), at least 32
-        // K chunks per block so that the fp32 slab traffic stays small next to the MFMA work
+        // split-K factor: ONE round of workgroups, as close to 256 as the tile count allows (round-4 sweep over the factor,
+        // profiles/r04_wgrad_ksplit.txt: 128 <-> 128 3x3 at W = 2656 takes 185 us with 255 workgroups and 220-290 us with 504 / 768
+        // / 1008; 256 <-> 256 3x3 504 us with 252 against 528 with 768; the 1x1 256 <-> 256 107 us with 256 against 155 with 1024;
+        // 512 <-> 512 the same with 240 and 768 -- every extra round pays the per-workgroup prologue, the 196 KB slab and its
+        // share of the reduction again), at least 32 K chunks per block so that the fp32 slab traffic stays small next to the MFMA
+        // work; layers with more tiles than CUs take no split at all
         int64_t ks_max = p->chunks / 32;
         if (ks_max < 1) ks_max = 1;
-        if (ks_max * base2 > 1024) ks_max = 1024 / base2 > 0 ? 1024 / base2 : 1;
-        int64_t ks2 = 1;
-        double best = -1.0;
-        for (int64_t k = 1; k <= ks_max; ++k) {
-            const int64_t grid = k * base2, rounds = (grid + 255) / 256;
-            const double eff = (double)grid / (double)(rounds * 256) + 1e-6 * (double)grid;
-            if (eff > best) {
-                best = eff;
-                ks2 = k;
-            }
+        int64_t ks2 = 256 / base2;
+        if (ks2 < 1) ks2 = 1;
+        if (ks2 > ks_max) ks2 = ks_max;
+        if (const char* force = getenv("RV3D_WGRAD_KSPLIT")) {  // (experiments: profiles/tools/sweep_wgrad_ksplit.py)
+            const int64_t f = atoll(force);
+            if (f >= 1) ks2 = f < ks_max ? f : ks_max;
         }
         p->chunks_per_split = (int)((p->chunks + ks2 - 1) / ks2);
         p->ksplit = (p->chunks + p->chunks_per_split - 1) / p->chunks_per_split;
