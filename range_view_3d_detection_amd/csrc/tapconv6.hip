@@ -463,8 +463,10 @@ int g_tapconv6_min_blocks = getenv("RV3D_TC6_MIN_BLOCKS") ? atoi(getenv("RV3D_TC
 bool rv_tapconv6_plan(TapConvArgs* a, int* tiles, size_t* lds) {
     if (a->step != 1) return false;
     if (a->flags & (RV_IN_AFFINE | RV_IN_RELU | RV_OUT_F32)) return false;  // the DMA path has no register prologue
-    if ((a->flags & RV_OUT_BNB) && (a->flags & RV_OUT_ACCUM) && !a->bnb_mask) return false;  // (accumulating sums: the masked last-writer form only)
-    if ((a->flags & RV_OUT_BNB) && a->bnb_mask && !(a->flags & RV_OUT_ACCUM)) return false;
+    // the masked last-writer form (sums over an ACCUMULATED gradient: three 16-byte prefetches per pass, 192 registers over this
+    // tile's sixteen passes) spills 177 registers here and ran at 16 % matrix-pipe occupancy (profiles/r04_mfma_counters.json,
+    // first collection): those few launches stay on the fifth generation, whose 8-pass 128-channel instance holds them
+    if ((a->flags & RV_OUT_BNB) && (a->flags & RV_OUT_ACCUM) && getenv("RV3D_T6_EPI3") == nullptr) return false;
     if (a->C_src % kBK != 0 || a->C_dst % kBN != 0) return false;
     const int wm_total = a->W_dst / a->phases;
     if (wm_total < kTC || a->H < kTR) return false;

@@ -463,8 +463,11 @@ DEFER_WGRAD_REDUCE = os.environ.get("RV3D_DEFER_WGRAD_REDUCE") is not None
 # conv -> BatchNorm(+ReLU) -> conv: the second conv's backward-data launch also forms the BatchNorm-backward sums (rv_tap_data_grad_bnb)
 BNB_FUSE = os.environ.get("RV3D_NO_BNB_FUSE") is None
 # ... and where the gradient of a block output relu(bn(y) + x) has several writers, its LAST writer (the accumulating
-# backward-data launch of the next block's first conv) forms them over the complete gradient (RV_BNB_MASK)
-BNB_LAST_WRITER = os.environ.get("RV3D_NO_BNB_LAST_WRITER") is None
+# backward-data launch of the next block's first conv) can form them over the complete gradient (RV_BNB_MASK).  OPT-IN since
+# round 4 (RV3D_BNB_LAST_WRITER=1): built in round 3 as time-neutral (9 reduce passes fewer, three 16-byte prefetches per
+# epilogue pass); with the round-4 kernels the same A/B reads 97.2 / 98.4 ms per step without it against 97.7-98.3 with it
+# (same box, profiles/r04_ab_notes.md) -- the masked epilogue runs at 16 % matrix-pipe occupancy.
+BNB_LAST_WRITER = os.environ.get("RV3D_BNB_LAST_WRITER") is not None
 
 
 def _dma_eligible(geom, n: int, h: int, wu: int, wv: int, ld_src: int, ld_dst: int, scatter: bool) -> bool:

@@ -575,6 +575,8 @@ def test_last_writer_forms_the_block_output_batchnorm_sums(C, W):
         x = torch.randn(2, C, 16, W, generator=gen).to(DEV)
         probe = torch.randn(2, C, 16, W, generator=gen).to(DEV)
 
+        default = E.BNB_LAST_WRITER  # (opt-in since round 4)
+
         def run(on: bool):
             E.BNB_LAST_WRITER = on
             n0 = engine_bwd.LAST_WRITER_LAUNCHES
@@ -585,7 +587,7 @@ def test_last_writer_forms_the_block_output_batchnorm_sums(C, W):
                 return ({k: p.grad.detach().float().cpu() for k, p in m.named_parameters()}, xi.grad.detach().float().cpu(),
                         engine_bwd.LAST_WRITER_LAUNCHES - n0)
             finally:
-                E.BNB_LAST_WRITER = True
+                E.BNB_LAST_WRITER = default
 
         ga, dxa, na = run(True)
         gb, dxb, nb = run(False)
