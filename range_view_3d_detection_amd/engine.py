@@ -248,13 +248,20 @@ class GradSync:
             total += (p.numel() + 63) // 64 * 64  # 256-byte aligned views
         dev = self.params[0].device
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._views: Dict[int, Tensor] = {}
         self.works: List[tuple] = []
         self.pending: List[nn.Parameter] = []  # parameters whose gradient sits in the flat buffer since the last finish()
         self.bytes = 4 * sum(p.numel() for p in self.params)
 
     def view(self, p: nn.Parameter) -> Tensor:
-        o, n = self.offsets[id(p)]
-        return self.flat[o : o + n].view_as(p)  # (a fresh tensor object each time: autograd may keep it as p.grad without a copy)
+        """This parameter's region of the flat buffer, shaped like it.  ONE tensor object per parameter for the life of the
+        GradSync (autograd never sees these: ``finish()`` installs them): making 238 views per step was 2-3 ms of host time with
+        the GPU idle at the end of the backward pass (profiles/r04_syncbn_collectives.md)."""
+        v = self._views.get(id(p))
+        if v is None:
+            o, n = self.offsets[id(p)]
+            v = self._views[id(p)] = self.flat[o : o + n].view_as(p)
+        return v
 
     def broadcast_parameters(self, module: nn.Module) -> None:
         """Rank 0's parameters and buffers to every rank, once (what DDP does at construction)."""
@@ -275,8 +282,7 @@ class GradSync:
         if not idx:
             return out
         for i in idx:
-            g = params[i].grad
-            if g is not None and g.data_ptr() == self.flat.data_ptr() + 4 * self.offsets[id(params[i])][0]:
+            if params[i].grad is not None and params[i].grad is self._views.get(id(params[i])):
                 raise L.RvError("GradSync: p.grad still is last step's view of the flat buffer -- call zero_grad(set_to_none=True) "
                                 "before backward (gradient accumulation over several backward passes is not supported)")
         dst = [self.view(params[i]) for i in idx]
@@ -1084,7 +1090,7 @@ class SmallKOp(Op):
                 # SyncBN: the moments are sums over pixels -> all-reduce them together with this rank's pixel count (the slot
                 # behind them); the closed form then reads the GLOBAL count on the device (count = -1): no host round trip
                 cin_pad = 4 if cin <= 4 else 8
-                moments[cin_pad + cin_pad * cin_pad] = float(x.pixels)
+                moments[cin_pad + cin_pad * cin_pad : cin_pad + cin_pad * cin_pad + 1].fill_(float(x.pixels))  # (fill: a kernel argument, not a blocking host-to-device copy)
                 COLLECTIVES.add(moments)
                 all_reduce_(moments)
                 self.count = -1

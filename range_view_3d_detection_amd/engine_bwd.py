@@ -257,7 +257,8 @@ def _global_s01(sums: Tensor, cp: int, pixels: int) -> Tensor:
     kernel reads the GLOBAL count there (``count = -1``), so no value comes back to the host."""
     g01 = torch.empty(2 * cp + 1, dtype=torch.float64, device=sums.device)
     g01[: 2 * cp] = sums[: 2 * cp]
-    g01[2 * cp] = float(pixels)
+    g01[2 * cp : 2 * cp + 1].fill_(float(pixels))  # (a kernel argument; `g01[i] = python_float` is a pageable host-to-device copy that blocks the
+                                        #  host until the stream has drained -- 25 ms twice per step, profiles/r04_syncbn_collectives.md)
     E.COLLECTIVES.add(g01)
     E.all_reduce_(g01)
     return g01
@@ -440,12 +441,16 @@ def combine_backward(op: "E.CombineOp", t: Tape) -> None:
                la.raw.ptr(), L.i32(la.raw.ld), L.ptr(la.bn.mean), L.ptr(la.bn.invstd), lb.raw.ptr(), L.i32(lb.raw.ld), L.ptr(lb.bn.mean),
                L.ptr(lb.bn.invstd), L.ptr(pa), L.ptr(pb), L.stream_ptr())
         ops = [t.bn_of.get(id(x)) for x in lazies]
-        if all(o is not None and o.sync_world == 1 for o in ops):
-            # ... and both apply passes as one (no collective between the sums and the coefficients): the gradients w.r.t. both raw
-            # conv outputs leave now; the two BatchNorm ops find nothing pending when the tape reaches them
+        if all(o is not None for o in ops) and (all(o.sync_world == 1 for o in ops) or (E.GROUP_SYNC_BN and all(o.sync_world > 1 for o in ops))):
+            # ... and both apply passes as one: the gradients w.r.t. both raw conv outputs leave now; the two BatchNorm ops find
+            # nothing pending when the tape reaches them.  SyncBN: the sums of both layers travel in ONE all-reduce first.
+            globs, locs = [None, None], [None, None]
+            if ops[0].sync_world > 1:
+                locs = [torch.empty((2, gout.cp), dtype=torch.float32, device=t.device) for _ in ops]
+                globs = E.allreduce_partial_rows_many([(pa, rows, gout.pixels, locs[0]), (pb, rows, gout.pixels, locs[1])])
             coefs = []
-            for o, part in zip(ops, (pa, pb)):
-                dgamma, dbeta, coef = _bn_finalize(o, t, part, rows, gout.pixels)
+            for o, part, gl, lo in zip(ops, (pa, pb), globs, locs):
+                dgamma, dbeta, coef = _bn_finalize(o, t, part, rows, gout.pixels, glob=gl, local=lo)
                 c = o.lazy.bn.module.num_features
                 t.add_param_grad(o.lazy.bn.module.weight, dgamma[:c])
                 t.add_param_grad(o.lazy.bn.module.bias, dbeta[:c])

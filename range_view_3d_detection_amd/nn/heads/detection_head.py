@@ -74,8 +74,14 @@ def compute_targets(x: Dict[str, Any], tasks_config: Mapping, fpn_strides: Seque
     counts_per = np.bincount(cub[:, -1].astype(np.int64), minlength=B) if cub.shape[0] else np.zeros(B, dtype=np.int64)
     offsets = np.concatenate([[0], np.cumsum(counts_per)]).astype(np.int32)
     m = int(cub.shape[0])
-    cub_d = torch.from_numpy(np.ascontiguousarray(cub)).to(dev)
-    off_d = torch.from_numpy(offsets).to(dev)
+    # ONE pinned staging buffer, uploaded without blocking the host: a pageable `.to(device)` waits until the stream has drained
+    # (the whole forward pass, ~20 ms twice per step: the host lost its lead over the GPU right before the backward pass)
+    stage = torch.empty(10 * max(m, 1) + (B + 1 + 1) // 2, dtype=torch.float64, pin_memory=True)
+    stage[: 10 * m].view(m, 10).copy_(torch.from_numpy(np.ascontiguousarray(cub)))
+    stage[10 * max(m, 1) :].view(torch.int32)[: B + 1].copy_(torch.from_numpy(offsets))
+    stage_d = stage.to(dev, non_blocking=True)
+    cub_d = stage_d[: 10 * m].view(m, 10)
+    off_d = stage_d[10 * max(m, 1) :].view(torch.int32)[: B + 1]
     scratch = torch.empty((3, max(m, 1)), dtype=torch.int32, device=dev)
     cart32 = cart.detach().float().contiguous()
     labels = torch.empty((B, H, W), dtype=torch.int64, device=dev)
