@@ -615,6 +615,7 @@ __global__ __launch_bounds__(256) void ew_combine_kernel(const EwArgs e) {
 // The same map with thread = (pixel lane, channel octet): the folded-BatchNorm constants of the thread's octet stay in
 // registers, and every workgroup walks one CONTIGUOUS pixel range with two pixels in flight (see bn_bwd_apply_kernel:
 // contiguous ranges read + write ~15 % faster than a grid-stride comb).  c8 <= 256.
+template <bool NT>  // NT: non-temporal loads and stores (tensors beyond the Infinity Cache: nothing of them is found there again)
 __global__ __launch_bounds__(256) void ew_combine_rows_kernel(const EwArgs e) {
     const int tid = threadIdx.x;
     const int lanes_px = 256 / e.c8;
@@ -652,23 +653,31 @@ __global__ __launch_bounds__(256) void ew_combine_rows_kernel(const EwArgs e) {
             if (e.flags & RV_EW_RELU_OUT) x = fmaxf(x, 0.f);
             va[j] = x;
         }
-        store8(e.out + px * e.ld_out + c, va);
+        if (NT) {
+            u32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = pack_bf2(va[2 * j], va[2 * j + 1]);
+            __builtin_nontemporal_store(v, (u32x4*)(e.out + px * e.ld_out + c));
+        } else {
+            store8(e.out + px * e.ld_out + c, va);
+        }
     };
+    auto ld = [&](const bf16_t* p) -> u32x4 { return NT ? __builtin_nontemporal_load((const u32x4*)p) : *(const u32x4*)p; };
     int64_t px = (int64_t)blockIdx.x * per + pl;
     for (; px + lanes_px < end; px += 2 * lanes_px) {
-        const u32x4 a0 = *(const u32x4*)(e.a + px * e.ld_a + c), a1 = *(const u32x4*)(e.a + (px + lanes_px) * e.ld_a + c);
+        const u32x4 a0 = ld(e.a + px * e.ld_a + c), a1 = ld(e.a + (px + lanes_px) * e.ld_a + c);
         u32x4 b0 = {}, b1 = {};
         if (e.b) {
-            b0 = *(const u32x4*)(e.b + px * e.ld_b + c);
-            b1 = *(const u32x4*)(e.b + (px + lanes_px) * e.ld_b + c);
+            b0 = ld(e.b + px * e.ld_b + c);
+            b1 = ld(e.b + (px + lanes_px) * e.ld_b + c);
         }
         finish(px, a0, b0);
         finish(px + lanes_px, a1, b1);
     }
     if (px < end) {
-        const u32x4 a0 = *(const u32x4*)(e.a + px * e.ld_a + c);
+        const u32x4 a0 = ld(e.a + px * e.ld_a + c);
         u32x4 b0 = {};
-        if (e.b) b0 = *(const u32x4*)(e.b + px * e.ld_b + c);
+        if (e.b) b0 = ld(e.b + px * e.ld_b + c);
         finish(px, a0, b0);
     }
 }
@@ -693,7 +702,8 @@ extern "C" int rv_ew_combine(int64_t pixels, int32_t c, const void* a, int32_t l
         const int lanes_px = 256 / e.c8;
         int64_t blocks = (pixels + lanes_px - 1) / lanes_px;
         if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(ew_combine_rows_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, e);
+        if (getenv("RV3D_EW_NO_NT") == nullptr) hipLaunchKernelGGL(ew_combine_rows_kernel<true>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, e);
+        else hipLaunchKernelGGL(ew_combine_rows_kernel<false>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, e);
     } else {
         hipLaunchKernelGGL(ew_combine_kernel, dim3(ew_grid(pixels * (c / 8))), dim3(256), 0, (hipStream_t)stream, e);
     }

@@ -46,6 +46,7 @@ struct TapConvArgs {
     // RV_OUT_ACCUM: the tensor added to the result -- dst itself (gradient fan-in) or a residual (rv_tap_residual), same pixels as dst
     const bf16_t* res;
     int32_t ld_res;
+    int32_t stats_per_wg;  // tapconv6: RV_OUT_STATS rows per WORKGROUP (accumulated over its tiles in LDS) instead of per tile
     TapTable tt;
 };
 
@@ -70,6 +71,7 @@ bool rv_tapconv5_plan(TapConvArgs* a, int* tiles, size_t* lds, int* bn);
 int rv_tapconv5_launch(const TapConvArgs& a, size_t lds, int bn, hipStream_t stream);
 
 // sixth-generation kernel (tapconv6.hip): 512-pixel x 128-channel tiles, 32-channel chunks, input halo resident in LDS across
-// the taps; stats rows = 4 * tiles, BatchNorm-backward rows = tiles
-bool rv_tapconv6_plan(TapConvArgs* a, int* tiles, size_t* lds);
+// the taps; *stats_rows = rows of the partial-statistics buffer (4 per group of workgroups that share a pixel tile when the
+// launch is persistent, else 4 per tile), BatchNorm-backward rows = tiles
+bool rv_tapconv6_plan(TapConvArgs* a, int* tiles, size_t* lds, int* stats_rows);
 int rv_tapconv6_launch(const TapConvArgs& a, size_t lds, hipStream_t stream);

@@ -51,7 +51,8 @@ constexpr int kAhead = RV_T6_AHEAD;                         // a weight piece is
 constexpr int kRing = 2 * kHaloBytes;                       // weight ring behind the two halo buffers
 constexpr int kScratch = kRing + kNRing * kPiece;           // 1 KB target of the dummy halo instructions
 constexpr int kTab = kScratch + 1024;                       // tap table (prologue hand-off)
-constexpr int kLds = kTab + 32 * 4;
+constexpr int kStatAcc = kTab + 32 * 4;                     // per-workgroup statistic accumulators: float [8 waves][4 j][16 channels][2]
+constexpr int kLds = kStatAcc + 8 * 4 * 16 * 2 * 4;
 constexpr int kMinTaps = kAhead + 2 > 6 ? kAhead + 2 : 6;  // (the K-tile bodies 0..5 are unconditional)
 
 __device__ __attribute__((aligned(256))) uint32_t g_zero_page6[64];
@@ -87,6 +88,18 @@ __global__ __launch_bounds__(512, 2) void tapconv6_kernel(const TapConvArgs a) {
     // one XCD (they read the same halo through that XCD's L2)
     const int gy = a.n_tiles;
     const int xcd = blockIdx.x & 7, wslot = blockIdx.x >> 3, nslots = gridDim.x >> 3;  // (gridDim.x % 8 == 0)
+    // RV_OUT_STATS of a persistent launch: the (sum, sum of squares) rows of a workgroup's tiles are accumulated here and written
+    // once at the end -- 4 rows per group of gy workgroups instead of 4 per tile (4096 rows behind a 4 x 64 x 2048 launch: the
+    // finalize then needs its two-stage column reduction; <= 1024 rows take the one-launch form).  Slots are private to one lane.
+    auto stat_slot = [&]() { return (float*)(smem + kStatAcc) + (wave * 4 * 16 + l15) * 2; };  // + j * 32 (recomputed where used: no register held over the K loop)
+    if (a.stats_per_wg && lg == 0) {
+        float* stat_acc = stat_slot();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            stat_acc[j * 32] = 0.f;
+            stat_acc[j * 32 + 1] = 0.f;
+        }
+    }
     for (int k = 0;; ++k) {
     const int xslot = wslot + nslots * k;
     if (xslot >= a.tiles_per_xcd * gy) break;
@@ -285,6 +298,7 @@ __global__ __launch_bounds__(512, 2) void tapconv6_kernel(const TapConvArgs a) {
     }
     if (a.flags & RV_OUT_STATS) {
         float* prow = a.stats + ((int64_t)(tile * 4 + wr) * 2) * a.C_dst;
+        float* stat_acc = stat_slot();
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float s = 0.f, q = 0.f;
@@ -302,8 +316,13 @@ __global__ __launch_bounds__(512, 2) void tapconv6_kernel(const TapConvArgs a) {
             q += __shfl_xor(q, 32, 64);
             const int c = n0 + wc * 64 + j * 16 + l15;
             if (lg == 0) {
-                prow[c] = s;
-                prow[a.C_dst + c] = q;
+                if (a.stats_per_wg) {
+                    stat_acc[j * 32] += s;
+                    stat_acc[j * 32 + 1] += q;
+                } else {
+                    prow[c] = s;
+                    prow[a.C_dst + c] = q;
+                }
             }
         }
     }
@@ -452,6 +471,18 @@ __global__ __launch_bounds__(512, 2) void tapconv6_kernel(const TapConvArgs a) {
     }
     __syncthreads();  // the staged output / BatchNorm sums of this tile are dead before the next tile's loads land in LDS
     }  // persistent tile loop
+    if ((a.flags & RV_OUT_STATS) && a.stats_per_wg && lg == 0) {
+        // (nslots % gy == 0, checked by the host: the channel tile of a workgroup is the same for all of its tiles, and the gy
+        //  workgroups wslot / gy == const of one XCD fill one row group between them -- workgroups without a tile write zeros)
+        float* prow = a.stats + ((int64_t)((xcd * (nslots / gy) + wslot / gy) * 4 + wr) * 2) * a.C_dst;
+        const float* stat_acc = stat_slot();
+        const int c0 = (wslot % gy) * kBN + wc * 64 + l15;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            prow[c0 + j * 16] = stat_acc[j * 32];
+            prow[a.C_dst + c0 + j * 16] = stat_acc[j * 32 + 1];
+        }
+    }
 }
 
 }  // namespace
@@ -460,7 +491,13 @@ extern int g_tapconv5_persist;
 int g_tapconv6_min_blocks = getenv("RV3D_TC6_MIN_BLOCKS") ? atoi(getenv("RV3D_TC6_MIN_BLOCKS")) : 256;  // rv_set_option("tapconv6_min_blocks")
 
 // returns false when the layer is not eligible (caller falls back to tapconv5 / tapconv4 / ...)
-bool rv_tapconv6_plan(TapConvArgs* a, int* tiles, size_t* lds) {
+static int tapconv6_grid(const TapConvArgs& a) {
+    int grid = 8 * a.tiles_per_xcd * a.n_tiles;
+    if (g_tapconv5_persist > 0 && grid > g_tapconv5_persist) grid = g_tapconv5_persist >= 8 ? g_tapconv5_persist & ~7 : 8;  // one workgroup per CU
+    return grid;
+}
+
+bool rv_tapconv6_plan(TapConvArgs* a, int* tiles, size_t* lds, int* stats_rows) {
     if (a->step != 1) return false;
     if (a->flags & (RV_IN_AFFINE | RV_IN_RELU | RV_OUT_F32)) return false;  // the DMA path has no register prologue
     // the masked last-writer form (sums over an ACCUMULATED gradient: three 16-byte prefetches per pass, 192 registers over this
@@ -500,7 +537,10 @@ bool rv_tapconv6_plan(TapConvArgs* a, int* tiles, size_t* lds) {
     a->n_tiles = a->C_dst / kBN;
     a->tiles_per_xcd = rv_ceil_div(a->total_tiles, 8);
     if ((int64_t)a->total_tiles * a->n_tiles < g_tapconv6_min_blocks) return false;  // fewer tiles than CUs: the 256-pixel tiles fill the chip better
-    *tiles = a->total_tiles;  // stats rows = 4 * tiles, BatchNorm-backward rows = tiles
+    *tiles = a->total_tiles;  // BatchNorm-backward rows = tiles
+    const int grid = tapconv6_grid(*a), nslots = grid / 8;
+    a->stats_per_wg = (nslots % a->n_tiles == 0 && getenv("RV3D_T6_TILE_STATS") == nullptr) ? 1 : 0;
+    *stats_rows = a->stats_per_wg ? (grid / a->n_tiles) * 4 : a->total_tiles * 4;
     *lds = (size_t)kLds;
     const size_t epi = (size_t)kTR * kTC * (kBN + 8) * sizeof(bf16_t);
     if (*lds < epi) *lds = epi;
@@ -516,8 +556,7 @@ int rv_tapconv6_launch(const TapConvArgs& a, size_t lds, hipStream_t stream) {
         (void)hipFuncSetAttribute((const void*)tapconv6_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    int grid = 8 * a.tiles_per_xcd * a.n_tiles;
-    if (g_tapconv5_persist > 0 && grid > g_tapconv5_persist) grid = g_tapconv5_persist >= 8 ? g_tapconv5_persist & ~7 : 8;  // one workgroup per CU
+    const int grid = tapconv6_grid(a);
     const int epi = (a.flags & RV_OUT_BNB) ? ((a.flags & RV_OUT_ACCUM) ? 3 : 1) : ((a.flags & RV_OUT_ACCUM) ? 2 : 0);
 #ifdef RV_T6_DIAG_BUILD
     if (const char* dv = getenv("RV3D_T6_DIAG")) {

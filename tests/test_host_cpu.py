@@ -50,7 +50,8 @@ def test_host_side_geometry(lib):
     info = (ctypes.c_int32 * 4)()
     assert h.rv_tap_launch_info(ctypes.byref(g), ctypes.byref(s), 0, info) == 0
     assert list(info) == [6, 128, 64 * 4 * 4, 2]  # tapconv6: (16 rows x 32 cols) pixel tiles x two 128-channel tiles
-    assert h.rv_tap_stats_rows(ctypes.byref(g), ctypes.byref(s), 0) == 4 * 64 * 4 * 4
+    # statistic rows of a persistent launch: 4 wave rows per group of workgroups sharing a pixel tile (256 workgroups / 2 channel tiles)
+    assert h.rv_tap_stats_rows(ctypes.byref(g), ctypes.byref(s), 0) == 4 * 128
     assert h.rv_set_option(b"tapconv6_enable", 0) == 1
     assert h.rv_tap_launch_info(ctypes.byref(g), ctypes.byref(s), 0, info) == 0
     assert list(info) == [5, 256, 64 * 8 * 4, 1]  # tapconv5<256>: (8 rows x 32 cols) pixel tiles x one 256-channel tile
