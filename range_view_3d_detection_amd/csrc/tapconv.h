@@ -46,7 +46,7 @@ struct TapConvArgs {
     // RV_OUT_ACCUM: the tensor added to the result -- dst itself (gradient fan-in) or a residual (rv_tap_residual), same pixels as dst
     const bf16_t* res;
     int32_t ld_res;
-    int32_t stats_per_wg;  // tapconv6: RV_OUT_STATS rows per WORKGROUP (accumulated over its tiles in LDS) instead of per tile
+    int32_t stats_per_wg;  // tapconv6: RV_OUT_STATS / RV_OUT_BNB rows per WORKGROUP (accumulated over its tiles in LDS) instead of per tile
     TapTable tt;
 };
 
@@ -72,6 +72,6 @@ int rv_tapconv5_launch(const TapConvArgs& a, size_t lds, int bn, hipStream_t str
 
 // sixth-generation kernel (tapconv6.hip): 512-pixel x 128-channel tiles, 32-channel chunks, input halo resident in LDS across
 // the taps; *stats_rows = rows of the partial-statistics buffer (4 per group of workgroups that share a pixel tile when the
-// launch is persistent, else 4 per tile), BatchNorm-backward rows = tiles
-bool rv_tapconv6_plan(TapConvArgs* a, int* tiles, size_t* lds, int* stats_rows);
+// launch is persistent, else 4 per tile), *bnb_rows = rows of the BatchNorm-backward partial sums (one per such group, else per tile)
+bool rv_tapconv6_plan(TapConvArgs* a, int* tiles, size_t* lds, int* stats_rows, int* bnb_rows);
 int rv_tapconv6_launch(const TapConvArgs& a, size_t lds, hipStream_t stream);

@@ -470,12 +470,12 @@ static int tap_launch(const rvTapGeom* g, const rvTapShape* s, bool scatter, con
 
     // multi-tap layers with at least one round of 512-pixel x 128-channel tiles (tapconv6.hip)
     if (g_tapconv6_enable && g_tapconv5_enable && getenv("RV3D_NO_TAPCONV6") == nullptr) {
-        int tiles, srows;
+        int tiles, srows, brows;
         size_t lds6;
         TapConvArgs a6 = a;
-        if (rv_tapconv6_plan(&a6, &tiles, &lds6, &srows)) {
+        if (rv_tapconv6_plan(&a6, &tiles, &lds6, &srows, &brows)) {
             if (stats_rows) *stats_rows = srows;
-            if (bnb_rows) *bnb_rows = tiles;
+            if (bnb_rows) *bnb_rows = brows;
             if (info) {
                 info[0] = 6;
                 info[1] = 128;

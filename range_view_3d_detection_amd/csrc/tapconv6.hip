@@ -52,7 +52,8 @@ constexpr int kRing = 2 * kHaloBytes;                       // weight ring behin
 constexpr int kScratch = kRing + kNRing * kPiece;           // 1 KB target of the dummy halo instructions
 constexpr int kTab = kScratch + 1024;                       // tap table (prologue hand-off)
 constexpr int kStatAcc = kTab + 32 * 4;                     // per-workgroup statistic accumulators: float [8 waves][4 j][16 channels][2]
-constexpr int kLds = kStatAcc + 8 * 4 * 16 * 2 * 4;
+constexpr int kBnbAcc = kStatAcc + 8 * 4 * 16 * 2 * 4;      // per-workgroup BatchNorm-backward sums: float [16 chunks][16] (thread tid < 256 owns one)
+constexpr int kLds = kBnbAcc + 256 * 4;
 constexpr int kMinTaps = kAhead + 2 > 6 ? kAhead + 2 : 6;  // (the K-tile bodies 0..5 are unconditional)
 
 __device__ __attribute__((aligned(256))) uint32_t g_zero_page6[64];
@@ -100,6 +101,7 @@ __global__ __launch_bounds__(512, 2) void tapconv6_kernel(const TapConvArgs a) {
             stat_acc[j * 32 + 1] = 0.f;
         }
     }
+    if ((EPI == 1 || EPI == 3) && a.stats_per_wg && tid < 256) ((float*)(smem + kBnbAcc))[tid] = 0.f;  // (same rows rule for the BatchNorm-backward sums)
     for (int k = 0;; ++k) {
     const int xslot = wslot + nslots * k;
     if (xslot >= a.tiles_per_xcd * gy) break;
@@ -466,11 +468,17 @@ __global__ __launch_bounds__(512, 2) void tapconv6_kernel(const TapConvArgs a) {
             float sum = 0.f;
 #pragma unroll
             for (int w = 0; w < 8; ++w) sum += red[(w * kChunks + chunk) * 16 + jj];
-            a.bnb_partial[((int64_t)tile * 2 + (jj >> 3)) * a.C_dst + n0 + chunk * 8 + (jj & 7)] = sum;
+            if (a.stats_per_wg) ((float*)(smem + kBnbAcc))[tid] += sum;  // (tid = chunk * 16 + jj: a private slot)
+            else a.bnb_partial[((int64_t)tile * 2 + (jj >> 3)) * a.C_dst + n0 + chunk * 8 + (jj & 7)] = sum;
         }
     }
     __syncthreads();  // the staged output / BatchNorm sums of this tile are dead before the next tile's loads land in LDS
     }  // persistent tile loop
+    if ((EPI == 1 || EPI == 3) && a.stats_per_wg && tid < 256) {
+        const int chunk = tid >> 4, jj = tid & 15;
+        a.bnb_partial[((int64_t)(xcd * (nslots / gy) + wslot / gy) * 2 + (jj >> 3)) * a.C_dst + (wslot % gy) * kBN + chunk * 8 + (jj & 7)] =
+            ((const float*)(smem + kBnbAcc))[tid];
+    }
     if ((a.flags & RV_OUT_STATS) && a.stats_per_wg && lg == 0) {
         // (nslots % gy == 0, checked by the host: the channel tile of a workgroup is the same for all of its tiles, and the gy
         //  workgroups wslot / gy == const of one XCD fill one row group between them -- workgroups without a tile write zeros)
@@ -497,7 +505,7 @@ static int tapconv6_grid(const TapConvArgs& a) {
     return grid;
 }
 
-bool rv_tapconv6_plan(TapConvArgs* a, int* tiles, size_t* lds, int* stats_rows) {
+bool rv_tapconv6_plan(TapConvArgs* a, int* tiles, size_t* lds, int* stats_rows, int* bnb_rows) {
     if (a->step != 1) return false;
     if (a->flags & (RV_IN_AFFINE | RV_IN_RELU | RV_OUT_F32)) return false;  // the DMA path has no register prologue
     // the masked last-writer form (sums over an ACCUMULATED gradient: three 16-byte prefetches per pass, 192 registers over this
@@ -537,10 +545,11 @@ bool rv_tapconv6_plan(TapConvArgs* a, int* tiles, size_t* lds, int* stats_rows) 
     a->n_tiles = a->C_dst / kBN;
     a->tiles_per_xcd = rv_ceil_div(a->total_tiles, 8);
     if ((int64_t)a->total_tiles * a->n_tiles < g_tapconv6_min_blocks) return false;  // fewer tiles than CUs: the 256-pixel tiles fill the chip better
-    *tiles = a->total_tiles;  // BatchNorm-backward rows = tiles
+    *tiles = a->total_tiles;
     const int grid = tapconv6_grid(*a), nslots = grid / 8;
     a->stats_per_wg = (nslots % a->n_tiles == 0 && getenv("RV3D_T6_TILE_STATS") == nullptr) ? 1 : 0;
     *stats_rows = a->stats_per_wg ? (grid / a->n_tiles) * 4 : a->total_tiles * 4;
+    *bnb_rows = a->stats_per_wg ? grid / a->n_tiles : a->total_tiles;
     *lds = (size_t)kLds;
     const size_t epi = (size_t)kTR * kTC * (kBN + 8) * sizeof(bf16_t);
     if (*lds < epi) *lds = epi;
