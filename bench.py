@@ -15,9 +15,14 @@ across ranks (weak scaling, 4 sweeps per GPU), gradient all-reduce over RCCL per
 BatchNorm statistics all-reduced (SyncBN as in conf/trainer/train.yaml:15).
 
 Rank 0 prints ONE JSON line (contract in the task statement) including
-  "roofline":     the dominant kernel (tapconv5: 256 x 256-tile bf16 MFMA tap-conv with the input halo resident in LDS)
+  "roofline":     the dominant kernel (tapconv6: 512-pixel x 128-channel-tile bf16 MFMA tap-conv with the input halo resident in LDS)
                   against the dense bf16 MFMA peak, timed live with events around each of its launches inside the timed
-                  region; `traffic` = its HBM-side bytes per launch from this round's PMC passes (profiles/);
+                  region; `traffic` = its HBM-side bytes per launch from this round's PMC passes (profiles/), `algorithmic_bytes`
+                  = operands once in + result once out per launch (SURVEY 8d);
+  "whole_step":   3 x the model's forward FLOPs (BASELINE.md section 2) over the step time, against the same peak;
+  "loss_first_step": the loss of the seed-0 model on sweep 0 of the seed-1234 batch before any update (one reproducible number;
+                  tests/test_gpu_fullsize_train.py compares it with the fp32 oracle);
+  "kernels" / "kernels_isolated": per-kernel event timings inside the timed region / with nothing else on the GPU;
   "cpu_baseline": the oracle (CPU restatement of the reference, ``oracle/``) timed on this box's host
                   cores on a bounded sample (N == 1 only).
 """
@@ -37,7 +42,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PMC_TRAFFIC = "profiles/r03_pmc_traffic.json"  # HBM bytes per launch per kernel, collected over this same command this round
+PMC_TRAFFIC = "profiles/r04_pmc_traffic.json"  # HBM bytes per launch per kernel, collected over this same command this round
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 (MI355X_MICROARCH.md: ~2.5 PF dense; 2:1-sparsity figures are not used)
 HBM_PEAK_GBS = 8000.0
 
@@ -370,6 +375,8 @@ def roofline(prof, iso) -> dict:
         # kernel family and tile width): launch-weighted mean over the instances whose name starts like ours
         stem = name[:-1] if name.endswith(">") else name
         hits = [v for k, v in rows.items() if k == name or k.startswith(stem + ",") or k.startswith(stem + ">")] or [v for k, v in rows.items() if k == name.split("<")[0]]
+        if not hits and name.startswith("tapconv6_kernel"):  # (its template arguments are the epilogue kind, not the tile width: all instances)
+            hits = [v for k, v in rows.items() if k.startswith("tapconv6_kernel<")]
         if hits:
             n = sum(v["launches"] for v in hits)
             r["traffic"] = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hits) / n
