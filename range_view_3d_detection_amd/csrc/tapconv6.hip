@@ -65,25 +65,37 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 // (two per K tile at positions 0..2) issued since the piece of the NEXT K tile went out, kAhead - 1 K tiles ago; from position
 // kAhead + 1 on the window holds no halo instruction (and the last K tile of a chunk, U >= kMinTaps - 1, thereby retires the
 // whole halo of the next chunk)
-// (late: the weight instruction is the LAST load of its K tile, so the window is one K tile shorter)
-constexpr int wait_count(int U, bool late = false) {
+constexpr int wait_count(int U) {
     if (U > kAhead) return kAhead - 1;
     int n = 0;
-    for (int u = U - kAhead + 1 + (late ? 1 : 0); u <= U; ++u) n += (u >= 0 && u < 3) ? 2 : 0;
+    for (int u = U - kAhead + 1; u <= U; ++u) n += (u >= 0 && u < 3) ? 2 : 0;
     return kAhead - 1 + n;
 }
 
-// EPI: 0 plain store (+ statistics / bias), 1 BatchNorm-sum epilogue (RV_OUT_BNB), 2 accumulate (RV_OUT_ACCUM), 3 both (the
-// masked last-writer form) -- template parameter for the reason given in tapconv5.hip (spills)
+// EPI: 0 plain store (+ statistics / bias), 1 BatchNorm-sum epilogue (RV_OUT_BNB), 2 accumulate (RV_OUT_ACCUM) -- template parameter
+// for the reason given in tapconv5.hip (spills); the masked last-writer form (both) stays on tapconv5
 // DIAG (diagnostic builds only, -DRV_T6_DIAG_BUILD; results wrong, timing only): 1 no DMA in the loop, 2 no fragment reads, 3 no MFMAs,
-// 4 every DMA lane reads the zero page, 5 no halo DMA, 6 no weight DMA, 7 weight DMA in the second load section
-template <int EPI, int DIAG = 0>
+// 4 every DMA lane reads the zero page, 8 no global stores in the epilogue, 9 no epilogue at all
+// SPLIT (round 4, A/B only -- RV3D_T6_SPLIT=1; measured SLOWER, default off).  The tile boundary costs ~7-10 us per tile and most of
+// it is the 128 KB of output stores: the same kernel without its global stores is 9 % / 10 % / 18 % faster on the 512- / 256- /
+// 128-channel layers (profiles/r04_tapconv6_ablation.md section 4).  First reading: vmcnt retires in order and counts stores with
+// loads, so the waves sit behind their own stores in the next tile's prologue.  SPLIT tests that: waves 0-3 issue ALL LDS-DMA and
+// never store, waves 4-7 issue ALL stores and never load in the K loop -- nobody waits behind a store.  Result: 0 % (512 channels),
+// -5 % (256), -9 % (128): the stores are not waited for by a wave, they occupy the CU's ONE vector-memory pipeline (~13-17 GB/s of
+// stores per CU = ~150 cycles per 1 KB store instruction, the guide's "store-issue-bound epilogue tail"), and every later load of any
+// wave queues behind them in that pipeline.  Staggering the workgroups' starts (a chip-wide burst?) changed nothing either.
+template <int EPI, int DIAG = 0, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void tapconv6_kernel(const TapConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     const int l15 = lane & 15, lg = lane >> 4;
+    constexpr int kIss = SPLIT ? 4 : 8;         // waves that issue LDS-DMA
+    constexpr int kHaloPer = 48 / kIss;         // halo instruction slots per issuing wave (41 real ones, the rest dummies)
+    constexpr int kHaloPerTile = kHaloPer / 3;  // ... issued per K tile at positions 0..2 of a chunk
+    const bool issuer = !SPLIT || wave < 4;     // (wave-uniform)
+    const bool storer = !SPLIT || wave >= 4;
 
     // XCD-aware persistent block order as in tapconv5: the channel tiles of one pixel tile sit on neighbouring workgroups of
     // one XCD (they read the same halo through that XCD's L2)
@@ -101,7 +113,8 @@ __global__ __launch_bounds__(512, 2) void tapconv6_kernel(const TapConvArgs a) {
             stat_acc[j * 32 + 1] = 0.f;
         }
     }
-    if ((EPI == 1 || EPI == 3) && a.stats_per_wg && tid < 256) ((float*)(smem + kBnbAcc))[tid] = 0.f;  // (same rows rule for the BatchNorm-backward sums)
+    if ((EPI == 1) && a.stats_per_wg && storer && (SPLIT ? tid - 256 : tid) < 256)
+        ((float*)(smem + kBnbAcc))[SPLIT ? tid - 256 : tid] = 0.f;  // (same rows rule for the BatchNorm-backward sums; slot owner = the thread that adds to it)
     for (int k = 0;; ++k) {
     const int xslot = wslot + nslots * k;
     if (xslot >= a.tiles_per_xcd * gy) break;
@@ -147,13 +160,18 @@ __global__ __launch_bounds__(512, 2) void tapconv6_kernel(const TapConvArgs a) {
     const int64_t w_img = (int64_t)a.C_dst * a.C_src;
     const bf16_t* w_ph = a.w + (int64_t)a.tt.w_first[ph] * w_img;
     const int b_voff = (n0 + wave * 16 + s_row) * a.C_src + kq8;
+    const int b_half = 64 * a.C_src;  // SPLIT: an issuing wave also covers channels 16 (w + 4) + s_row
     int bq = 0, bt = 0;  // K tile / tap of the piece being issued
     int b_so = 0;        // element offset of its (tap image, chunk) in the packed weight -- kept scalar
     auto stage_b = [&](int j) {
         const int so = __builtin_amdgcn_readfirstlane(b_so);
         const bf16_t* p = DIAG == 4 ? zero : w_ph + so + b_voff;
-        if (DIAG != 1 && DIAG != 6)
+        if (DIAG != 1) {
             __builtin_amdgcn_global_load_lds((glb_void_t*)p, (lds_void_t*)(smem + kRing + (j & (kNRing - 1)) * kPiece + wave * 1024), 16, 0, 0);
+            if (SPLIT)
+                __builtin_amdgcn_global_load_lds((glb_void_t*)(DIAG == 4 ? p : p + b_half),
+                                                 (lds_void_t*)(smem + kRing + (j & (kNRing - 1)) * kPiece + (wave + 4) * 1024), 16, 0, 0);
+        }
         const bool go = bq + 1 < nkt;  // pieces past the last K tile re-fetch it (never read; keeps the wait counts uniform)
         const bool wrap = bt + 1 == T;
         bq += go ? 1 : 0;
@@ -162,21 +180,21 @@ __global__ __launch_bounds__(512, 2) void tapconv6_kernel(const TapConvArgs a) {
     };
     // Halo: instruction q (0..40) covers pixel slots 16 q + s_row of the [18 rows][36 slots] image; wave w issues q = w, w + 8,
     // ..., w + 40 (q >= 41: dummies, zero page -> a scratch KB).  Source offsets once per tile (-1 = zero page).
-    int hoff[6];
+    int hoff[kHaloPer];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const int q = wave + 8 * i;
+    for (int i = 0; i < kHaloPer; ++i) {
+        const int q = wave + kIss * i;
         const int p = q * 16 + s_row;
         const int hr = (p * 1821) >> 16, hc = p - hr * kPitch;  // 1821 = ceil(65536 / 36): exact for p < 2^12
         const int row = row_base + hr, col = col_base + hc;
         const int bad = (q >= kHaloInstr) | (hc >= HW) | (hr >= HR) | (row < 0) | (row >= a.H) | (col < 0) | (col >= a.W_src);
         hoff[i] = ((row * a.W_src + col) * a.ld_src + kq8) | -bad;
     }
-    auto stage_halo = [&](int buf, int i, int kc) {  // i: compile-time index 0..5
-        const int q = wave + 8 * i;
+    auto stage_halo = [&](int buf, int i, int kc) {  // i: compile-time index 0 .. kHaloPer - 1
+        const int q = wave + kIss * i;
         const bf16_t* src = (hoff[i] >= 0 && DIAG != 4) ? src_img + (hoff[i] + kc * kBK) : zero;
         const int dst = q < kHaloInstr ? buf * kHaloBytes + q * 1024 : kScratch;
-        if (DIAG != 1 && DIAG != 5) __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(smem + dst), 16, 0, 0);
+        if (DIAG != 1) __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(smem + dst), 16, 0, 0);
     };
 
     // ---- fragment reads ---------------------------------------------------------------------------------------------
@@ -228,11 +246,13 @@ __global__ __launch_bounds__(512, 2) void tapconv6_kernel(const TapConvArgs a) {
     __builtin_amdgcn_s_barrier();
 
     // ---- prologue: halo of chunk 0, weight pieces 0 .. kAhead - 1 -------------------------------------------------------
+    if (issuer) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) stage_halo(0, i, 0);
+        for (int i = 0; i < kHaloPer; ++i) stage_halo(0, i, 0);
 #pragma unroll
-    for (int j = 0; j < kAhead; ++j) stage_b(j);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int j = 0; j < kAhead; ++j) stage_b(j);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (SPLIT: the issuing waves hold no stores -- this waits for loads only)
+    }
     __builtin_amdgcn_s_barrier();
     if (wave >= 4) __builtin_amdgcn_s_barrier();  // the second half of the workgroup runs one barrier behind the first
 
@@ -243,19 +263,26 @@ __global__ __launch_bounds__(512, 2) void tapconv6_kernel(const TapConvArgs a) {
     // during positions U = 0, 1, 2.  The wait (with the barrier behind it) makes piece kt + 1 visible to the next K tile.
 #define RV_KTILE(U, HALO)                                                                                         \
     {                                                                                                              \
-        constexpr int W = (HALO) ? wait_count(U, DIAG == 7) : kAhead - 1;                                          \
+        constexpr int W = (kIss == 4 ? 2 : 1) * ((HALO) ? wait_count(U) : kAhead - 1);                             \
         const int hbuf = (kc + 1) & 1;                                                                             \
-        if (DIAG != 7) stage_b(kt + kAhead);                                                                       \
-        if constexpr ((HALO) && (U) <= 2) stage_halo(hbuf, 2 * (U), kc + 1);                                       \
+        if (issuer) {                                                                                              \
+            stage_b(kt + kAhead);                                                                                  \
+            if constexpr ((HALO) && (U) <= 2) {                                                                    \
+                _Pragma("unroll") for (int h = 0; h < kHaloPerTile / 2; ++h) stage_halo(hbuf, kHaloPerTile * (U) + h, kc + 1); \
+            }                                                                                                      \
+        }                                                                                                          \
         addr_a((kc & 1) * kHaloBytes, sh);                                                                         \
         read_b(kt);                                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                                         \
         read_a(0);                                                                                                 \
         RV_PHASE_COMPUTE(0);                                                                                       \
-        if constexpr ((HALO) && (U) <= 2) stage_halo(hbuf, 2 * (U) + 1, kc + 1);                                   \
-        if (DIAG == 7) stage_b(kt + kAhead);                                                                       \
         read_a(1);                                                                                                 \
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W) : "memory");                                                   \
+        if (issuer) {                                                                                              \
+            if constexpr ((HALO) && (U) <= 2) {                                                                    \
+                _Pragma("unroll") for (int h = kHaloPerTile / 2; h < kHaloPerTile; ++h) stage_halo(hbuf, kHaloPerTile * (U) + h, kc + 1); \
+            }                                                                                                      \
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W) : "memory");                                               \
+        }                                                                                                          \
         RV_PHASE_COMPUTE(1);                                                                                       \
         ++kt;                                                                                                      \
         const bool wrap = ix + 1 == ncol;                                                                          \
@@ -341,6 +368,16 @@ __global__ __launch_bounds__(512, 2) void tapconv6_kernel(const TapConvArgs a) {
     }
     constexpr int kEpi = kBN + 8;
     bf16_t* epi = (bf16_t*)smem;  // [16 rows * 32 cols][kEpi]
+    if (DIAG == 9) {  // (timing only: no staging, no stores; keep the accumulators observable)
+        float s9 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s9 += acc[i][j][0];
+        if (s9 == 12345.678f) a.stats[0] = s9;
+        __syncthreads();
+        continue;
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -352,12 +389,17 @@ __global__ __launch_bounds__(512, 2) void tapconv6_kernel(const TapConvArgs a) {
                 epi[pm * kEpi + pc] = f2bf(acc[i][j][r]);
             }
     constexpr int kChunks = kBN / 8;  // 16
-    constexpr bool accum = EPI == 2 || EPI == 3;
-    constexpr bool bnb = EPI == 1 || EPI == 3;    // BatchNorm-backward sums of the layer whose output gradient is being written
-    constexpr bool bmask = EPI == 3;              // ... with the ReLU mask taken from the block output (last writer)
+    constexpr bool accum = EPI == 2;
+    constexpr bool bnb = EPI == 1;  // BatchNorm-backward sums of the layer whose output gradient is being written
+    static_assert(EPI >= 0 && EPI <= 2, "the masked last-writer epilogue (three prefetches per pass) stays on tapconv5");
+    // the store loop: thread st of the storing waves keeps ONE 8-channel chunk (st % 16) through all passes
+    constexpr int kStoreThreads = SPLIT ? 256 : 512;
+    constexpr int kPasses = kTR * kTC * kChunks / kStoreThreads;  // 16 (all waves store) / 32 (SPLIT: waves 4-7 store)
+    int st = SPLIT ? tid - 256 : tid;
+    asm volatile("" : "+v"(st));  // opaque HERE: the store loop's per-pass offsets are formed after the K loop, not hoisted above it (spills)
     float bsc[8], bsh[8], bmu[8], bis[8], s0[8], s1[8];
-    if (bnb) {
-        const int c = n0 + (tid & (kChunks - 1)) * 8;  // (512 % kChunks == 0: the chunk of a thread is the same in every pass)
+    if (bnb && storer) {
+        const int c = n0 + (st & (kChunks - 1)) * 8;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             bsc[j] = a.bnb_scale[c + j];
@@ -368,116 +410,105 @@ __global__ __launch_bounds__(512, 2) void tapconv6_kernel(const TapConvArgs a) {
             s1[j] = 0.f;
         }
     }
-    constexpr int kPasses = kTR * kTC * kChunks / 512;  // 16
-    u32x4 yv[kPasses];
-    u32x4 ov[bmask ? kPasses : 1], mv[bmask ? kPasses : 1];
-    if (bnb) {  // all of this thread's y chunks in flight at once, before the barrier that publishes the staged tile
+    // Passes in ROUNDS of eight with the next round's global reads (y of the BatchNorm sums / the old values of an accumulating
+    // launch) in flight while the current one is stored: 2 x 8 prefetch registers per array instead of one per pass (32 passes under
+    // SPLIT).  The reads are unconditional (clamped coordinates): straight-line code, so the compiler counts its vmcnt waits exactly
+    // instead of draining the queue at the first use.
+    constexpr int kRound = 8, kRounds = kPasses / kRound;
+    constexpr bool pre = bnb || accum;
+    u32x4 yv[pre ? 2 : 1][pre ? kRound : 1];
+    auto prefetch = [&](int r, int buf) {
 #pragma unroll
-        for (int it = 0; it < kPasses; ++it) {
-            const int q = tid + it * 512, pm = q / kChunks, c8 = q - pm * kChunks;
+        for (int i = 0; i < kRound; ++i) {
+            const int q = st + (r * kRound + i) * kStoreThreads, pm = q / kChunks, c8 = q - pm * kChunks;
             const int rr = pm / kTC, mm = pm - rr * kTC;
-            const int m = m0 + mm, c = n0 + c8 * 8, hh = h0 + rr;
-            yv[it] = u32x4{0u, 0u, 0u, 0u};
-            if (m < Wm && hh < a.H) yv[it] = *(const u32x4*)(a.bnb_y + (((int64_t)(n * a.H + hh) * a.W_dst) + (a.phases * m + ph)) * a.ld_bnb_y + c);
-        }
-    }
-    if (accum) {  // the old values of this thread's sixteen chunks likewise
-#pragma unroll
-        for (int it = 0; it < kPasses; ++it) {
-            const int q = tid + it * 512, pm = q / kChunks, c8 = q - pm * kChunks;
-            const int rr = pm / kTC, mm = pm - rr * kTC;
-            const int m = m0 + mm, c = n0 + c8 * 8, hh = h0 + rr;
-            u32x4 o = u32x4{0u, 0u, 0u, 0u}, kk = u32x4{0u, 0u, 0u, 0u};
+            const int m = min(m0 + mm, Wm - 1), hh = min(h0 + rr, a.H - 1), c = n0 + c8 * 8;
             const int64_t px = ((int64_t)(n * a.H + hh) * a.W_dst) + (a.phases * m + ph);
-            if (m < Wm && hh < a.H) {
-                o = *(const u32x4*)(a.res + px * a.ld_res + c);
-                if (bmask) kk = *(const u32x4*)(a.bnb_mask + px * a.ld_bnb_mask + c);
+            yv[pre ? buf : 0][pre ? i : 0] = bnb ? *(const u32x4*)(a.bnb_y + px * a.ld_bnb_y + c) : *(const u32x4*)(a.res + px * a.ld_res + c);
+        }
+    };
+    if (pre && storer) prefetch(0, 0);  // (before the barrier that publishes the staged tile)
+    __syncthreads();
+    if (storer) {
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+        if (pre && r + 1 < kRounds) prefetch(r + 1, (r + 1) & 1);
+#pragma unroll
+        for (int i = 0; i < kRound; ++i) {
+            const int q = st + (r * kRound + i) * kStoreThreads;
+            const int pm = q / kChunks, c8 = q - pm * kChunks;
+            const int rr = pm / kTC, mm = pm - rr * kTC;
+            const int m = m0 + mm, c = n0 + c8 * 8, hh = h0 + rr;
+            if (m >= Wm || hh >= a.H) continue;
+            u32x4 v = *(const u32x4*)(epi + pm * kEpi + c8 * 8);
+            const int64_t px = ((int64_t)(n * a.H + hh) * a.W_dst) + (a.phases * m + ph);
+            bf16_t* p = (bf16_t*)a.dst + px * a.ld_dst + c;
+            const u32x4 pv = yv[pre ? (r & 1) : 0][pre ? i : 0];
+            if (accum) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = pack_bf2(bf_lo(v[j]) + bf_lo(pv[j]), bf_hi(v[j]) + bf_hi(pv[j]));
+                if (a.flags & RV_OUT_RES_RELU) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = pack_bf2(fmaxf(bf_lo(v[j]), 0.f), fmaxf(bf_hi(v[j]), 0.f));
+                }
             }
-            if (bmask) {
-                ov[it] = o;
-                mv[it] = kk;
-            } else {
-                yv[it] = o;
+            if (DIAG != 8) *(u32x4*)p = v;
+            if (bnb) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float y0 = bf_lo(pv[j]), y1 = bf_hi(pv[j]);
+                    float g0 = bf_lo(v[j]), g1 = bf_hi(v[j]);
+                    if (a.bnb_flags & 1) {  // RV_BNB_RELU_Z
+                        g0 = y0 * bsc[2 * j] + bsh[2 * j] > 0.f ? g0 : 0.f;
+                        g1 = y1 * bsc[2 * j + 1] + bsh[2 * j + 1] > 0.f ? g1 : 0.f;
+                    }
+                    s0[2 * j] += g0;
+                    s0[2 * j + 1] += g1;
+                    s1[2 * j] += g0 * ((y0 - bmu[2 * j]) * bis[2 * j]);
+                    s1[2 * j + 1] += g1 * ((y1 - bmu[2 * j + 1]) * bis[2 * j + 1]);
+                }
             }
         }
     }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < kPasses; ++it) {
-        const int q = tid + it * 512;
-        const int pm = q / kChunks, c8 = q - pm * kChunks;
-        const int rr = pm / kTC, mm = pm - rr * kTC;
-        const int m = m0 + mm, c = n0 + c8 * 8, hh = h0 + rr;
-        if (m >= Wm || hh >= a.H) continue;
-        u32x4 v = *(const u32x4*)(epi + pm * kEpi + c8 * 8);
-        const int64_t px = ((int64_t)(n * a.H + hh) * a.W_dst) + (a.phases * m + ph);
-        bf16_t* p = (bf16_t*)a.dst + px * a.ld_dst + c;
-        if (accum) {
-            const u32x4 o = bmask ? ov[bmask ? it : 0] : yv[it];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = pack_bf2(bf_lo(v[j]) + bf_lo(o[j]), bf_hi(v[j]) + bf_hi(o[j]));
-            if (a.flags & RV_OUT_RES_RELU) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = pack_bf2(fmaxf(bf_lo(v[j]), 0.f), fmaxf(bf_hi(v[j]), 0.f));
-            }
-        }
-        *(u32x4*)p = v;
-        if (bnb) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float y0 = bf_lo(yv[it][j]), y1 = bf_hi(yv[it][j]);
-                float g0 = bf_lo(v[j]), g1 = bf_hi(v[j]);
-                if (bmask) {
-                    const uint32_t kk = mv[bmask ? it : 0][j];
-                    g0 = bf_lo(kk) > 0.f ? g0 : 0.f;
-                    g1 = bf_hi(kk) > 0.f ? g1 : 0.f;
-                }
-                if (a.bnb_flags & 1) {  // RV_BNB_RELU_Z
-                    g0 = y0 * bsc[2 * j] + bsh[2 * j] > 0.f ? g0 : 0.f;
-                    g1 = y1 * bsc[2 * j + 1] + bsh[2 * j + 1] > 0.f ? g1 : 0.f;
-                }
-                s0[2 * j] += g0;
-                s0[2 * j + 1] += g1;
-                s1[2 * j] += g0 * ((y0 - bmu[2 * j]) * bis[2 * j]);
-                s1[2 * j + 1] += g1 * ((y1 - bmu[2 * j + 1]) * bis[2 * j + 1]);
-            }
-        }
     }
     if (bnb) {
-        // lanes kChunks apart hold the same chunk; then the eight waves through LDS (the staged tile is dead now)
+        // lanes kChunks apart hold the same chunk; then the storing waves through LDS (the staged tile is dead now)
         __syncthreads();
-        float* red = (float*)smem;  // [8 waves][kChunks][16]
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-#pragma unroll
-            for (int d = kChunks; d < 64; d <<= 1) {
-                s0[j] += __shfl_xor(s0[j], d, 64);
-                s1[j] += __shfl_xor(s1[j], d, 64);
-            }
-        }
-        if (lane < kChunks) {
+        float* red = (float*)smem;  // [storing waves][kChunks][16]
+        constexpr int kSW = kStoreThreads / 64;
+        if (storer) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                red[(wave * kChunks + lane) * 16 + j] = s0[j];
-                red[(wave * kChunks + lane) * 16 + 8 + j] = s1[j];
+#pragma unroll
+                for (int d = kChunks; d < 64; d <<= 1) {
+                    s0[j] += __shfl_xor(s0[j], d, 64);
+                    s1[j] += __shfl_xor(s1[j], d, 64);
+                }
+            }
+            if (lane < kChunks) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    red[((st >> 6) * kChunks + lane) * 16 + j] = s0[j];
+                    red[((st >> 6) * kChunks + lane) * 16 + 8 + j] = s1[j];
+                }
             }
         }
         __syncthreads();
-        const int chunk = tid >> 4, jj = tid & 15;  // kChunks x 16 values
-        if (chunk < kChunks) {
+        const int chunk = st >> 4, jj = st & 15;  // kChunks x 16 values, summed by the first 256 storing threads
+        if (storer && chunk < kChunks) {
             float sum = 0.f;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) sum += red[(w * kChunks + chunk) * 16 + jj];
-            if (a.stats_per_wg) ((float*)(smem + kBnbAcc))[tid] += sum;  // (tid = chunk * 16 + jj: a private slot)
+            for (int w = 0; w < kSW; ++w) sum += red[(w * kChunks + chunk) * 16 + jj];
+            if (a.stats_per_wg) ((float*)(smem + kBnbAcc))[st] += sum;  // (st = chunk * 16 + jj: a private slot)
             else a.bnb_partial[((int64_t)tile * 2 + (jj >> 3)) * a.C_dst + n0 + chunk * 8 + (jj & 7)] = sum;
         }
     }
     __syncthreads();  // the staged output / BatchNorm sums of this tile are dead before the next tile's loads land in LDS
     }  // persistent tile loop
-    if ((EPI == 1 || EPI == 3) && a.stats_per_wg && tid < 256) {
-        const int chunk = tid >> 4, jj = tid & 15;
+    if ((EPI == 1) && a.stats_per_wg && storer && (SPLIT ? tid - 256 : tid) < 256) {
+        const int so = SPLIT ? tid - 256 : tid, chunk = so >> 4, jj = so & 15;
         a.bnb_partial[((int64_t)(xcd * (nslots / gy) + wslot / gy) * 2 + (jj >> 3)) * a.C_dst + (wslot % gy) * kBN + chunk * 8 + (jj & 7)] =
-            ((const float*)(smem + kBnbAcc))[tid];
+            ((const float*)(smem + kBnbAcc))[so];
     }
     if ((a.flags & RV_OUT_STATS) && a.stats_per_wg && lg == 0) {
         // (nslots % gy == 0, checked by the host: the channel tile of a workgroup is the same for all of its tiles, and the gy
@@ -511,7 +542,7 @@ bool rv_tapconv6_plan(TapConvArgs* a, int* tiles, size_t* lds, int* stats_rows, 
     // the masked last-writer form (sums over an ACCUMULATED gradient: three 16-byte prefetches per pass, 192 registers over this
     // tile's sixteen passes) spills 177 registers here and ran at 16 % matrix-pipe occupancy (profiles/r04_mfma_counters.json,
     // first collection): those few launches stay on the fifth generation, whose 8-pass 128-channel instance holds them
-    if ((a->flags & RV_OUT_BNB) && (a->flags & RV_OUT_ACCUM) && getenv("RV3D_T6_EPI3") == nullptr) return false;
+    if ((a->flags & RV_OUT_BNB) && (a->flags & RV_OUT_ACCUM)) return false;
     if (a->C_src % kBK != 0 || a->C_dst % kBN != 0) return false;
     const int wm_total = a->W_dst / a->phases;
     if (wm_total < kTC || a->H < kTR) return false;
@@ -559,32 +590,38 @@ bool rv_tapconv6_plan(TapConvArgs* a, int* tiles, size_t* lds, int* stats_rows, 
 int rv_tapconv6_launch(const TapConvArgs& a, size_t lds, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)tapconv6_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)tapconv6_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)tapconv6_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)tapconv6_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define RV_T6_ATTR(E_, S_) (void)hipFuncSetAttribute((const void*)tapconv6_kernel<E_, 0, S_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        RV_T6_ATTR(0, true) RV_T6_ATTR(1, true) RV_T6_ATTR(2, true)
+        RV_T6_ATTR(0, false) RV_T6_ATTR(1, false) RV_T6_ATTR(2, false)
+#undef RV_T6_ATTR
         attr_set = true;
     }
     const int grid = tapconv6_grid(a);
-    const int epi = (a.flags & RV_OUT_BNB) ? ((a.flags & RV_OUT_ACCUM) ? 3 : 1) : ((a.flags & RV_OUT_ACCUM) ? 2 : 0);
+    const int epi = (a.flags & RV_OUT_BNB) ? 1 : ((a.flags & RV_OUT_ACCUM) ? 2 : 0);
+    const bool split = getenv("RV3D_T6_SPLIT") != nullptr;  // (A/B only: the role-split form, measured slower -- see the SPLIT note)
 #ifdef RV_T6_DIAG_BUILD
     if (const char* dv = getenv("RV3D_T6_DIAG")) {
         const int d = atoi(dv);
 #define RV_T6_DIAG_CASE(D_)                                                                                              \
     if (d == D_) {                                                                                                       \
-        (void)hipFuncSetAttribute((const void*)tapconv6_kernel<0, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        hipLaunchKernelGGL((tapconv6_kernel<0, D_>), dim3(grid), dim3(512), lds, stream, a);                              \
+        (void)hipFuncSetAttribute((const void*)tapconv6_kernel<0, D_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        (void)hipFuncSetAttribute((const void*)tapconv6_kernel<0, D_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        if (split) hipLaunchKernelGGL((tapconv6_kernel<0, D_, true>), dim3(grid), dim3(512), lds, stream, a);             \
+        else hipLaunchKernelGGL((tapconv6_kernel<0, D_, false>), dim3(grid), dim3(512), lds, stream, a);                  \
         RV_CHECK_LAUNCH("tapconv6_kernel diag");                                                                         \
         return 0;                                                                                                        \
     }
-        RV_T6_DIAG_CASE(1) RV_T6_DIAG_CASE(2) RV_T6_DIAG_CASE(3) RV_T6_DIAG_CASE(4) RV_T6_DIAG_CASE(5) RV_T6_DIAG_CASE(6) RV_T6_DIAG_CASE(7)
+        RV_T6_DIAG_CASE(1) RV_T6_DIAG_CASE(2) RV_T6_DIAG_CASE(3) RV_T6_DIAG_CASE(4) RV_T6_DIAG_CASE(8) RV_T6_DIAG_CASE(9)
 #undef RV_T6_DIAG_CASE
     }
 #endif
-    if (epi == 1) hipLaunchKernelGGL((tapconv6_kernel<1>), dim3(grid), dim3(512), lds, stream, a);
-    else if (epi == 2) hipLaunchKernelGGL((tapconv6_kernel<2>), dim3(grid), dim3(512), lds, stream, a);
-    else if (epi == 3) hipLaunchKernelGGL((tapconv6_kernel<3>), dim3(grid), dim3(512), lds, stream, a);
-    else hipLaunchKernelGGL((tapconv6_kernel<0>), dim3(grid), dim3(512), lds, stream, a);
+#define RV_T6_LAUNCH(E_)                                                                                   \
+    if (split) hipLaunchKernelGGL((tapconv6_kernel<E_, 0, true>), dim3(grid), dim3(512), lds, stream, a);  \
+    else hipLaunchKernelGGL((tapconv6_kernel<E_, 0, false>), dim3(grid), dim3(512), lds, stream, a);
+    if (epi == 1) { RV_T6_LAUNCH(1) }
+    else if (epi == 2) { RV_T6_LAUNCH(2) }
+    else { RV_T6_LAUNCH(0) }
+#undef RV_T6_LAUNCH
     RV_CHECK_LAUNCH("tapconv6_kernel");
     return 0;
 }
