@@ -22,14 +22,18 @@ from test_gpu_tapconv4 import _ints
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True)
-def _small_grids_allowed():
+@pytest.fixture(autouse=True, params=[5, 6], ids=["gen5", "gen6"])
+def _small_grids_allowed(request):
+    """Crops this small stay below the libraries' tile-count thresholds: lift them, once with the halo-resident layers on the fifth
+    generation (256 x 256 / 256 x 128 tiles) and once on the sixth (512 x 128 tiles, where H >= 16), on both operand builds."""
     from range_view_3d_detection_amd import _lib as L
 
-    olds = {tag: L.load(tag).rv_set_option(b"tapconv4_min_blocks", ctypes.c_int32(1)) for tag in ("bf16", "f16")}
+    olds = {tag: (L.load(tag).rv_set_option(b"tapconv4_min_blocks", ctypes.c_int32(1)),
+                  L.load(tag).rv_set_option(b"tapconv6_min_blocks", ctypes.c_int32(1 if request.param == 6 else 1 << 30))) for tag in ("bf16", "f16")}
     yield
-    for tag, old in olds.items():
-        L.load(tag).rv_set_option(b"tapconv4_min_blocks", ctypes.c_int32(old))
+    for tag, (o4, o6) in olds.items():
+        L.load(tag).rv_set_option(b"tapconv4_min_blocks", ctypes.c_int32(o4))
+        L.load(tag).rv_set_option(b"tapconv6_min_blocks", ctypes.c_int32(o6))
 
 
 def _exact_bn(c, g):
