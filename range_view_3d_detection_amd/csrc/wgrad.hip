@@ -412,7 +412,7 @@ __device__ __forceinline__ void wgrad2_body(const Wgrad2Args& a, bf16_t (*lds)[2
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int j = 0; j < 2; ++j)
-                            acc[t][i][j] = RV_MFMA_16x16x32(fa[i], fb[j], acc[t][i][j], 0, 0, 0);
+                            acc[t][i][j] = RV_MFMA_16x16x32(fb[j], fa[i], acc[t][i][j], 0, 0, 0);  // (transposed: as wgrad3)
                 }
             }
             if (has_next) store(buf ^ 1);
@@ -424,17 +424,15 @@ __device__ __forceinline__ void wgrad2_body(const Wgrad2Args& a, bf16_t (*lds)[2
     for (int t = 0; t < TG; ++t) {
         float* slab = a.slabs + ((int64_t)ks * a.taps + tap0 + t) * a.cu_pad * a.cv_pad;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
+            const int cu = u0 + wm * 64 + i * 16 + (lane & 15);
+            if (cu >= a.cu_pad) continue;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int cu = u0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
-                if (cu >= a.cu_pad) continue;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int cv = v0 + wn * 32 + j * 16 + (lane & 15);
-                    if (cv < a.cv_pad) slab[(int64_t)cu * a.cv_pad + cv] = acc[t][i][j][r];
-                }
+            for (int j = 0; j < 2; ++j) {
+                const int cv = v0 + wn * 32 + j * 16 + (lane >> 4) * 4;  // (cv_pad % 32 == 0: a quad is inside or outside as a whole)
+                if (cv < a.cv_pad) *(f32x4*)(slab + (int64_t)cu * a.cv_pad + cv) = acc[t][i][j];
             }
+        }
     }
 }
 
@@ -634,8 +632,9 @@ __device__ __forceinline__ void wgrad3_body(const Wgrad2Args& a, uint8_t* smem) 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bf16x8 ai = w3_join(fa[kk & 1][i]);
-            acc[t][i][0] = RV_MFMA_16x16x32(ai, b0, acc[t][i][0], 0, 0, 0);
-            acc[t][i][1] = RV_MFMA_16x16x32(ai, b1, acc[t][i][1], 0, 0, 0);
+            // (operands swapped: D = V^T U, so that a lane holds FOUR CONSECUTIVE cv of one cu -- 16-byte slab stores, see the epilogue)
+            acc[t][i][0] = RV_MFMA_16x16x32(b0, ai, acc[t][i][0], 0, 0, 0);
+            acc[t][i][1] = RV_MFMA_16x16x32(b1, ai, acc[t][i][1], 0, 0, 0);
         }
     };
     // The two halves of the workgroup (waves w and w + 4 share a SIMD) issue their DMA at different points of the chunk -- half A
@@ -699,17 +698,18 @@ __device__ __forceinline__ void wgrad3_body(const Wgrad2Args& a, uint8_t* smem) 
 #pragma unroll
     for (int t = 0; t < TG; ++t) {
         float* slab = a.slabs + ((int64_t)ks * a.taps + tap0 + t) * a.cu_pad * a.cv_pad;
+        // acc[t][i][j][r] = dT[cu = 16 i + l15][cv = 16 j + 4 lg + r] of this wave's 64 x 32 tile (transposed accumulation, above): one
+        // 16-byte store per accumulator register quad -- 24 store instructions per thread instead of 96 four-byte ones (a CU's store
+        // path takes ~150 cycles per instruction whatever its width: -5 us per block, a quarter of a small layer's launch)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
+            const int cu = u0 + wm * 64 + i * 16 + (lane & 15);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int cu = u0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int cv = v0 + wn * 32 + j * 16 + (lane & 15);
-                    slab[(int64_t)cu * a.cv_pad + cv] = acc[t][i][j][r];
-                }
+            for (int j = 0; j < 2; ++j) {
+                const int cv = v0 + wn * 32 + j * 16 + (lane >> 4) * 4;
+                *(f32x4*)(slab + (int64_t)cu * a.cv_pad + cv) = acc[t][i][j];
             }
+        }
     }
 }
 
