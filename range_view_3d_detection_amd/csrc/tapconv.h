@@ -46,6 +46,7 @@ struct TapConvArgs {
     // RV_OUT_ACCUM: the tensor added to the result -- dst itself (gradient fan-in) or a residual (rv_tap_residual), same pixels as dst
     const bf16_t* res;
     int32_t ld_res;
+    int32_t nt_store;       // tapconv6: non-temporal output stores
     int32_t stats_per_wg;  // tapconv6: RV_OUT_STATS / RV_OUT_BNB rows per WORKGROUP (accumulated over its tiles in LDS) instead of per tile
     TapTable tt;
 };

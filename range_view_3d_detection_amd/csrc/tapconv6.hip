@@ -452,7 +452,10 @@ __global__ __launch_bounds__(512, 2) void tapconv6_kernel(const TapConvArgs a) {
                     for (int j = 0; j < 4; ++j) v[j] = pack_bf2(fmaxf(bf_lo(v[j]), 0.f), fmaxf(bf_hi(v[j]), 0.f));
                 }
             }
-            if (DIAG != 8) *(u32x4*)p = v;
+            if (DIAG != 8) {
+                if (a.nt_store) __builtin_nontemporal_store(v, (u32x4*)p);  // (RV3D_T6_NT_STORES=1: profiles/r04_tapconv6_ablation.md section 4)
+                else *(u32x4*)p = v;
+            }
             if (bnb) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -597,6 +600,7 @@ int rv_tapconv6_launch(const TapConvArgs& a, size_t lds, hipStream_t stream) {
         attr_set = true;
     }
     const int grid = tapconv6_grid(a);
+    const_cast<TapConvArgs&>(a).nt_store = getenv("RV3D_T6_NT_STORES") != nullptr;  // (A/B only: +0.6..2.4 % isolated, nothing in the bench mix)
     const int epi = (a.flags & RV_OUT_BNB) ? 1 : ((a.flags & RV_OUT_ACCUM) ? 2 : 0);
     const bool split = getenv("RV3D_T6_SPLIT") != nullptr;  // (A/B only: the role-split form, measured slower -- see the SPLIT note)
 #ifdef RV_T6_DIAG_BUILD
