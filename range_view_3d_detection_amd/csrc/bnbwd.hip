@@ -5,11 +5,19 @@
 //
 // Replaces cuDNN batch-norm backward + ReLU backward + add backward of
 // nn/blocks/__init__.py:41-51,63,78-81,158-180 (and the Conv2dNormActivation triples).
+#include <algorithm>
 #include <stdlib.h>
 
 #include "common.h"
 
 int rv_col_reduce(const float* partial, int rows, int cols, double* scratch, int* groups, hipStream_t st);
+
+// Register budget of the bandwidth-bound passes: at most 96 VGPRs, so that one of their workgroups (one wave per SIMD) fits on a CU
+// BESIDE a resident wgrad3 workgroup (2 waves per SIMD x 200 VGPRs; 28 KB of LDS left) -- the weight-gradient launches run on the
+// side stream during the backward sweep, and these passes then use the HBM bandwidth the MFMA-bound kernel leaves idle.
+#ifndef RV_EW_WG_PER_CU
+#define RV_EW_WG_PER_CU 1
+#endif
 
 namespace {
 
@@ -75,7 +83,7 @@ __device__ __forceinline__ void masked_grad(const BnbArgs& a, const BnbLoad& r, 
 
 // Thread layout shared by both passes: thread = (pixel lane, channel octet), so a thread keeps one octet for the whole
 // launch and its per-channel constants live in registers; consecutive threads read consecutive 16-byte octets.
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnbArgs a) {
+__global__ __launch_bounds__(256, RV_EW_WG_PER_CU) void bn_bwd_reduce_kernel(const BnbArgs a) {
     __shared__ float red[256][17];
     const int tid = threadIdx.x;
     const int lanes_px = 256 / a.c8;           // pixels handled per pass
@@ -148,7 +156,7 @@ struct Bnb2Args {
     int c, c8, ld_dout, ld_out, ld_ya, ld_yb;
     float *partial_a, *partial_b;
 };
-__global__ __launch_bounds__(256) void bn_bwd_reduce2_kernel(const Bnb2Args a) {
+__global__ __launch_bounds__(256, RV_EW_WG_PER_CU) void bn_bwd_reduce2_kernel(const Bnb2Args a) {
     __shared__ float red[256][25];
     const int tid = threadIdx.x;
     const int lanes_px = 256 / a.c8;
@@ -333,7 +341,7 @@ __device__ __forceinline__ void apply_px_m(const BnbArgs& a, int64_t px, int c0,
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnbArgs a) {
+__global__ __launch_bounds__(256, RV_EW_WG_PER_CU) void bn_bwd_apply_kernel(const BnbArgs a) {
     const int tid = threadIdx.x;
     const int lanes_px = 256 / a.c8;
     const int oct = tid % a.c8, pl = tid / a.c8;
@@ -373,6 +381,98 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnbArgs a) {
     }
 }
 
+// The LEAN form of the apply pass: thread = (pixel lane, channel QUAD), 8-byte loads, four pixels in flight per thread -- the
+// same per-element arithmetic (bit-identical results) in at most 96 VGPRs, so that a workgroup of it (one wave per SIMD) fits on a
+// CU BESIDE a resident wgrad3 workgroup (2 waves per SIMD x 200 VGPRs) and streams while that kernel computes
+// (engine.py RV3D_OVERLAP=chain).  The per-channel constants are what a thread of these passes spends its registers on (7 per
+// channel); halving the channels per thread pays for twice the loads in flight.  F: bit 0 streaming loads / stores, bit 1 ReLU
+// mask tensor, bit 2 residual-gradient output, bit 3 ... accumulated onto what is there.
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+template <int F>
+__global__ __launch_bounds__(256, 5) void bn_bwd_apply_lean_kernel(const BnbArgs a) {
+    constexpr bool kNt = F & 1, kOut = F & 2, kRes = F & 4, kAcc = F & 8;
+    constexpr int U = 4;
+    const int tid = threadIdx.x;
+    const int c4 = a.c8 * 2;
+    const int lanes_px = 256 / c4;
+    const int quad = tid % c4, pl = tid / c4;
+    if (pl >= lanes_px) return;
+    const int c0 = quad * 4;
+    float sc[4], sh[4], mu[4], is[4], k0[4], k1[4], k2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        sc[j] = a.scale[c0 + j];
+        sh[j] = a.shift[c0 + j];
+        mu[j] = a.mean[c0 + j];
+        is[j] = a.invstd[c0 + j];
+        k0[j] = a.coef[c0 + j];
+        k1[j] = a.coef[a.c + c0 + j];
+        k2[j] = a.coef[2 * a.c + c0 + j];
+    }
+    const bool relu_z = (a.flags & RV_BNB_RELU_Z) != 0;
+    // 32-bit byte offsets from the (uniform) tensor bases: the loads take the `saddr + voffset` form and the addresses of the
+    // pixels in flight cost one register each (64-bit pointers: two, for every (pixel, tensor) pair -- 40 registers)
+    auto ld8 = [&](const bf16_t* base, uint32_t off) -> u32x2 {
+        const u32x2* p = (const u32x2*)((const char*)base + off);
+        return kNt ? __builtin_nontemporal_load(p) : *p;
+    };
+    auto st8 = [&](bf16_t* base, uint32_t off, const u32x2 v) {
+        u32x2* p = (u32x2*)((char*)base + off);
+        if (kNt) __builtin_nontemporal_store(v, p);
+        else *p = v;
+    };
+    auto one = [&](uint32_t o_dy, uint32_t o_dr, const u32x2 dv, const u32x2 yv, const u32x2 ov, const u32x2 old) {
+        u32x2 dy, dr;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float g[2] = {bf_lo(dv[h]), bf_hi(dv[h])};
+            const float y[2] = {bf_lo(yv[h]), bf_hi(yv[h])};
+            float o[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int j = 2 * h + e;
+                if (kOut && !((e ? bf_hi(ov[h]) : bf_lo(ov[h])) > 0.f)) g[e] = 0.f;
+                if (relu_z && !(y[e] * sc[j] + sh[j] > 0.f)) g[e] = 0.f;
+                const float xh = (y[e] - mu[j]) * is[j];
+                o[e] = k0[j] * (g[e] - k1[j] - xh * k2[j]);
+                if (kAcc) g[e] += e ? bf_hi(old[h]) : bf_lo(old[h]);
+            }
+            dy[h] = pack_bf2(o[0], o[1]);
+            dr[h] = pack_bf2(g[0], g[1]);
+        }
+        st8(a.dy, o_dy, dy);
+        if (kRes) st8(a.dres, o_dr, dr);
+    };
+    const int64_t per = ((a.pixels + gridDim.x - 1) / gridDim.x + lanes_px - 1) / lanes_px * lanes_px;
+    const int64_t end = (int64_t)(blockIdx.x + 1) * per < a.pixels ? (int64_t)(blockIdx.x + 1) * per : a.pixels;
+    const int64_t first = (int64_t)blockIdx.x * per + pl;
+    const int n_px = first < end ? (int)((end - first + lanes_px - 1) / lanes_px) : 0;  // pixels of this thread
+    uint32_t o_d = (uint32_t)((first * a.ld_dout + c0) * 2), o_y = (uint32_t)((first * a.ld_y + c0) * 2),
+             o_o = kOut ? (uint32_t)((first * a.ld_out + c0) * 2) : 0u, o_dy = (uint32_t)((first * a.ld_dy + c0) * 2),
+             o_dr = kRes ? (uint32_t)((first * a.ld_dres + c0) * 2) : 0u;
+    const uint32_t s_d = lanes_px * a.ld_dout * 2, s_y = lanes_px * a.ld_y * 2, s_o = lanes_px * a.ld_out * 2, s_dy = lanes_px * a.ld_dy * 2,
+                   s_dr = lanes_px * a.ld_dres * 2;  // (uniform: scalar registers)
+    int i = 0;
+    for (; i + U <= n_px; i += U) {
+        u32x2 dv[U], yv[U], ov[U], old[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            dv[u] = ld8(a.dout, o_d + u * s_d);
+            yv[u] = ld8(a.y, o_y + u * s_y);
+            ov[u] = kOut ? ld8(a.out, o_o + u * s_o) : u32x2{0, 0};
+            old[u] = kAcc ? *(const u32x2*)((const char*)a.dres + (o_dr + u * s_dr)) : u32x2{0, 0};
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) one(o_dy + u * s_dy, o_dr + u * s_dr, dv[u], yv[u], ov[u], old[u]);
+        o_d += U * s_d, o_y += U * s_y, o_o += U * s_o, o_dy += U * s_dy, o_dr += U * s_dr;
+    }
+    for (; i < n_px; ++i) {
+        one(o_dy, o_dr, ld8(a.dout, o_d), ld8(a.y, o_y), kOut ? ld8(a.out, o_o) : u32x2{0, 0},
+            kAcc ? *(const u32x2*)((const char*)a.dres + o_dr) : u32x2{0, 0});
+        o_d += s_d, o_y += s_y, o_o += s_o, o_dy += s_dy, o_dr += s_dr;
+    }
+}
+
 // The apply pass for the two BatchNorms under one block sum (see bn_bwd_reduce2_kernel): g = dOut * [out > 0] is formed once,
 // dYa / dYb leave together -- four reads and two writes where two apply passes take six and two.
 struct Bnb2Apply {
@@ -383,7 +483,7 @@ struct Bnb2Apply {
     int c, c8, ld_dout, ld_out, ld_ya, ld_yb, ld_dya, ld_dyb;
 };
 template <int MODE>
-__global__ __launch_bounds__(256) void bn_bwd_apply2_kernel(const Bnb2Apply a) {
+__global__ __launch_bounds__(256, RV_EW_WG_PER_CU) void bn_bwd_apply2_kernel(const Bnb2Apply a) {
     const int tid = threadIdx.x;
     const int lanes_px = 256 / a.c8;
     const int oct = tid % a.c8, pl = tid / a.c8;
@@ -800,6 +900,29 @@ extern "C" int rv_bn_bwd_apply(int64_t pixels, int32_t c, const void* dout, int3
     a.ld_dy = ld_dy;
     a.dres = (bf16_t*)dres;
     a.ld_dres = ld_dres;
+    // lean form by default (RV3D_BNB_LEAN=0: the octet form; =1: one workgroup per CU): alone it takes the same time (96.7 against 96.5-96.9 ms
+    // per rv-av2 step), beside a weight gradient on the side stream (engine.py RV3D_OVERLAP=chain) it is what fits on the CU
+    static const int lean = getenv("RV3D_BNB_LEAN") ? atoi(getenv("RV3D_BNB_LEAN")) : 2;
+    const int64_t ld_max = std::max(std::max((int64_t)ld_dout, (int64_t)ld_y), std::max(std::max((int64_t)ld_out, (int64_t)ld_dy), (int64_t)ld_dres));
+    if (lean && c <= 1024 && pixels * ld_max * 2 < ((int64_t)1 << 32)) {  // (32-bit byte offsets)
+        const int lanes4 = 256 / (2 * a.c8);
+        int64_t blocks4 = (pixels + lanes4 - 1) / lanes4;
+        if (blocks4 > 4096) blocks4 = 4096;
+        // RV3D_BNB_LEAN=1 (A/B): ONE workgroup per CU, so that whichever of this launch and the weight gradient on the side stream reaches
+        // the CUs first, the other one still fits beside it -- 2.6 ms per step slower alone, 1.8 of them recovered beside the weight
+        // gradients: a net loss against as many workgroups as the octet form (the default)
+        if (lean == 1 && blocks4 > 256) blocks4 = 256;
+        const int f = ((int64_t)pixels * c * 2 >= ((int64_t)256 << 20) ? 1 : 0) | (out ? 2 : 0) | (dres ? 4 : 0) |
+                      (dres && (flags & RV_BNB_RES_ACCUM) ? 8 : 0);
+        using K = void (*)(const BnbArgs);
+        static const K table[16] = {bn_bwd_apply_lean_kernel<0>,  bn_bwd_apply_lean_kernel<1>,  bn_bwd_apply_lean_kernel<2>,  bn_bwd_apply_lean_kernel<3>,
+                                    bn_bwd_apply_lean_kernel<4>,  bn_bwd_apply_lean_kernel<5>,  bn_bwd_apply_lean_kernel<6>,  bn_bwd_apply_lean_kernel<7>,
+                                    bn_bwd_apply_lean_kernel<4>,  bn_bwd_apply_lean_kernel<5>,  bn_bwd_apply_lean_kernel<6>,  bn_bwd_apply_lean_kernel<7>,
+                                    bn_bwd_apply_lean_kernel<12>, bn_bwd_apply_lean_kernel<13>, bn_bwd_apply_lean_kernel<14>, bn_bwd_apply_lean_kernel<15>};
+        hipLaunchKernelGGL(table[f], dim3((int)blocks4), dim3(256), 0, (hipStream_t)stream, a);
+        RV_CHECK_LAUNCH("bn_bwd_apply_lean_kernel");
+        return 0;
+    }
     const int lanes_px = 256 / a.c8;
     int64_t blocks = (pixels + lanes_px - 1) / lanes_px;
     if (blocks > 4096) blocks = 4096;

@@ -109,16 +109,23 @@ PROFILE: Optional[KernelProfile] = None
 #   RV3D_OVERLAP=free        every weight gradient on the side stream.  Round-3 A/B on the final kernels
 #                            (profiles/r03_overlap_ab.md): 3.6 % SLOWER than one stream -- two persistent one-workgroup-per-CU
 #                            kernels with 150 KB of LDS each cannot share a CU, the big layers only take turns;
-#   RV3D_OVERLAP=small[:T]   (DEFAULT, T = 0.1) only the weight gradients of layers below T TFLOP (the 128-channel DLA stages at
+#   RV3D_OVERLAP=small[:T]   (T = 0.1; the round-3 default) only the weight gradients of layers below T TFLOP (the 128-channel DLA stages at
 #                            W <= 1024 and the 1x1 layers, whose kernels have fewer tiles than the chip has CUs) -- they run
 #                            beside the equally small backward-data / BatchNorm kernels of the main chain on CUs those leave
 #                            idle: -2.0 ms per step (103.1 / 103.3 -> 101.1 at T = 0.1, 101.2 / 101.7 at 0.35, 101.9 at 0.7);
+#   RV3D_OVERLAP=chain[:T]   (DEFAULT since round 4: -0.5 .. -0.9 ms per rv-av2 step, profiles/r04_ab_notes.md) the small layers as above, and the BIG weight gradients on the side stream too, but chained: the next
+#                            backward-data launch of the main stream waits for the weight gradient issued before it, so the two
+#                            MFMA families still take turns on the CUs (dgrad(L), wgrad(L), dgrad(L-1), ...) -- what runs BESIDE
+#                            wgrad(L) is the bandwidth-bound BatchNorm backward of layer L-1 on the main stream, whose kernels are
+#                            sized (<= 96 VGPRs, <= 28 KB of LDS) to fit on a CU next to a resident wgrad3 workgroup;
 #   RV3D_OVERLAP=off         one stream.
-_OVERLAP = os.environ.get("RV3D_OVERLAP", "small")
+_OVERLAP = os.environ.get("RV3D_OVERLAP", "chain")
 if os.environ.get("RV3D_NO_OVERLAP") is not None:
     _OVERLAP = "off"
-OVERLAP_WGRAD = _OVERLAP == "free" or _OVERLAP.startswith("small")
-OVERLAP_MAX_TFLOP: Optional[float] = (float(_OVERLAP.split(":")[1]) if ":" in _OVERLAP else 0.1) if _OVERLAP.startswith("small") else None
+OVERLAP_WGRAD = _OVERLAP == "free" or _OVERLAP.startswith("small") or _OVERLAP.startswith("chain")
+OVERLAP_CHAIN = _OVERLAP.startswith("chain")
+OVERLAP_MAX_TFLOP: Optional[float] = ((float(_OVERLAP.split(":")[1]) if ":" in _OVERLAP else 0.1)
+                                      if (_OVERLAP.startswith("small") or _OVERLAP.startswith("chain")) else None)
 _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 
 
@@ -724,6 +731,7 @@ class Tape:
         self.deferred_params: set = set()
         self.params: Dict[int, nn.Parameter] = {}
         self.used_side_stream = False
+        self.chained_wgrad = None  # (RV3D_OVERLAP=chain) event behind the last big weight gradient on the side stream
         self.bn_counters: List[Tensor] = []
 
     # ---- gradient buffers (views follow their parents) ----

@@ -75,6 +75,7 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
     if fused_first:
         # second positional layer of the MetaKernel stem: dh1 = dy2 W2 is consumed in registers by the first layer's BatchNorm
         # backward + weight gradient (rv_pos_backward_sums) -- no input-gradient tensor, no second pass over it
+        _wait_chained_wgrad(t)
         _pos_pair_backward(op, t, dout)
     elif op.need_input_grad:
         if isinstance(op.x, Lazy):
@@ -132,6 +133,7 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
                 call = lambda: L.call("rv_tap_data_grad_bnb", ctypes.byref(g), ctypes.byref(shape), L.i32(1 if bwd == "scatter" else 0), dout.ptr(),
                                       L.ptr(wp), dst.ptr(), ctypes.byref(epi), L.stream_ptr())
                 t.lazy_sums[id(lz)] = (partial, rows, dst)
+        _wait_chained_wgrad(t)
         if E.PROFILE is not None:
             E._launch(E.tap_kernel_name(bg, bshape, bwd == "scatter"), E.tap_flops(g, shape), call, E.tap_bytes(g, shape))
         else:
@@ -184,16 +186,28 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
             L.call("rv_unfold_weight_grad", ctypes.byref(g), L.ptr(folded), L.ptr(grad), L.i32(0), L.stream_ptr())
         t.add_param_grad(layer.weight, layer.unpermute_grad(grad))
 
-    if E.OVERLAP_WGRAD and (E.OVERLAP_MAX_TFLOP is None or E.tap_flops(g, wshape) < 1e12 * E.OVERLAP_MAX_TFLOP):
+    small = E.OVERLAP_MAX_TFLOP is None or E.tap_flops(g, wshape) < 1e12 * E.OVERLAP_MAX_TFLOP
+    if E.OVERLAP_WGRAD and (small or E.OVERLAP_CHAIN):
         side = E.side_stream(t.device)
         ready = torch.cuda.Event()
         ready.record()  # dout (and everything before it on the main stream) is complete at this point of the main stream
         side.wait_event(ready)
         with torch.cuda.stream(side):
             run_wgrad()
+            if not small:  # chained: the main stream's next MFMA-bound launch waits for this one (_wait_chained_wgrad)
+                t.chained_wgrad = torch.cuda.Event()
+                t.chained_wgrad.record()
         t.used_side_stream = True
     else:
         run_wgrad()
+
+
+def _wait_chained_wgrad(t: Tape) -> None:
+    """RV3D_OVERLAP=chain: a big weight gradient is running on the side stream -- the main stream's next backward-data launch starts
+    after it (two persistent MFMA kernels only take CUs from each other); the bandwidth-bound passes in between do not wait."""
+    if t.chained_wgrad is not None:
+        torch.cuda.current_stream().wait_event(t.chained_wgrad)
+        t.chained_wgrad = None
 
 
 LAST_WRITER_LAUNCHES = 0  # backward-data launches that formed a block output's BatchNorm-backward sums (tests)

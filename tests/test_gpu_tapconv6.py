@@ -22,11 +22,16 @@ from test_gpu_tapconv4 import _ints
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True)
-def _small_grids_allowed():
-    """The library keeps grids below one round of CUs on the smaller tiles (speed heuristic); lift that here."""
+@pytest.fixture(autouse=True, params=["plain", "pipelined"])
+def _small_grids_allowed(request, monkeypatch):
+    """The library keeps grids below one round of CUs on the smaller tiles (speed heuristic); lift that here.  Every test runs twice:
+    with the default tile loop and with the opt-in pipelined tile boundary (RV3D_T6_PIPE=1: tapconv6p, read at every launch)."""
     from range_view_3d_detection_amd import _lib as L
 
+    if request.param == "pipelined":
+        monkeypatch.setenv("RV3D_T6_PIPE", "1")
+    else:
+        monkeypatch.delenv("RV3D_T6_PIPE", raising=False)
     old4 = L.load().rv_set_option(b"tapconv4_min_blocks", ctypes.c_int32(1))
     old6 = L.load().rv_set_option(b"tapconv6_min_blocks", ctypes.c_int32(1))
     yield
