@@ -124,6 +124,9 @@ if os.environ.get("RV3D_NO_OVERLAP") is not None:
     _OVERLAP = "off"
 OVERLAP_WGRAD = _OVERLAP == "free" or _OVERLAP.startswith("small") or _OVERLAP.startswith("chain")
 OVERLAP_CHAIN = _OVERLAP.startswith("chain")
+# chain mode: a big weight gradient is released before (not after) the backward-data launch of its layer when that launch's last round of
+# persistent tiles fills less than this fraction of the CUs (rv-waymo: W = 2656 gives 1328 tiles = 5.19 rounds); 0 = never
+EARLY_WGRAD_FILL = float(os.environ.get("RV3D_EARLY_WGRAD_FILL", "0.9"))
 OVERLAP_MAX_TFLOP: Optional[float] = ((float(_OVERLAP.split(":")[1]) if ":" in _OVERLAP else 0.1)
                                       if (_OVERLAP.startswith("small") or _OVERLAP.startswith("chain")) else None)
 _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}

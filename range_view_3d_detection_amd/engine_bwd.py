@@ -72,6 +72,7 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
     sp = op.shape
     # ---- input gradient: the opposite tap form -------------------------------------------------
     fused_first = POS_BWD_FUSE and op.pos_first is not None and op.need_input_grad and t.training
+    early_ready = None
     if fused_first:
         # second positional layer of the MetaKernel stem: dh1 = dy2 W2 is consumed in registers by the first layer's BatchNorm
         # backward + weight gradient (rv_pos_backward_sums) -- no input-gradient tensor, no second pass over it
@@ -133,6 +134,17 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
                 call = lambda: L.call("rv_tap_data_grad_bnb", ctypes.byref(g), ctypes.byref(shape), L.i32(1 if bwd == "scatter" else 0), dout.ptr(),
                                       L.ptr(wp), dst.ptr(), ctypes.byref(epi), L.stream_ptr())
                 t.lazy_sums[id(lz)] = (partial, rows, dst)
+        if E.OVERLAP_CHAIN and E.EARLY_WGRAD_FILL > 0:
+            # a persistent backward-data launch whose LAST round of tiles fills only part of the chip (1328 tiles on 256 CUs: five full
+            # rounds and 48 tiles): the weight gradient of the same layer -- it reads dOut and the layer input, both complete -- is
+            # released BEFORE this launch, queues behind it and takes the CUs as they fall idle in that last round
+            info = (ctypes.c_int32 * 4)()
+            if (L.load().rv_tap_launch_info(ctypes.byref(bg), ctypes.byref(bshape), 1 if bwd == "scatter" else 0, info) == 0 and info[0] == 6):
+                wg_tiles, cus = info[2] * info[3], 256
+                if wg_tiles / (cus * ((wg_tiles + cus - 1) // cus)) < E.EARLY_WGRAD_FILL:
+                    early_ready = torch.cuda.Event()
+                    early_ready.record()
+                    t.chained_wgrad = None  # ... and this launch does not wait for the weight gradient before it either: its own tail is where that one ends
         _wait_chained_wgrad(t)
         if E.PROFILE is not None:
             E._launch(E.tap_kernel_name(bg, bshape, bwd == "scatter"), E.tap_flops(g, shape), call, E.tap_bytes(g, shape))
@@ -189,8 +201,10 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
     small = E.OVERLAP_MAX_TFLOP is None or E.tap_flops(g, wshape) < 1e12 * E.OVERLAP_MAX_TFLOP
     if E.OVERLAP_WGRAD and (small or E.OVERLAP_CHAIN):
         side = E.side_stream(t.device)
-        ready = torch.cuda.Event()
-        ready.record()  # dout (and everything before it on the main stream) is complete at this point of the main stream
+        ready = early_ready
+        if ready is None or small:
+            ready = torch.cuda.Event()
+            ready.record()  # dout (and everything before it on the main stream) is complete at this point of the main stream
         side.wait_event(ready)
         with torch.cuda.stream(side):
             run_wgrad()
