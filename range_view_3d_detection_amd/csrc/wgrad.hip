@@ -290,6 +290,7 @@ struct Wgrad2Args {
     int32_t cu_pad, cv_pad, ld_u, ld_v;
     int32_t taps, groups;
     int32_t ksplit, chunks_per_split, chunks;  // 64-pixel chunks
+    int32_t main_blocks, left_m;               // wgrad3's balanced split (plan()): blocks >= main_blocks take the K remainder of left_m tiles each
     int32_t tiles_u, tiles_v;
     int32_t flags, v_affine;
     int32_t xcd_remap;
@@ -490,31 +491,19 @@ __device__ __forceinline__ bf16x8 w3_join(const W3Frag& f) {
     return __builtin_bit_cast(bf16x8, both);
 }
 
+// One (tile, K range) of the launch: tile (tu, tv, tap group grp), chunks [c_begin, c_end), partial sums into slab `ks`.
 template <int TG>
-__device__ __forceinline__ void wgrad3_body(const Wgrad2Args& a, uint8_t* smem) {
-    const int tid = threadIdx.x, lane = tid & 63;
+__device__ __forceinline__ void wgrad3_body(const Wgrad2Args& a, uint8_t* smem, const int tu, const int tv, const int grp, const int ks,
+                                            const int c_begin, const int c_end) {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));  // (per-lane addresses are formed per segment: hoisted out of the remainder blocks' loop they stay live through the epilogue)
+    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
-    // XCD-aware block order: workgroups are dealt round-robin over the 8 XCDs (one L2 each).  Blocks that share a K slice
-    // read the same pixels of U and V, so each XCD gets a CONTIGUOUS range of the (K-slice-major) block list: a slice is
-    // then fetched into one or two L2s instead of all eight (bijective for any grid size).
-    int bx = blockIdx.x;
-    if (a.xcd_remap) {
-        const int total = gridDim.x, q = total >> 3, r = total & 7, xcd = bx & 7;
-        bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bx >> 3);
-    }
-    const int tv = bx % a.tiles_v;
-    bx /= a.tiles_v;
-    const int tu = bx % a.tiles_u;
-    bx /= a.tiles_u;
-    const int grp = bx % a.groups;
-    const int ks = bx / a.groups;
     const int u0 = tu * 128, v0 = tv * 128;
     const int tap0 = a.g_first[grp];
     const int dh = a.dh[tap0], dw0 = a.dw[tap0];
     const int wchunks = (a.Wu + 63) / 64;  // the last chunk of an image row may be partial (W = 1808, 2656 ...): zero-filled
-    const int c_begin = ks * a.chunks_per_split;
-    const int c_end = (c_begin + a.chunks_per_split < a.chunks) ? c_begin + a.chunks_per_split : a.chunks;
     if (c_begin >= c_end) return;  // (the plan never makes an empty slice; its slab would be left unwritten)
 
     // ---- operand stream.  One wave-instruction = 4 pixel rows x 16 chunks of 16 bytes; wave w owns rows 8w .. 8w+7 of both
@@ -713,21 +702,44 @@ __device__ __forceinline__ void wgrad3_body(const Wgrad2Args& a, uint8_t* smem) 
     }
 }
 
+__device__ __forceinline__ void wgrad3_segment(const Wgrad2Args& a, uint8_t* smem, int tile, int ks, int c_begin, int c_end) {
+    const int tv = tile % a.tiles_v;
+    tile /= a.tiles_v;
+    const int tu = tile % a.tiles_u;
+    const int grp = tile / a.tiles_u;
+    const int cnt = a.g_count[grp];  // uniform per block
+    if (cnt == 3)
+        wgrad3_body<3>(a, smem, tu, tv, grp, ks, c_begin, c_end);
+    else if (cnt == 2)
+        wgrad3_body<2>(a, smem, tu, tv, grp, ks, c_begin, c_end);
+    else
+        wgrad3_body<1>(a, smem, tu, tv, grp, ks, c_begin, c_end);
+}
+
 __global__ __launch_bounds__(512, 2) void wgrad3_kernel(const Wgrad2Args a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t w3_smem[];
+    // XCD-aware block order: workgroups are dealt round-robin over the 8 XCDs (one L2 each).  Blocks that share a K slice
+    // read the same pixels of U and V, so each XCD gets a CONTIGUOUS range of the (K-slice-major) block list: a slice is
+    // then fetched into one or two L2s instead of all eight (bijective for any grid size).
     int bx = blockIdx.x;
     if (a.xcd_remap) {
         const int total = gridDim.x, q = total >> 3, r = total & 7, xcd = bx & 7;
         bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bx >> 3);
     }
-    bx /= (a.tiles_v * a.tiles_u);
-    const int cnt = a.g_count[bx % a.groups];  // uniform per block
-    if (cnt == 3)
-        wgrad3_body<3>(a, w3_smem);
-    else if (cnt == 2)
-        wgrad3_body<2>(a, w3_smem);
-    else
-        wgrad3_body<1>(a, w3_smem);
+    const int n_tiles = a.tiles_v * a.tiles_u * a.groups;
+    // regular block: one tile, one K slice of chunks_per_split chunks.  Remainder block of the balanced split (plan()): the K remainder
+    // [ks_main * chunks_per_split, chunks) of left_m tiles, one after the other, into the last slab.
+    const bool left = bx >= a.main_blocks;
+    const int ks = left ? a.main_blocks / n_tiles : bx / n_tiles;
+    const int first = left ? (bx - a.main_blocks) * a.left_m : bx - ks * n_tiles;
+    const int last = left ? (first + a.left_m < n_tiles ? first + a.left_m : n_tiles) : first + 1;
+    const int c_begin = ks * a.chunks_per_split;
+    const int c_end = (left || c_begin + a.chunks_per_split > a.chunks) ? a.chunks : c_begin + a.chunks_per_split;
+    for (int t = first; t < last; ++t) {
+        if (t != first) __syncthreads();  // (the ring is rewritten: every wave has read its last fragments)
+        wgrad3_segment(a, w3_smem, __builtin_amdgcn_readfirstlane(t), __builtin_amdgcn_readfirstlane(ks), __builtin_amdgcn_readfirstlane(c_begin),
+                       __builtin_amdgcn_readfirstlane(c_end));
+    }
 }
 
 struct WgradPlan {
@@ -735,7 +747,10 @@ struct WgradPlan {
     int64_t elems;
     bool v2;
     int groups, chunks, chunks_per_split;
+    int main_blocks, left_m, left_blocks;  // wgrad3's balanced split
 };
+
+bool wgrad_dma_eligible(const rvTapGeom* g, const rvTapShape* s);
 
 int plan(const rvTapGeom* g, const rvTapShape* s, WgradPlan* p) {
     p->taps = g->kh * g->kw;
@@ -775,6 +790,29 @@ int plan(const rvTapGeom* g, const rvTapShape* s, WgradPlan* p) {
         }
         p->chunks_per_split = (int)((p->chunks + ks2 - 1) / ks2);
         p->ksplit = (p->chunks + p->chunks_per_split - 1) / p->chunks_per_split;
+        p->main_blocks = base2 * p->ksplit;
+        p->left_m = 0;
+        p->left_blocks = 0;
+        // Balanced split (wgrad3): 48 tiles (512 <-> 512, 3x3) take 5 slices each = 240 workgroups on 256 CUs.  The 16 idle CUs get
+        // work: every tile keeps 5 slices of L chunks and leaves a remainder R = C - 5 L that a "remainder" workgroup sums for m = 3
+        // tiles in turn (one more slab per tile, three epilogues for that workgroup), with m R + (m - 1) overhead = L so that all 256
+        // workgroups finish together.  The regular slices of all tiles still cover the same pixels at the same time (L2 sharing), and
+        // so do the remainders.
+        const int64_t free_cus = 256 - (int64_t)base2 * ks2;
+        if (wgrad_dma_eligible(g, s) && getenv("RV3D_WGRAD_NO_BALANCE") == nullptr && ks2 >= 2 && p->ksplit == ks2 && free_cus >= 8 &&
+            (int64_t)base2 * ks2 * 100 < 256 * 96) {
+            const int64_t m = (base2 + free_cus - 1) / free_cus;
+            const int64_t ovh = getenv("RV3D_WGRAD_BALANCE_OVH") ? atoll(getenv("RV3D_WGRAD_BALANCE_OVH")) : 24;  // chunks one more prologue + epilogue is worth
+            const int64_t len = (m * p->chunks + (m - 1) * ovh + m * ks2) / (m * ks2 + 1);  // (rounded up)
+            const int64_t rem = p->chunks - ks2 * len;
+            if (m <= 4 && rem >= 32 && len >= 32) {
+                p->chunks_per_split = (int)len;
+                p->ksplit = (int)ks2 + 1;
+                p->main_blocks = base2 * (int)ks2;
+                p->left_m = (int)m;
+                p->left_blocks = (int)((base2 + m - 1) / m);
+            }
+        }
     }
     return 0;
 }
@@ -787,10 +825,12 @@ extern "C" int64_t rv_tap_wgrad_workspace_bytes(const rvTapGeom* g, const rvTapS
     return p.elems * p.ksplit * (int64_t)sizeof(float);
 }
 
-static bool wgrad_dma_eligible(const rvTapGeom* g, const rvTapShape* s) {
+namespace {
+bool wgrad_dma_eligible(const rvTapGeom* g, const rvTapShape* s) {
     return !(s->flags & (RV_IN_AFFINE | RV_IN_RELU)) && rv_pad32(g->cu) % 128 == 0 && rv_pad32(g->cv) % 128 == 0 &&
            getenv("RV3D_NO_WGRAD3") == nullptr;
 }
+}  // namespace
 
 extern "C" int rv_tap_wgrad_info(const rvTapGeom* g, const rvTapShape* s, int32_t* host_info) {
     RV_REQUIRE(g && s && host_info, "rv_tap_wgrad_info: null argument");
@@ -798,7 +838,7 @@ extern "C" int rv_tap_wgrad_info(const rvTapGeom* g, const rvTapShape* s, int32_
     plan(g, s, &p);
     host_info[0] = p.v2 ? (wgrad_dma_eligible(g, s) ? 3 : 2) : 1;
     host_info[1] = p.ksplit;
-    host_info[2] = p.v2 ? p.tiles_v * p.tiles_u * p.groups * p.ksplit : p.tiles_v * p.tiles_u * p.taps * p.ksplit;
+    host_info[2] = p.v2 ? p.main_blocks + p.left_blocks : p.tiles_v * p.tiles_u * p.taps * p.ksplit;
     return 0;
 }
 
@@ -839,6 +879,8 @@ extern "C" int rv_tap_wgrad(const rvTapGeom* g, const rvTapShape* s, const void*
         b.ksplit = p.ksplit;
         b.chunks_per_split = p.chunks_per_split;
         b.chunks = p.chunks;
+        b.main_blocks = p.main_blocks;
+        b.left_m = p.left_m;
         b.tiles_u = p.tiles_u;
         b.tiles_v = p.tiles_v;
         b.flags = s->flags & ~(RV_WGRAD_TORCH_LAYOUT | RV_WGRAD_DEFER_REDUCE);
@@ -856,7 +898,7 @@ extern "C" int rv_tap_wgrad(const rvTapGeom* g, const rvTapShape* s, const void*
                 }
             }
         hipStream_t st2 = (hipStream_t)stream;
-        const int grid2 = p.tiles_v * p.tiles_u * p.groups * p.ksplit;
+        const int grid2 = p.main_blocks + p.left_blocks;
         const bool dma = wgrad_dma_eligible(g, s);
         if (dma) {
             static bool attr_set = false;
