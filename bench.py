@@ -36,6 +36,9 @@ import os
 import sys
 import time
 
+if os.environ.get("RV3D_DIRECT_RCCL") is None:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before the HIP runtime starts (see range_view_3d_detection_amd/__init__.py)
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -417,7 +420,9 @@ def main() -> None:
         os.environ.setdefault("MASTER_PORT", "29655")
         backend = os.environ.get("RV3D_DIST_BACKEND", "nccl")  # "gloo": the 2-ranks-on-one-GPU test of this script
         local_rank %= max(torch.cuda.device_count(), 1)
-        if backend == "nccl":
+        if backend == "nccl" and os.environ.get("RV3D_LAZY_PG") is not None:  # (timing experiments: no eager communicator)
+            dist.init_process_group("nccl", rank=rank, world_size=world)
+        elif backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"), rank=rank, world_size=world)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
@@ -437,7 +442,7 @@ def main() -> None:
     use_ddp = os.environ.get("RV3D_DDP") is not None  # A/B: torch's DistributedDataParallel instead of engine.GradSync
     if dist_on and use_ddp:
         step_model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], gradient_as_bucket_view=True, static_graph=True)
-    elif dist_on:
+    elif dist_on and os.environ.get("RV3D_NO_GRADSYNC") is None:  # (RV3D_NO_GRADSYNC: timing experiments, one rank only)
         # the model's backward is three autograd nodes: one flat gradient buffer, one multi-tensor copy + one asynchronous RCCL
         # all-reduce per finished node, instead of DDP's per-parameter hooks / bucket copies / divisions (engine.GradSync)
         E.GRAD_SYNC = E.GradSync(params, world)

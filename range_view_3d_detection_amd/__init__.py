@@ -10,3 +10,15 @@ gfx950 behind the C ABI of ``include/rv3d.h``; there is no CPU fallback.
 """
 
 __version__ = "0.1"
+
+
+import os as _os
+
+# The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  A training step here uses
+# the compute stream, the weight-gradient side stream and -- data parallel -- ProcessGroupNCCL's stream; with four queues the side
+# stream ended up sharing a queue with another one as soon as a process group existed, and the step lost its overlap: +2.6..3 ms per
+# rv-av2 step from merely initialising RCCL, +5.1 with the collectives, against +1.6..3.2 (and -0.5 ms with no process group) at 8
+# (profiles/r04_hw_queues.md).  Read by the runtime when it initialises, i.e. at the first HIP call after this import; an explicit
+# setting wins.  The opt-in direct RCCL binding (rccl.py) is the exception: 124 ms per step at 8 queues against 101 at the default.
+if _os.environ.get("RV3D_DIRECT_RCCL") is None:
+    _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")

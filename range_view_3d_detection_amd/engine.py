@@ -305,6 +305,8 @@ class GradSync:
             else:
                 runs.append([o, o + n])
         live = torch.distributed.is_available() and torch.distributed.is_initialized()  # (also with ONE rank: the one-GPU test of the path)
+        if os.environ.get("RV3D_GRADSYNC_DRY") is not None:  # (timing experiments: everything but the collective itself)
+            live = False
         for lo, hi in runs:
             seg = self.flat[lo:hi]
             self.works.append((torch.distributed.all_reduce(seg, async_op=True) if live else None, seg))
