@@ -473,6 +473,159 @@ __global__ __launch_bounds__(256, 5) void bn_bwd_apply_lean_kernel(const BnbArgs
     }
 }
 
+// ---- lean forms of the other three passes (same layout and register budget as bn_bwd_apply_lean_kernel) ---------------------------
+__device__ __forceinline__ u32x2 ldq(const bf16_t* base, uint32_t off) { return *(const u32x2*)((const char*)base + off); }
+
+// one workgroup = kPixPerBlock pixels, like bn_bwd_reduce_kernel; rows [block][2][c]
+template <bool OUT>
+__global__ __launch_bounds__(256, 5) void bn_bwd_reduce_lean_kernel(const BnbArgs a) {
+    __shared__ float red[256][9];
+    constexpr int U = 8;
+    const int tid = threadIdx.x;
+    const int c4 = a.c8 * 2;
+    const int lanes_px = 256 / c4;
+    const int quad = tid % c4, pl = tid / c4;
+    const int c0 = quad * 4;
+    float sc[4], sh[4], mu[4], is[4], s0[4], s1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        sc[j] = a.scale[c0 + j];
+        sh[j] = a.shift[c0 + j];
+        mu[j] = a.mean[c0 + j];
+        is[j] = a.invstd[c0 + j];
+        s0[j] = 0.f;
+        s1[j] = 0.f;
+    }
+    const bool relu_z = (a.flags & RV_BNB_RELU_Z) != 0;
+    const int64_t p0 = (int64_t)blockIdx.x * kPixPerBlock;
+    const int64_t p1 = p0 + kPixPerBlock < a.pixels ? p0 + kPixPerBlock : a.pixels;
+    const int64_t first = p0 + pl;
+    const int n_px = (pl < lanes_px && first < p1) ? (int)((p1 - first + lanes_px - 1) / lanes_px) : 0;
+    uint32_t o_d = (uint32_t)((first * a.ld_dout + c0) * 2), o_y = (uint32_t)((first * a.ld_y + c0) * 2),
+             o_o = OUT ? (uint32_t)((first * a.ld_out + c0) * 2) : 0u;
+    const uint32_t s_d = lanes_px * a.ld_dout * 2, s_y = lanes_px * a.ld_y * 2, s_o = lanes_px * a.ld_out * 2;
+    auto add = [&](const u32x2 dv, const u32x2 yv, const u32x2 ov) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int j = 2 * h + e;
+                float g = e ? bf_hi(dv[h]) : bf_lo(dv[h]);
+                const float y = e ? bf_hi(yv[h]) : bf_lo(yv[h]);
+                if (OUT && !((e ? bf_hi(ov[h]) : bf_lo(ov[h])) > 0.f)) g = 0.f;
+                if (relu_z && !(y * sc[j] + sh[j] > 0.f)) g = 0.f;
+                s0[j] += g;
+                s1[j] = fmaf(g, (y - mu[j]) * is[j], s1[j]);  // (explicit: the pair kernel must add the same values in the same way)
+            }
+    };
+    int i = 0;
+    for (; i + U <= n_px; i += U) {
+        u32x2 dv[U], yv[U], ov[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            dv[u] = ldq(a.dout, o_d + u * s_d);
+            yv[u] = ldq(a.y, o_y + u * s_y);
+            ov[u] = OUT ? ldq(a.out, o_o + u * s_o) : u32x2{0, 0};
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) add(dv[u], yv[u], ov[u]);
+        o_d += U * s_d, o_y += U * s_y, o_o += U * s_o;
+    }
+    for (; i < n_px; ++i) {
+        add(ldq(a.dout, o_d), ldq(a.y, o_y), OUT ? ldq(a.out, o_o) : u32x2{0, 0});
+        o_d += s_d, o_y += s_y, o_o += s_o;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        red[tid][j] = s0[j];
+        red[tid][4 + j] = s1[j];
+    }
+    __syncthreads();
+    for (int k = tid; k < c4 * 8; k += 256) {  // thread (quad, j in 0..7) sums over the pixel lanes
+        const int q = k >> 3, j = k & 7;
+        float sum = 0.f;
+        for (int l = 0; l < lanes_px; ++l) sum += red[l * c4 + q][j];
+        a.partial[((int64_t)blockIdx.x * 2 + (j >> 2)) * a.c + q * 4 + (j & 3)] = sum;
+    }
+}
+
+__global__ __launch_bounds__(256, 5) void bn_bwd_reduce2_lean_kernel(const Bnb2Args a) {
+    __shared__ float red[256][13];
+    constexpr int U = 4;
+    const int tid = threadIdx.x;
+    const int c4 = a.c8 * 2;
+    const int lanes_px = 256 / c4;
+    const int quad = tid % c4, pl = tid / c4;
+    const int c0 = quad * 4;
+    float mua[4], isa[4], mub[4], isb[4], s0[4], sa[4], sb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        mua[j] = a.mean_a[c0 + j];
+        isa[j] = a.invstd_a[c0 + j];
+        mub[j] = a.mean_b[c0 + j];
+        isb[j] = a.invstd_b[c0 + j];
+        s0[j] = sa[j] = sb[j] = 0.f;
+    }
+    const int64_t p0 = (int64_t)blockIdx.x * kPixPerBlock;
+    const int64_t p1 = p0 + kPixPerBlock < a.pixels ? p0 + kPixPerBlock : a.pixels;
+    const int64_t first = p0 + pl;
+    const int n_px = (pl < lanes_px && first < p1) ? (int)((p1 - first + lanes_px - 1) / lanes_px) : 0;
+    uint32_t o_d = (uint32_t)((first * a.ld_dout + c0) * 2), o_o = (uint32_t)((first * a.ld_out + c0) * 2),
+             o_a = (uint32_t)((first * a.ld_ya + c0) * 2), o_b = (uint32_t)((first * a.ld_yb + c0) * 2);
+    const uint32_t s_d = lanes_px * a.ld_dout * 2, s_o = lanes_px * a.ld_out * 2, s_a = lanes_px * a.ld_ya * 2, s_b = lanes_px * a.ld_yb * 2;
+    auto add = [&](const u32x2 dv, const u32x2 ov, const u32x2 av, const u32x2 bv) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int j = 2 * h + e;
+                const float g = (e ? bf_hi(ov[h]) : bf_lo(ov[h])) > 0.f ? (e ? bf_hi(dv[h]) : bf_lo(dv[h])) : 0.f;
+                s0[j] += g;
+                sa[j] = fmaf(g, ((e ? bf_hi(av[h]) : bf_lo(av[h])) - mua[j]) * isa[j], sa[j]);
+                sb[j] = fmaf(g, ((e ? bf_hi(bv[h]) : bf_lo(bv[h])) - mub[j]) * isb[j], sb[j]);
+            }
+    };
+    int i = 0;
+    for (; i + U <= n_px; i += U) {
+        u32x2 dv[U], ov[U], av[U], bv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            dv[u] = ldq(a.dout, o_d + u * s_d);
+            ov[u] = ldq(a.out, o_o + u * s_o);
+            av[u] = ldq(a.ya, o_a + u * s_a);
+            bv[u] = ldq(a.yb, o_b + u * s_b);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) add(dv[u], ov[u], av[u], bv[u]);
+        o_d += U * s_d, o_o += U * s_o, o_a += U * s_a, o_b += U * s_b;
+    }
+    for (; i < n_px; ++i) {
+        add(ldq(a.dout, o_d), ldq(a.out, o_o), ldq(a.ya, o_a), ldq(a.yb, o_b));
+        o_d += s_d, o_o += s_o, o_a += s_a, o_b += s_b;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        red[tid][j] = s0[j];
+        red[tid][4 + j] = sa[j];
+        red[tid][8 + j] = sb[j];
+    }
+    __syncthreads();
+    for (int k = tid; k < c4 * 12; k += 256) {
+        const int q = k / 12, j = k - q * 12;
+        float sum = 0.f;
+        for (int l = 0; l < lanes_px; ++l) sum += red[l * c4 + q][j];
+        const int ch = q * 4 + (j & 3);
+        if (j < 4) {
+            a.partial_a[((int64_t)blockIdx.x * 2) * a.c + ch] = sum;
+            a.partial_b[((int64_t)blockIdx.x * 2) * a.c + ch] = sum;
+        } else if (j < 8) {
+            a.partial_a[((int64_t)blockIdx.x * 2 + 1) * a.c + ch] = sum;
+        } else {
+            a.partial_b[((int64_t)blockIdx.x * 2 + 1) * a.c + ch] = sum;
+        }
+    }
+}
+
 // The apply pass for the two BatchNorms under one block sum (see bn_bwd_reduce2_kernel): g = dOut * [out > 0] is formed once,
 // dYa / dYb leave together -- four reads and two writes where two apply passes take six and two.
 struct Bnb2Apply {
@@ -805,6 +958,12 @@ __global__ void sum_rows_f64_kernel(const double* rows, int n_rows, int cols, do
     }
 }
 
+// RV3D_BNB_LEAN (default 2): the lean (quad layout, <= 96 VGPRs) forms of the four BatchNorm-backward passes; 0: the octet forms
+int bnb_lean() {
+    static const int lean = getenv("RV3D_BNB_LEAN") ? atoi(getenv("RV3D_BNB_LEAN")) : 2;
+    return lean;
+}
+
 int grid_for(int64_t work) {
     int64_t b = (work + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -844,6 +1003,12 @@ extern "C" int rv_bn_bwd_reduce(int64_t pixels, int32_t c, const void* dout, int
     if (fill(&a, pixels, c, dout, ld_dout, out, ld_out, y, ld_y, scale, shift, mean, invstd, flags)) return 1;
     RV_REQUIRE(partial, "rv_bn_bwd_reduce: null partial buffer");
     a.partial = partial;
+    if (bnb_lean() && c <= 1024 && pixels * std::max(std::max((int64_t)ld_dout, (int64_t)ld_y), (int64_t)ld_out) * 2 < ((int64_t)1 << 32)) {
+        if (out) hipLaunchKernelGGL(bn_bwd_reduce_lean_kernel<true>, dim3(rv_bn_bwd_rows(pixels)), dim3(256), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(bn_bwd_reduce_lean_kernel<false>, dim3(rv_bn_bwd_rows(pixels)), dim3(256), 0, (hipStream_t)stream, a);
+        RV_CHECK_LAUNCH("bn_bwd_reduce_lean_kernel");
+        return 0;
+    }
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rv_bn_bwd_rows(pixels)), dim3(256), 0, (hipStream_t)stream, a);
     RV_CHECK_LAUNCH("bn_bwd_reduce_kernel");
     return 0;
@@ -861,6 +1026,11 @@ extern "C" int rv_bn_bwd_reduce_pair(int64_t pixels, int32_t c, const void* dout
     a.mean_a = mean_a, a.invstd_a = invstd_a, a.mean_b = mean_b, a.invstd_b = invstd_b;
     a.pixels = pixels, a.c = c, a.c8 = c / 8, a.ld_dout = ld_dout, a.ld_out = ld_out, a.ld_ya = ld_ya, a.ld_yb = ld_yb;
     a.partial_a = partial_a, a.partial_b = partial_b;
+    if (bnb_lean() && c <= 1024 && pixels * std::max(std::max((int64_t)ld_dout, (int64_t)ld_out), std::max((int64_t)ld_ya, (int64_t)ld_yb)) * 2 < ((int64_t)1 << 32)) {
+        hipLaunchKernelGGL(bn_bwd_reduce2_lean_kernel, dim3(rv_bn_bwd_rows(pixels)), dim3(256), 0, (hipStream_t)stream, a);
+        RV_CHECK_LAUNCH("bn_bwd_reduce2_lean_kernel");
+        return 0;
+    }
     hipLaunchKernelGGL(bn_bwd_reduce2_kernel, dim3(rv_bn_bwd_rows(pixels)), dim3(256), 0, (hipStream_t)stream, a);
     RV_CHECK_LAUNCH("bn_bwd_reduce2_kernel");
     return 0;
@@ -902,7 +1072,7 @@ extern "C" int rv_bn_bwd_apply(int64_t pixels, int32_t c, const void* dout, int3
     a.ld_dres = ld_dres;
     // lean form by default (RV3D_BNB_LEAN=0: the octet form; =1: one workgroup per CU): alone it takes the same time (96.7 against 96.5-96.9 ms
     // per rv-av2 step), beside a weight gradient on the side stream (engine.py RV3D_OVERLAP=chain) it is what fits on the CU
-    static const int lean = getenv("RV3D_BNB_LEAN") ? atoi(getenv("RV3D_BNB_LEAN")) : 2;
+    const int lean = bnb_lean();
     const int64_t ld_max = std::max(std::max((int64_t)ld_dout, (int64_t)ld_y), std::max(std::max((int64_t)ld_out, (int64_t)ld_dy), (int64_t)ld_dres));
     if (lean && c <= 1024 && pixels * ld_max * 2 < ((int64_t)1 << 32)) {  // (32-bit byte offsets)
         const int lanes4 = 256 / (2 * a.c8);
@@ -948,6 +1118,8 @@ extern "C" int rv_bn_bwd_apply_pair(int64_t pixels, int32_t c, const void* dout,
     a.dya = (bf16_t*)dya, a.dyb = (bf16_t*)dyb;
     a.pixels = pixels, a.c = c, a.c8 = c / 8;
     a.ld_dout = ld_dout, a.ld_out = ld_out, a.ld_ya = ld_ya, a.ld_yb = ld_yb, a.ld_dya = ld_dya, a.ld_dyb = ld_dyb;
+    // (no lean form of this one: ten constants per channel -- 40 registers at four channels per thread -- leave no room for loads in
+    //  flight within 96 registers; it runs beside a weight gradient only where that one leaves more)
     const int lanes_px = 256 / a.c8;
     int64_t blocks = (pixels + lanes_px - 1) / lanes_px;
     if (blocks > 4096) blocks = 4096;

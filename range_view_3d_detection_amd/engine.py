@@ -106,20 +106,24 @@ PROFILE: Optional[KernelProfile] = None
 
 # Weight gradients can run on a second HIP stream: wgrad(L) is independent of the main backward chain (dgrad(L) -> BatchNorm
 # backward(L-1) -> dgrad(L-1) ...).
-#   RV3D_OVERLAP=free        every weight gradient on the side stream.  Round-3 A/B on the final kernels
+#   RV3D_OVERLAP=free        (DEFAULT since the end of round 4, see below) every weight gradient on the side stream.  Round-3 A/B on the final kernels
 #                            (profiles/r03_overlap_ab.md): 3.6 % SLOWER than one stream -- two persistent one-workgroup-per-CU
 #                            kernels with 150 KB of LDS each cannot share a CU, the big layers only take turns;
 #   RV3D_OVERLAP=small[:T]   (T = 0.1; the round-3 default) only the weight gradients of layers below T TFLOP (the 128-channel DLA stages at
 #                            W <= 1024 and the 1x1 layers, whose kernels have fewer tiles than the chip has CUs) -- they run
 #                            beside the equally small backward-data / BatchNorm kernels of the main chain on CUs those leave
 #                            idle: -2.0 ms per step (103.1 / 103.3 -> 101.1 at T = 0.1, 101.2 / 101.7 at 0.35, 101.9 at 0.7);
-#   RV3D_OVERLAP=chain[:T]   (DEFAULT since round 4: -0.5 .. -0.9 ms per rv-av2 step, profiles/r04_ab_notes.md) the small layers as above, and the BIG weight gradients on the side stream too, but chained: the next
+#   RV3D_OVERLAP=chain[:T]   (-0.5 .. -0.9 ms per rv-av2 step against small, profiles/r04_ab_notes.md) the small layers as above, and the BIG weight gradients on the side stream too, but chained: the next
 #                            backward-data launch of the main stream waits for the weight gradient issued before it, so the two
 #                            MFMA families still take turns on the CUs (dgrad(L), wgrad(L), dgrad(L-1), ...) -- what runs BESIDE
 #                            wgrad(L) is the bandwidth-bound BatchNorm backward of layer L-1 on the main stream, whose kernels are
 #                            sized (<= 96 VGPRs, <= 28 KB of LDS) to fit on a CU next to a resident wgrad3 workgroup;
 #   RV3D_OVERLAP=off         one stream.
-_OVERLAP = os.environ.get("RV3D_OVERLAP", "chain")
+# Round 4, after the lean BatchNorm-backward kernels, the balanced wgrad3 split and GPU_MAX_HW_QUEUES=8: `free` is the fastest again
+# (93.55 / 93.77 against 95.03 / 95.02 chain, 95.59 / 95.46 small, 96.77 off on one box; 94.08 / 95.50 against 96.64 / 96.35 on
+# another; rv-waymo 53.7 against 53.9) -- the chained mode pays an event round trip per layer, and with the lean passes resident
+# beside the weight gradients (`RV3D_BNB_LEAN=0`: +1 ms in this mode) there is now something to run beside them.
+_OVERLAP = os.environ.get("RV3D_OVERLAP", "free")
 if os.environ.get("RV3D_NO_OVERLAP") is not None:
     _OVERLAP = "off"
 OVERLAP_WGRAD = _OVERLAP == "free" or _OVERLAP.startswith("small") or _OVERLAP.startswith("chain")
@@ -135,8 +139,10 @@ _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 def side_stream(device) -> "torch.cuda.Stream":
     idx = torch.device(device).index or 0
     if idx not in _SIDE_STREAMS:
-        prio = os.environ.get("RV3D_SIDE_PRIORITY")
-        _SIDE_STREAMS[idx] = torch.cuda.Stream(device=device, priority=int(prio)) if prio is not None else torch.cuda.Stream(device=device)
+        # high priority (-1): a weight gradient that is ready takes the CUs before the backward-data launch behind it on the main stream --
+        # the order the dependencies give anyway (RV3D_SIDE_PRIORITY=0: 94.08 / 95.50 against 93.99 / 94.69 ms, profiles/r04_ab_notes.md)
+        prio = int(os.environ.get("RV3D_SIDE_PRIORITY", "-1"))
+        _SIDE_STREAMS[idx] = torch.cuda.Stream(device=device, priority=prio)
     return _SIDE_STREAMS[idx]
 
 

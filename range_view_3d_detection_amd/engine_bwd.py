@@ -134,7 +134,7 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
                 call = lambda: L.call("rv_tap_data_grad_bnb", ctypes.byref(g), ctypes.byref(shape), L.i32(1 if bwd == "scatter" else 0), dout.ptr(),
                                       L.ptr(wp), dst.ptr(), ctypes.byref(epi), L.stream_ptr())
                 t.lazy_sums[id(lz)] = (partial, rows, dst)
-        if E.OVERLAP_CHAIN and E.EARLY_WGRAD_FILL > 0:
+        if E.OVERLAP_WGRAD and E.EARLY_WGRAD_FILL > 0:
             # a persistent backward-data launch whose LAST round of tiles fills only part of the chip (1328 tiles on 256 CUs: five full
             # rounds and 48 tiles): the weight gradient of the same layer -- it reads dOut and the layer input, both complete -- is
             # released BEFORE this launch, queues behind it and takes the CUs as they fall idle in that last round
@@ -202,13 +202,13 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
     if E.OVERLAP_WGRAD and (small or E.OVERLAP_CHAIN):
         side = E.side_stream(t.device)
         ready = early_ready
-        if ready is None or small:
+        if ready is None:
             ready = torch.cuda.Event()
             ready.record()  # dout (and everything before it on the main stream) is complete at this point of the main stream
         side.wait_event(ready)
         with torch.cuda.stream(side):
             run_wgrad()
-            if not small:  # chained: the main stream's next MFMA-bound launch waits for this one (_wait_chained_wgrad)
+            if E.OVERLAP_CHAIN and not small:  # chained: the main stream's next MFMA-bound launch waits for this one (_wait_chained_wgrad)
                 t.chained_wgrad = torch.cuda.Event()
                 t.chained_wgrad.record()
         t.used_side_stream = True
