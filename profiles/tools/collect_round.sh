@@ -18,6 +18,10 @@ pass() {  # pass <dir> <rocprofv3 args...>
 db() { find /tmp/prof/${tag}_$1 -name '*_results.db' | head -1; }
 pass trace --kernel-trace --stats
 python3 "$root/profiles/kernel_stats.py" "$(db trace)" > "$root/gpurun_out/${tag}_bench_kernel_stats.csv"
+# the same with every kernel on ONE stream: the kernels' own durations (bench.py's roofline.achieved; with the weight gradients
+# free-running on the side stream a launch's begin-to-end time includes the time its workgroups wait for CUs: roofline.live)
+RV3D_OVERLAP=off pass trace1 --kernel-trace --stats
+python3 "$root/profiles/kernel_stats.py" "$(db trace1)" > "$root/gpurun_out/${tag}_bench_kernel_stats_one_stream.csv"
 pass fetch --pmc FETCH_SIZE --kernel-trace
 pass write --pmc WRITE_SIZE --kernel-trace
 python3 "$root/profiles/pmc_traffic.py" "$(db fetch)" "$(db write)" > "$root/gpurun_out/${tag}_pmc_traffic.json"
