@@ -615,8 +615,11 @@ __global__ __launch_bounds__(256) void ew_combine_kernel(const EwArgs e) {
 // The same map with thread = (pixel lane, channel octet): the folded-BatchNorm constants of the thread's octet stay in
 // registers, and every workgroup walks one CONTIGUOUS pixel range with two pixels in flight (see bn_bwd_apply_kernel:
 // contiguous ranges read + write ~15 % faster than a grid-stride comb).  c8 <= 256.
-template <bool NT>  // NT: non-temporal loads and stores (tensors beyond the Infinity Cache: nothing of them is found there again)
-__global__ __launch_bounds__(256) void ew_combine_rows_kernel(const EwArgs e) {
+// HAS_B = false: the one-operand form (writing relu(bn(y)) out for a DMA kernel) in at most 64 VGPRs, so that a workgroup of it
+// fits on a CU beside a resident tapconv6 workgroup (2 waves per SIMD x 224 VGPRs): the towers of a head run on two streams
+// (program.dense_head_pair_program) and one tower's write-out pass streams while the other tower's conv computes.
+template <bool NT, bool HAS_B>  // NT: non-temporal loads and stores (tensors beyond the Infinity Cache: nothing of them is found there again)
+__global__ __launch_bounds__(256, HAS_B ? 1 : 8) void ew_combine_rows_kernel(const EwArgs e) {
     const int tid = threadIdx.x;
     const int lanes_px = 256 / e.c8;
     const int oct = tid % e.c8, pl = tid / e.c8;
@@ -627,8 +630,8 @@ __global__ __launch_bounds__(256) void ew_combine_rows_kernel(const EwArgs e) {
     for (int j = 0; j < 8; ++j) {
         as[j] = e.a_scale ? e.a_scale[c + j] : 1.f;
         ah[j] = e.a_scale ? e.a_shift[c + j] : 0.f;
-        bs[j] = e.b_scale ? e.b_scale[c + j] : 1.f;
-        bh[j] = e.b_scale ? e.b_shift[c + j] : 0.f;
+        bs[j] = (HAS_B && e.b_scale) ? e.b_scale[c + j] : 1.f;
+        bh[j] = (HAS_B && e.b_scale) ? e.b_shift[c + j] : 0.f;
     }
     const int64_t per = ((e.pixels + gridDim.x - 1) / gridDim.x + lanes_px - 1) / lanes_px * lanes_px;
     const int64_t end = (int64_t)(blockIdx.x + 1) * per < e.pixels ? (int64_t)(blockIdx.x + 1) * per : e.pixels;
@@ -645,7 +648,7 @@ __global__ __launch_bounds__(256) void ew_combine_rows_kernel(const EwArgs e) {
         for (int j = 0; j < 8; ++j) {
             float x = e.a_scale ? va[j] * as[j] + ah[j] : va[j];
             if (e.flags & RV_EW_RELU_A) x = fmaxf(x, 0.f);
-            if (e.b) {
+            if (HAS_B && e.b) {
                 float y = e.b_scale ? vb[j] * bs[j] + bh[j] : vb[j];
                 if (e.flags & RV_EW_RELU_B) y = fmaxf(y, 0.f);
                 x += y;
@@ -667,7 +670,7 @@ __global__ __launch_bounds__(256) void ew_combine_rows_kernel(const EwArgs e) {
     for (; px + lanes_px < end; px += 2 * lanes_px) {
         const u32x4 a0 = ld(e.a + px * e.ld_a + c), a1 = ld(e.a + (px + lanes_px) * e.ld_a + c);
         u32x4 b0 = {}, b1 = {};
-        if (e.b) {
+        if (HAS_B && e.b) {
             b0 = ld(e.b + px * e.ld_b + c);
             b1 = ld(e.b + (px + lanes_px) * e.ld_b + c);
         }
@@ -677,7 +680,7 @@ __global__ __launch_bounds__(256) void ew_combine_rows_kernel(const EwArgs e) {
     if (px < end) {
         const u32x4 a0 = ld(e.a + px * e.ld_a + c);
         u32x4 b0 = {};
-        if (e.b) b0 = ld(e.b + px * e.ld_b + c);
+        if (HAS_B && e.b) b0 = ld(e.b + px * e.ld_b + c);
         finish(px, a0, b0);
     }
 }
@@ -702,8 +705,14 @@ extern "C" int rv_ew_combine(int64_t pixels, int32_t c, const void* a, int32_t l
         const int lanes_px = 256 / e.c8;
         int64_t blocks = (pixels + lanes_px - 1) / lanes_px;
         if (blocks > 4096) blocks = 4096;
-        if (getenv("RV3D_EW_NO_NT") == nullptr) hipLaunchKernelGGL(ew_combine_rows_kernel<true>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, e);
-        else hipLaunchKernelGGL(ew_combine_rows_kernel<false>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, e);
+        const bool nt = getenv("RV3D_EW_NO_NT") == nullptr;
+        if (e.b) {
+            if (nt) hipLaunchKernelGGL((ew_combine_rows_kernel<true, true>), dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, e);
+            else hipLaunchKernelGGL((ew_combine_rows_kernel<false, true>), dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, e);
+        } else {
+            if (nt) hipLaunchKernelGGL((ew_combine_rows_kernel<true, false>), dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, e);
+            else hipLaunchKernelGGL((ew_combine_rows_kernel<false, false>), dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, e);
+        }
     } else {
         hipLaunchKernelGGL(ew_combine_kernel, dim3(ew_grid(pixels * (c / 8))), dim3(256), 0, (hipStream_t)stream, e);
     }

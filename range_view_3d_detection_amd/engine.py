@@ -146,6 +146,20 @@ def side_stream(device) -> "torch.cuda.Stream":
     return _SIDE_STREAMS[idx]
 
 
+# RV3D_TWO_STREAM_TOWERS=1: forward pass of a head's tower pair on two streams (program.dense_head_pair_program).  OPT-IN: measured
+# 0.6 ms per rv-av2 step SLOWER (98.16 / 98.62 against 97.59 / 97.94, same box; rv-waymo +0.1): two persistent tapconv6 launches
+# take the CUs from each other, and the write-out pass beside a power-capped conv is not free (profiles/r04_ab_notes.md).
+TWO_STREAM_TOWERS = os.environ.get("RV3D_TWO_STREAM_TOWERS", "0") != "0"
+_SECOND_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
+
+
+def second_stream(device) -> "torch.cuda.Stream":
+    idx = torch.device(device).index or 0
+    if idx not in _SECOND_STREAMS:
+        _SECOND_STREAMS[idx] = torch.cuda.Stream(device=device)
+    return _SECOND_STREAMS[idx]
+
+
 def _launch(name: str, flops: float, fn, nbytes: float = 0.0) -> None:
     if PROFILE is not None:
         PROFILE.launch(name, flops, fn, nbytes)
