@@ -493,9 +493,11 @@ def main() -> None:
     if dist_on:
         torch.distributed.barrier()
     torch.cuda.synchronize()
-    E.PROFILE = E.KernelProfile()  # events around each tap-conv / wgrad launch inside the timed region
+    # events around each tap-conv / wgrad launch inside the timed region
+    prof = E.KernelProfile()
     E.COLLECTIVES.reset()
     t0 = time.perf_counter()
+    E.PROFILE = prof
     for _ in range(args.steps):
         loss = step()
     torch.cuda.synchronize()
@@ -504,7 +506,7 @@ def main() -> None:
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     _progress(f"timed region done: {1e3 * elapsed / args.steps:.1f} ms per step")
-    prof = E.PROFILE
+    E.PROFILE = None
     sync_calls, sync_bytes = E.COLLECTIVES.calls / args.steps, E.COLLECTIVES.bytes / args.steps
     # the same per-kernel events once more, outside the timed region, with the weight-gradient side stream off: with
     # it on, kernels of the two streams share the CUs and each one's event-to-event time includes its neighbour's

@@ -213,6 +213,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
                 if (cv < a.cv_pad) slab[(int64_t)cu * a.cv_pad + cv] = acc[i][j][r];
             }
         }
+    __syncthreads();
+    if (threadIdx.x < 64) __threadfence();  // (explicit release of the slabs: see wgrad3_body)
 }
 
 // torch layout of the result (RV_WGRAD_TORCH_LAYOUT): dT[cu][cv][kh][kw] instead of the packed [tap][cu_pad][cv_pad]
@@ -293,7 +295,7 @@ struct Wgrad2Args {
     int32_t main_blocks, left_m;               // wgrad3's balanced split (plan()): blocks >= main_blocks take the K remainder of left_m tiles each
     int32_t tiles_u, tiles_v;
     int32_t flags, v_affine;
-    int32_t xcd_remap;
+    int32_t xcd_remap, no_fence;
     int8_t g_first[kMaxTaps], g_count[kMaxTaps];  // tap group -> first tap index / number of taps (<= 3)
     int8_t dh[kMaxTaps], dw[kMaxTaps];
 };
@@ -434,6 +436,10 @@ __device__ __forceinline__ void wgrad2_body(const Wgrad2Args& a, bf16_t (*lds)[2
                 if (cv < a.cv_pad) *(f32x4*)(slab + (int64_t)cu * a.cv_pad + cv) = acc[t][i][j];
             }
         }
+    }
+    if (!a.no_fence) {  // (explicit release of the slabs: see wgrad3_body)
+        __syncthreads();
+        if (threadIdx.x < 64) __threadfence();
     }
 }
 
@@ -700,6 +706,17 @@ __device__ __forceinline__ void wgrad3_body(const Wgrad2Args& a, uint8_t* smem, 
             }
         }
     }
+    // Explicit agent-scope release of the slabs.  These launches run on the side stream while other queues are busy; once in ~2500
+    // training steps the split-K reduction that follows on the SAME stream summed a slab region that still held its previous
+    // contents (always the 64-workgroup launch of one 1x1 layer: one wrong weight gradient, nothing else -- profiles/r04_ab_notes.md,
+    // "A wrong step").  With the fence: 0 wrong steps in 60 runs where 4-5 were expected.  The kernel boundary alone is not enough
+    // there; the fence costs nothing measurable.
+    // (one wave per workgroup, after all of its waves have stored: every wave doing it cost 4 ms per training step -- each
+    //  `buffer_wbl2` walks the L2 of its XCD, which the concurrently running tap-conv launches keep full of dirty output lines)
+    if (!a.no_fence) {
+        __syncthreads();
+        if (threadIdx.x < 64) __threadfence();
+    }
 }
 
 __device__ __forceinline__ void wgrad3_segment(const Wgrad2Args& a, uint8_t* smem, int tile, int ks, int c_begin, int c_end) {
@@ -886,6 +903,7 @@ extern "C" int rv_tap_wgrad(const rvTapGeom* g, const rvTapShape* s, const void*
         b.flags = s->flags & ~(RV_WGRAD_TORCH_LAYOUT | RV_WGRAD_DEFER_REDUCE);
         b.v_affine = v_affine;
         b.xcd_remap = 1;
+        b.no_fence = getenv("RV3D_WGRAD_NO_FENCE") != nullptr;  // (A/B of the release fence at the end of the weight-gradient kernels)
         int gi = 0;
         for (int ky = 0; ky < g->kh; ++ky)
             for (int kx = 0; kx < g->kw; ++kx) {

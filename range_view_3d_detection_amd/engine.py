@@ -128,6 +128,18 @@ if os.environ.get("RV3D_NO_OVERLAP") is not None:
     _OVERLAP = "off"
 OVERLAP_WGRAD = _OVERLAP == "free" or _OVERLAP.startswith("small") or _OVERLAP.startswith("chain")
 OVERLAP_CHAIN = _OVERLAP.startswith("chain")
+# Synchronised BatchNorm over real ranks: weight gradients are held until the next BatchNorm-backward all-reduce is under way
+# (engine_bwd.conv_backward); RV3D_HOLD_WGRAD=0: launch them at once, as in the local case
+HOLD_WGRAD_FOR_SYNC_BN = os.environ.get("RV3D_HOLD_WGRAD", "1") != "0"
+
+
+def sync_bn_active() -> bool:
+    """True when BatchNorm statistics are all-reduced in this process (SyncBN over > 1 ranks, or the one-rank test of that path)."""
+    if SYNC_BN is False or not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+        return False
+    return _dist_world() > 1 or (SYNC_WORLD1 and SYNC_BN is True)
+
+
 # chain mode: a big weight gradient is released before (not after) the backward-data launch of its layer when that launch's last round of
 # persistent tiles fills less than this fraction of the CUs (rv-waymo: W = 2656 gives 1328 tiles = 5.19 rounds); 0 = never
 EARLY_WGRAD_FILL = float(os.environ.get("RV3D_EARLY_WGRAD_FILL", "0.9"))
@@ -757,6 +769,7 @@ class Tape:
         self.params: Dict[int, nn.Parameter] = {}
         self.used_side_stream = False
         self.chained_wgrad = None  # (RV3D_OVERLAP=chain) event behind the last big weight gradient on the side stream
+        self.held_wgrads: List = []  # weight-gradient launches held back for a SyncBN all-reduce (engine_bwd._release_held_wgrads)
         self.bn_counters: List[Tensor] = []
 
     # ---- gradient buffers (views follow their parents) ----
@@ -902,6 +915,7 @@ class Tape:
             op.backward(self)
         if pending:
             engine_bwd.bn_backward_finish(pending, self)
+        engine_bwd._release_held_wgrads(self)
         if self.used_side_stream:  # parameter gradients (and the buffers the side stream read) are final after this
             torch.cuda.current_stream().wait_stream(side_stream(self.device))
         self.flush_wgrad_reduces()

@@ -63,6 +63,7 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
     dout = _conv_out_grad(op, t)
     if dout is None:
         return
+    _release_held_wgrads(t)  # (weight gradients of earlier layers that met no all-reduce since)
     layer, g = op.layer, op.layer.geom
     src, sc, sh, in_flags = E._operand_parts(op.x)
     if op.x_plain is not None:  # the forward pass wrote relu(bn(.)) out for the DMA kernel: the weight gradient reads it too
@@ -199,7 +200,15 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
         t.add_param_grad(layer.weight, layer.unpermute_grad(grad))
 
     small = E.OVERLAP_MAX_TFLOP is None or E.tap_flops(g, wshape) < 1e12 * E.OVERLAP_MAX_TFLOP
-    if E.OVERLAP_WGRAD and (small or E.OVERLAP_CHAIN):
+    if E.OVERLAP_WGRAD and E.HOLD_WGRAD_FOR_SYNC_BN and E.sync_bn_active():
+        # Synchronised BatchNorm statistics over real ranks: the all-reduce of the NEXT BatchNorm backward is an RCCL kernel that needs a
+        # CU slot, and it becomes ready at the same moment as this weight gradient (both wait for the backward-data launch above).  A
+        # weight gradient that reaches the CUs first holds all of them for its whole duration and the collective -- the critical chain --
+        # waits behind it.  So the launch is HELD until that all-reduce has been enqueued and waited for on the main stream
+        # (_release_held_wgrads: bn_backward_finish / the next conv / the end of the pass); it then runs beside the finalize + apply passes
+        # exactly as in the local case.
+        t.held_wgrads.append(run_wgrad)
+    elif E.OVERLAP_WGRAD and (small or E.OVERLAP_CHAIN):
         side = E.side_stream(t.device)
         ready = early_ready
         if ready is None:
@@ -214,6 +223,22 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
         t.used_side_stream = True
     else:
         run_wgrad()
+
+
+def _release_held_wgrads(t: Tape) -> None:
+    """Launch the weight gradients held back for a SyncBN all-reduce (see conv_backward) on the side stream, behind everything the
+    main stream has been given so far."""
+    if not t.held_wgrads:
+        return
+    side = E.side_stream(t.device)
+    ready = torch.cuda.Event()
+    ready.record()
+    side.wait_event(ready)
+    with torch.cuda.stream(side):
+        for run in t.held_wgrads:
+            run()
+    t.held_wgrads = []
+    t.used_side_stream = True
 
 
 def _wait_chained_wgrad(t: Tape) -> None:
@@ -387,6 +412,7 @@ def bn_backward_finish(recs, t: Tape) -> None:
         views = E.allreduce_partial_rows_many([(recs[i][2], recs[i][3], recs[i][4], local[i]) for i in sync])
         for i, v in zip(sync, views):
             glob[i] = v
+        _release_held_wgrads(t)  # (the collective is enqueued and the main stream waits for it: the held weight gradients may take the CUs now)
     for (op, common, partial, rows, pixels, flags, res, _keep), g, loc in zip(recs, glob, local):
         lazy = op.lazy
         st, raw = lazy.bn, lazy.raw
@@ -417,6 +443,7 @@ def _bn_finalize(op: "E.BnOp", t: Tape, partial: Tensor, rows: int, pixels: int,
         if glob is None:
             local = torch.empty((2, cp), dtype=torch.float32, device=t.device)
             glob = E.allreduce_partial_rows(partial, rows, pixels, local)
+            _release_held_wgrads(t)
         L.call("rv_bn_bwd_finalize", L.ptr(glob), L.i32(1), L.i32(cp), L.i64(-1), L.ptr(op.gamma_p), L.ptr(st.invstd),
                None, None, L.i32(0), L.ptr(coef), L.stream_ptr())
         return local[1], local[0], coef
@@ -476,6 +503,7 @@ def combine_backward(op: "E.CombineOp", t: Tape) -> None:
             if ops[0].sync_world > 1:
                 locs = [torch.empty((2, gout.cp), dtype=torch.float32, device=t.device) for _ in ops]
                 globs = E.allreduce_partial_rows_many([(pa, rows, gout.pixels, locs[0]), (pb, rows, gout.pixels, locs[1])])
+                _release_held_wgrads(t)
             coefs = []
             for o, part, gl, lo in zip(ops, (pa, pb), globs, locs):
                 dgamma, dbeta, coef = _bn_finalize(o, t, part, rows, gout.pixels, glob=gl, local=lo)
