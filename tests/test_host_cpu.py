@@ -84,6 +84,33 @@ def test_host_side_geometry(lib):
     assert h.rv_bn_bwd_rows(ctypes.c_int64(4 * 64 * 2048)) == 1024
 
 
+def test_weight_gradient_split_plans(lib):
+    """rv_tap_wgrad_info (host only): kernel generation, split-K slabs and workgroups of the weight-gradient launch.  One round of
+    workgroups as close to 256 as the tile count allows; the 48-tile 512 <-> 512 layer takes the BALANCED split (five regular slices per
+    tile + sixteen remainder workgroups that each finish three tiles: a sixth slab, all 256 CUs busy), which `RV3D_WGRAD_NO_BALANCE=1`
+    switches off."""
+    h = lib.load()
+    info = (ctypes.c_int32 * 4)()
+    s = lib.TapShape(4, 64, 2048, 2048, 0, 0, 0)
+
+    def plan(cu, cv, k):
+        g = lib.TapGeom(k, k, 1, k // 2, k // 2, cu, cv)
+        assert h.rv_tap_wgrad_info(ctypes.byref(g), ctypes.byref(s), info) == 0
+        nbytes = h.rv_tap_wgrad_workspace_bytes(ctypes.byref(g), ctypes.byref(s))
+        assert nbytes == info[1] * k * k * cu * cv * 4  # one fp32 slab per split
+        return list(info)[:3]
+
+    assert plan(512, 512, 3) == [3, 6, 256]       # wgrad3, 5 + 1 slabs, 240 regular + 16 remainder workgroups
+    assert plan(256, 256, 3) == [3, 21, 252]      # 12 tiles x 21 slices: already 98 % of the CUs, plain split
+    assert plan(128, 128, 3) == [3, 85, 255]
+    assert plan(128, 128, 1) == [3, 128, 128]     # 1x1: at least 32 chunks of 64 pixels per workgroup
+    os.environ["RV3D_WGRAD_NO_BALANCE"] = "1"
+    try:
+        assert plan(512, 512, 3) == [3, 5, 240]
+    finally:
+        del os.environ["RV3D_WGRAD_NO_BALANCE"]
+
+
 def test_null_arguments_fail_with_message(lib):
     h = lib.load()
     assert h.rv_ew_combine(ctypes.c_int64(10), 32, None, 32, None, None, None, 0, None, None, None, 32, 0, None) != 0
