@@ -103,7 +103,7 @@ def test_weight_gradient_split_plans(lib):
     assert plan(512, 512, 3) == [3, 6, 256]       # wgrad3, 5 + 1 slabs, 240 regular + 16 remainder workgroups
     assert plan(256, 256, 3) == [3, 21, 252]      # 12 tiles x 21 slices: already 98 % of the CUs, plain split
     assert plan(128, 128, 3) == [3, 85, 255]
-    assert plan(128, 128, 1) == [3, 128, 128]     # 1x1: at least 32 chunks of 64 pixels per workgroup
+    assert plan(128, 128, 1) == [3, 256, 256]     # 1x1, one tile: 8192 chunks of 64 pixels over 256 workgroups (never fewer than 32 per workgroup)
     os.environ["RV3D_WGRAD_NO_BALANCE"] = "1"
     try:
         assert plan(512, 512, 3) == [3, 5, 240]
