@@ -254,6 +254,12 @@ __device__ __forceinline__ void wgrad_reduce_body(const float* slabs, int ksplit
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, int ksplit, int64_t elems, float* out, const UnpackTo up) {
     wgrad_reduce_body(slabs, ksplit, elems, out, up, blockIdx.x * (int64_t)blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
+    // small launches (the strided layers' folded gradients, which rv_unfold_weight_grad reads right behind this one on the same stream):
+    // the same explicit release as at the end of the weight-gradient kernels (wgrad3_body); the big ones are read across a stream join
+    if (gridDim.x <= 128) {
+        __syncthreads();
+        if (threadIdx.x < 64) __threadfence();
+    }
 }
 
 // the reductions of up to 64 layers in one launch (rv_wgrad_reduce_batch): blockIdx.y = layer, the table travels as kernel arguments
