@@ -213,8 +213,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
                 if (cv < a.cv_pad) slab[(int64_t)cu * a.cv_pad + cv] = acc[i][j][r];
             }
         }
-    __syncthreads();
-    if (threadIdx.x < 64) __threadfence();  // (explicit release of the slabs: see wgrad3_body)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (no wave ends with slab stores in flight: see wgrad3_body)
 }
 
 // torch layout of the result (RV_WGRAD_TORCH_LAYOUT): dT[cu][cv][kh][kw] instead of the packed [tap][cu_pad][cv_pad]
@@ -254,12 +253,7 @@ __device__ __forceinline__ void wgrad_reduce_body(const float* slabs, int ksplit
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, int ksplit, int64_t elems, float* out, const UnpackTo up) {
     wgrad_reduce_body(slabs, ksplit, elems, out, up, blockIdx.x * (int64_t)blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
-    // small launches (the strided layers' folded gradients, which rv_unfold_weight_grad reads right behind this one on the same stream):
-    // the same explicit release as at the end of the weight-gradient kernels (wgrad3_body); the big ones are read across a stream join
-    if (gridDim.x <= 128) {
-        __syncthreads();
-        if (threadIdx.x < 64) __threadfence();
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (no wave ends with stores in flight: see wgrad3_body; rv_unfold_weight_grad may follow)
 }
 
 // the reductions of up to 64 layers in one launch (rv_wgrad_reduce_batch): blockIdx.y = layer, the table travels as kernel arguments
@@ -443,10 +437,7 @@ __device__ __forceinline__ void wgrad2_body(const Wgrad2Args& a, bf16_t (*lds)[2
             }
         }
     }
-    if (!a.no_fence) {  // (explicit release of the slabs: see wgrad3_body)
-        __syncthreads();
-        if (threadIdx.x < 64) __threadfence();
-    }
+    if (a.no_fence != 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (no wave ends with slab stores in flight: see wgrad3_body)
 }
 
 __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const Wgrad2Args a) {
@@ -712,16 +703,17 @@ __device__ __forceinline__ void wgrad3_body(const Wgrad2Args& a, uint8_t* smem, 
             }
         }
     }
-    // Explicit agent-scope release of the slabs.  These launches run on the side stream while other queues are busy; once in ~2500
-    // training steps the split-K reduction that follows on the SAME stream summed a slab region that still held its previous
-    // contents (always the 64-workgroup launch of one 1x1 layer: one wrong weight gradient, nothing else -- profiles/r04_ab_notes.md,
-    // "A wrong step").  With the fence: 0 wrong steps in 60 runs where 4-5 were expected.  The kernel boundary alone is not enough
-    // there; the fence costs nothing measurable.
-    // (one wave per workgroup, after all of its waves have stored: every wave doing it cost 4 ms per training step -- each
-    //  `buffer_wbl2` walks the L2 of its XCD, which the concurrently running tap-conv launches keep full of dirty output lines)
-    if (!a.no_fence) {
+    // A wave must not END with its slab stores still in flight.  These launches run on the side stream while other queues are busy;
+    // once in ~2500 training steps the split-K reduction that follows on the SAME stream summed slab lines that still held the previous
+    // tenant of the recycled workspace (always the 64-workgroup launch of one 1x1 layer: one wrong weight gradient, nothing else --
+    // profiles/r04_ab_notes.md, "One wrong weight gradient").  Waiting for the stores' acknowledgement before the wave ends: 0 wrong
+    // steps in 75 runs of 25 steps where 5-6 were expected (an explicit agent-scope release after a barrier, `__threadfence()`: 0 in
+    // 240; it costs 0.1-0.3 ms per step and is kept as RV3D_WGRAD_NO_FENCE=3; =1: neither, for A/B).
+    if (a.no_fence == 3) {
         __syncthreads();
         if (threadIdx.x < 64) __threadfence();
+    } else if (a.no_fence != 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 }
 
@@ -909,7 +901,7 @@ extern "C" int rv_tap_wgrad(const rvTapGeom* g, const rvTapShape* s, const void*
         b.flags = s->flags & ~(RV_WGRAD_TORCH_LAYOUT | RV_WGRAD_DEFER_REDUCE);
         b.v_affine = v_affine;
         b.xcd_remap = 1;
-        b.no_fence = getenv("RV3D_WGRAD_NO_FENCE") != nullptr;  // (A/B of the release fence at the end of the weight-gradient kernels)
+        b.no_fence = getenv("RV3D_WGRAD_NO_FENCE") ? atoi(getenv("RV3D_WGRAD_NO_FENCE")) : 0;  // (A/B of the release fence at the end of the weight-gradient kernels)
         int gi = 0;
         for (int ky = 0; ky < g->kh; ++ky)
             for (int kx = 0; kx < g->kw; ++kx) {
