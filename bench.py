@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Headline benchmark: training-step throughput (sweeps/s, fwd+bwd) of the rv-av2 range-view detector.
 
-    python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus N --steps 10 --warmup 3        (N > 1: this process starts the N ranks itself, `self_launch`)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-           bench.py --gpus N --steps K --warmup W
+           bench.py --gpus N --steps K --warmup W          (already a rank: WORLD_SIZE must equal --gpus)
 
 One "step" = one pass of the hot path over one batch of synthetic sweeps per GPU: MetaKernel stem +
 DLA backbone + cls/reg towers (forward), device target assignment + varifocal/L1 loss, backward
@@ -38,6 +38,78 @@ import os
 import sys
 import time
 
+AV2_CLASSES = 26
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1, help="ranks = GPUs of this node; N > 1 without WORLD_SIZE in the environment: this process "
+                                                         "starts the N ranks itself (torch.distributed.run as a child process)")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4, help="sweeps per GPU")
+    ap.add_argument("--width", type=int, default=2048)
+    ap.add_argument("--height", type=int, default=64)
+    ap.add_argument("--widths", default="rv-av2", help="rv-av2 (the metric's configuration), rv-waymo, or c<int> debug widths")
+    ap.add_argument("--features", type=int, default=5, help="input channels: 5 (AV2) or 6 (Waymo)")
+    ap.add_argument("--classes", type=int, default=AV2_CLASSES)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", choices=["auto", "sample", "full"], default="auto",
+                    help="auto: the whole 64x2048 sweep when the host is fast enough (one or two timed iterations), else the cropped sample; "
+                         "sample: a 64xW crop (~45 s); full: 1 warm-up + 2 timed iterations of the whole sweep (minutes)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the forward_only and rv_waymo legs (extra keys of the JSON line)")
+    ap.add_argument("--no-sync-bn", action="store_true")
+    return ap.parse_args(argv)
+
+
+def self_launch(args, argv) -> int | None:
+    """``python bench.py --gpus N`` from ONE command, as the reference starts its N ranks from one (`scripts/train.sh:16-21`,
+    Lightning's `devices` + DDP strategy, `conf/trainer/train.yaml:39-44`).  With N > 1 and no ``WORLD_SIZE`` in the environment
+    this process is only the launcher: it starts ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py ...`` as a
+    CHILD process (never exec: a process that has initialised the GPU must not be replaced, and this one has not even imported
+    torch yet), passes rank 0's single JSON line through on stdout, the ranks' stderr on stderr, and returns the child's exit
+    code.  Returns None when this process is itself a rank (or N == 1).  A ``--gpus`` that disagrees with ``WORLD_SIZE`` is an
+    error: a record labelled N GPUs must have been produced by N ranks."""
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is not None:
+        if int(world_env) != args.gpus and os.environ.get("RV3D_FORCE_DIST") is None:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_env}: launch with --nproc-per-node {args.gpus} "
+                  f"(or drop WORLD_SIZE and let bench.py start the ranks)", file=sys.stderr)
+            return 2
+        return None
+    if args.gpus <= 1:
+        return None
+    import socket
+    import subprocess
+
+    assert "torch" not in sys.modules, "the launcher must start the ranks before anything can initialise HIP"
+    with socket.socket() as s:  # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    print(f"[bench launcher] {args.gpus} ranks: {' '.join(cmd)} (torch imported in the launcher: {'torch' in sys.modules})", file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = []
+    for ln in child.stdout:  # rank 0's JSON line (anything else a rank prints on stdout goes to stderr)
+        if ln.startswith("{"):
+            lines.append(ln)
+        else:
+            sys.stderr.write(ln)
+    rc = child.wait()
+    for ln in lines:
+        sys.stdout.write(ln)
+    sys.stdout.flush()
+    return rc
+
+
+if __name__ == "__main__":
+    _ARGS = parse_args()
+    _rc = self_launch(_ARGS, sys.argv[1:])
+    if _rc is not None:
+        sys.exit(_rc)
+
 if os.environ.get("RV3D_DIRECT_RCCL") is None:
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before the HIP runtime starts (see range_view_3d_detection_amd/__init__.py)
 
@@ -51,7 +123,6 @@ PMC_TRAFFIC = "profiles/r04_pmc_traffic.json"  # HBM bytes per launch per kernel
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 (MI355X_MICROARCH.md: ~2.5 PF dense; 2:1-sparsity figures are not used)
 HBM_PEAK_GBS = 8000.0
 
-AV2_CLASSES = 26
 # forward FLOPs per sweep (forward hooks on the reference's own modules); fwd + bwd = 3x
 FWD_TFLOP_PER_SWEEP = {("rv-av2", 2048): 7.736, ("rv-waymo", 2656): 2.905}
 
@@ -407,29 +478,15 @@ def roofline(prof, iso) -> dict:
     return r
 
 
-def main() -> None:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=4, help="sweeps per GPU")
-    ap.add_argument("--width", type=int, default=2048)
-    ap.add_argument("--height", type=int, default=64)
-    ap.add_argument("--widths", default="rv-av2", help="rv-av2 (the metric's configuration), rv-waymo, or c<int> debug widths")
-    ap.add_argument("--features", type=int, default=5, help="input channels: 5 (AV2) or 6 (Waymo)")
-    ap.add_argument("--classes", type=int, default=AV2_CLASSES)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline", choices=["auto", "sample", "full"], default="auto",
-                    help="auto: the whole 64x2048 sweep when the host is fast enough (one or two timed iterations), else the cropped sample; "
-                         "sample: a 64xW crop (~45 s); full: 1 warm-up + 2 timed iterations of the whole sweep (minutes)")
-    ap.add_argument("--no-extra", action="store_true", help="skip the forward_only and rv_waymo legs (extra keys of the JSON line)")
-    ap.add_argument("--no-sync-bn", action="store_true")
-    args = ap.parse_args()
+def main(args=None) -> None:
+    args = args if args is not None else parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist_on = world > 1 or os.environ.get("RV3D_FORCE_DIST") is not None  # (forced: the RCCL path with one rank, tests/test_gpu_ddp.py)
+    if torch.cuda.device_count() == 0:  # (counting devices does not initialise HIP)
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     if dist_on:
         import torch.distributed as dist
 
@@ -569,4 +626,4 @@ def main() -> None:
 
 
 if __name__ == "__main__":
-    main()
+    main(_ARGS)

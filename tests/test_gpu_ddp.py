@@ -17,12 +17,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _run(n: int, extra=()):
-    env = dict(os.environ, RV3D_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", "29631",
-           os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--widths", "c32", "--width", "512", "--height", "16",
+    # ONE command, as the driver issues it: `python bench.py --gpus N` starts its N ranks itself (bench.self_launch)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(RV3D_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--widths", "c32", "--width", "512", "--height", "16",
            "--batch", "2", "--classes", "5", "--no-cpu-baseline", *extra]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
+    assert f"[bench launcher] {n} ranks" in out.stderr and "torch imported in the launcher: False" in out.stderr
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]  # rank 0 prints ONE JSON line
     return json.loads(lines[0])

@@ -364,3 +364,25 @@ def test_training_recipe_glue():
         sched.step() if len(lrs) < 50 else None
     assert abs(max(lrs) - 0.00075 * math.sqrt(32)) < 1e-6 and lrs[0] < lrs[10] and lrs[-1] < lrs[20]
     assert configure_optimizers(p, 1, 4, 10, debug=True)[1] is None
+
+
+def test_bench_gpus_flag_launches_the_ranks_itself():
+    """``python bench.py --gpus N`` is ONE command for N ranks (reference: scripts/train.sh:16-21 + conf/trainer/train.yaml:39-44):
+    without WORLD_SIZE the process is a launcher that starts torch.distributed.run as a child BEFORE torch is imported (so nothing
+    in it can have initialised HIP) and hands the child's exit code back; with a WORLD_SIZE that disagrees it refuses.  On this
+    GPU-less box every rank stops at "needs an MI355X", which is how the test sees that two ranks were started."""
+    if torch.cuda.device_count() > 0:
+        pytest.skip("the GPU form of this test is tests/test_gpu_ddp.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--widths", "c32", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and out.stdout.strip() == ""
+    assert "[bench launcher] 2 ranks" in out.stderr and "torch imported in the launcher: False" in out.stderr
+    assert "--nproc-per-node=2" in out.stderr and "--master-addr 127.0.0.1" in out.stderr
+    assert out.stderr.count("bench.py needs an MI355X") == 2, out.stderr[-2000:]
+    # a rank count that disagrees with the environment is refused (a record labelled N GPUs must come from N ranks)
+    bad = subprocess.run(cmd, env=dict(env, WORLD_SIZE="1", RANK="0"), cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert bad.returncode == 2 and "WORLD_SIZE=1" in bad.stderr
+    # N = 1 is not a launcher
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert "[bench launcher]" not in one.stderr and "needs an MI355X" in one.stderr
