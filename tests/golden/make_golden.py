@@ -54,8 +54,17 @@ def npy(t):
     return a.astype(str) if a.dtype == object else a  # string columns read back from feather files
 
 
+OUT_DIR = os.environ.get("RV3D_GOLDEN_OUT", HERE)  # (tests/test_oracle_golden.py regenerates into a temporary directory)
+
+
+def _fixture(name: str) -> str:
+    """A fixture another one is built from: the freshly generated file when this run has made it, else the committed one."""
+    fresh = os.path.join(OUT_DIR, name + ".npz")
+    return fresh if os.path.exists(fresh) else os.path.join(HERE, name + ".npz")
+
+
 def save(name: str, **arrays) -> None:
-    path = os.path.join(HERE, name + ".npz")
+    path = os.path.join(OUT_DIR, name + ".npz")
     np.savez_compressed(path, **{k: npy(v) for k, v in arrays.items()})
     print(f"{name}.npz: {os.path.getsize(path) / 1024:.1f} KiB, {len(arrays)} arrays")
 
@@ -100,6 +109,7 @@ def module_case(prefix: str, module: torch.nn.Module, inputs, g: torch.Generator
 # --------------------------------------------------------------------------------------
 def gen_conv_blocks() -> None:
     g = torch.Generator().manual_seed(1)
+    torch.manual_seed(1)  # module constructors draw their initial weights from the GLOBAL generator
     out: dict = {}
     x = torch.randn(2, 8, 6, 32, generator=g)
     for name, k, s in (("conv3_s11", 3, (1, 1)), ("conv3_s12", 3, (1, 2)), ("conv1_s12", 1, (1, 2)), ("conv1_s11", 1, 1)):
@@ -141,6 +151,7 @@ def synthetic_sweep(g: torch.Generator, B: int, H: int, W: int, n_feat: int = 5,
 
 def gen_meta_kernel() -> None:
     g = torch.Generator().manual_seed(2)
+    torch.manual_seed(2)  # (as above: MetaKernel's conv / BatchNorm initialisation)
     out: dict = {}
     features, cart, _ = synthetic_sweep(g, 2, 6, 32)
     m = MetaKernel(in_channels=5, out_channels=16, num_neighbors=3, num_layers=2)
@@ -657,7 +668,7 @@ def gen_nms_wrapper() -> None:
     out["a/empty/categories_is_int64"] = np.array(c.dtype == torch.int64)
 
     # ---- (b) RangeDecoder.decode(use_nms=True) on the tiny model's eval outputs (tests/golden/tiny_model.npz) ----
-    tm = np.load(os.path.join(HERE, "tiny_model.npz"))
+    tm = np.load(_fixture("tiny_model"))
     NC = tm["eval/logits"].shape[1]
     tasks = DictConfig({0: ListConfig([f"C{i}" for i in range(NC)])})
     dec = RangeDecoder(True, True, ListConfig([0, 15, 30]), ListConfig([15, 30, math.inf]), ListConfig([8, 2, 1]))
@@ -668,7 +679,7 @@ def gen_nms_wrapper() -> None:
     out["b/tiny/params"], out["b/tiny/scores"], out["b/tiny/categories"], out["b/tiny/batch_index"] = p, s, c, b
     print("b tiny", tuple(p.shape), "from", int((torch.as_tensor(tm["eval/dec_scores"]) >= 0.1).sum()), "candidates")
     # and on the decode fixture's dense logits (7 classes, exact class ties, 20 % dropped pixels), dense + sampled decoders
-    dg = np.load(os.path.join(HERE, "decode.npz"))
+    dg = np.load(_fixture("decode"))
     mo = {1: {"cart": torch.as_tensor(dg["cart"]), "mask": torch.as_tensor(dg["mask"]),
               0: {"logits": torch.as_tensor(dg["logits"]), "regressands": torch.as_tensor(dg["regressands"])}}}
     tasks7 = DictConfig({0: ListConfig(["c"] * dg["logits"].shape[1])})
@@ -791,7 +802,7 @@ def gen_detections_frame() -> None:
     import polars as pl  # stub
     from torchbox3d.math.ops.coding import build_dataframe
 
-    nw = np.load(os.path.join(HERE, "nms_wrapper.npz"))
+    nw = np.load(_fixture("nms_wrapper"))
     params, scores = torch.as_tensor(nw["b/tiny/params"]), torch.as_tensor(nw["b/tiny/scores"])
     cats, bidx = torch.as_tensor(nw["b/tiny/categories"]), torch.as_tensor(nw["b/tiny/batch_index"])
     names = ["REGULAR_VEHICLE", "PEDESTRIAN", "BUS", "BICYCLE", "TRUCK"]
@@ -808,28 +819,14 @@ def gen_detections_frame() -> None:
     save("detections_frame", **out)
 
 
+ALL = ("conv_blocks", "meta_kernel", "decode", "projection", "tiny_model", "augment", "loader_item", "raw_sweep", "nms_wrapper",
+       "loader_train_item", "detections_frame")  # in dependency order: nms_wrapper reads tiny_model / decode, detections_frame reads nms_wrapper
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    if len(sys.argv) > 1 and sys.argv[1] == "nms_wrapper":  # needs tiny_model.npz and decode.npz (reads their arrays)
-        gen_nms_wrapper()
-        sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == "loader_train_item":
-        gen_loader_train_item()
-        sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == "detections_frame":  # needs nms_wrapper.npz
-        gen_detections_frame()
-        sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == "raw_sweep":
-        gen_raw_sweep()
-        sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == "loader_item":
-        gen_loader_item()
-        sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == "augment":  # (the other fixtures are unchanged since round 1)
-        gen_augment()
-        sys.exit(0)
-    gen_conv_blocks()
-    gen_meta_kernel()
-    gen_decode()
-    gen_projection()
-    gen_tiny_model()
+    names = sys.argv[1:] or ["conv_blocks", "meta_kernel", "decode", "projection", "tiny_model"]
+    if names == ["all"]:
+        names = list(ALL)
+    for name in names:
+        globals()["gen_" + name]()

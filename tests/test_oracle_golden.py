@@ -10,10 +10,13 @@ accumulation-order noise between two CPU formulations); integer outputs exact.
 from __future__ import annotations
 
 import math
+import os
 
 import numpy as np
 import pytest
 import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 from oracle import decode as odec
 from oracle import model as om
@@ -433,3 +436,19 @@ def test_loader_train_item_augments_before_padding(golden):
         assert np.max(np.abs(a[:6] - ref_a[:6])) <= 1e-9 * max(1.0, np.max(np.abs(ref_a[:6]))), tag
         dyaw = oaug.yaw_of(a[6:10]) - oaug.yaw_of(ref_a[6:10])
         assert np.max(np.abs(np.arctan2(np.sin(dyaw), np.cos(dyaw)))) < 1e-9, tag
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src/torchbox3d"), reason="build container only: regenerating the fixtures runs the reference")
+def test_fixture_generator_reproduces_every_committed_fixture(tmp_path):
+    """tests/golden/make_golden.py (the reference itself, run in the build container) regenerates all eleven fixtures BYTE for byte:
+    every generator seeds its own torch.Generator and the global one (module constructors initialise from it)."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, RV3D_GOLDEN_OUT=str(tmp_path), PYTORCH_JIT="0")
+    out = subprocess.run([sys.executable, os.path.join(GOLDEN, "make_golden.py"), "all"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    names = sorted(f for f in os.listdir(GOLDEN) if f.endswith(".npz"))
+    assert len(names) == 11
+    for f in names:
+        assert open(os.path.join(GOLDEN, f), "rb").read() == open(tmp_path / f, "rb").read(), f"{f} is not reproduced"
