@@ -59,6 +59,8 @@ def parse_args(argv=None):
                          "sample: a 64xW crop (~45 s); full: 1 warm-up + 2 timed iterations of the whole sweep (minutes)")
     ap.add_argument("--no-extra", action="store_true", help="skip the forward_only and rv_waymo legs (extra keys of the JSON line)")
     ap.add_argument("--no-sync-bn", action="store_true")
+    ap.add_argument("--timed-only", action="store_true", help="warm-up + timed steps and nothing else (no isolated / HBM-group passes, no extra legs, "
+                                                              "no CPU baseline): the command the profiler passes of profiles/tools/collect_round.sh run")
     return ap.parse_args(argv)
 
 
@@ -119,12 +121,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PMC_TRAFFIC = "profiles/r04_pmc_traffic.json"  # HBM bytes per launch per kernel, collected over this same command this round
+PMC_TRAFFIC = "profiles/r05_pmc_traffic.json"  # HBM bytes per launch per kernel, collected over this same command this round
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 (MI355X_MICROARCH.md: ~2.5 PF dense; 2:1-sparsity figures are not used)
 HBM_PEAK_GBS = 8000.0
 
 # forward FLOPs per sweep (forward hooks on the reference's own modules); fwd + bwd = 3x
 FWD_TFLOP_PER_SWEEP = {("rv-av2", 2048): 7.736, ("rv-waymo", 2656): 2.905}
+# algorithmic activation bytes per sweep, forward, bf16 (each conv reads its input once and writes its output once)
+FWD_ALG_GB_PER_SWEEP = {("rv-av2", 2048): 8.40, ("rv-waymo", 2656): 5.97}
 
 
 def synthetic_batch(B: int, H: int, W: int, seed: int, device, n_feat: int = 5, boxes_per_sweep: int = 16, n_cls: int = AV2_CLASSES):
@@ -407,14 +411,16 @@ def rv_waymo_leg(dev, batch_size: int = 4, warmup: int = 3, steps: int = 10) -> 
     E.OVERLAP_WGRAD = overlap
     E.PROFILE = None
     summ, isum = prof.summary(), iso.summary()
-    dom = max((k for k in isum if not k.startswith("wgrad")), key=lambda k: isum[k]["ms"])  # the dominant tap-conv kernel of this model
-    roof = iso.roofline(MFMA_BF16_PEAK_TFLOPS, dom)
-    if dom in summ:
-        roof["live"] = {"achieved": summ[dom]["tflops"], "frac": summ[dom]["tflops"] / MFMA_BF16_PEAK_TFLOPS, "avg_launch_us": summ[dom]["avg_us"]}
+    roof = roofline(prof, iso, pmc_key="rv_waymo")  # in-run figures; `isolated` beside them; traffic from the waymo PMC passes
+    ws = whole_step("rv-waymo", 2656, batch_size, dt / steps)
+    tr = traffic_ratio("rv_waymo", "rv-waymo", 2656, batch_size)
+    if tr is not None:
+        ws["traffic_ratio"] = tr
+    hbm = measure_hbm_group(step, pmc_key="rv_waymo")
     return {"workload": f"rv-waymo full model, fwd+bwd+AdamW, {batch_size} synthetic 64x2656x6 sweeps (single-GPU shard of BASELINE configs[4])",
             "sweeps_per_s": round(batch_size * steps / dt, 2), "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps, "warmup": warmup,
             "loss": float(loss.detach().item()), "dtype": "bf16",
-            "roofline": roof, "whole_step": whole_step("rv-waymo", 2656, batch_size, dt / steps),
+            "roofline": roof, "roofline_hbm": hbm, "whole_step": ws,
             "kernels": {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "tflops": round(v["tflops"], 1)} for k, v in summ.items()},
             "kernels_isolated": {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "tflops": round(v["tflops"], 1)} for k, v in isum.items()}}
 
@@ -438,44 +444,134 @@ def first_step_loss(dev, widths: str = "rv-av2", n_cls: int = AV2_CLASSES, n_fea
         return float(model(batch).item())
 
 
-def roofline(prof, iso) -> dict:
-    """Dominant kernel of the timed region against the dense bf16 MFMA peak; ``traffic`` = HBM bytes per launch of that
-    kernel from the committed PMC passes over this same command (``PMC_TRAFFIC``, made by profiles/pmc_traffic.py:
-    FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate passes; null when that file has no row for the kernel)."""
-    iso_sum = iso.summary()
-    if not iso_sum:
-        return {}
-    # `achieved` / `frac` / `avg_launch_us`: the kernel's own launch duration -- events around each launch with the weight-gradient side
-    # stream off, which is also what `rocprofv3 --kernel-trace --stats` reports (it serialises kernels; profiles/rNN_bench_kernel_stats.csv).
-    # `live`: the same events inside the timed region.  Since the weight gradients run free on a second stream (engine.py, RV3D_OVERLAP)
-    # a backward-data launch is often queued behind a resident wgrad3 workgroup, and its event-to-event time includes that wait: the
-    # step is faster for it, the per-launch figure reads lower.  `live_forward_only` would be identical to the isolated figure (nothing
-    # runs beside the forward pass).
-    name = max(iso_sum, key=lambda k: iso_sum[k]["ms"])
-    r = iso.roofline(MFMA_BF16_PEAK_TFLOPS, name)
-    r["measured"] = "HIP events around every launch of the kernel in 2 training steps with the side stream off (the kernel alone on the GPU)"
-    live = prof.summary().get(name)
-    if live:
-        r["live"] = {"achieved": live["tflops"], "frac": live["tflops"] / MFMA_BF16_PEAK_TFLOPS, "avg_launch_us": live["avg_us"], "launches": live["launches"],
-                     "measured": "the same events inside the timed region, weight gradients free-running on the side stream (includes time queued behind them)"}
+def _pmc_rows() -> dict:
     try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), PMC_TRAFFIC)) as f:
-            rows = json.load(f)["kernels"]
-        name = r["kernel"].replace("(+reduce)", "")
-        # the profiler names template instances in full ("tapconv5_kernel<256, false>", "... <256, true>": the launches of one
-        # kernel family and tile width): launch-weighted mean over the instances whose name starts like ours
-        stem = name[:-1] if name.endswith(">") else name
-        hits = [v for k, v in rows.items() if k == name or k.startswith(stem + ",") or k.startswith(stem + ">")] or [v for k, v in rows.items() if k == name.split("<")[0]]
-        if not hits and name.startswith("tapconv6_kernel"):  # (its template arguments are the epilogue kind, not the tile width: all instances)
-            hits = [v for k, v in rows.items() if k.startswith("tapconv6_kernel<")]
-        if hits:
-            n = sum(v["launches"] for v in hits)
-            r["traffic"] = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hits) / n
-            r["traffic_source"] = PMC_TRAFFIC + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 gfx950 correction)"
+        with open(os.path.join(ROOT, PMC_TRAFFIC)) as f:
+            return json.load(f)
     except OSError:
-        pass
-    r.setdefault("traffic", None)
+        return {}
+
+
+def _pmc_section(key: str) -> dict:
+    """The headline's rows (key "kernels": the top level of the file) or a named section of the same shape (``rv_waymo``)."""
+    pmc = _pmc_rows()
+    return pmc if key == "kernels" else pmc.get(key, {})
+
+
+def _pmc_traffic_of(kernel: str, pmc: dict):
+    """HBM-side bytes per launch of ``kernel`` from the committed PMC passes (launch-weighted over its template instances)."""
+    rows = pmc.get("kernels", {})
+    name = kernel.replace("(+reduce)", "")
+    stem = name[:-1] if name.endswith(">") else name
+    hits = [v for k, v in rows.items() if k == name or k.startswith(stem + ",") or k.startswith(stem + ">")] or [v for k, v in rows.items() if k == name.split("<")[0]]
+    if not hits and name.startswith("tapconv6_kernel"):  # (its template arguments are the epilogue kind, not the tile width: all instances)
+        hits = [v for k, v in rows.items() if k.startswith("tapconv6_kernel<")]
+    if not hits:
+        return None
+    n = sum(v["launches"] for v in hits)
+    return sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hits) / n
+
+
+def roofline(prof, iso, pmc_key: str = "kernels") -> dict:
+    """Dominant kernel against the dense bf16 MFMA peak.  ``achieved`` / ``frac`` / ``avg_launch_us`` are the IN-RUN figures: HIP
+    events around every launch of the kernel inside the timed region, on the stream it runs on, in the configuration that produced
+    ``ms_per_step`` (weight gradients free-running on the side stream: a backward-data launch queued behind a resident wgrad3
+    workgroup has that wait in its event-to-event time).  ``isolated`` = the same events in two extra steps with the side stream
+    off (the kernel's own duration; what ``rocprofv3 --kernel-trace`` of the one-stream run reports).  The dominant kernel is the
+    one with the most time of its own (isolated), so that a wait does not choose it.  ``traffic`` = HBM-side bytes per launch from
+    the committed PMC passes over this same command (``PMC_TRAFFIC``, profiles/pmc_traffic.py: FETCH_SIZE x 2 on gfx950 +
+    WRITE_SIZE, separate passes; null when that file has no row for the kernel)."""
+    iso_sum, live_sum = iso.summary(), prof.summary()
+    if not iso_sum or not live_sum:
+        return {}
+    name = max((k for k in iso_sum if k in live_sum), key=lambda k: iso_sum[k]["ms"])
+    r = prof.roofline(MFMA_BF16_PEAK_TFLOPS, name)
+    r["measured"] = "HIP events around every launch of the kernel INSIDE the timed region (the configuration of ms_per_step: weight gradients on the side stream)"
+    i = iso_sum[name]
+    r["isolated"] = {"achieved": i["tflops"], "frac": i["tflops"] / MFMA_BF16_PEAK_TFLOPS, "avg_launch_us": i["avg_us"], "launches": i["launches"],
+                     "measured": "the same events in 2 extra training steps with the side stream off (the kernel alone on the GPU)"}
+    pmc = _pmc_section(pmc_key)
+    t = _pmc_traffic_of(r["kernel"], pmc) if pmc else None
+    r["traffic"] = t
+    if t is not None:
+        r["traffic_source"] = PMC_TRAFFIC + (f" [{pmc_key}]" if pmc_key != "kernels" else "") + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 gfx950 correction)"
     return r
+
+
+# entry point of the C ABI -> the kernels it launches (profiler names), for the HBM-bound group of the step
+HBM_GROUP_KERNELS = {
+    "rv_ew_combine": ("ew_combine",), "rv_bn_bwd_reduce": ("bn_bwd_reduce_",), "rv_bn_bwd_apply": ("bn_bwd_apply_",),
+    "rv_bn_bwd_reduce_pair": ("bn_bwd_reduce2",), "rv_bn_bwd_apply_pair": ("bn_bwd_apply2",), "rv_meta_modulate": ("meta_modulate_kernel",),
+    "rv_meta_modulate_bwd_sums": ("meta_bwd_sums",), "rv_meta_modulate_bwd_apply": ("meta_bwd_apply",), "rv_pos_forward": ("pos_fwd_kernel",),
+    "rv_pos_backward_sums": ("pos_bwd_kernel",),
+}
+
+
+def measure_hbm_group(step, steps: int = 2, pmc_key: str = "kernels") -> dict:
+    """The HBM-bound kernels of the step (BatchNorm backward reduce / apply, the element-wise block passes, the MetaKernel stem's
+    gather / modulation and positional-pair kernels) against the HBM roofline: HIP events around each of their launches in
+    ``steps`` extra training steps in the SAME configuration as the timed region (two streams), algorithmic bytes per launch from
+    the entry points' own arguments (range_view_3d_detection_amd/_lib.py::HBM_BYTES: operands once in, results once out)."""
+    from range_view_3d_detection_amd import _lib as L
+
+    recs = []
+
+    def hook(name, nbytes, launch):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        launch()
+        b.record()
+        recs.append((name, nbytes, a, b))
+
+    L.HBM_HOOK = hook
+    try:
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+    finally:
+        L.HBM_HOOK = None
+    agg = {}
+    for name, nbytes, a, b in recs:
+        d = agg.setdefault(name, {"launches": 0, "ms": 0.0, "gbyte": 0.0})
+        d["launches"] += 1
+        d["ms"] += a.elapsed_time(b)
+        d["gbyte"] += nbytes / 1e9
+    pmc = _pmc_section(pmc_key).get("kernels", {})
+    out_k, tot_ms, tot_gb, tot_traffic, traffic_ok = {}, 0.0, 0.0, 0.0, bool(pmc)
+    for name, d in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+        per_step = {"launches": d["launches"] / steps, "ms": round(d["ms"] / steps, 3), "algorithmic_gb": round(d["gbyte"] / steps, 3),
+                    "achieved_gbs": round(d["gbyte"] / max(d["ms"] * 1e-3, 1e-12), 1)}
+        hits = [v for k, v in pmc.items() if any(k.startswith(pre) for pre in HBM_GROUP_KERNELS[name])]
+        if hits:  # HBM-side bytes per step of this entry point's kernels: bytes per launch (PMC) x this run's launches per step
+            n = sum(v["launches"] for v in hits)
+            per_step["traffic_gb"] = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hits) / n * per_step["launches"] / 1e9, 3)
+            tot_traffic += per_step["traffic_gb"]
+        else:
+            traffic_ok = False
+        out_k[name] = per_step
+        tot_ms += d["ms"] / steps
+        tot_gb += d["gbyte"] / steps
+    if not agg:
+        return {}
+    ach = tot_gb / max(tot_ms * 1e-3, 1e-12)
+    return {"bound": "hbm", "kernels": "BatchNorm backward reduce/apply, element-wise block passes, MetaKernel stem gather/modulation + positional pair",
+            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+            "ms_per_step": round(tot_ms, 3), "algorithmic_gb_per_step": round(tot_gb, 3),
+            "traffic": round(1e9 * tot_traffic, 1) if traffic_ok else None, "traffic_gb_per_step": round(tot_traffic, 3) if traffic_ok else None,
+            "measured": f"HIP events around each launch of the group in {steps} extra training steps, same two-stream configuration as the timed region; "
+                        "algorithmic bytes from the C-ABI arguments; traffic from " + PMC_TRAFFIC,
+            "per_entry_point": out_k}
+
+
+def traffic_ratio(pmc_key: str, widths: str, width: int, sweeps: int):
+    """Whole-step HBM-side bytes (all kernels, PMC passes) over the algorithmic bytes of the step (activations once in /
+    once out per conv with BatchNorm / ReLU / add fused, bf16: forward figure x 3 for fwd + bwd)."""
+    sec = _pmc_section(pmc_key)
+    if not sec or "total_gb_all_kernels" not in sec or not sec.get("steps_profiled"):
+        return None
+    alg = 3.0 * FWD_ALG_GB_PER_SWEEP[(widths, width)] * sweeps
+    per_step = sec["total_gb_all_kernels"] / sec["steps_profiled"]
+    return {"hbm_gb_per_step": round(per_step, 1), "algorithmic_gb_per_step": round(alg, 1), "ratio": round(per_step / alg, 3), "source": PMC_TRAFFIC}
 
 
 def main(args=None) -> None:
@@ -494,9 +590,7 @@ def main(args=None) -> None:
         os.environ.setdefault("MASTER_PORT", "29655")
         backend = os.environ.get("RV3D_DIST_BACKEND", "nccl")  # "gloo": the 2-ranks-on-one-GPU test of this script
         local_rank %= max(torch.cuda.device_count(), 1)
-        if backend == "nccl" and os.environ.get("RV3D_LAZY_PG") is not None:  # (timing experiments: no eager communicator)
-            dist.init_process_group("nccl", rank=rank, world_size=world)
-        elif backend == "nccl":
+        if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"), rank=rank, world_size=world)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
@@ -516,7 +610,7 @@ def main(args=None) -> None:
     use_ddp = os.environ.get("RV3D_DDP") is not None  # A/B: torch's DistributedDataParallel instead of engine.GradSync
     if dist_on and use_ddp:
         step_model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], gradient_as_bucket_view=True, static_graph=True)
-    elif dist_on and os.environ.get("RV3D_NO_GRADSYNC") is None:  # (RV3D_NO_GRADSYNC: timing experiments, one rank only)
+    elif dist_on:
         # the model's backward is three autograd nodes: one flat gradient buffer, one multi-tensor copy + one asynchronous RCCL
         # all-reduce per finished node, instead of DDP's per-parameter hooks / bucket copies / divisions (engine.GradSync)
         E.GRAD_SYNC = E.GradSync(params, world)
@@ -525,7 +619,7 @@ def main(args=None) -> None:
     # the reference's recipe (nn/meta/arch.py:48-75): AdamW(1e-3) + OneCycleLR(max_lr = 0.00075 * sqrt(devices * batch)), per step
     from range_view_3d_detection_amd.nn.meta.arch import configure_optimizers
 
-    fused_opt = os.environ.get("RV3D_TORCH_OPTIMIZER") is None  # (A/B: torch.optim.AdamW + clip_grad_norm_, ~10 foreach launches)
+    fused_opt = True  # (False: torch.optim.AdamW + clip_grad_norm_, ~10 foreach launches -- tests/test_gpu_model.py compares the two)
     opt, sched = configure_optimizers(params, num_devices=world, batch_size=args.batch, total_steps=args.warmup + args.steps + 8,
                                       fused=fused_opt, max_grad_norm=35.0 if fused_opt else None)
     batch = synthetic_batch(args.batch, args.height, args.width, seed=1234 + rank, device=dev, n_feat=args.features, n_cls=args.classes)
@@ -568,13 +662,17 @@ def main(args=None) -> None:
     # the same per-kernel events once more, outside the timed region, with the weight-gradient side stream off: with
     # it on, kernels of the two streams share the CUs and each one's event-to-event time includes its neighbour's
     iso = E.KernelProfile()
-    E.PROFILE, overlap = iso, E.OVERLAP_WGRAD
-    E.OVERLAP_WGRAD = False
-    for _ in range(2):
-        step()
-    torch.cuda.synchronize()
-    E.OVERLAP_WGRAD = overlap
-    E.PROFILE = None
+    hbm_group = {}
+    if not args.timed_only:
+        E.PROFILE, overlap = iso, E.OVERLAP_WGRAD
+        E.OVERLAP_WGRAD = False
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        E.OVERLAP_WGRAD = overlap
+        E.PROFILE = None
+        # ... and the HBM-bound group (BatchNorm backward, element-wise, stem) in the timed configuration again, with events around ITS launches
+        hbm_group = measure_hbm_group(step) if rank == 0 else {}
     if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -597,6 +695,7 @@ def main(args=None) -> None:
                                        "note": "SyncBN: (2C+1) fp32 per BatchNorm layer and direction, layers that become available together share one all-reduce"},
                        "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 2)},
             "roofline": roofline(prof, iso),
+            "roofline_hbm": hbm_group,
             "kernels": prof.summary(),
             # the same launches with nothing else on the GPU (side stream off, two steps outside the timed region): with the small
             # layers' weight gradients on the side stream the live event-to-event times of overlapping kernels include their neighbour
@@ -604,12 +703,15 @@ def main(args=None) -> None:
         }
         if (args.widths, args.width) in FWD_TFLOP_PER_SWEEP and args.height == 64:
             out["whole_step"] = whole_step(args.widths, args.width, args.batch * world, elapsed / args.steps)
+            tr = traffic_ratio("kernels", args.widths, args.width, args.batch) if (args.widths, args.batch) == ("rv-av2", 4) else None
+            if tr is not None:  # (per GPU: the PMC passes are one rank's)
+                out["whole_step"]["traffic_ratio"] = tr
         headline = (args.widths, args.width, args.height, args.features) == ("rv-av2", 2048, 64, 5)
-        if world == 1 and headline:
+        if world == 1 and headline and not args.timed_only:
             # (the model of the timed region has taken optimizer steps; this is a fresh one: 0.3 s)
             out["loss_first_step"] = {"value": first_step_loss(dev), "what": "train-mode loss of the seed-0 model on sweep 0 of the seed-1234 batch, B = 1, "
                                       "before any update; the fp32 oracle's value of the same quantity is asserted in tests/test_gpu_fullsize_train.py (1e-2)"}
-        if world == 1 and not args.no_extra and headline:
+        if world == 1 and not args.no_extra and headline and not args.timed_only:
             # extra keys, outside the timed region: BASELINE configs[1] (forward only + decode + NMS) and the one-GPU shard of configs[4]
             _progress("forward_only leg (eval forward + decode + weighted NMS)")
             out["forward_only"] = forward_only_leg(model, batch, args.classes, dev)
@@ -618,7 +720,7 @@ def main(args=None) -> None:
             torch.cuda.empty_cache()
             _progress("rv_waymo leg (64x2656x6, training step)")
             out["rv_waymo"] = rv_waymo_leg(dev)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.timed_only:
             out["cpu_baseline"] = cpu_baseline(full=args.cpu_baseline == "full", auto_full_limit=160.0 if args.cpu_baseline == "auto" else 0.0)
         print(json.dumps(out))
     if dist_on:

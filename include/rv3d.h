@@ -113,6 +113,14 @@ int rv_unpack_weight_grad(const rvTapGeom* g, const float* packed, float* dT, in
 #define RV_OUT_RES_RELU 256 /* rv_tap_residual only: ReLU AFTER the residual has been added (RV_OUT_RELU: before) */
 #define RV_WGRAD_TORCH_LAYOUT 128 /* rv_tap_wgrad only: dT_packed receives the torch layout dT[cu][cv][kh][kw] (cu*cv*kh*kw fp32,
                                   * no padding) straight from the split-K reduction -- no rv_unpack_weight_grad pass */
+/* Kernel-selection hints, also in rvTapShape.flags: speed heuristics only, never results.  PER CALL -- the library keeps no
+ * mutable state; the parity tests use them so that crops the CPU oracle can afford run the kernels of the
+ * full-size sweeps, and to pin a kernel generation. */
+#define RV_SEL_SMALL_GRIDS (1 << 20)  /* the LDS-DMA tap-convs of generations 4 and 5 also take layers with fewer tiles than CUs */
+#define RV_SEL_SMALL_GRIDS6 (1 << 21) /* ... and generation 6 */
+#define RV_SEL_NO_GEN6 (1 << 22)      /* do not select generation 6 */
+#define RV_SEL_NO_GEN5 (1 << 23)      /* do not select generations 5 and 6 (multi-tap layers stay on generation 4) */
+#define RV_SEL_MASK (15 << 20)
 
 typedef struct {
     int32_t N, H, Wu, Wv; /* U is (N,H,Wu), V is (N,H,Wv) */
@@ -126,14 +134,9 @@ int32_t rv_tap_stats_rows(const rvTapGeom* g, const rvTapShape* s, int32_t scatt
 /* Launch plan the library picks for a tap op: info = {kernel generation, variant, grid.x, grid.y}:
  * generation 1 = tapconv_kernel<MT,NT> (variant = 16*MT + NT, block tile 32*MT pixels x 32*NT channels),
  * generation 2 = tapconv2_kernel<KS> (variant = KS, block tile 2 rows x 64 columns x 128 channels, 32*KS-channel
- * chunks), generation 3 = tapconv3_kernel<KS> (8 waves, 4 rows x 64 columns x 128 channels, 3-tap weight stages).  Used by bench.py to label per-kernel timings. */
+ * chunks), generations 4 / 5 / 6 = the LDS-DMA kernels (variant = channels per workgroup, grid.x = pixel tiles, grid.y = channel
+ * tiles).  Used by bench.py to label per-kernel timings. */
 int rv_tap_launch_info(const rvTapGeom* g, const rvTapShape* s, int32_t scatter, int32_t* host_info);
-/* Process-wide kernel-selection knob (speed heuristics only, never results).  Returns the previous value, -1 for an
- * unknown key.  Keys: "tapconv4_min_blocks" -- smallest grid the LDS-DMA tap-conv (generation 4) is chosen for
- * (default 256 = one round of CUs); the parity tests set 1 so that crops the CPU oracle can afford run the same
- * kernels as the full-size sweeps; "tapconv5_enable" (default 1) -- 0 keeps multi-tap layers on generation 4 (the tests
- * of that kernel). */
-int32_t rv_set_option(const char* key, int32_t value);
 /* Every partial-statistics buffer handed to rv_bn_finalize / rv_bn_bwd_finalize must have room
  * for this many extra rows after its `rows` partial rows (second-stage reduction scratch). */
 #define RV_STATS_SCRATCH_ROWS 128
@@ -170,11 +173,8 @@ int rv_tap_residual(const rvTapGeom* g, const rvTapShape* s, int32_t scatter, co
  * rv_tap_gather / rv_tap_scatter (scatter != 0: the SCATTER form) without RV_OUT_ACCUM; from the bf16 values it stores,
  *   g = dx * [scale*y+shift > 0 if flags & RV_BNB_RELU_Z],   partial[row][0][c] = sum g,  partial[row][1][c] = sum g * (y-mean)*invstd
  * over the row's pixels -- the layout rv_bn_bwd_finalize takes (rv_bn_bwd_reduce then is not needed).
- * With RV_BNB_MASK (and RV_OUT_ACCUM in s->flags) the launch is the LAST of several writers of dx -- the gradient of a block
- * output relu(bn(y) + x) whose other consumers have already written their share: dx += result, g = dx * [e->mask > 0] with the
- * block output itself as the mask, sums as above: bn_bwd_reduce's pass over (gradient, output, y) disappears for that layer.
- * rv_tap_bnb_rows: partial rows such a launch writes (s->flags with RV_OUT_ACCUM asks about the masked form); 0 = the kernel (g, s) selects has no such epilogue (only the
- * fifth-generation tap-conv has): use rv_tap_gather/scatter + rv_bn_bwd_reduce. */
+ * rv_tap_bnb_rows: partial rows such a launch writes; 0 = the kernel (g, s) selects has no such epilogue (generations 5 and 6
+ * have it, for non-accumulating launches): use rv_tap_gather/scatter + rv_bn_bwd_reduce. */
 typedef struct rvBnbEpilogue {
     const void* y;      /* bf16 NHWC pre-BatchNorm conv output of the destination layer, same pixels as dx */
     int32_t ld_y;       /* its channel stride (elements) */
@@ -184,8 +184,6 @@ typedef struct rvBnbEpilogue {
     const float* mean;
     const float* invstd;
     float* partial;     /* [rows + RV_STATS_SCRATCH_ROWS][2][c_pad] fp32 */
-    const void* mask;   /* RV_BNB_MASK: bf16 NHWC tensor of dx's pixels, g = dx * [mask > 0] -- the block output relu(bn(y) + x) itself */
-    int32_t ld_mask;
 } rvBnbEpilogue;
 int32_t rv_tap_bnb_rows(const rvTapGeom* g, const rvTapShape* s, int32_t scatter);
 int rv_tap_data_grad_bnb(const rvTapGeom* g, const rvTapShape* s, int32_t scatter, const void* dout, const void* w, void* dx,
@@ -203,22 +201,6 @@ int rv_tap_wgrad_info(const rvTapGeom* g, const rvTapShape* s, int32_t* host_inf
 int rv_tap_wgrad(const rvTapGeom* g, const rvTapShape* s, const void* U, int32_t ld_u, const void* V, int32_t ld_v,
                  const float* in_scale, const float* in_shift, int32_t v_affine, float* dT_packed,
                  void* workspace, rvStream stream);
-
-/* Deferred split-K reduction.  With RV_WGRAD_DEFER_REDUCE in s->flags rv_tap_wgrad only fills the slabs; the sums of MANY layers
- * are then formed by ONE launch per 64 layers (rv_wgrad_reduce_batch) instead of one latency-bound reduce launch behind every
- * weight-gradient kernel (78 per training step of the rv-av2 model).  rv_wgrad_reduce_entry describes one layer's reduction
- * (same plan as rv_tap_wgrad: call it with the same g, s, workspace, dT); the batch takes a HOST array of entries (passed to
- * the kernel by value, no device table).  Same slab order per element as the immediate reduction: bit-identical results.
- * The workspaces must stay alive, and all rv_tap_wgrad launches must precede the batch in stream order. */
-#define RV_WGRAD_DEFER_REDUCE 512
-typedef struct {
-    const void* slabs;
-    float* out;
-    int64_t elems;
-    int32_t ksplit, torch_layout, cu, cv, cu_pad, cv_pad, taps, reserved;
-} rvWgradReduceEntry;
-int rv_wgrad_reduce_entry(const rvTapGeom* g, const rvTapShape* s, const void* workspace, float* dT_packed, rvWgradReduceEntry* entry);
-int rv_wgrad_reduce_batch(const rvWgradReduceEntry* host_entries, int32_t n_entries, rvStream stream);
 
 /* ---------------------------------------------------------------------------------------
  * BatchNorm2d (nn.BatchNorm2d train/eval; nn/blocks/__init__.py:41,51,63,158; torchvision
@@ -264,8 +246,6 @@ int rv_ew_combine(int64_t pixels, int32_t c, const void* a, int32_t ld_a, const 
  * Replaces cuDNN BatchNorm backward + ReLU backward + the add's gradient fan-out. */
 #define RV_BNB_RELU_Z 1
 #define RV_BNB_RES_ACCUM 2
-#define RV_BNB_MASK 8 /* rvBnbEpilogue only: the sums take their ReLU mask from e->mask and the launch ACCUMULATES into dx (s->flags has
-                       * RV_OUT_ACCUM): the last writer of a block output's gradient forms the sums of the COMPLETE gradient */
 #define RV_BNB_Y_FROM_INPUT 4 /* rv_bn_bwd_smallk*: y (may be NULL) is recomputed as W v from the conv input and w_packed */
 int32_t rv_bn_bwd_rows(int64_t pixels);
 int rv_bn_bwd_reduce(int64_t pixels, int32_t c, const void* dout, int32_t ld_dout, const void* out, int32_t ld_out,

@@ -22,7 +22,9 @@ def per_kernel(path):
     return out
 
 
-fetch, write = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+opts = dict(a[2:].split("=", 1) for a in sys.argv[1:] if a.startswith("--") and "=" in a)
+fetch, write = per_kernel(args[0]), per_kernel(args[1])
 res = {}
 for name in fetch:
     n, f = fetch[name]
@@ -30,5 +32,15 @@ for name in fetch:
     short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
     res[short] = {"launches": n, "fetch_bytes_per_launch": 2.0 * 1024.0 * f / n, "write_bytes_per_launch": 1024.0 * w / n,
                   "hbm_bytes_per_launch": (2.0 * 1024.0 * f + 1024.0 * w) / n, "total_gb": (2.0 * 1024.0 * f + 1024.0 * w) / 1e9}
-res = dict(sorted(res.items(), key=lambda kv: -kv[1]["total_gb"])[:28])
-print(json.dumps({"corrections": "FETCH_SIZE KiB x 1024 x 2 (gfx950 wide-read undercount), WRITE_SIZE KiB x 1024", "kernels": res}, indent=1))
+total_all = sum(v["total_gb"] for v in res.values())
+res = dict(sorted(res.items(), key=lambda kv: -kv[1]["total_gb"])[:40])
+out = {"corrections": "FETCH_SIZE KiB x 1024 x 2 (gfx950 wide-read undercount), WRITE_SIZE KiB x 1024", "kernels": res,
+       # every kernel of the run (not only the rows kept above) and the training steps the profiled command ran (--steps=N):
+       # bench.py's whole_step.traffic_ratio = total_gb_all_kernels / steps_profiled over the algorithmic bytes of a step
+       "total_gb_all_kernels": total_all, "steps_profiled": int(opts["steps"]) if "steps" in opts else None}
+if "into" in opts:  # --section=NAME --into=FILE: store this run as a named section of an existing file (the rv-waymo passes)
+    with open(opts["into"]) as fh:
+        top = json.load(fh)
+    top[opts["section"]] = out
+    out = top
+print(json.dumps(out, indent=1))

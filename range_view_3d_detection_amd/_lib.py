@@ -24,9 +24,12 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "rv3d.h")
 IN_AFFINE, IN_RELU, OUT_F32, OUT_BIAS, OUT_STATS, OUT_ACCUM, OUT_RELU = 1, 2, 4, 8, 16, 32, 64
 OUT_RES_RELU = 256
 WGRAD_TORCH_LAYOUT = 128  # rv_tap_wgrad: result in dT[cu][cv][kh][kw] (no unpack pass)
-WGRAD_DEFER_REDUCE = 512  # rv_tap_wgrad: slabs only, the sums later in one batched launch (rv_wgrad_reduce_batch)
+# kernel-selection hints (rvTapShape.flags, per call: the library keeps no mutable state).  SELECT is OR-ed into every TapShape
+# built while a `select(...)` block is active -- the parity tests' way of running the production kernels on crops / pinning a generation.
+SEL_SMALL_GRIDS, SEL_SMALL_GRIDS6, SEL_NO_GEN6, SEL_NO_GEN5 = 1 << 20, 1 << 21, 1 << 22, 1 << 23
+SELECT = 0
 EW_RELU_A, EW_RELU_B, EW_RELU_OUT = 1, 2, 4
-BNB_RELU_Z, BNB_RES_ACCUM, BNB_Y_FROM_INPUT, BNB_MASK = 1, 2, 4, 8
+BNB_RELU_Z, BNB_RES_ACCUM, BNB_Y_FROM_INPUT = 1, 2, 4
 STATS_SCRATCH_ROWS = 128
 
 
@@ -37,19 +40,32 @@ class TapGeom(ctypes.Structure):
 class TapShape(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ("N", "H", "Wu", "Wv", "ld_src", "ld_dst", "flags")]
 
+    def __init__(self, *args, **kw) -> None:
+        super().__init__(*args, **kw)
+        self.flags |= SELECT
+
+
+class select:
+    """``with select(SEL_SMALL_GRIDS | ...):`` -- every tap-conv / weight-gradient call issued inside carries these RV_SEL_* hints."""
+
+    def __init__(self, flags: int) -> None:
+        self.flags = flags
+
+    def __enter__(self):
+        global SELECT
+        self.old, SELECT = SELECT, SELECT | self.flags
+        return self
+
+    def __exit__(self, *exc):
+        global SELECT
+        SELECT = self.old
+
 
 class BnbEpilogue(ctypes.Structure):
     """``rvBnbEpilogue`` of include/rv3d.h (rv_tap_data_grad_bnb)."""
 
     _fields_ = [("y", ctypes.c_void_p), ("ld_y", ctypes.c_int32), ("flags", ctypes.c_int32), ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p),
-                ("mean", ctypes.c_void_p), ("invstd", ctypes.c_void_p), ("partial", ctypes.c_void_p), ("mask", ctypes.c_void_p), ("ld_mask", ctypes.c_int32)]
-
-
-class WgradReduceEntry(ctypes.Structure):
-    """``rvWgradReduceEntry`` of include/rv3d.h (rv_wgrad_reduce_entry / rv_wgrad_reduce_batch)."""
-
-    _fields_ = [("slabs", ctypes.c_void_p), ("out", ctypes.c_void_p), ("elems", ctypes.c_int64)] + [
-        (n, ctypes.c_int32) for n in ("ksplit", "torch_layout", "cu", "cv", "cu_pad", "cv_pad", "taps", "reserved")]
+                ("mean", ctypes.c_void_p), ("invstd", ctypes.c_void_p), ("partial", ctypes.c_void_p)]
 
 
 class RvError(RuntimeError):
@@ -144,11 +160,45 @@ def _as_arg(v):
 _DEBUG = bool(int(os.environ.get("RV3D_DEBUG_SYNC", "0")))
 
 
+def _v(a):
+    return getattr(a, "value", a)
+
+
+def _px_c(a):
+    return float(_v(a[0])) * float(_v(a[1]))
+
+
+# Algorithmic bytes (every operand tensor once in, every result once out, 16-bit activations) of the HBM-bound entry
+# points, from their own arguments -- bench.py's `roofline_hbm` prices the group against the HBM roofline.  Argument positions as
+# declared in include/rv3d.h.
+HBM_BYTES = {
+    "rv_ew_combine": lambda a: 2.0 * _px_c(a) * (2 + (_v(a[6]) is not None)),
+    "rv_bn_bwd_reduce": lambda a: 2.0 * _px_c(a) * (2 + (_v(a[4]) is not None)),
+    "rv_bn_bwd_apply": lambda a: 2.0 * _px_c(a) * (3 + (_v(a[4]) is not None) + 2 * (_v(a[16]) is not None)),
+    "rv_bn_bwd_reduce_pair": lambda a: 2.0 * _px_c(a) * 4,
+    "rv_bn_bwd_apply_pair": lambda a: 2.0 * _px_c(a) * 6,
+    # MetaKernel stem: pixels = N H W, the 9x-grid tensors hold 9 C values per pixel
+    "rv_meta_modulate": lambda a: 2.0 * _v(a[5]) * _v(a[6]) * _v(a[7]) * _v(a[8]) * 19,
+    "rv_meta_modulate_bwd_sums": lambda a: 2.0 * _v(a[8]) * _v(a[9]) * _v(a[10]) * _v(a[11]) * 20,
+    "rv_meta_modulate_bwd_apply": lambda a: 2.0 * _v(a[9]) * _v(a[10]) * _v(a[11]) * _v(a[12]) * 28,
+    "rv_pos_forward": lambda a: float(_v(a[3])) * (16 + 4.0 * _v(a[9])),
+    "rv_pos_backward_sums": lambda a: float(_v(a[0])) * (16 + 2.0 * _v(a[1])),
+}
+HBM_HOOK = None  # callable(name, algorithmic bytes, launch) or None: set by bench.py around its HBM-group measurement
+
+
 def call(name: str, *args) -> None:
     """Invoke an int-returning entry point; raise with rv_last_error() on failure.
 
     ``RV3D_DEBUG_SYNC=1`` prints every call and synchronises after it (locates a faulting launch).
     """
+    if HBM_HOOK is not None and name in HBM_BYTES:
+        hook, nbytes = HBM_HOOK, HBM_BYTES[name](args)
+        return hook(name, nbytes, lambda: _call(name, *args))
+    return _call(name, *args)
+
+
+def _call(name: str, *args) -> None:
     fn = getattr(load(), name)
     if _DEBUG:
         import sys

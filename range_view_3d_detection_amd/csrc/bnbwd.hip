@@ -958,11 +958,9 @@ __global__ void sum_rows_f64_kernel(const double* rows, int n_rows, int cols, do
     }
 }
 
-// RV3D_BNB_LEAN (default 2): the lean (quad layout, <= 96 VGPRs) forms of the four BatchNorm-backward passes; 0: the octet forms
-int bnb_lean() {
-    static const int lean = getenv("RV3D_BNB_LEAN") ? atoi(getenv("RV3D_BNB_LEAN")) : 2;
-    return lean;
-}
+// the lean (quad layout, <= 96 VGPRs) forms of the four BatchNorm-backward passes are what runs; the octet forms take tensors whose byte
+// offsets do not fit 32 bits (A/B of the two and of a one-workgroup-per-CU launch: profiles/r04_ab_notes.md)
+constexpr int bnb_lean() { return 2; }
 
 int grid_for(int64_t work) {
     int64_t b = (work + 255) / 256;
@@ -1042,13 +1040,13 @@ extern "C" int rv_bn_bwd_finalize(const float* partial, int32_t rows, int32_t c,
     RV_REQUIRE(partial && gamma && invstd && coef, "rv_bn_bwd_finalize: null argument");
     RV_REQUIRE(count > 0 || (count < 0 && rows == 1), "rv_bn_bwd_finalize: a device-side count (count < 0) needs the single row of all-reduced totals");
     const float* count_dev = count < 0 ? partial + 2 * c : nullptr;
-    if (rows <= 1024 && getenv("RV3D_NO_FUSED_FINALIZE") == nullptr) {
+    if (rows <= 1024) {
         hipLaunchKernelGGL(bn_bwd_reduce_finalize_kernel, dim3(rv_ceil_div(c, 16)), dim3(256), 0, (hipStream_t)stream, partial, rows, c,
                            1.0 / (double)count, gamma, invstd, dgamma, dbeta, accumulate, coef, count_dev);
         RV_CHECK_LAUNCH("bn_bwd_reduce_finalize_kernel");
         return 0;
     }
-    RV_REQUIRE(count > 0, "rv_bn_bwd_finalize: the two-stage path (RV3D_NO_FUSED_FINALIZE / > 1024 rows) takes a host-side count only");
+    RV_REQUIRE(count > 0, "rv_bn_bwd_finalize: the two-stage path (> 1024 rows) takes a host-side count only");
     double* scratch = (double*)(partial + (int64_t)rows * 2 * c);
     int groups;
     if (rv_col_reduce(partial, rows, 2 * c, scratch, &groups, (hipStream_t)stream)) return 1;
@@ -1070,7 +1068,7 @@ extern "C" int rv_bn_bwd_apply(int64_t pixels, int32_t c, const void* dout, int3
     a.ld_dy = ld_dy;
     a.dres = (bf16_t*)dres;
     a.ld_dres = ld_dres;
-    // lean form by default (RV3D_BNB_LEAN=0: the octet form; =1: one workgroup per CU): alone it takes the same time (96.7 against 96.5-96.9 ms
+    // lean form: alone it takes the same time (96.7 against 96.5-96.9 ms
     // per rv-av2 step), beside a weight gradient on the side stream (engine.py RV3D_OVERLAP=chain) it is what fits on the CU
     const int lean = bnb_lean();
     const int64_t ld_max = std::max(std::max((int64_t)ld_dout, (int64_t)ld_y), std::max(std::max((int64_t)ld_out, (int64_t)ld_dy), (int64_t)ld_dres));
@@ -1078,10 +1076,6 @@ extern "C" int rv_bn_bwd_apply(int64_t pixels, int32_t c, const void* dout, int3
         const int lanes4 = 256 / (2 * a.c8);
         int64_t blocks4 = (pixels + lanes4 - 1) / lanes4;
         if (blocks4 > 4096) blocks4 = 4096;
-        // RV3D_BNB_LEAN=1 (A/B): ONE workgroup per CU, so that whichever of this launch and the weight gradient on the side stream reaches
-        // the CUs first, the other one still fits beside it -- 2.6 ms per step slower alone, 1.8 of them recovered beside the weight
-        // gradients: a net loss against as many workgroups as the octet form (the default)
-        if (lean == 1 && blocks4 > 256) blocks4 = 256;
         const int f = ((int64_t)pixels * c * 2 >= ((int64_t)256 << 20) ? 1 : 0) | (out ? 2 : 0) | (dres ? 4 : 0) |
                       (dres && (flags & RV_BNB_RES_ACCUM) ? 8 : 0);
         using K = void (*)(const BnbArgs);

@@ -49,6 +49,17 @@ void rv_set_error(const char* fmt, ...);
 
 static inline int rv_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int rv_pad32(int c) { return (c + 31) & ~31; }
+// compute units of the current device (a read-only cache of a device property; 256 = an MI355X when no device is visible: the
+// host-side planning entry points also run on GPU-less build boxes)
+static inline int rv_cu_count() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+        else cus = 256;
+    }
+    return cus;
+}
 
 // ---------------------------------------------------------------------------------------
 // bf16 <-> f32

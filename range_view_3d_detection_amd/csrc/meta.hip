@@ -359,10 +359,7 @@ __global__ __launch_bounds__(256) void meta_bwd_apply_kernel(const MetaBwdArgs a
     }
 }
 
-int meta_piece() {  // RV3D_META_PIECE: experiment switch (items per contiguous piece)
-    static const int v = getenv("RV3D_META_PIECE") ? atoi(getenv("RV3D_META_PIECE")) : kPieceItems;
-    return v > 0 ? v : kPieceItems;
-}
+constexpr int meta_piece() { return kPieceItems; }  // items per contiguous piece
 
 int grid_for(int64_t work) {
     int64_t b = (work + 255) / 256;

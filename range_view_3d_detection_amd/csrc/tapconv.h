@@ -36,17 +36,15 @@ struct TapConvArgs {
     int32_t lds_a_elems;
     int32_t lds_tab_offset;  // byte offset of the per-tap offset table in dynamic LDS
     int32_t flags;
+    int32_t sel;  // RV_SEL_* kernel-selection hints of the call (rvTapShape.flags & RV_SEL_MASK)
     // RV_OUT_BNB (backward-data launches): BatchNorm-backward sums of the layer whose output gradient this launch writes
     const bf16_t* bnb_y;
     const float *bnb_scale, *bnb_shift, *bnb_mean, *bnb_invstd;
     float* bnb_partial;  // [tiles][2][C_dst]
     int32_t ld_bnb_y, bnb_flags;
-    const bf16_t* bnb_mask;  // RV_BNB_MASK: g = dOut * [mask > 0] (the block output itself), together with RV_OUT_ACCUM
-    int32_t ld_bnb_mask;
     // RV_OUT_ACCUM: the tensor added to the result -- dst itself (gradient fan-in) or a residual (rv_tap_residual), same pixels as dst
     const bf16_t* res;
     int32_t ld_res;
-    int32_t nt_store;       // tapconv6: non-temporal output stores
     int32_t stats_per_wg;  // tapconv6: RV_OUT_STATS / RV_OUT_BNB rows per WORKGROUP (accumulated over its tiles in LDS) instead of per tile
     TapTable tt;
 };
@@ -57,10 +55,6 @@ int rv_build_tap_table(const rvTapGeom* g, bool scatter, TapTable* tt, int* phas
 // second-generation kernel (tapconv2.hip): plan returns false when the layer is not eligible
 bool rv_tapconv2_plan(TapConvArgs* a, int* grid_x, int* grid_y, size_t* lds, int* ks);
 int rv_tapconv2_launch(const TapConvArgs& a, int grid_x, int grid_y, size_t lds, int ks, hipStream_t stream);
-
-// third-generation kernel (tapconv3.hip): 8 waves, 4-row tiles, 3-tap weight stages; stats rows = 4 * grid_x
-bool rv_tapconv3_plan(TapConvArgs* a, int* grid_x, int* grid_y, size_t* lds, int* ks);
-int rv_tapconv3_launch(const TapConvArgs& a, int grid_x, int grid_y, size_t lds, int ks, hipStream_t stream);
 
 // fourth-generation kernel (tapconv4.hip): 256 x 256 tiles, LDS-DMA staging, counted waits; stats rows = 2 * tiles
 bool rv_tapconv4_plan(TapConvArgs* a, int* tiles, size_t* lds, int* bn);

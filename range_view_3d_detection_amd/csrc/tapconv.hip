@@ -391,11 +391,6 @@ int rv_build_tap_table(const rvTapGeom* g, bool scatter, TapTable* tt, int* phas
     return 0;
 }
 
-extern int g_tapconv5_persist;
-static int g_tapconv6_enable = 1;  // rv_set_option("tapconv6_enable", 0): tests of the fifth generation
-extern int g_tapconv6_min_blocks;
-static int g_tapconv5_enable = 1;  // rv_set_option("tapconv5_enable", 0): multi-tap layers stay on tapconv4 (tests of that kernel)
-
 static int tap_launch(const rvTapGeom* g, const rvTapShape* s, bool scatter, const void* src, const float* in_scale,
                       const float* in_shift, const void* w, const float* bias, void* dst, float* stats,
                       rvStream stream, bool dry_run, int* stats_rows, int* info = nullptr, const rvBnbEpilogue* bnb = nullptr,
@@ -420,7 +415,8 @@ static int tap_launch(const rvTapGeom* g, const rvTapShape* s, bool scatter, con
     RV_REQUIRE(a.ld_src % 8 == 0 && a.ld_dst % 8 == 0, "tap shape: channel strides must be multiples of 8");
     a.phases = phases;
     a.step = step;
-    a.flags = s->flags;
+    a.flags = s->flags & ~RV_SEL_MASK;
+    a.sel = s->flags & RV_SEL_MASK;  // per-call kernel-selection hints (tests pin a generation / lift the tile-count heuristics)
     a.res = (const bf16_t*)dst;  // RV_OUT_ACCUM adds into dst ...
     a.ld_res = a.ld_dst;
     if (residual) {  // ... rv_tap_residual adds another tensor of the same pixels
@@ -446,8 +442,6 @@ static int tap_launch(const rvTapGeom* g, const rvTapShape* s, bool scatter, con
     if (bnb_rows) *bnb_rows = 0;
     if (bnb || bnb_rows) {  // backward-data launch that also forms the BatchNorm-backward sums of its destination layer
         a.flags |= RV_OUT_BNB;
-        // (row query for an ACCUMULATING launch = the masked last-writer form: a dry run, the pointer is never followed)
-        if (!bnb && (a.flags & RV_OUT_ACCUM)) a.bnb_mask = (const bf16_t*)(uintptr_t)16;
         if (bnb) {
             RV_REQUIRE(bnb->y && bnb->scale && bnb->shift && bnb->mean && bnb->invstd && bnb->partial, "rv_tap_data_grad_bnb: null epilogue pointer");
             RV_REQUIRE(bnb->ld_y >= a.C_dst && bnb->ld_y % 8 == 0, "rv_tap_data_grad_bnb: bad channel stride of y (%d)", bnb->ld_y);
@@ -459,17 +453,11 @@ static int tap_launch(const rvTapGeom* g, const rvTapShape* s, bool scatter, con
             a.bnb_mean = bnb->mean;
             a.bnb_invstd = bnb->invstd;
             a.bnb_partial = bnb->partial;
-            if (bnb->flags & RV_BNB_MASK) {
-                RV_REQUIRE(bnb->mask && bnb->ld_mask >= a.C_dst && bnb->ld_mask % 8 == 0, "rv_tap_data_grad_bnb: RV_BNB_MASK without a mask tensor");
-                RV_REQUIRE(a.flags & RV_OUT_ACCUM, "rv_tap_data_grad_bnb: RV_BNB_MASK is the accumulating (last-writer) form");
-                a.bnb_mask = (const bf16_t*)bnb->mask;
-                a.ld_bnb_mask = bnb->ld_mask;
-            }
         }
     }
 
     // multi-tap layers with at least one round of 512-pixel x 128-channel tiles (tapconv6.hip)
-    if (g_tapconv6_enable && g_tapconv5_enable && getenv("RV3D_NO_TAPCONV6") == nullptr) {
+    if (!(a.sel & (RV_SEL_NO_GEN6 | RV_SEL_NO_GEN5))) {
         int tiles, srows, brows;
         size_t lds6;
         TapConvArgs a6 = a;
@@ -487,7 +475,7 @@ static int tap_launch(const rvTapGeom* g, const rvTapShape* s, bool scatter, con
         }
     }
     // multi-tap layers with 256-channel output tiles: input halo resident in LDS across the taps (tapconv5.hip)
-    if (g_tapconv5_enable && getenv("RV3D_NO_TAPCONV5") == nullptr) {
+    if (!(a.sel & RV_SEL_NO_GEN5)) {
         int tiles, bn5;
         size_t lds5;
         TapConvArgs a5 = a;
@@ -509,7 +497,7 @@ static int tap_launch(const rvTapGeom* g, const rvTapShape* s, bool scatter, con
         RV_FAIL("rv_tap_data_grad_bnb: this launch has no fused BatchNorm-backward sums (rv_tap_bnb_rows returned 0)");
     }
     // 256 x 256 (or x 128) tiles streamed by LDS-DMA, counted waits (tapconv4.hip); plain bf16 inputs only
-    if (getenv("RV3D_NO_TAPCONV4") == nullptr) {
+    {
         int tiles, bn;
         size_t lds4;
         TapConvArgs a4 = a;
@@ -523,23 +511,6 @@ static int tap_launch(const rvTapGeom* g, const rvTapShape* s, bool scatter, con
             }
             if (dry_run) return 0;
             return rv_tapconv4_launch(a4, lds4, bn, (hipStream_t)stream);
-        }
-    }
-    // 8 waves, 4-row x 64-column x 128-channel tiles, 3-tap weight stages, register staging (tapconv3.hip)
-    if (getenv("RV3D_NO_TAPCONV3") == nullptr) {
-        int gx, gy, ks;
-        size_t lds3;
-        TapConvArgs a3 = a;
-        if (rv_tapconv3_plan(&a3, &gx, &gy, &lds3, &ks)) {
-            if (stats_rows) *stats_rows = gx * 4;
-            if (info) {
-                info[0] = 3;
-                info[1] = ks;
-                info[2] = gx;
-                info[3] = gy;
-            }
-            if (dry_run) return 0;
-            return rv_tapconv3_launch(a3, gx, gy, lds3, ks, (hipStream_t)stream);
         }
     }
     // fast path: 2-row x 64-column tiles, 64-channel chunks (tapconv2.hip)
@@ -597,39 +568,7 @@ static int tap_launch(const rvTapGeom* g, const rvTapShape* s, bool scatter, con
     RV_FAIL("tap conv: no kernel for tile %dx%d", mt, nt);
 }
 
-extern int g_tapconv4_min_blocks;
-
 extern "C" {
-
-int32_t rv_set_option(const char* key, int32_t value) {
-    if (key && strcmp(key, "tapconv4_min_blocks") == 0) {
-        const int32_t old = g_tapconv4_min_blocks;
-        if (value >= 0) g_tapconv4_min_blocks = value;
-        return old;
-    }
-    if (key && strcmp(key, "tapconv5_enable") == 0) {
-        const int32_t old = g_tapconv5_enable;
-        if (value >= 0) g_tapconv5_enable = value ? 1 : 0;
-        return old;
-    }
-    if (key && strcmp(key, "tapconv6_enable") == 0) {
-        const int32_t old = g_tapconv6_enable;
-        if (value >= 0) g_tapconv6_enable = value ? 1 : 0;
-        return old;
-    }
-    if (key && strcmp(key, "tapconv6_min_blocks") == 0) {
-        const int32_t old = g_tapconv6_min_blocks;
-        if (value >= 0) g_tapconv6_min_blocks = value;
-        return old;
-    }
-    if (key && strcmp(key, "tapconv5_persist_blocks") == 0) {
-        const int32_t old = g_tapconv5_persist;
-        if (value >= 0) g_tapconv5_persist = value;
-        return old;
-    }
-    rv_set_error("rv_set_option: unknown key '%s'", key ? key : "(null)");
-    return -1;
-}
 
 int32_t rv_tap_stats_rows(const rvTapGeom* g, const rvTapShape* s, int32_t scatter) {
     int rows = 0;

@@ -384,23 +384,13 @@ bool rv_tapconv2_plan(TapConvArgs* a, int* grid_x, int* grid_y, size_t* lds, int
 
 int rv_tapconv2_launch(const TapConvArgs& a, int grid_x, int grid_y, size_t lds, int ks, hipStream_t stream) {
     static bool attr_set = false;
-    static bool dma = true;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)tapconv2_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)tapconv2_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)tapconv2_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)tapconv2_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        dma = getenv("RV3D_NO_BDMA") == nullptr;
         attr_set = true;
     }
-    if (ks == 2 && dma)
-        hipLaunchKernelGGL((tapconv2_kernel<2, true>), dim3(grid_x, grid_y), dim3(256), lds, stream, a);
-    else if (ks == 2)
-        hipLaunchKernelGGL((tapconv2_kernel<2, false>), dim3(grid_x, grid_y), dim3(256), lds, stream, a);
-    else if (dma)
-        hipLaunchKernelGGL((tapconv2_kernel<1, true>), dim3(grid_x, grid_y), dim3(256), lds, stream, a);
-    else
-        hipLaunchKernelGGL((tapconv2_kernel<1, false>), dim3(grid_x, grid_y), dim3(256), lds, stream, a);
+    if (ks == 2) hipLaunchKernelGGL((tapconv2_kernel<2, true>), dim3(grid_x, grid_y), dim3(256), lds, stream, a);  // (weights by LDS-DMA)
+    else hipLaunchKernelGGL((tapconv2_kernel<1, true>), dim3(grid_x, grid_y), dim3(256), lds, stream, a);
     RV_CHECK_LAUNCH("tapconv2_kernel");
     return 0;
 }

@@ -374,12 +374,10 @@ __global__ __launch_bounds__(512, 2) void tapconv4_kernel(const TapConvArgs a) {
 
 }  // namespace
 
-extern int g_tapconv5_persist;
 
 // Smallest grid (workgroups) the DMA kernel is chosen for: below one round of 256 CUs the register-staged kernels with
 // their smaller tiles fill the chip better.  A speed heuristic only -- rv_set_option("tapconv4_min_blocks", 1) lets the
 // parity tests run the production kernels on crops the CPU oracle can afford.
-int g_tapconv4_min_blocks = getenv("RV3D_TC4_MIN_BLOCKS") ? atoi(getenv("RV3D_TC4_MIN_BLOCKS")) : 256;  // rv_set_option("tapconv4_min_blocks") / RV3D_TC4_MIN_BLOCKS
 
 // returns false when the layer is not eligible (caller falls back to tapconv3 / tapconv2 / the generic kernel)
 bool rv_tapconv4_plan(TapConvArgs* a, int* tiles, size_t* lds, int* bn) {
@@ -397,7 +395,7 @@ bool rv_tapconv4_plan(TapConvArgs* a, int* tiles, size_t* lds, int* bn) {
     a->total_tiles = a->m_tiles * a->h_tiles * a->N * a->phases;
     a->n_tiles = a->C_dst / BN;
     a->tiles_per_xcd = rv_ceil_div(a->total_tiles, 8);
-    if ((int64_t)a->total_tiles * a->n_tiles < g_tapconv4_min_blocks) return false;  // too few tiles to fill the chip
+    if ((int64_t)a->total_tiles * a->n_tiles < ((a->sel & RV_SEL_SMALL_GRIDS) ? 1 : rv_cu_count())) return false;  // too few tiles to fill the chip
     *tiles = a->total_tiles;  // stats rows = 2 * tiles
     *bn = BN;
     *lds = (size_t)(BN == 256 ? kTabOffset : 9 * kPiece) + 256;
@@ -416,7 +414,7 @@ int rv_tapconv4_launch(const TapConvArgs& a, size_t lds, int bn, hipStream_t str
         attr_set = true;
     }
     int grid = 8 * a.tiles_per_xcd * a.n_tiles;
-    if (g_tapconv5_persist > 0 && grid > g_tapconv5_persist) grid = g_tapconv5_persist >= 8 ? g_tapconv5_persist & ~7 : 8;
+    if (grid > rv_cu_count()) grid = rv_cu_count() & ~7;  // persistent: one workgroup per CU
     const bool acc = (a.flags & RV_OUT_ACCUM) != 0;
     if (bn == 256) {
         if (acc) hipLaunchKernelGGL((tapconv4_kernel<256, true>), dim3(grid), dim3(512), lds, stream, a);

@@ -59,8 +59,7 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 // constants, merely PRESENT in the code behind a run-time flag, cost every launch 154 spilled registers per tile (11 without:
 // forward launches and plain backward-data launches run the lean instance); the accumulate instance can then afford the
 // same prefetch for the old values it adds to.
-template <int kBN, int EPI>  // EPI: 0 plain store (+ statistics / bias), 1 BatchNorm-sum epilogue (RV_OUT_BNB), 2 accumulate (RV_OUT_ACCUM),
-                             // 3 both, with the ReLU mask of the sums taken from a tensor (the LAST writer of a block output's gradient)
+template <int kBN, int EPI>  // EPI: 0 plain store (+ statistics / bias), 1 BatchNorm-sum epilogue (RV_OUT_BNB), 2 accumulate (RV_OUT_ACCUM)
 __global__ __launch_bounds__(512, 2) void tapconv5_kernel(const TapConvArgs a) {
     constexpr int NJ = kBN / 64;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -423,16 +422,13 @@ __global__ __launch_bounds__(512, 2) void tapconv5_kernel(const TapConvArgs a) {
                 epi[pm * kEpi + pc] = f2bf(acc[i][j][r]);
             }
     constexpr int kChunks = kBN / 8;
-    constexpr bool accum = EPI == 2 || EPI == 3;
+    constexpr bool accum = EPI == 2;
     // RV_OUT_BNB: this launch writes dOut of a BatchNorm(+ReLU) layer -- its backward needs sum(g) and sum(g * xhat) per channel
     // with g = dOut * [scale*y+shift > 0], xhat = (y - mean) * invstd.  A thread keeps ONE 8-channel chunk through the store loop
     // (512 threads = 16 pixels x 32 chunks per pass), so the sums are formed here, from the bf16 values being stored, with one
     // extra 16-byte read of y per chunk: the separate reduce pass over (dOut, y) disappears (bnbwd.hip: bn_bwd_reduce_kernel).
-    constexpr bool bnb = EPI == 1 || EPI == 3;
-    // EPI 3: dst already holds the other consumers' share of the gradient of out = relu(bn(y) + x) and this launch is its last
-    // writer: g = (old + result) * [out > 0] (the mask read from `out` itself, bnb_mask), sums of g and g * xhat(y) -- what
-    // bn_bwd_reduce_kernel would form in a pass of its own over (gradient, out, y)
-    constexpr bool bmask = EPI == 3;
+    constexpr bool bnb = EPI == 1;
+    static_assert(EPI >= 0 && EPI <= 2, "epilogue kinds: plain, BatchNorm sums, accumulate");
     float bsc[8], bsh[8], bmu[8], bis[8], s0[8], s1[8];
     if (bnb) {
         const int c = n0 + (tid & (kChunks - 1)) * 8;  // (512 % kChunks == 0: the chunk of a thread is the same in every pass)
@@ -448,7 +444,6 @@ __global__ __launch_bounds__(512, 2) void tapconv5_kernel(const TapConvArgs a) {
     }
     constexpr int kPasses = kTR * kTC * kChunks / 512;  // 16
     u32x4 yv[kPasses];
-    u32x4 ov[bmask ? kPasses : 1], mv[bmask ? kPasses : 1];
     if (bnb) {  // (before the barrier that publishes the staged tile) all of this thread's y chunks in flight at once (the staged tile is being read meanwhile): one HBM latency, not sixteen
 #pragma unroll
         for (int it = 0; it < kPasses; ++it) {
@@ -466,18 +461,10 @@ __global__ __launch_bounds__(512, 2) void tapconv5_kernel(const TapConvArgs a) {
             const int q = tid + it * 512, pm = q / kChunks, c8 = q - pm * kChunks;
             const int rr = pm / kTC, mm = pm - rr * kTC;
             const int m = m0 + mm, c = n0 + c8 * 8, hh = h0 + rr;
-            u32x4 o = u32x4{0u, 0u, 0u, 0u}, k = u32x4{0u, 0u, 0u, 0u};
+            u32x4 o = u32x4{0u, 0u, 0u, 0u};
             const int64_t px = ((int64_t)(n * a.H + hh) * a.W_dst) + (a.phases * m + ph);
-            if (m < Wm && hh < a.H) {
-                o = *(const u32x4*)(a.res + px * a.ld_res + c);
-                if (bmask) k = *(const u32x4*)(a.bnb_mask + px * a.ld_bnb_mask + c);
-            }
-            if (bmask) {
-                ov[it] = o;
-                mv[it] = k;
-            } else {
-                yv[it] = o;
-            }
+            if (m < Wm && hh < a.H) o = *(const u32x4*)(a.res + px * a.ld_res + c);
+            yv[it] = o;
         }
     }
     __syncthreads();
@@ -492,7 +479,7 @@ __global__ __launch_bounds__(512, 2) void tapconv5_kernel(const TapConvArgs a) {
         const int64_t px = ((int64_t)(n * a.H + hh) * a.W_dst) + (a.phases * m + ph);
         bf16_t* p = (bf16_t*)a.dst + px * a.ld_dst + c;
         if (accum) {
-            const u32x4 o = bmask ? ov[bmask ? it : 0] : yv[it];
+            const u32x4 o = yv[it];
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = pack_bf2(bf_lo(v[j]) + bf_lo(o[j]), bf_hi(v[j]) + bf_hi(o[j]));
             if (a.flags & RV_OUT_RES_RELU) {
@@ -506,11 +493,6 @@ __global__ __launch_bounds__(512, 2) void tapconv5_kernel(const TapConvArgs a) {
             for (int j = 0; j < 4; ++j) {
                 const float y0 = bf_lo(yv[it][j]), y1 = bf_hi(yv[it][j]);
                 float g0 = bf_lo(v[j]), g1 = bf_hi(v[j]);
-                if (bmask) {
-                    const uint32_t k = mv[bmask ? it : 0][j];
-                    g0 = bf_lo(k) > 0.f ? g0 : 0.f;
-                    g1 = bf_hi(k) > 0.f ? g1 : 0.f;
-                }
                 if (a.bnb_flags & 1) {  // RV_BNB_RELU_Z
                     g0 = y0 * bsc[2 * j] + bsh[2 * j] > 0.f ? g0 : 0.f;
                     g1 = y1 * bsc[2 * j + 1] + bsh[2 * j + 1] > 0.f ? g1 : 0.f;
@@ -556,15 +538,12 @@ __global__ __launch_bounds__(512, 2) void tapconv5_kernel(const TapConvArgs a) {
 
 }  // namespace
 
-extern int g_tapconv4_min_blocks;
-int g_tapconv5_persist = getenv("RV3D_TC_PERSIST") ? atoi(getenv("RV3D_TC_PERSIST")) : 256;  // rv_set_option("tapconv5_persist_blocks") / RV3D_TC_PERSIST: workgroups of a persistent launch (0: one workgroup per tile)
 
 // returns false when the layer is not eligible (caller falls back to tapconv4 / tapconv3 / ...)
 bool rv_tapconv5_plan(TapConvArgs* a, int* tiles, size_t* lds, int* bn) {
     if (a->step != 1) return false;
     if (a->flags & (RV_IN_AFFINE | RV_IN_RELU | RV_OUT_F32)) return false;  // the DMA path has no register prologue
-    if ((a->flags & RV_OUT_BNB) && (a->flags & RV_OUT_ACCUM) && !a->bnb_mask) return false;  // (accumulating sums: the masked last-writer form only)
-    if ((a->flags & RV_OUT_BNB) && a->bnb_mask && !(a->flags & RV_OUT_ACCUM)) return false;
+    if ((a->flags & RV_OUT_BNB) && (a->flags & RV_OUT_ACCUM)) return false;  // (sums over an ACCUMULATED gradient: not formed in an epilogue)
     if (a->C_src % kBK != 0 || a->C_dst % 128 != 0) return false;
     const int kBN = a->C_dst % 256 == 0 ? 256 : 128;  // narrow layers: 128-channel tiles, one weight piece per K tile
     const int min_taps = kBN == 256 ? 3 : 6;          // (K tiles the next chunk's halo needs to land, see the kernel)
@@ -600,7 +579,7 @@ bool rv_tapconv5_plan(TapConvArgs* a, int* tiles, size_t* lds, int* bn) {
     a->total_tiles = a->m_tiles * a->h_tiles * a->N * a->phases;
     a->n_tiles = a->C_dst / kBN;
     a->tiles_per_xcd = rv_ceil_div(a->total_tiles, 8);
-    if ((int64_t)a->total_tiles * a->n_tiles < g_tapconv4_min_blocks) return false;  // too few tiles to fill the chip
+    if ((int64_t)a->total_tiles * a->n_tiles < ((a->sel & RV_SEL_SMALL_GRIDS) ? 1 : rv_cu_count())) return false;  // too few tiles to fill the chip
     *tiles = a->total_tiles;  // stats rows = 2 * tiles
     *lds = (size_t)kLds;
     const size_t epi = (size_t)kTR * kTC * (kBN + 8) * sizeof(bf16_t);
@@ -617,23 +596,19 @@ int rv_tapconv5_launch(const TapConvArgs& a, size_t lds, int bn, hipStream_t str
         (void)hipFuncSetAttribute((const void*)tapconv5_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)tapconv5_kernel<256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)tapconv5_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)tapconv5_kernel<256, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)tapconv5_kernel<128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     int grid = 8 * a.tiles_per_xcd * a.n_tiles;
-    if (g_tapconv5_persist > 0 && grid > g_tapconv5_persist) grid = g_tapconv5_persist >= 8 ? g_tapconv5_persist & ~7 : 8;  // one workgroup per CU (154 KB of LDS each)
-    const int epi = (a.flags & RV_OUT_BNB) ? ((a.flags & RV_OUT_ACCUM) ? 3 : 1) : ((a.flags & RV_OUT_ACCUM) ? 2 : 0);
+    if (grid > rv_cu_count()) grid = rv_cu_count() & ~7;  // one workgroup per CU (154 KB of LDS each)
+    const int epi = (a.flags & RV_OUT_BNB) ? 1 : ((a.flags & RV_OUT_ACCUM) ? 2 : 0);
 #define RV_T5_LAUNCH(BN_, EPI_) hipLaunchKernelGGL((tapconv5_kernel<BN_, EPI_>), dim3(grid), dim3(512), lds, stream, a)
     if (bn == 256) {
         if (epi == 1) RV_T5_LAUNCH(256, 1);
         else if (epi == 2) RV_T5_LAUNCH(256, 2);
-        else if (epi == 3) RV_T5_LAUNCH(256, 3);
         else RV_T5_LAUNCH(256, 0);
     } else {
         if (epi == 1) RV_T5_LAUNCH(128, 1);
         else if (epi == 2) RV_T5_LAUNCH(128, 2);
-        else if (epi == 3) RV_T5_LAUNCH(128, 3);
         else RV_T5_LAUNCH(128, 0);
     }
 #undef RV_T5_LAUNCH

@@ -74,28 +74,18 @@ constexpr int wait_count(int U) {
 
 // EPI: 0 plain store (+ statistics / bias), 1 BatchNorm-sum epilogue (RV_OUT_BNB), 2 accumulate (RV_OUT_ACCUM) -- template parameter
 // for the reason given in tapconv5.hip (spills); the masked last-writer form (both) stays on tapconv5
-// DIAG (diagnostic builds only, -DRV_T6_DIAG_BUILD; results wrong, timing only): 1 no DMA in the loop, 2 no fragment reads, 3 no MFMAs,
-// 4 every DMA lane reads the zero page, 8 no global stores in the epilogue, 9 no epilogue at all
-// SPLIT (round 4, A/B only -- RV3D_T6_SPLIT=1; measured SLOWER, default off).  The tile boundary costs ~7-10 us per tile and most of
-// it is the 128 KB of output stores: the same kernel without its global stores is 9 % / 10 % / 18 % faster on the 512- / 256- /
-// 128-channel layers (profiles/r04_tapconv6_ablation.md section 4).  First reading: vmcnt retires in order and counts stores with
-// loads, so the waves sit behind their own stores in the next tile's prologue.  SPLIT tests that: waves 0-3 issue ALL LDS-DMA and
-// never store, waves 4-7 issue ALL stores and never load in the K loop -- nobody waits behind a store.  Result: 0 % (512 channels),
-// -5 % (256), -9 % (128): the stores are not waited for by a wave, they occupy the CU's ONE vector-memory pipeline (~13-17 GB/s of
-// stores per CU = ~150 cycles per 1 KB store instruction, the guide's "store-issue-bound epilogue tail"), and every later load of any
-// wave queues behind them in that pipeline.  Staggering the workgroups' starts (a chip-wide burst?) changed nothing either.
-template <int EPI, int DIAG = 0, bool SPLIT = false>
+// (Measured and dropped in round 4, profiles/r04_tapconv6_ablation.md: a role split -- four waves issue every LDS-DMA and never store, four
+//  store and never load -- 0 % / -5 % / -9 % on the 512- / 256- / 128-channel layers; a pipelined tile boundary with the next tile's
+//  prologue issued before the stores, 2 ms per step slower; non-temporal epilogue stores, neutral.  Neither is in the library.)
+template <int EPI>
 __global__ __launch_bounds__(512, 2) void tapconv6_kernel(const TapConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     const int l15 = lane & 15, lg = lane >> 4;
-    constexpr int kIss = SPLIT ? 4 : 8;         // waves that issue LDS-DMA
-    constexpr int kHaloPer = 48 / kIss;         // halo instruction slots per issuing wave (41 real ones, the rest dummies)
+    constexpr int kHaloPer = 6;                 // halo instruction slots per wave (41 real ones over 8 waves, the rest dummies)
     constexpr int kHaloPerTile = kHaloPer / 3;  // ... issued per K tile at positions 0..2 of a chunk
-    const bool issuer = !SPLIT || wave < 4;     // (wave-uniform)
-    const bool storer = !SPLIT || wave >= 4;
 
     // XCD-aware persistent block order as in tapconv5: the channel tiles of one pixel tile sit on neighbouring workgroups of
     // one XCD (they read the same halo through that XCD's L2)
@@ -113,8 +103,8 @@ __global__ __launch_bounds__(512, 2) void tapconv6_kernel(const TapConvArgs a) {
             stat_acc[j * 32 + 1] = 0.f;
         }
     }
-    if ((EPI == 1) && a.stats_per_wg && storer && (SPLIT ? tid - 256 : tid) < 256)
-        ((float*)(smem + kBnbAcc))[SPLIT ? tid - 256 : tid] = 0.f;  // (same rows rule for the BatchNorm-backward sums; slot owner = the thread that adds to it)
+    if ((EPI == 1) && a.stats_per_wg && tid < 256)
+        ((float*)(smem + kBnbAcc))[tid] = 0.f;  // (same rows rule for the BatchNorm-backward sums; slot owner = the thread that adds to it)
     for (int k = 0;; ++k) {
     const int xslot = wslot + nslots * k;
     if (xslot >= a.tiles_per_xcd * gy) break;
@@ -160,18 +150,12 @@ __global__ __launch_bounds__(512, 2) void tapconv6_kernel(const TapConvArgs a) {
     const int64_t w_img = (int64_t)a.C_dst * a.C_src;
     const bf16_t* w_ph = a.w + (int64_t)a.tt.w_first[ph] * w_img;
     const int b_voff = (n0 + wave * 16 + s_row) * a.C_src + kq8;
-    const int b_half = 64 * a.C_src;  // SPLIT: an issuing wave also covers channels 16 (w + 4) + s_row
     int bq = 0, bt = 0;  // K tile / tap of the piece being issued
     int b_so = 0;        // element offset of its (tap image, chunk) in the packed weight -- kept scalar
     auto stage_b = [&](int j) {
         const int so = __builtin_amdgcn_readfirstlane(b_so);
-        const bf16_t* p = DIAG == 4 ? zero : w_ph + so + b_voff;
-        if (DIAG != 1) {
-            __builtin_amdgcn_global_load_lds((glb_void_t*)p, (lds_void_t*)(smem + kRing + (j & (kNRing - 1)) * kPiece + wave * 1024), 16, 0, 0);
-            if (SPLIT)
-                __builtin_amdgcn_global_load_lds((glb_void_t*)(DIAG == 4 ? p : p + b_half),
-                                                 (lds_void_t*)(smem + kRing + (j & (kNRing - 1)) * kPiece + (wave + 4) * 1024), 16, 0, 0);
-        }
+        const bf16_t* p = w_ph + so + b_voff;
+        __builtin_amdgcn_global_load_lds((glb_void_t*)p, (lds_void_t*)(smem + kRing + (j & (kNRing - 1)) * kPiece + wave * 1024), 16, 0, 0);
         const bool go = bq + 1 < nkt;  // pieces past the last K tile re-fetch it (never read; keeps the wait counts uniform)
         const bool wrap = bt + 1 == T;
         bq += go ? 1 : 0;
@@ -183,7 +167,7 @@ __global__ __launch_bounds__(512, 2) void tapconv6_kernel(const TapConvArgs a) {
     int hoff[kHaloPer];
 #pragma unroll
     for (int i = 0; i < kHaloPer; ++i) {
-        const int q = wave + kIss * i;
+        const int q = wave + 8 * i;
         const int p = q * 16 + s_row;
         const int hr = (p * 1821) >> 16, hc = p - hr * kPitch;  // 1821 = ceil(65536 / 36): exact for p < 2^12
         const int row = row_base + hr, col = col_base + hc;
@@ -191,10 +175,10 @@ __global__ __launch_bounds__(512, 2) void tapconv6_kernel(const TapConvArgs a) {
         hoff[i] = ((row * a.W_src + col) * a.ld_src + kq8) | -bad;
     }
     auto stage_halo = [&](int buf, int i, int kc) {  // i: compile-time index 0 .. kHaloPer - 1
-        const int q = wave + kIss * i;
-        const bf16_t* src = (hoff[i] >= 0 && DIAG != 4) ? src_img + (hoff[i] + kc * kBK) : zero;
+        const int q = wave + 8 * i;
+        const bf16_t* src = hoff[i] >= 0 ? src_img + (hoff[i] + kc * kBK) : zero;
         const int dst = q < kHaloInstr ? buf * kHaloBytes + q * 1024 : kScratch;
-        if (DIAG != 1) __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(smem + dst), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(smem + dst), 16, 0, 0);
     };
 
     // ---- fragment reads ---------------------------------------------------------------------------------------------
@@ -210,7 +194,6 @@ __global__ __launch_bounds__(512, 2) void tapconv6_kernel(const TapConvArgs a) {
         a_b1 = a_b0 ^ 32;
     };
     auto read_a = [&](int mq) {
-        if (DIAG == 2) return;
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
@@ -218,7 +201,6 @@ __global__ __launch_bounds__(512, 2) void tapconv6_kernel(const TapConvArgs a) {
                 fa[rr * 2 + cc] = *(const bf16x8*)(smem + (((2 * mq + rr) & 1) ? a_b1 : a_b0) + (2 * mq + rr) * (kPitch * 64) + cc * 1024);
     };
     auto read_b = [&](int j) {
-        if (DIAG == 2) return;
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) fb[jj] = *(const bf16x8*)(smem + kRing + (j & (kNRing - 1)) * kPiece + jj * 1024 + b_rd);
     };
@@ -235,24 +217,18 @@ __global__ __launch_bounds__(512, 2) void tapconv6_kernel(const TapConvArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                  \
     __builtin_amdgcn_s_setprio(1);                                                                      \
-    if (DIAG != 3) {                                                                                    \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int jj = 0; jj < 4; ++jj)      \
         acc[(MQ) * 4 + i][jj] = RV_MFMA_16x16x32(fa[i], fb[jj], acc[(MQ) * 4 + i][jj], 0, 0, 0);        \
-    } else {                                                                                            \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fa[i]), "v"(fb[i]));            \
-    }                                                                                                   \
     __builtin_amdgcn_s_setprio(0);                                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                                  \
     __builtin_amdgcn_s_barrier();
 
     // ---- prologue: halo of chunk 0, weight pieces 0 .. kAhead - 1 -------------------------------------------------------
-    if (issuer) {
 #pragma unroll
-        for (int i = 0; i < kHaloPer; ++i) stage_halo(0, i, 0);
+    for (int i = 0; i < kHaloPer; ++i) stage_halo(0, i, 0);
 #pragma unroll
-        for (int j = 0; j < kAhead; ++j) stage_b(j);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (SPLIT: the issuing waves hold no stores -- this waits for loads only)
-    }
+    for (int j = 0; j < kAhead; ++j) stage_b(j);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (wave >= 4) __builtin_amdgcn_s_barrier();  // the second half of the workgroup runs one barrier behind the first
 
@@ -263,26 +239,18 @@ __global__ __launch_bounds__(512, 2) void tapconv6_kernel(const TapConvArgs a) {
     // during positions U = 0, 1, 2.  The wait (with the barrier behind it) makes piece kt + 1 visible to the next K tile.
 #define RV_KTILE(U, HALO)                                                                                         \
     {                                                                                                              \
-        constexpr int W = (kIss == 4 ? 2 : 1) * ((HALO) ? wait_count(U) : kAhead - 1);                             \
+        constexpr int W = (HALO) ? wait_count(U) : kAhead - 1;                                                     \
         const int hbuf = (kc + 1) & 1;                                                                             \
-        if (issuer) {                                                                                              \
-            stage_b(kt + kAhead);                                                                                  \
-            if constexpr ((HALO) && (U) <= 2) {                                                                    \
-                _Pragma("unroll") for (int h = 0; h < kHaloPerTile / 2; ++h) stage_halo(hbuf, kHaloPerTile * (U) + h, kc + 1); \
-            }                                                                                                      \
-        }                                                                                                          \
+        stage_b(kt + kAhead);                                                                                      \
+        if constexpr ((HALO) && (U) <= 2) stage_halo(hbuf, kHaloPerTile * (U), kc + 1);                            \
         addr_a((kc & 1) * kHaloBytes, sh);                                                                         \
         read_b(kt);                                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                                         \
         read_a(0);                                                                                                 \
         RV_PHASE_COMPUTE(0);                                                                                       \
         read_a(1);                                                                                                 \
-        if (issuer) {                                                                                              \
-            if constexpr ((HALO) && (U) <= 2) {                                                                    \
-                _Pragma("unroll") for (int h = kHaloPerTile / 2; h < kHaloPerTile; ++h) stage_halo(hbuf, kHaloPerTile * (U) + h, kc + 1); \
-            }                                                                                                      \
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W) : "memory");                                               \
-        }                                                                                                          \
+        if constexpr ((HALO) && (U) <= 2) stage_halo(hbuf, kHaloPerTile * (U) + 1, kc + 1);                        \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W) : "memory");                                                   \
         RV_PHASE_COMPUTE(1);                                                                                       \
         ++kt;                                                                                                      \
         const bool wrap = ix + 1 == ncol;                                                                          \
@@ -368,16 +336,6 @@ __global__ __launch_bounds__(512, 2) void tapconv6_kernel(const TapConvArgs a) {
     }
     constexpr int kEpi = kBN + 8;
     bf16_t* epi = (bf16_t*)smem;  // [16 rows * 32 cols][kEpi]
-    if (DIAG == 9) {  // (timing only: no staging, no stores; keep the accumulators observable)
-        float s9 = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) s9 += acc[i][j][0];
-        if (s9 == 12345.678f) a.stats[0] = s9;
-        __syncthreads();
-        continue;
-    }
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -393,12 +351,12 @@ __global__ __launch_bounds__(512, 2) void tapconv6_kernel(const TapConvArgs a) {
     constexpr bool bnb = EPI == 1;  // BatchNorm-backward sums of the layer whose output gradient is being written
     static_assert(EPI >= 0 && EPI <= 2, "the masked last-writer epilogue (three prefetches per pass) stays on tapconv5");
     // the store loop: thread st of the storing waves keeps ONE 8-channel chunk (st % 16) through all passes
-    constexpr int kStoreThreads = SPLIT ? 256 : 512;
-    constexpr int kPasses = kTR * kTC * kChunks / kStoreThreads;  // 16 (all waves store) / 32 (SPLIT: waves 4-7 store)
-    int st = SPLIT ? tid - 256 : tid;
+    constexpr int kStoreThreads = 512;
+    constexpr int kPasses = kTR * kTC * kChunks / kStoreThreads;  // 16
+    int st = tid;
     asm volatile("" : "+v"(st));  // opaque HERE: the store loop's per-pass offsets are formed after the K loop, not hoisted above it (spills)
     float bsc[8], bsh[8], bmu[8], bis[8], s0[8], s1[8];
-    if (bnb && storer) {
+    if (bnb) {
         const int c = n0 + (st & (kChunks - 1)) * 8;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -411,8 +369,7 @@ __global__ __launch_bounds__(512, 2) void tapconv6_kernel(const TapConvArgs a) {
         }
     }
     // Passes in ROUNDS of eight with the next round's global reads (y of the BatchNorm sums / the old values of an accumulating
-    // launch) in flight while the current one is stored: 2 x 8 prefetch registers per array instead of one per pass (32 passes under
-    // SPLIT).  The reads are unconditional (clamped coordinates): straight-line code, so the compiler counts its vmcnt waits exactly
+    // launch) in flight while the current one is stored: 2 x 8 prefetch registers per array instead of one per pass.  The reads are unconditional (clamped coordinates): straight-line code, so the compiler counts its vmcnt waits exactly
     // instead of draining the queue at the first use.
     constexpr int kRound = 8, kRounds = kPasses / kRound;
     constexpr bool pre = bnb || accum;
@@ -427,9 +384,8 @@ __global__ __launch_bounds__(512, 2) void tapconv6_kernel(const TapConvArgs a) {
             yv[pre ? buf : 0][pre ? i : 0] = bnb ? *(const u32x4*)(a.bnb_y + px * a.ld_bnb_y + c) : *(const u32x4*)(a.res + px * a.ld_res + c);
         }
     };
-    if (pre && storer) prefetch(0, 0);  // (before the barrier that publishes the staged tile)
+    if (pre) prefetch(0, 0);  // (before the barrier that publishes the staged tile)
     __syncthreads();
-    if (storer) {
 #pragma unroll
     for (int r = 0; r < kRounds; ++r) {
         if (pre && r + 1 < kRounds) prefetch(r + 1, (r + 1) & 1);
@@ -452,14 +408,7 @@ __global__ __launch_bounds__(512, 2) void tapconv6_kernel(const TapConvArgs a) {
                     for (int j = 0; j < 4; ++j) v[j] = pack_bf2(fmaxf(bf_lo(v[j]), 0.f), fmaxf(bf_hi(v[j]), 0.f));
                 }
             }
-            // (timing only) 10: the tile goes to ONE contiguous 128 KB region per workgroup, rewritten by every tile (stays in L2: no
-            // write-back traffic); 11: to a contiguous 128 KB region per tile (fresh memory, but one DRAM page run instead of 16 image rows)
-            if (DIAG == 10) p = (bf16_t*)a.dst + (int64_t)blockIdx.x * 65536 + (int64_t)q * 8;
-            if (DIAG == 11) p = (bf16_t*)a.dst + ((int64_t)tile * gy + n0 / kBN) * 65536 + (int64_t)q * 8;
-            if (DIAG != 8) {
-                if (a.nt_store) __builtin_nontemporal_store(v, (u32x4*)p);  // (RV3D_T6_NT_STORES=1: profiles/r04_tapconv6_ablation.md section 4)
-                else *(u32x4*)p = v;
-            }
+            *(u32x4*)p = v;
             if (bnb) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -477,32 +426,29 @@ __global__ __launch_bounds__(512, 2) void tapconv6_kernel(const TapConvArgs a) {
             }
         }
     }
-    }
     if (bnb) {
         // lanes kChunks apart hold the same chunk; then the storing waves through LDS (the staged tile is dead now)
         __syncthreads();
         float* red = (float*)smem;  // [storing waves][kChunks][16]
         constexpr int kSW = kStoreThreads / 64;
-        if (storer) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+            for (int d = kChunks; d < 64; d <<= 1) {
+                s0[j] += __shfl_xor(s0[j], d, 64);
+                s1[j] += __shfl_xor(s1[j], d, 64);
+            }
+        }
+        if (lane < kChunks) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-#pragma unroll
-                for (int d = kChunks; d < 64; d <<= 1) {
-                    s0[j] += __shfl_xor(s0[j], d, 64);
-                    s1[j] += __shfl_xor(s1[j], d, 64);
-                }
-            }
-            if (lane < kChunks) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    red[((st >> 6) * kChunks + lane) * 16 + j] = s0[j];
-                    red[((st >> 6) * kChunks + lane) * 16 + 8 + j] = s1[j];
-                }
+                red[((st >> 6) * kChunks + lane) * 16 + j] = s0[j];
+                red[((st >> 6) * kChunks + lane) * 16 + 8 + j] = s1[j];
             }
         }
         __syncthreads();
         const int chunk = st >> 4, jj = st & 15;  // kChunks x 16 values, summed by the first 256 storing threads
-        if (storer && chunk < kChunks) {
+        if (chunk < kChunks) {
             float sum = 0.f;
 #pragma unroll
             for (int w = 0; w < kSW; ++w) sum += red[(w * kChunks + chunk) * 16 + jj];
@@ -512,8 +458,8 @@ __global__ __launch_bounds__(512, 2) void tapconv6_kernel(const TapConvArgs a) {
     }
     __syncthreads();  // the staged output / BatchNorm sums of this tile are dead before the next tile's loads land in LDS
     }  // persistent tile loop
-    if ((EPI == 1) && a.stats_per_wg && storer && (SPLIT ? tid - 256 : tid) < 256) {
-        const int so = SPLIT ? tid - 256 : tid, chunk = so >> 4, jj = so & 15;
+    if ((EPI == 1) && a.stats_per_wg && tid < 256) {
+        const int so = tid, chunk = so >> 4, jj = so & 15;
         a.bnb_partial[((int64_t)(xcd * (nslots / gy) + wslot / gy) * 2 + (jj >> 3)) * a.C_dst + (wslot % gy) * kBN + chunk * 8 + (jj & 7)] =
             ((const float*)(smem + kBnbAcc))[so];
     }
@@ -532,444 +478,13 @@ __global__ __launch_bounds__(512, 2) void tapconv6_kernel(const TapConvArgs a) {
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// tapconv6p: the same tile and K loop with a PIPELINED tile boundary.
-//
-// Measured (profiles/r04_tapconv6_ablation.md section 4): 7-10 us of every tile are its 128 KB of output stores, which occupy the
-// CU's one vector-memory pipeline (~150 cycles per 1 KB store instruction) while the next tile's prologue loads queue behind them.
-// Here the NEXT tile's prologue (halo of its chunk 0, weight pieces 0 .. kAhead - 1) is issued BEFORE the current tile's stores --
-// it is older in the pipeline, lands during the epilogue, and the first kAhead - 1 K tiles of the next tile run without any wait
-// (everything they read came with that prologue) while the stores drain.  For the LDS to hold both, the epilogue goes in two
-// halves of 256 pixels through the regions the prologue does not touch: halo buffer 1 (R1) and ring slots kAhead .. 7 (+ 2 KB
-// spare, R2) -- 128 pixels x 272 B each.  Stores are unconditional (pixels outside the image go to a sink) so that `vmcnt(16)`
-// before the next K loop means exactly "everything but this tile's 16 stores has landed".
-// Requires the per-workgroup statistic rows (no global statistic stores per tile, channel tile constant per workgroup).
-constexpr int kQR1 = kHaloBytes;                 // staging region 1: halo buffer 1
-constexpr int kQR2 = kRing + kAhead * kPiece;    // staging region 2: ring slots kAhead .. 7 and the spare behind them
-constexpr int kQHalf = 128 * (kBN + 8) * 2;      // 34816 B: 128 staged pixels
-static_assert(kQR1 + kQHalf <= kRing, "staging region 1 must fit halo buffer 1");
-constexpr int kQScratch = kQR2 + kQHalf > kRing + kNRing * kPiece ? kQR2 + kQHalf : kRing + kNRing * kPiece;
-constexpr int kQTab = kQScratch + 1024;
-constexpr int kQStatAcc = kQTab + 32 * 4;
-constexpr int kQBnbAcc = kQStatAcc + 8 * 4 * 16 * 2 * 4;
-constexpr int kQLds = kQBnbAcc + 256 * 4;
-static_assert(kQLds <= 160 * 1024, "LDS budget");
-__device__ __attribute__((aligned(256))) uint32_t g_store_sink6[512 * 4];  // 16 B per thread: where stores of out-of-image pixels go
-
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void tapconv6p_kernel(const TapConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
-    const int l15 = lane & 15, lg = lane >> 4;
-    constexpr bool accum = EPI == 2;
-    constexpr bool bnb = EPI == 1;
-    constexpr bool pre = bnb || accum;
-
-    const int gy = a.n_tiles;
-    const int xcd = blockIdx.x & 7, wslot = blockIdx.x >> 3, nslots = gridDim.x >> 3;  // (gridDim.x % 8 == 0, nslots % gy == 0)
-    const int n0 = (wslot % gy) * kBN;  // the channel tile of this workgroup (the same for all of its pixel tiles)
-    auto stat_slot = [&]() { return (float*)(smem + kQStatAcc) + (wave * 4 * 16 + l15) * 2; };
-    if (lg == 0) {
-        float* stat_acc = stat_slot();
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            stat_acc[j * 32] = 0.f;
-            stat_acc[j * 32 + 1] = 0.f;
-        }
-    }
-    if (bnb && tid < 256) ((float*)(smem + kQBnbAcc))[tid] = 0.f;
-
-    // ---- tile-independent lane constants ---------------------------------------------------------------------------------
-    const int s_row = lane >> 2, s_slot = lane & 3;
-    const int kq8 = (s_slot ^ (((s_row >> 2) & 1) << 1)) * 8;
-    const bf16_t* zero = (const bf16_t*)g_zero_page6 + s_slot * 8;
-    const int64_t w_img = (int64_t)a.C_dst * a.C_src;
-    const int b_voff = (n0 + wave * 16 + s_row) * a.C_src + kq8;
-    const int p_lane = (4 * wr) * kPitch + l15;
-    const int b_rd = (wc * 64 + l15) * 64 + ((lg ^ (((l15 >> 2) & 1) << 1)) * 16);
-    const int nkc = a.C_src / kBK;
-    const int Wm = a.W_dst / a.phases;
-
-    // ---- per-tile state (the tile being computed / whose prologue is in flight) -----------------------------------------------
-    int k_iter = 0;
-    auto next_tile = [&]() -> int {  // next pixel tile of this workgroup, -1 when there is none
-        for (;; ++k_iter) {
-            const int xslot = wslot + nslots * k_iter;
-            if (xslot >= a.tiles_per_xcd * gy) return -1;
-            const int tile = xcd * a.tiles_per_xcd + xslot / gy;
-            if (tile < a.total_tiles) {
-                ++k_iter;
-                return tile;
-            }
-        }
-    };
-    int n = 0, ph = 0, m0 = 0, h0 = 0, T = 0, nkt = 0, ncol = 1, sh0 = 0, sh_dcol = 0, sh_drow = 0;
-    const bf16_t *src_img = a.src, *w_ph = a.w;
-    int hoff[6];
-    int bq = 0, bt = 0, b_so = 0;
-    auto setup = [&](int tile) {  // (contains a workgroup barrier: called by all waves)
-        int bx = tile;
-        const int tc = bx % a.m_tiles;
-        bx /= a.m_tiles;
-        const int th = bx % a.h_tiles;
-        bx /= a.h_tiles;
-        n = bx % a.N;
-        ph = bx / a.N;
-        m0 = tc * kTC;
-        h0 = th * kTR;
-        T = a.tt.ntaps[ph];
-        nkt = T * nkc;
-        const int HW = kTC + a.tt.dw_max[ph] - a.tt.dw_min[ph], HR = kTR + a.tt.rows - 1;
-        src_img = a.src + ((int64_t)n * a.H * a.W_src) * a.ld_src;
-        w_ph = a.w + (int64_t)a.tt.w_first[ph] * w_img;
-        int* tap_tab = (int*)(smem + kQTab);
-        if (tid < 16) tap_tab[tid] = tid < T ? (a.tt.dh[ph][tid] - a.tt.dh_min) * kPitch + (a.tt.dw[ph][tid] - a.tt.dw_min[ph]) : 0;
-        __syncthreads();
-        ncol = T / a.tt.rows;
-        sh0 = __builtin_amdgcn_readfirstlane(tap_tab[0]);
-        sh_dcol = ncol > 1 ? __builtin_amdgcn_readfirstlane(tap_tab[1]) - sh0 : 0;
-        sh_drow = ncol < T ? __builtin_amdgcn_readfirstlane(tap_tab[ncol]) - __builtin_amdgcn_readfirstlane(tap_tab[ncol - 1]) : 0;
-        const int row_base = h0 + a.tt.dh_min, col_base = m0 + a.tt.dw_min[ph];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int q = wave + 8 * i;
-            const int p = q * 16 + s_row;
-            const int hr = (p * 1821) >> 16, hc = p - hr * kPitch;
-            const int row = row_base + hr, col = col_base + hc;
-            const int bad = (q >= kHaloInstr) | (hc >= HW) | (hr >= HR) | (row < 0) | (row >= a.H) | (col < 0) | (col >= a.W_src);
-            hoff[i] = ((row * a.W_src + col) * a.ld_src + kq8) | -bad;
-        }
-        bq = 0, bt = 0, b_so = 0;
-        __syncthreads();  // (the tap table may be rewritten by the next setup only after everybody has read it)
-    };
-    auto stage_b = [&](int j) {
-        const int so = __builtin_amdgcn_readfirstlane(b_so);
-        const bf16_t* p = w_ph + so + b_voff;
-        __builtin_amdgcn_global_load_lds((glb_void_t*)p, (lds_void_t*)(smem + kRing + (j & (kNRing - 1)) * kPiece + wave * 1024), 16, 0, 0);
-        const bool go = bq + 1 < nkt;
-        const bool wrap = bt + 1 == T;
-        bq += go ? 1 : 0;
-        b_so += go ? (wrap ? kBK - (T - 1) * (int)w_img : (int)w_img) : 0;
-        bt = go ? (wrap ? 0 : bt + 1) : bt;
-    };
-    auto stage_halo = [&](int buf, int i, int kc) {
-        const int q = wave + 8 * i;
-        const bf16_t* src = hoff[i] >= 0 ? src_img + (hoff[i] + kc * kBK) : zero;
-        const int dst = q < kHaloInstr ? buf * kHaloBytes + q * 1024 : kQScratch;
-        __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(smem + dst), 16, 0, 0);
-    };
-    auto issue_prologue = [&]() {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) stage_halo(0, i, 0);
-#pragma unroll
-        for (int j = 0; j < kAhead; ++j) stage_b(j);
-    };
-
-    bf16x8 fa[4], fb[4];
-    int a_b0 = 0, a_b1 = 0;
-    auto addr_a = [&](int halo_byte, int shift) {
-        const int p = p_lane + shift;
-        a_b0 = halo_byte + p * 64 + ((lg ^ (((p >> 2) & 1) << 1)) * 16);
-        a_b1 = a_b0 ^ 32;
-    };
-    auto read_a = [&](int mq) {
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-            for (int cc = 0; cc < 2; ++cc)
-                fa[rr * 2 + cc] = *(const bf16x8*)(smem + (((2 * mq + rr) & 1) ? a_b1 : a_b0) + (2 * mq + rr) * (kPitch * 64) + cc * 1024);
-    };
-    auto read_b = [&](int j) {
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) fb[jj] = *(const bf16x8*)(smem + kRing + (j & (kNRing - 1)) * kPiece + jj * 1024 + b_rd);
-    };
-
-    int tile = next_tile();
-    if (tile >= 0) {
-    setup(tile);
-    issue_prologue();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (wave >= 4) __builtin_amdgcn_s_barrier();  // the second half of the workgroup runs one barrier behind the first
-
-    for (;;) {
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-#define RV_PHASE_COMPUTE(MQ)                                                                            \
-    __builtin_amdgcn_s_barrier();                                                                       \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                  \
-    __builtin_amdgcn_sched_barrier(0);                                                                  \
-    __builtin_amdgcn_s_setprio(1);                                                                      \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int jj = 0; jj < 4; ++jj)      \
-        acc[(MQ) * 4 + i][jj] = RV_MFMA_16x16x32(fa[i], fb[jj], acc[(MQ) * 4 + i][jj], 0, 0, 0);        \
-    __builtin_amdgcn_s_setprio(0);                                                                      \
-    __builtin_amdgcn_sched_barrier(0);                                                                  \
-    __builtin_amdgcn_s_barrier();
-    int kt = 0, kc = 0;
-    int sh = sh0, ix = 0;
-    // NOWAIT: the first kAhead - 1 K tiles of a TILE read only what its prologue brought (pieces 0 .. kAhead - 1, halo 0): no
-    // vmcnt wait, so nothing here sits behind the previous tile's stores
-#define RV_KTILE(U, HALO, NOWAIT)                                                                                  \
-    {                                                                                                              \
-        constexpr int W = (HALO) ? wait_count(U) : kAhead - 1;                                                     \
-        const int hbuf = (kc + 1) & 1;                                                                             \
-        stage_b(kt + kAhead);                                                                                      \
-        if constexpr ((HALO) && (U) <= 2) stage_halo(hbuf, 2 * (U), kc + 1);                                       \
-        addr_a((kc & 1) * kHaloBytes, sh);                                                                         \
-        read_b(kt);                                                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                                         \
-        read_a(0);                                                                                                 \
-        RV_PHASE_COMPUTE(0);                                                                                       \
-        if constexpr ((HALO) && (U) <= 2) stage_halo(hbuf, 2 * (U) + 1, kc + 1);                                   \
-        read_a(1);                                                                                                 \
-        if constexpr (!(NOWAIT)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W) : "memory");                          \
-        RV_PHASE_COMPUTE(1);                                                                                       \
-        ++kt;                                                                                                      \
-        const bool wrap = ix + 1 == ncol;                                                                          \
-        sh += wrap ? sh_drow : sh_dcol;                                                                            \
-        ix = wrap ? 0 : ix + 1;                                                                                    \
-    }
-    static_assert(kAhead - 1 <= 3 && kMinTaps >= 6, "the wait-free K tiles are positions 0 .. kAhead - 2 of the first chunk");
-    if (nkc > 1) {  // first chunk, with a successor
-        RV_KTILE(0, true, kAhead - 1 > 0)
-        RV_KTILE(1, true, kAhead - 1 > 1)
-        RV_KTILE(2, true, kAhead - 1 > 2)
-        RV_KTILE(3, true, false)
-        RV_KTILE(4, true, false)
-        RV_KTILE(5, true, false)
-        if (T > 6) RV_KTILE(6, true, false)
-        if (T > 7) RV_KTILE(7, true, false)
-        if (T > 8) RV_KTILE(8, true, false)
-        for (int t = 9; t < T; ++t) RV_KTILE(9, true, false)
-        sh = sh0;
-        ix = 0;
-        ++kc;
-        for (; kc + 1 < nkc; ++kc) {
-            RV_KTILE(0, true, false)
-            RV_KTILE(1, true, false)
-            RV_KTILE(2, true, false)
-            RV_KTILE(3, true, false)
-            RV_KTILE(4, true, false)
-            RV_KTILE(5, true, false)
-            if (T > 6) RV_KTILE(6, true, false)
-            if (T > 7) RV_KTILE(7, true, false)
-            if (T > 8) RV_KTILE(8, true, false)
-            for (int t = 9; t < T; ++t) RV_KTILE(9, true, false)
-            sh = sh0;
-            ix = 0;
-        }
-        for (int t = 0; t < T; ++t) RV_KTILE(9, false, false)  // last chunk: no halo to load
-    } else {  // a single chunk: its first K tiles are the wait-free ones
-        RV_KTILE(9, false, kAhead - 1 > 0)
-        RV_KTILE(9, false, kAhead - 1 > 1)
-        RV_KTILE(9, false, kAhead - 1 > 2)
-        for (int t = 3; t < T; ++t) RV_KTILE(9, false, false)
-    }
-#undef RV_KTILE
-#undef RV_PHASE_COMPUTE
-    if (wave < 4) __builtin_amdgcn_s_barrier();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the trailing re-fetches of the ring; the PREVIOUS tile's stores drained long ago)
-    __syncthreads();
-
-    // ------------------------------------ epilogue, part A: on the accumulators -----------------------------------------------
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const bool row_ok = h0 + 4 * wr + (i >> 1) < a.H;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + (i & 1) * 16 + lg * 4 + r;
-            if (m >= Wm || !row_ok) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j][r] = 0.f;
-            }
-        }
-    }
-    if (a.flags & RV_OUT_STATS) {
-        float* stat_acc = stat_slot();
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float s = 0.f, q = 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = acc[i][j][r];
-                    s += v;
-                    q += v * v;
-                }
-            s += __shfl_xor(s, 16, 64);
-            q += __shfl_xor(q, 16, 64);
-            s += __shfl_xor(s, 32, 64);
-            q += __shfl_xor(q, 32, 64);
-            if (lg == 0) {
-                stat_acc[j * 32] += s;
-                stat_acc[j * 32 + 1] += q;
-            }
-        }
-    }
-    if (a.flags & RV_OUT_BIAS) {
-        const bool relu_out = (a.flags & RV_OUT_RELU) != 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float b = a.bias[n0 + wc * 64 + j * 16 + l15];
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][j][r] = relu_out ? fmaxf(acc[i][j][r] + b, 0.f) : acc[i][j][r] + b;
-        }
-    }
-    // ---- the NEXT tile's prologue goes out now: older than this tile's stores in the CU's memory pipeline ---------------------
-    const int c_n = n, c_ph = ph, c_m0 = m0, c_h0 = h0;  // this tile's coordinates for the store loop
-    const int nxt = next_tile();
-    if (nxt >= 0) {
-        setup(nxt);
-        issue_prologue();
-    }
-    // ------------------------------------ epilogue, part B: two halves of 256 pixels ------------------------------------------
-    constexpr int kEpi = kBN + 8;
-    int mm = tid >> 4, c8 = tid & 15;  // this thread's tile column and 8-channel chunk in every pass; pass `it` of half h = tile row 8 h + it
-    asm volatile("" : "+v"(mm), "+v"(c8));  // (the store loop's offsets are formed here, not hoisted above the K loop)
-    const int m = c_m0 + mm, cch = n0 + c8 * 8;
-    const bool col_ok = m < Wm;
-    const int m_cl = min(m, Wm - 1);
-    auto pixel = [&](int hh) { return ((int64_t)(c_n * a.H + hh) * a.W_dst) + (a.phases * m_cl + c_ph); };
-    float bsc[8], bsh[8], bmu[8], bis[8], s0[8], s1[8];
-    if (bnb) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            bsc[j] = a.bnb_scale[cch + j];
-            bsh[j] = a.bnb_shift[cch + j];
-            bmu[j] = a.bnb_mean[cch + j];
-            bis[j] = a.bnb_invstd[cch + j];
-            s0[j] = 0.f;
-            s1[j] = 0.f;
-        }
-    }
-    u32x4 yv[pre ? 16 : 1];
-    if (pre) {  // all sixteen reads (clamped coordinates: unconditional) before the first store
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int64_t px = pixel(min(c_h0 + it, a.H - 1));
-            yv[it] = bnb ? *(const u32x4*)(a.bnb_y + px * a.ld_bnb_y + cch) : *(const u32x4*)(a.res + px * a.ld_res + cch);
-        }
-    }
-    bf16_t* sink = (bf16_t*)g_store_sink6 + tid * 8;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        if ((wr >> 1) == h) {  // the four waves that own tile rows 8 h .. 8 h + 7 stage them: rows 4 (wr & 1) .. + 3 of the half
-            bf16_t* reg = (bf16_t*)(smem + ((wr & 1) ? kQR2 : kQR1));
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int pl = (i >> 1) * kTC + (i & 1) * 16 + lg * 4 + r;  // pixel 0..127 of the region
-                        reg[pl * kEpi + wc * 64 + j * 16 + l15] = f2bf(acc[i][j][r]);
-                    }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const bf16_t* reg = (const bf16_t*)(smem + (it < 4 ? kQR1 : kQR2));
-            u32x4 v = *(const u32x4*)(reg + ((it & 3) * kTC + mm) * kEpi + c8 * 8);
-            const int hh = c_h0 + 8 * h + it;
-            const bool ok = col_ok && hh < a.H;
-            bf16_t* p = ok ? (bf16_t*)a.dst + pixel(hh) * a.ld_dst + cch : sink;
-            const u32x4 pv = yv[pre ? 8 * h + it : 0];
-            if (accum) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = pack_bf2(bf_lo(v[j]) + bf_lo(pv[j]), bf_hi(v[j]) + bf_hi(pv[j]));
-                if (a.flags & RV_OUT_RES_RELU) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = pack_bf2(fmaxf(bf_lo(v[j]), 0.f), fmaxf(bf_hi(v[j]), 0.f));
-                }
-            }
-            *(u32x4*)p = v;  // (always issued: the wait before the next K loop counts on 16 stores per thread)
-            if (bnb && ok) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float y0 = bf_lo(pv[j]), y1 = bf_hi(pv[j]);
-                    float g0 = bf_lo(v[j]), g1 = bf_hi(v[j]);
-                    if (a.bnb_flags & 1) {  // RV_BNB_RELU_Z
-                        g0 = y0 * bsc[2 * j] + bsh[2 * j] > 0.f ? g0 : 0.f;
-                        g1 = y1 * bsc[2 * j + 1] + bsh[2 * j + 1] > 0.f ? g1 : 0.f;
-                    }
-                    s0[2 * j] += g0;
-                    s0[2 * j + 1] += g1;
-                    s1[2 * j] += g0 * ((y0 - bmu[2 * j]) * bis[2 * j]);
-                    s1[2 * j + 1] += g1 * ((y1 - bmu[2 * j + 1]) * bis[2 * j + 1]);
-                }
-            }
-        }
-        __syncthreads();  // (the regions are rewritten by the other half / handed back to the K loop)
-    }
-    if (bnb) {
-        // lanes 16 apart hold the same chunk; then the eight waves through LDS (region 1 is free: the staged pixels are out)
-        float* red = (float*)(smem + kQR1);  // [8 waves][16 chunks][16]
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-#pragma unroll
-            for (int d = 16; d < 64; d <<= 1) {
-                s0[j] += __shfl_xor(s0[j], d, 64);
-                s1[j] += __shfl_xor(s1[j], d, 64);
-            }
-        }
-        if (lane < 16) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                red[(wave * 16 + lane) * 16 + j] = s0[j];
-                red[(wave * 16 + lane) * 16 + 8 + j] = s1[j];
-            }
-        }
-        __syncthreads();
-        if (tid < 256) {  // tid = chunk * 16 + jj
-            float sum = 0.f;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) sum += red[(w * 16 + (tid >> 4)) * 16 + (tid & 15)];
-            ((float*)(smem + kQBnbAcc))[tid] += sum;
-        }
-        __syncthreads();
-    }
-    if (nxt < 0) break;
-    // everything but this tile's 16 stores has landed -- i.e. the next tile's prologue, issued before them -- and is published
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (wave >= 4) __builtin_amdgcn_s_barrier();
-    }  // tiles of this workgroup
-    }
-    if (bnb && tid < 256) {
-        const int chunk = tid >> 4, jj = tid & 15;
-        a.bnb_partial[((int64_t)(xcd * (nslots / gy) + wslot / gy) * 2 + (jj >> 3)) * a.C_dst + n0 + chunk * 8 + (jj & 7)] =
-            ((const float*)(smem + kQBnbAcc))[tid];
-    }
-    if ((a.flags & RV_OUT_STATS) && lg == 0) {
-        float* prow = a.stats + ((int64_t)((xcd * (nslots / gy) + wslot / gy) * 4 + wr) * 2) * a.C_dst;
-        const float* stat_acc = stat_slot();
-        const int c0 = n0 + wc * 64 + l15;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            prow[c0 + j * 16] = stat_acc[j * 32];
-            prow[a.C_dst + c0 + j * 16] = stat_acc[j * 32 + 1];
-        }
-    }
-}
-
 }  // namespace
 
-extern int g_tapconv5_persist;
-int g_tapconv6_min_blocks = getenv("RV3D_TC6_MIN_BLOCKS") ? atoi(getenv("RV3D_TC6_MIN_BLOCKS")) : 256;  // rv_set_option("tapconv6_min_blocks")
 
 // returns false when the layer is not eligible (caller falls back to tapconv5 / tapconv4 / ...)
 static int tapconv6_grid(const TapConvArgs& a) {
     int grid = 8 * a.tiles_per_xcd * a.n_tiles;
-    if (g_tapconv5_persist > 0 && grid > g_tapconv5_persist) grid = g_tapconv5_persist >= 8 ? g_tapconv5_persist & ~7 : 8;  // one workgroup per CU
+    if (grid > rv_cu_count()) grid = rv_cu_count() & ~7;  // one workgroup per CU
     return grid;
 }
 
@@ -1012,13 +527,13 @@ bool rv_tapconv6_plan(TapConvArgs* a, int* tiles, size_t* lds, int* stats_rows, 
     a->total_tiles = a->m_tiles * a->h_tiles * a->N * a->phases;
     a->n_tiles = a->C_dst / kBN;
     a->tiles_per_xcd = rv_ceil_div(a->total_tiles, 8);
-    if ((int64_t)a->total_tiles * a->n_tiles < g_tapconv6_min_blocks) return false;  // fewer tiles than CUs: the 256-pixel tiles fill the chip better
+    if ((int64_t)a->total_tiles * a->n_tiles < ((a->sel & RV_SEL_SMALL_GRIDS6) ? 1 : rv_cu_count())) return false;  // fewer tiles than CUs: the 256-pixel tiles fill the chip better
     *tiles = a->total_tiles;
     const int grid = tapconv6_grid(*a), nslots = grid / 8;
-    a->stats_per_wg = (nslots % a->n_tiles == 0 && getenv("RV3D_T6_TILE_STATS") == nullptr) ? 1 : 0;
+    a->stats_per_wg = (nslots % a->n_tiles == 0) ? 1 : 0;
     *stats_rows = a->stats_per_wg ? (grid / a->n_tiles) * 4 : a->total_tiles * 4;
     *bnb_rows = a->stats_per_wg ? grid / a->n_tiles : a->total_tiles;
-    *lds = (size_t)(kLds > kQLds ? kLds : kQLds);
+    *lds = (size_t)kLds;
     const size_t epi = (size_t)kTR * kTC * (kBN + 8) * sizeof(bf16_t);
     if (*lds < epi) *lds = epi;
     return true;
@@ -1027,57 +542,16 @@ bool rv_tapconv6_plan(TapConvArgs* a, int* tiles, size_t* lds, int* stats_rows, 
 int rv_tapconv6_launch(const TapConvArgs& a, size_t lds, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-#define RV_T6_ATTR(E_, S_) (void)hipFuncSetAttribute((const void*)tapconv6_kernel<E_, 0, S_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        RV_T6_ATTR(0, true) RV_T6_ATTR(1, true) RV_T6_ATTR(2, true)
-        RV_T6_ATTR(0, false) RV_T6_ATTR(1, false) RV_T6_ATTR(2, false)
-#undef RV_T6_ATTR
+        (void)hipFuncSetAttribute((const void*)tapconv6_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)tapconv6_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)tapconv6_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     const int grid = tapconv6_grid(a);
-    const_cast<TapConvArgs&>(a).nt_store = getenv("RV3D_T6_NT_STORES") != nullptr;  // (A/B only: +0.6..2.4 % isolated, nothing in the bench mix)
     const int epi = (a.flags & RV_OUT_BNB) ? 1 : ((a.flags & RV_OUT_ACCUM) ? 2 : 0);
-    const bool split = getenv("RV3D_T6_SPLIT") != nullptr;  // (A/B only: the role-split form, measured slower -- see the SPLIT note)
-#ifdef RV_T6_DIAG_BUILD
-    if (const char* dv = getenv("RV3D_T6_DIAG")) {
-        const int d = atoi(dv);
-#define RV_T6_DIAG_CASE(D_)                                                                                              \
-    if (d == D_) {                                                                                                       \
-        (void)hipFuncSetAttribute((const void*)tapconv6_kernel<0, D_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        (void)hipFuncSetAttribute((const void*)tapconv6_kernel<0, D_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        if (split) hipLaunchKernelGGL((tapconv6_kernel<0, D_, true>), dim3(grid), dim3(512), lds, stream, a);             \
-        else hipLaunchKernelGGL((tapconv6_kernel<0, D_, false>), dim3(grid), dim3(512), lds, stream, a);                  \
-        RV_CHECK_LAUNCH("tapconv6_kernel diag");                                                                         \
-        return 0;                                                                                                        \
-    }
-        RV_T6_DIAG_CASE(1) RV_T6_DIAG_CASE(2) RV_T6_DIAG_CASE(3) RV_T6_DIAG_CASE(4) RV_T6_DIAG_CASE(8) RV_T6_DIAG_CASE(9) RV_T6_DIAG_CASE(10)
-        RV_T6_DIAG_CASE(11)
-#undef RV_T6_DIAG_CASE
-    }
-#endif
-    // RV3D_T6_PIPE=1: the pipelined tile boundary (tapconv6p) wherever its preconditions hold.  Opt-in: measured 2.1-2.5 ms SLOWER on
-    // the rv-av2 step (98.4 / 98.8 against 96.3 ms, one box) -- only kAhead - 1 K tiles run before the K loop's own loads queue behind
-    // the stores again, and the two-half epilogue costs two more barriers per tile (profiles/r04_tapconv6_ablation.md section 5)
-    if (a.stats_per_wg && !split && getenv("RV3D_T6_PIPE") != nullptr) {
-        static bool pattr = false;
-        if (!pattr) {
-            (void)hipFuncSetAttribute((const void*)tapconv6p_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)tapconv6p_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)tapconv6p_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            pattr = true;
-        }
-        if (epi == 1) hipLaunchKernelGGL((tapconv6p_kernel<1>), dim3(grid), dim3(512), lds, stream, a);
-        else if (epi == 2) hipLaunchKernelGGL((tapconv6p_kernel<2>), dim3(grid), dim3(512), lds, stream, a);
-        else hipLaunchKernelGGL((tapconv6p_kernel<0>), dim3(grid), dim3(512), lds, stream, a);
-        RV_CHECK_LAUNCH("tapconv6p_kernel");
-        return 0;
-    }
-#define RV_T6_LAUNCH(E_)                                                                                   \
-    if (split) hipLaunchKernelGGL((tapconv6_kernel<E_, 0, true>), dim3(grid), dim3(512), lds, stream, a);  \
-    else hipLaunchKernelGGL((tapconv6_kernel<E_, 0, false>), dim3(grid), dim3(512), lds, stream, a);
-    if (epi == 1) { RV_T6_LAUNCH(1) }
-    else if (epi == 2) { RV_T6_LAUNCH(2) }
-    else { RV_T6_LAUNCH(0) }
-#undef RV_T6_LAUNCH
+    if (epi == 1) hipLaunchKernelGGL((tapconv6_kernel<1>), dim3(grid), dim3(512), lds, stream, a);
+    else if (epi == 2) hipLaunchKernelGGL((tapconv6_kernel<2>), dim3(grid), dim3(512), lds, stream, a);
+    else hipLaunchKernelGGL((tapconv6_kernel<0>), dim3(grid), dim3(512), lds, stream, a);
     RV_CHECK_LAUNCH("tapconv6_kernel");
     return 0;
 }

@@ -222,19 +222,50 @@ struct UnpackTo {
 };
 
 // sum of the split-K slabs in slab order (bitwise reproducible); elems is a multiple of 1024 (padded channel counts)
+// 16-byte slab loads at AGENT scope (sc1): served by the memory side, never by a line of the recycled workspace that an earlier
+// reduction left in this XCD's L2.  Inline asm (the builtin loads carry no scope), so the wait for the data is part of the same
+// statement: the compiler does not track vmcnt for these.
+__device__ __forceinline__ void slab_load4(const f32x4* p0, const f32x4* p1, const f32x4* p2, const f32x4* p3, f32x4& a, f32x4& b, f32x4& c,
+                                           f32x4& d) {
+    asm volatile(
+        "global_load_dwordx4 %0, %4, off sc1\n\t"
+        "global_load_dwordx4 %1, %5, off sc1\n\t"
+        "global_load_dwordx4 %2, %6, off sc1\n\t"
+        "global_load_dwordx4 %3, %7, off sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)
+        : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+        : "memory");
+}
+__device__ __forceinline__ f32x4 slab_load1(const f32x4* p) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+    return v;
+}
+
 __device__ __forceinline__ void wgrad_reduce_body(const float* slabs, int ksplit, int64_t elems, float* out, const UnpackTo& up, int64_t first,
                                                   int64_t stride) {
     const int64_t n4 = elems >> 2;
     const f32x4* in = (const f32x4*)slabs;
     for (int64_t i = first; i < n4; i += stride) {
-        f32x4 s = in[i];
-        int k = 1;
+        // the slabs in slab order, left to right (bitwise reproducible, the order of every earlier form of this loop)
+        f32x4 s;
+        int k = 0;
+        if (ksplit >= 4) {
+            f32x4 a, b, c, d;
+            slab_load4(in + i, in + n4 + i, in + 2 * n4 + i, in + 3 * n4 + i, a, b, c, d);
+            s = ((a + b) + c) + d;
+            k = 4;
+        } else {
+            s = slab_load1(in + i);
+            k = 1;
+        }
         for (; k + 3 < ksplit; k += 4) {
-            const f32x4 a = in[(int64_t)k * n4 + i], b = in[(int64_t)(k + 1) * n4 + i], c = in[(int64_t)(k + 2) * n4 + i],
-                        d = in[(int64_t)(k + 3) * n4 + i];
+            f32x4 a, b, c, d;
+            slab_load4(in + (int64_t)k * n4 + i, in + (int64_t)(k + 1) * n4 + i, in + (int64_t)(k + 2) * n4 + i, in + (int64_t)(k + 3) * n4 + i, a, b, c, d);
             s = (((s + a) + b) + c) + d;
         }
-        for (; k < ksplit; ++k) s += in[(int64_t)k * n4 + i];
+        for (; k < ksplit; ++k) s += slab_load1(in + (int64_t)k * n4 + i);
         if (!up.on) {
             ((f32x4*)out)[i] = s;
             continue;
@@ -254,24 +285,6 @@ __device__ __forceinline__ void wgrad_reduce_body(const float* slabs, int ksplit
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, int ksplit, int64_t elems, float* out, const UnpackTo up) {
     wgrad_reduce_body(slabs, ksplit, elems, out, up, blockIdx.x * (int64_t)blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (no wave ends with stores in flight: see wgrad3_body; rv_unfold_weight_grad may follow)
-}
-
-// the reductions of up to 64 layers in one launch (rv_wgrad_reduce_batch): blockIdx.y = layer, the table travels as kernel arguments
-constexpr int kReduceBatch = 64;
-struct ReduceBatch {
-    rvWgradReduceEntry e[kReduceBatch];
-};
-__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const ReduceBatch b) {
-    const rvWgradReduceEntry& e = b.e[blockIdx.y];
-    UnpackTo up;
-    up.on = e.torch_layout;
-    up.cu = e.cu;
-    up.cv = e.cv;
-    up.cu_pad = e.cu_pad;
-    up.cv_pad = e.cv_pad;
-    up.taps = e.taps;
-    wgrad_reduce_body((const float*)e.slabs, e.ksplit, e.elems, e.out, up, blockIdx.x * (int64_t)blockDim.x + threadIdx.x,
-                      (int64_t)gridDim.x * blockDim.x);
 }
 
 
@@ -295,7 +308,7 @@ struct Wgrad2Args {
     int32_t main_blocks, left_m;               // wgrad3's balanced split (plan()): blocks >= main_blocks take the K remainder of left_m tiles each
     int32_t tiles_u, tiles_v;
     int32_t flags, v_affine;
-    int32_t xcd_remap, no_fence;
+    int32_t xcd_remap;
     int8_t g_first[kMaxTaps], g_count[kMaxTaps];  // tap group -> first tap index / number of taps (<= 3)
     int8_t dh[kMaxTaps], dw[kMaxTaps];
 };
@@ -437,7 +450,7 @@ __device__ __forceinline__ void wgrad2_body(const Wgrad2Args& a, bf16_t (*lds)[2
             }
         }
     }
-    if (a.no_fence != 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (no wave ends with slab stores in flight: see wgrad3_body)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (no wave ends with slab stores in flight: see wgrad3_body)
 }
 
 __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const Wgrad2Args a) {
@@ -703,18 +716,14 @@ __device__ __forceinline__ void wgrad3_body(const Wgrad2Args& a, uint8_t* smem, 
             }
         }
     }
-    // A wave must not END with its slab stores still in flight.  These launches run on the side stream while other queues are busy;
-    // once in ~2500 training steps the split-K reduction that follows on the SAME stream summed slab lines that still held the previous
-    // tenant of the recycled workspace (always the 64-workgroup launch of one 1x1 layer: one wrong weight gradient, nothing else --
-    // profiles/r04_ab_notes.md, "One wrong weight gradient").  Waiting for the stores' acknowledgement before the wave ends: 0 wrong
-    // steps in 75 runs of 25 steps where 5-6 were expected (an explicit agent-scope release after a barrier, `__threadfence()`: 0 in
-    // 240; it costs 0.1-0.3 ms per step and is kept as RV3D_WGRAD_NO_FENCE=3; =1: neither, for A/B).
-    if (a.no_fence == 3) {
-        __syncthreads();
-        if (threadIdx.x < 64) __threadfence();
-    } else if (a.no_fence != 1) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    // A wave does not END with its slab stores in flight, and the reduction reads the slabs with agent-scope loads (slab_load):
+    // once in ~2500 two-stream training steps of round 4 the split-K reduction that follows on the SAME stream summed slab lines that
+    // held the previous tenant of the recycled workspace -- always the 64-workgroup launch of one 1x1 layer, one wrong weight gradient,
+    // nothing else (profiles/r04_ab_notes.md, "One wrong weight gradient"; the round-5 soak: profiles/r05_race_soak.txt).  Two readings
+    // fit that symptom -- stores still in flight at the end of the kernel with another queue busy, or a line of the recycled workspace
+    // that the PREVIOUS reduction left in the reading XCD's L2 -- and both are closed: this wait, and loads that do not hit in a
+    // non-coherent L2 line.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 __device__ __forceinline__ void wgrad3_segment(const Wgrad2Args& a, uint8_t* smem, int tile, int ks, int c_begin, int c_end) {
@@ -783,7 +792,7 @@ int plan(const rvTapGeom* g, const rvTapShape* s, WgradPlan* p) {
     p->ksplit = (int)((chunks + per - 1) / per);
     p->elems = (int64_t)p->taps * cu * cv;
     // wgrad2: stride 1, whole 64-pixel chunks per image row
-    p->v2 = (g->stride_w == 1) && (s->Wu >= 64) && (getenv("RV3D_NO_WGRAD2") == nullptr);
+    p->v2 = (g->stride_w == 1) && (s->Wu >= 64);
     if (p->v2) {
         p->groups = g->kh * ((g->kw + 2) / 3);
         p->chunks = s->N * s->H * ((s->Wu + 63) / 64);
@@ -796,13 +805,10 @@ int plan(const rvTapGeom* g, const rvTapShape* s, WgradPlan* p) {
         // work; layers with more tiles than CUs take no split at all
         int64_t ks_max = p->chunks / 32;
         if (ks_max < 1) ks_max = 1;
-        int64_t ks2 = 256 / base2;
+        const int64_t cus = rv_cu_count();
+        int64_t ks2 = cus / base2;
         if (ks2 < 1) ks2 = 1;
         if (ks2 > ks_max) ks2 = ks_max;
-        if (const char* force = getenv("RV3D_WGRAD_KSPLIT")) {  // (experiments: profiles/tools/sweep_wgrad_ksplit.py)
-            const int64_t f = atoll(force);
-            if (f >= 1) ks2 = f < ks_max ? f : ks_max;
-        }
         p->chunks_per_split = (int)((p->chunks + ks2 - 1) / ks2);
         p->ksplit = (p->chunks + p->chunks_per_split - 1) / p->chunks_per_split;
         p->main_blocks = base2 * p->ksplit;
@@ -813,11 +819,11 @@ int plan(const rvTapGeom* g, const rvTapShape* s, WgradPlan* p) {
         // tiles in turn (one more slab per tile, three epilogues for that workgroup), with m R + (m - 1) overhead = L so that all 256
         // workgroups finish together.  The regular slices of all tiles still cover the same pixels at the same time (L2 sharing), and
         // so do the remainders.
-        const int64_t free_cus = 256 - (int64_t)base2 * ks2;
-        if (wgrad_dma_eligible(g, s) && getenv("RV3D_WGRAD_NO_BALANCE") == nullptr && ks2 >= 2 && p->ksplit == ks2 && free_cus >= 8 &&
-            (int64_t)base2 * ks2 * 100 < 256 * 96) {
+        const int64_t free_cus = cus - (int64_t)base2 * ks2;
+        if (wgrad_dma_eligible(g, s) && ks2 >= 2 && p->ksplit == ks2 && free_cus >= 8 &&
+            (int64_t)base2 * ks2 * 100 < cus * 96) {
             const int64_t m = (base2 + free_cus - 1) / free_cus;
-            const int64_t ovh = getenv("RV3D_WGRAD_BALANCE_OVH") ? atoll(getenv("RV3D_WGRAD_BALANCE_OVH")) : 24;  // chunks one more prologue + epilogue is worth
+            const int64_t ovh = 24;  // chunks one more prologue + epilogue is worth
             const int64_t len = (m * p->chunks + (m - 1) * ovh + m * ks2) / (m * ks2 + 1);  // (rounded up)
             const int64_t rem = p->chunks - ks2 * len;
             if (m <= 4 && rem >= 32 && len >= 32) {
@@ -842,8 +848,7 @@ extern "C" int64_t rv_tap_wgrad_workspace_bytes(const rvTapGeom* g, const rvTapS
 
 namespace {
 bool wgrad_dma_eligible(const rvTapGeom* g, const rvTapShape* s) {
-    return !(s->flags & (RV_IN_AFFINE | RV_IN_RELU)) && rv_pad32(g->cu) % 128 == 0 && rv_pad32(g->cv) % 128 == 0 &&
-           getenv("RV3D_NO_WGRAD3") == nullptr;
+    return !(s->flags & (RV_IN_AFFINE | RV_IN_RELU)) && rv_pad32(g->cu) % 128 == 0 && rv_pad32(g->cv) % 128 == 0;
 }
 }  // namespace
 
@@ -898,10 +903,9 @@ extern "C" int rv_tap_wgrad(const rvTapGeom* g, const rvTapShape* s, const void*
         b.left_m = p.left_m;
         b.tiles_u = p.tiles_u;
         b.tiles_v = p.tiles_v;
-        b.flags = s->flags & ~(RV_WGRAD_TORCH_LAYOUT | RV_WGRAD_DEFER_REDUCE);
+        b.flags = s->flags & ~(RV_WGRAD_TORCH_LAYOUT | RV_SEL_MASK);
         b.v_affine = v_affine;
         b.xcd_remap = 1;
-        b.no_fence = getenv("RV3D_WGRAD_NO_FENCE") ? atoi(getenv("RV3D_WGRAD_NO_FENCE")) : 0;  // (A/B of the release fence at the end of the weight-gradient kernels)
         int gi = 0;
         for (int ky = 0; ky < g->kh; ++ky)
             for (int kx = 0; kx < g->kw; ++kx) {
@@ -928,7 +932,6 @@ extern "C" int rv_tap_wgrad(const rvTapGeom* g, const rvTapShape* s, const void*
             hipLaunchKernelGGL(wgrad2_kernel, dim3(grid2), dim3(512), 0, st2, b);
             RV_CHECK_LAUNCH("wgrad2_kernel");
         }
-        if (s->flags & RV_WGRAD_DEFER_REDUCE) return 0;  // (the caller sums the slabs later: rv_wgrad_reduce_batch)
         const int rb2 = (int)((p.elems / 4 + 255) / 256 < 4096 ? (p.elems / 4 + 255) / 256 : 4096);
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb2), dim3(256), 0, st2, (const float*)workspace, p.ksplit, p.elems, dT_packed, up);
         RV_CHECK_LAUNCH("wgrad_reduce_kernel");
@@ -956,7 +959,7 @@ extern "C" int rv_tap_wgrad(const rvTapGeom* g, const rvTapShape* s, const void*
     a.k_per_split = p.k_per_split;
     a.tiles_u = p.tiles_u;
     a.tiles_v = p.tiles_v;
-    a.flags = s->flags & ~(RV_WGRAD_TORCH_LAYOUT | RV_WGRAD_DEFER_REDUCE);
+    a.flags = s->flags & ~(RV_WGRAD_TORCH_LAYOUT | RV_SEL_MASK);
     a.v_affine = v_affine;
     for (int ky = 0; ky < g->kh; ++ky)
         for (int kx = 0; kx < g->kw; ++kx) {
@@ -967,49 +970,8 @@ extern "C" int rv_tap_wgrad(const rvTapGeom* g, const rvTapShape* s, const void*
     const int grid = p.tiles_v * p.tiles_u * p.taps * p.ksplit;
     hipLaunchKernelGGL(wgrad_kernel, dim3(grid), dim3(256), 0, st, a);
     RV_CHECK_LAUNCH("wgrad_kernel");
-    if (s->flags & RV_WGRAD_DEFER_REDUCE) return 0;
     const int rb = (int)((p.elems / 4 + 255) / 256 < 4096 ? (p.elems / 4 + 255) / 256 : 4096);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, st, (const float*)workspace, p.ksplit, p.elems, dT_packed, up);
     RV_CHECK_LAUNCH("wgrad_reduce_kernel");
-    return 0;
-}
-
-extern "C" int rv_wgrad_reduce_entry(const rvTapGeom* g, const rvTapShape* s, const void* workspace, float* dT_packed, rvWgradReduceEntry* entry) {
-    RV_REQUIRE(g && s && workspace && dT_packed && entry, "rv_wgrad_reduce_entry: null argument");
-    WgradPlan p;
-    plan(g, s, &p);
-    memset(entry, 0, sizeof(*entry));
-    entry->slabs = workspace;
-    entry->out = dT_packed;
-    entry->elems = p.elems;
-    entry->ksplit = p.ksplit;
-    entry->torch_layout = (s->flags & RV_WGRAD_TORCH_LAYOUT) ? 1 : 0;
-    entry->cu = g->cu;
-    entry->cv = g->cv;
-    entry->cu_pad = rv_pad32(g->cu);
-    entry->cv_pad = rv_pad32(g->cv);
-    entry->taps = g->kh * g->kw;
-    return 0;
-}
-
-extern "C" int rv_wgrad_reduce_batch(const rvWgradReduceEntry* host_entries, int32_t n_entries, rvStream stream) {
-    RV_REQUIRE(host_entries && n_entries > 0, "rv_wgrad_reduce_batch: empty batch");
-    for (int first = 0; first < n_entries; first += kReduceBatch) {
-        const int n = n_entries - first < kReduceBatch ? n_entries - first : kReduceBatch;
-        ReduceBatch b;
-        memset(&b, 0, sizeof(b));
-        int64_t most = 0;
-        for (int i = 0; i < n; ++i) {
-            b.e[i] = host_entries[first + i];
-            RV_REQUIRE(b.e[i].slabs && b.e[i].out && b.e[i].ksplit > 0 && b.e[i].elems > 0, "rv_wgrad_reduce_batch: bad entry %d", first + i);
-            most = most > b.e[i].elems ? most : b.e[i].elems;
-        }
-        // blocks per layer: enough for the largest one to have one 16-byte element per thread, at most 128 (x up to 64 layers: the
-        // launch has thousands of workgroups either way; the small layers' surplus blocks exit at once)
-        int gx = (int)((most / 4 + 255) / 256);
-        gx = gx < 1 ? 1 : (gx > 128 ? 128 : gx);
-        hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, b);
-        RV_CHECK_LAUNCH("wgrad_reduce_batch_kernel");
-    }
     return 0;
 }

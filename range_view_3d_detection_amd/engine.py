@@ -122,10 +122,8 @@ PROFILE: Optional[KernelProfile] = None
 # Round 4, after the lean BatchNorm-backward kernels, the balanced wgrad3 split and GPU_MAX_HW_QUEUES=8: `free` is the fastest again
 # (93.55 / 93.77 against 95.03 / 95.02 chain, 95.59 / 95.46 small, 96.77 off on one box; 94.08 / 95.50 against 96.64 / 96.35 on
 # another; rv-waymo 53.7 against 53.9) -- the chained mode pays an event round trip per layer, and with the lean passes resident
-# beside the weight gradients (`RV3D_BNB_LEAN=0`: +1 ms in this mode) there is now something to run beside them.
+# beside the weight gradients (the octet forms: +1 ms in this mode) there is now something to run beside them.
 _OVERLAP = os.environ.get("RV3D_OVERLAP", "free")
-if os.environ.get("RV3D_NO_OVERLAP") is not None:
-    _OVERLAP = "off"
 OVERLAP_WGRAD = _OVERLAP == "free" or _OVERLAP.startswith("small") or _OVERLAP.startswith("chain")
 OVERLAP_CHAIN = _OVERLAP.startswith("chain")
 # Synchronised BatchNorm over real ranks: weight gradients are held until the next BatchNorm-backward all-reduce is under way
@@ -148,28 +146,29 @@ OVERLAP_MAX_TFLOP: Optional[float] = ((float(_OVERLAP.split(":")[1]) if ":" in _
 _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 
 
+_CU_COUNT: Dict[int, int] = {}
+
+
+def cu_count(device) -> int:
+    """Compute units of ``device`` (256 on an MI355X) -- from the device properties, not a literal."""
+    idx = torch.device(device).index or 0
+    if idx not in _CU_COUNT:
+        _CU_COUNT[idx] = int(torch.cuda.get_device_properties(idx).multi_processor_count)
+    return _CU_COUNT[idx]
+
+
 def side_stream(device) -> "torch.cuda.Stream":
     idx = torch.device(device).index or 0
     if idx not in _SIDE_STREAMS:
         # high priority (-1): a weight gradient that is ready takes the CUs before the backward-data launch behind it on the main stream --
-        # the order the dependencies give anyway (RV3D_SIDE_PRIORITY=0: 94.08 / 95.50 against 93.99 / 94.69 ms, profiles/r04_ab_notes.md)
-        prio = int(os.environ.get("RV3D_SIDE_PRIORITY", "-1"))
+        # the order the dependencies give anyway (priority 0: 94.08 / 95.50 against 93.99 / 94.69 ms, profiles/r04_ab_notes.md)
+        prio = -1
         _SIDE_STREAMS[idx] = torch.cuda.Stream(device=device, priority=prio)
     return _SIDE_STREAMS[idx]
 
 
-# RV3D_TWO_STREAM_TOWERS=1: forward pass of a head's tower pair on two streams (program.dense_head_pair_program).  OPT-IN: measured
-# 0.6 ms per rv-av2 step SLOWER (98.16 / 98.62 against 97.59 / 97.94, same box; rv-waymo +0.1): two persistent tapconv6 launches
-# take the CUs from each other, and the write-out pass beside a power-capped conv is not free (profiles/r04_ab_notes.md).
-TWO_STREAM_TOWERS = os.environ.get("RV3D_TWO_STREAM_TOWERS", "0") != "0"
-_SECOND_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
-
-
-def second_stream(device) -> "torch.cuda.Stream":
-    idx = torch.device(device).index or 0
-    if idx not in _SECOND_STREAMS:
-        _SECOND_STREAMS[idx] = torch.cuda.Stream(device=device)
-    return _SECOND_STREAMS[idx]
+# (Measured and dropped in round 4, profiles/r04_ab_notes.md: the forward pass of a head's two towers on two streams -- 0.6 ms per rv-av2
+#  step slower: two persistent tapconv6 launches take the CUs from each other.)
 
 
 def _launch(name: str, flops: float, fn, nbytes: float = 0.0) -> None:
@@ -337,8 +336,6 @@ class GradSync:
             else:
                 runs.append([o, o + n])
         live = torch.distributed.is_available() and torch.distributed.is_initialized()  # (also with ONE rank: the one-GPU test of the path)
-        if os.environ.get("RV3D_GRADSYNC_DRY") is not None:  # (timing experiments: everything but the collective itself)
-            live = False
         for lo, hi in runs:
             seg = self.flat[lo:hi]
             self.works.append((torch.distributed.all_reduce(seg, async_op=True) if live else None, seg))
@@ -503,21 +500,13 @@ Operand = Union[Act, Lazy]
 # apply a folded BatchNorm(+ReLU) on the way in.  On the layers it is eligible for it is enough faster than the
 # register-staged kernels (3x3 512 -> 512: 1330 vs 980 TFLOP/s, one box) to pay for writing the operand out once
 # (one HBM-bound pass); forward conv, and the weight gradient in backward, then both read the plain tensor.
-MATERIALIZE_FOR_DMA = os.environ.get("RV3D_NO_MATERIALIZE") is None
-# split-K sums of the weight gradients in one batched launch at the end of a program's backward (Tape.flush_wgrad_reduces) instead
-# of one reduce launch behind every weight-gradient kernel.  OPT-IN (RV3D_DEFER_WGRAD_REDUCE=1): bit-identical gradients and 76
-# launches fewer per step, but measured 1.0-1.6 ms per step SLOWER on rv-av2 (99.5 / 100.2 against 98.55 / 98.56 ms, same box):
-# the immediate reduction reads slabs that are still in the 256 MB Infinity Cache and every layer reuses one workspace block; the
-# deferred one keeps ~4 GB of slabs alive and reads them back from HBM.
-DEFER_WGRAD_REDUCE = os.environ.get("RV3D_DEFER_WGRAD_REDUCE") is not None
+MATERIALIZE_FOR_DMA = True  # (module attribute: tests and A/B tools flip it in-process; no environment switch)
+# (Measured and dropped in round 4: the split-K sums of all weight gradients in ONE batched launch at the end of a program's backward --
+#  bit-identical, 76 launches fewer, 1.0-1.6 ms per step SLOWER: the immediate reduction reads slabs that are still in the Infinity Cache.)
 # conv -> BatchNorm(+ReLU) -> conv: the second conv's backward-data launch also forms the BatchNorm-backward sums (rv_tap_data_grad_bnb)
-BNB_FUSE = os.environ.get("RV3D_NO_BNB_FUSE") is None
-# ... and where the gradient of a block output relu(bn(y) + x) has several writers, its LAST writer (the accumulating
-# backward-data launch of the next block's first conv) can form them over the complete gradient (RV_BNB_MASK).  OPT-IN since
-# round 4 (RV3D_BNB_LAST_WRITER=1): built in round 3 as time-neutral (9 reduce passes fewer, three 16-byte prefetches per
-# epilogue pass); with the round-4 kernels the same A/B reads 97.2 / 98.4 ms per step without it against 97.7-98.3 with it
-# (same box, profiles/r04_ab_notes.md) -- the masked epilogue runs at 16 % matrix-pipe occupancy.
-BNB_LAST_WRITER = os.environ.get("RV3D_BNB_LAST_WRITER") is not None
+BNB_FUSE = True
+# (Measured and dropped, rounds 3-4: the LAST writer of a block output's gradient forming those sums over the complete gradient in a
+#  masked epilogue -- three 16-byte prefetches per pass, time-neutral to slightly slower; profiles/r04_ab_notes.md.)
 
 
 def _dma_eligible(geom, n: int, h: int, wu: int, wv: int, ld_src: int, ld_dst: int, scatter: bool) -> bool:
@@ -531,10 +520,10 @@ def _dma_eligible(geom, n: int, h: int, wu: int, wv: int, ld_src: int, ld_dst: i
 # ---------------------------------------------------------------------------------------------
 _LAYERS: "weakref.WeakSet[TapLayer]" = weakref.WeakSet()
 _PACK_TABLES: Dict[tuple, Tensor] = {}
-BATCH_PACK = os.environ.get("RV3D_NO_BATCH_PACK") is None
+BATCH_PACK = True
 # Strided layers (stride-2 convs, the ConvTranspose2d up-samplers): run their strided gather and their weight gradient on the
 # stride-1 FOLDED view (fine tensor read as (N, H, W/s, s*C)) so that the LDS-DMA kernels take them.
-FOLD_STRIDED = os.environ.get("RV3D_NO_FOLD") is None
+FOLD_STRIDED = True
 
 
 def prepack_stale() -> None:
@@ -759,13 +748,8 @@ class Tape:
         self.meta_in: Dict[int, tuple] = {}      # id(Lazy) -> (dgeo, feat, partial sums, rows): MetaKernel modulation fused into the BatchNorm backward
         self.producers: Dict[int, "Op"] = {}     # id(block-output Act) -> the CombineOp that made it
         self.bn_of: Dict[int, "Op"] = {}         # id(Lazy) -> its BnOp
-        self.grad_version: Dict[int, int] = {}   # id(root Act) -> bumped whenever somebody asks for / writes its gradient buffer
-        self.acc_sums: Dict[int, tuple] = {}     # id(root Act) -> (partial, rows, gradient Act, version): BatchNorm-backward sums the last writer formed
         self.raw_grad: Dict[int, Act] = {}       # id(raw Act) -> gradient w.r.t. the raw conv output
         self._param_grads: Dict[int, Tensor] = {}  # id(param) -> fp32 gradient (read through `param_grads`)
-        # split-K reductions of weight gradients deferred to ONE batched launch (rv_wgrad_reduce_batch): (entry, workspace, gradient)
-        self.deferred_wgrad: List[tuple] = []
-        self.deferred_params: set = set()
         self.params: Dict[int, nn.Parameter] = {}
         self.used_side_stream = False
         self.chained_wgrad = None  # (RV3D_OVERLAP=chain) event behind the last big weight gradient on the side stream
@@ -780,7 +764,6 @@ class Tape:
             chain.append(root)
             root = root.parent
         key = id(root)
-        self.grad_version[key] = self.grad_version.get(key, 0) + 1
         if key not in self.grads:
             self.grads[key] = root.like(zero=bool(chain))  # partial (view) writers need a defined background
             if chain:
@@ -796,19 +779,6 @@ class Tape:
         while root.parent is not None:
             root = root.parent
         self.written.add(id(root))
-        self.grad_version[id(root)] = self.grad_version.get(id(root), 0) + 1
-
-    def touch_grad(self, g: Act) -> None:
-        """``g`` (a gradient Act handed out by ``grad_buffer``, or a view of one) has just been written outside ``grad_buffer``'s
-        own callers: invalidate what depends on its contents."""
-        root = g
-        while root.parent is not None:
-            root = root.parent
-        for key, buf in self.grads.items():
-            if buf is root:
-                self.grad_version[key] = self.grad_version.get(key, 0) + 1
-                self.acc_sums.pop(key, None)
-                return
 
     def set_grad(self, a: Act, g: Act) -> None:
         assert a.parent is None
@@ -847,7 +817,6 @@ class Tape:
             self._masked_into(dout, mask, res[0], res[1])
 
     def _masked_into(self, dout: Act, mask: Optional[Act], dst: Act, accumulate: bool) -> None:
-        self.touch_grad(dst)
         L.call("rv_ew_mask_grad", L.i64(dout.pixels), L.i32(dout.cp), dout.ptr(), L.i32(dout.ld), mask.ptr() if mask is not None else None,
                L.i32(mask.ld if mask is not None else 0), dst.ptr(), L.i32(dst.ld), L.i32(1 if accumulate else 0), L.stream_ptr())
 
@@ -864,37 +833,12 @@ class Tape:
 
     @property
     def param_grads(self) -> Dict[int, Tensor]:
-        """Parameter gradients; reading them first completes the deferred split-K reductions."""
-        self.flush_wgrad_reduces()
         return self._param_grads
 
-    def add_param_grad(self, p: nn.Parameter, g: Tensor, deferred: bool = False) -> None:
-        """``deferred``: ``g`` is the destination of a weight-gradient reduction still queued in ``deferred_wgrad``."""
+    def add_param_grad(self, p: nn.Parameter, g: Tensor) -> None:
         k = id(p)
         self.params[k] = p
-        if k in self._param_grads:
-            if deferred or k in self.deferred_params:  # (a parameter used by two layers: the sum needs both values now)
-                self.flush_wgrad_reduces()
-            self._param_grads[k] = self._param_grads[k] + g
-        else:
-            self._param_grads[k] = g
-            if deferred:
-                self.deferred_params.add(k)
-
-    def flush_wgrad_reduces(self) -> None:
-        """Sum the split-K slabs of every weight gradient queued since the last flush: one launch per 64 layers
-        (78 latency-bound reduce launches per training step of the rv-av2 model otherwise)."""
-        if not self.deferred_wgrad:
-            return
-        if self.used_side_stream:  # slabs written on the side stream
-            torch.cuda.current_stream().wait_stream(side_stream(self.device))
-        n = len(self.deferred_wgrad)
-        table = (L.WgradReduceEntry * n)(*[e for e, _, _ in self.deferred_wgrad])
-        L.call("rv_wgrad_reduce_batch", table, L.i32(n), L.stream_ptr())
-        for _, ws, _ in self.deferred_wgrad:
-            ws.record_stream(torch.cuda.current_stream())  # (allocated under the side stream's context in some cases)
-        self.deferred_wgrad = []
-        self.deferred_params = set()
+        self._param_grads[k] = self._param_grads[k] + g if k in self._param_grads else g  # (a parameter used by two layers: the sum)
 
     def backward(self) -> None:
         from . import engine_bwd
@@ -918,7 +862,6 @@ class Tape:
         engine_bwd._release_held_wgrads(self)
         if self.used_side_stream:  # parameter gradients (and the buffers the side stream read) are final after this
             torch.cuda.current_stream().wait_stream(side_stream(self.device))
-        self.flush_wgrad_reduces()
 
 
 class Op:
@@ -1099,7 +1042,7 @@ def _padded(p: Tensor, cp: int, fill: float = 0.0) -> Tensor:
     return out
 
 
-SMALLK_FORWARD = os.environ.get("RV3D_NO_SMALLK_FWD") is None
+SMALLK_FORWARD = True
 
 
 class SmallKOp(Op):
@@ -1172,7 +1115,7 @@ def _smallk_eligible(layer: TapLayer, x: Operand, relu: bool, need_input_grad: b
             and g.kw == 1 and g.stride_w == 1 and layer.c_in <= 8 and layer.in_perm is None and layer.bias is None)
 
 
-EVAL_FOLD = os.environ.get("RV3D_NO_EVAL_FOLD") is None
+EVAL_FOLD = True
 
 
 def conv_bn(t: Tape, layer: TapLayer, x: Operand, bn: nn.BatchNorm2d, relu: bool = True,
@@ -1190,7 +1133,7 @@ def conv_bn(t: Tape, layer: TapLayer, x: Operand, bn: nn.BatchNorm2d, relu: bool
     return BnOp(t, conv, bn, relu).lazy
 
 
-EVAL_RES_FUSE = os.environ.get("RV3D_NO_EVAL_RES_FUSE") is None
+EVAL_RES_FUSE = True
 
 
 def conv_bn_residual(t: Tape, layer: TapLayer, x: Operand, bn: nn.BatchNorm2d, res: Operand, relu_conv: bool, relu_out: bool,
@@ -1225,7 +1168,7 @@ def conv_bn_many(t: Tape, specs: Sequence[Tuple[TapLayer, Operand, nn.BatchNorm2
     return [BnOp(t, conv, bn, relu, reduced=r).lazy for conv, (_, _, bn, relu, _), r in zip(convs, specs, reduced)]
 
 
-POS_FUSE = os.environ.get("RV3D_NO_POS_FUSE") is None
+POS_FUSE = True
 
 
 def pos_pair_eligible(l0: TapLayer, l1: TapLayer, x: Operand) -> bool:
@@ -1257,7 +1200,7 @@ def pos_pair(t: Tape, l0: TapLayer, bn0: nn.BatchNorm2d, l1: TapLayer, bn1: nn.B
     return BnOp(t, conv, bn1, True).lazy
 
 
-POS_MOD_FUSE = os.environ.get("RV3D_NO_POS_MOD_FUSE") is None
+POS_MOD_FUSE = True
 
 
 def _eval_scale_shift(bn: nn.BatchNorm2d, cp: int, dev) -> Tuple[Tensor, Tensor]:

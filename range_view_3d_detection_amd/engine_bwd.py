@@ -108,22 +108,6 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
             wp = layer.packed(bwd)
         call = lambda: L.call("rv_tap_" + bwd, ctypes.byref(bg), ctypes.byref(bshape), dout.ptr(), None, None, L.ptr(wp), None,
                               dst.ptr(), None, L.stream_ptr())
-        acc_sums = None
-        lw = _last_writer_target(op, t) if (E.BNB_FUSE and E.BNB_LAST_WRITER and bg is g and accumulate and not isinstance(op.x, Lazy)) else None
-        if lw is not None:
-            # op.x = relu(bn(y) + x'), its gradient already holds the other consumers' shares and this launch adds the last one:
-            # the sums of that BatchNorm's backward over the COMPLETE gradient leave with it (mask = op.x itself)
-            rows = L.load().rv_tap_bnb_rows(ctypes.byref(g), ctypes.byref(shape), L.i32(1 if bwd == "scatter" else 0))
-            if rows > 0:
-                st = lw.bn
-                partial = torch.empty((rows + L.STATS_SCRATCH_ROWS, 2, dst.cp), dtype=torch.float32, device=t.device)
-                epi = L.BnbEpilogue(lw.raw.ptr().value, lw.raw.ld, L.BNB_MASK, L.ptr(st.scale).value, L.ptr(st.shift).value,
-                                    L.ptr(st.mean).value, L.ptr(st.invstd).value, L.ptr(partial).value, op.x.ptr().value, op.x.ld)
-                call = lambda: L.call("rv_tap_data_grad_bnb", ctypes.byref(g), ctypes.byref(shape), L.i32(1 if bwd == "scatter" else 0), dout.ptr(),
-                                      L.ptr(wp), dst.ptr(), ctypes.byref(epi), L.stream_ptr())
-                acc_sums = (partial, rows, dst)
-                global LAST_WRITER_LAUNCHES
-                LAST_WRITER_LAUNCHES += 1
         if E.BNB_FUSE and bg is g and isinstance(op.x, Lazy) and not accumulate and op.x.bn.mean is not None:
             # first (often only) consumer of relu(bn(y)): this launch can form that BatchNorm's backward sums on the way out
             rows = L.load().rv_tap_bnb_rows(ctypes.byref(g), ctypes.byref(shape), L.i32(1 if bwd == "scatter" else 0))
@@ -141,7 +125,7 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
             # released BEFORE this launch, queues behind it and takes the CUs as they fall idle in that last round
             info = (ctypes.c_int32 * 4)()
             if (L.load().rv_tap_launch_info(ctypes.byref(bg), ctypes.byref(bshape), 1 if bwd == "scatter" else 0, info) == 0 and info[0] == 6):
-                wg_tiles, cus = info[2] * info[3], 256
+                wg_tiles, cus = info[2] * info[3], E.cu_count(t.device)
                 if wg_tiles / (cus * ((wg_tiles + cus - 1) // cus)) < E.EARLY_WGRAD_FILL:
                     early_ready = torch.cuda.Event()
                     early_ready.record()
@@ -153,8 +137,6 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
             call()
         if not isinstance(op.x, Lazy):
             t.mark_written(op.x)
-            if acc_sums is not None:  # valid as long as nobody else touches this gradient buffer (checked by version in combine_backward)
-                t.acc_sums[id(op.x)] = acc_sums + (t.grad_version[id(op.x)],)
     # ---- weight gradient ---------------------------------------------------------------------------
     if fwd == "gather":
         u, v, v_affine = dout, src, 1
@@ -179,21 +161,12 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
             wname = ("wgrad_kernel", "wgrad_kernel", "wgrad2_kernel", "wgrad3_kernel")[winfo[0]] + "(+reduce)"
         if os.environ.get("RV3D_PROFILE_SHAPES"):
             wname += f" k{g.kh}x{g.kw}s{g.stride_w} {g.cu}<->{g.cv} {wshape.N}x{wshape.H}x{wshape.Wu}"
-        # the split-K reduction writes the torch layout dT[cu][cv][kh][kw] itself (RV_WGRAD_TORCH_LAYOUT): no unpack pass.
-        # Its launch is deferred to one batched launch at the end of the program's backward (Tape.flush_wgrad_reduces) unless
-        # something reads the sum right away (the folded form's unfold pass, a permuted parameter layout).
-        defer = E.DEFER_WGRAD_REDUCE and wg is g and layer.in_perm is None
-        wsh_run = L.TapShape(wsh.N, wsh.H, wsh.Wu, wsh.Wv, wsh.ld_src, wsh.ld_dst, wsh.flags | (L.WGRAD_DEFER_REDUCE if defer else 0))
+        # the split-K reduction (one small launch behind the kernel) writes the torch layout dT[cu][cv][kh][kw] itself
+        # (RV_WGRAD_TORCH_LAYOUT): no unpack pass
         E._launch(wname, E.tap_flops(g, wshape),
-                  lambda: L.call("rv_tap_wgrad", ctypes.byref(wg), ctypes.byref(wsh_run), u.ptr(), L.i32(u.ld), v.ptr(), L.i32(ld_v),
+                  lambda: L.call("rv_tap_wgrad", ctypes.byref(wg), ctypes.byref(wsh), u.ptr(), L.i32(u.ld), v.ptr(), L.i32(ld_v),
                                  L.ptr(sc), L.ptr(sh), L.i32(v_affine), L.ptr(grad), L.ptr(ws), L.stream_ptr()),
                   E.tap_bytes(g, wshape, wgrad=True))
-        if defer:
-            entry = L.WgradReduceEntry()
-            L.call("rv_wgrad_reduce_entry", ctypes.byref(wg), ctypes.byref(wsh), L.ptr(ws), L.ptr(grad), ctypes.byref(entry))
-            t.deferred_wgrad.append((entry, ws, grad))
-            t.add_param_grad(layer.weight, grad, deferred=True)
-            return
         if wg is not g:
             folded, grad = grad, torch.empty((g.cu, g.cv, g.kh, g.kw), dtype=torch.float32, device=t.device)
             L.call("rv_unfold_weight_grad", ctypes.byref(g), L.ptr(folded), L.ptr(grad), L.i32(0), L.stream_ptr())
@@ -249,27 +222,7 @@ def _wait_chained_wgrad(t: Tape) -> None:
         t.chained_wgrad = None
 
 
-LAST_WRITER_LAUNCHES = 0  # backward-data launches that formed a block output's BatchNorm-backward sums (tests)
-
-
-def _last_writer_target(op: "E.ConvOp", t: Tape) -> Optional[Lazy]:
-    """The Lazy ``bn(y)`` behind ``op.x = relu(bn(y) + x')`` when ``op.x`` is a whole block output of exactly that form (what
-    ``combine_backward`` hands to ONE BatchNorm with ``op.x`` as the mask), else None."""
-    x = op.x
-    prod = t.producers.get(id(x))
-    if prod is None or x.parent is not None or not isinstance(prod, E.CombineOp) or not prod.relu_out or not t.training:
-        return None
-    lazies = [v for v in (prod.a, prod.b) if isinstance(v, Lazy)]
-    plains = [v for v in (prod.a, prod.b) if v is not None and not isinstance(v, Lazy)]
-    if len(lazies) != 1 or len(plains) != 1 or lazies[0].relu or lazies[0].bn.mean is None:
-        return None
-    lz = lazies[0]
-    if lz.raw.cp != x.cp or lz.raw.pixels != x.pixels:
-        return None
-    return lz
-
-
-POS_BWD_FUSE = os.environ.get("RV3D_NO_POS_BWD_FUSE") is None
+POS_BWD_FUSE = True  # (module attribute: tests and A/B tools flip it in-process; no environment switch)
 
 
 def _pos_pair_backward(op: "E.ConvOp", t: Tape, dy2: Act) -> None:
@@ -345,7 +298,7 @@ def _smallk_grads(t: Tape, pixels: int, cp: int, dout: Act, mask: Optional[Act],
     return dgamma, dbeta, dw
 
 
-SMALLK_FUSION = os.environ.get("RV3D_NO_SMALLK") is None
+SMALLK_FUSION = True
 
 
 def bn_backward(op: "E.BnOp", t: Tape) -> None:
@@ -422,7 +375,6 @@ def bn_backward_finish(recs, t: Tape) -> None:
             rg, racc = res
             L.call("rv_bn_bwd_apply", *common, L.ptr(coef), L.i32(flags | (L.BNB_RES_ACCUM if racc else 0)), dy.ptr(), L.i32(dy.ld),
                    rg.ptr(), L.i32(rg.ld), L.stream_ptr())
-            t.touch_grad(rg)  # (a write into another tensor's gradient buffer: sums formed over it earlier are stale)
         else:
             L.call("rv_bn_bwd_apply", *common, L.ptr(coef), L.i32(flags), dy.ptr(), L.i32(dy.ld), None, L.i32(0), L.stream_ptr())
         t.raw_grad[id(raw)] = dy
@@ -470,10 +422,6 @@ def _bn_backward_meta(op: "E.BnOp", t: Tape, meta) -> None:
 
 
 def combine_backward(op: "E.CombineOp", t: Tape) -> None:
-    # sums the last writer of this output's gradient formed in its epilogue: good if nobody has touched the buffer since
-    acc = t.acc_sums.pop(id(op.out), None)
-    if acc is not None and acc[3] != t.grad_version.get(id(op.out)):
-        acc = None
     gout, have = t.grad_buffer(op.out)
     if not have:
         return
@@ -528,10 +476,7 @@ def combine_backward(op: "E.CombineOp", t: Tape) -> None:
             g, have_x = t.grad_buffer(plains[0])
             res = (g, have_x)
             t.mark_written(plains[0])
-        first = id(x) not in t.lazy_in
         t.add_lazy_grad(x, gout, mask, res)
-        if acc is not None and fuse_res and first and acc[2] is gout and mask is not None:
-            t.lazy_sums[id(x)] = (acc[0], acc[1], gout, True)  # (masked sums: bn_backward_begin skips its reduce pass)
     if fuse_res:
         return
     for x in plains:
@@ -542,8 +487,8 @@ def combine_backward(op: "E.CombineOp", t: Tape) -> None:
         t.mark_written(x)
 
 
-BNB_PAIR = os.environ.get("RV3D_NO_BNB_PAIR") is None
-META_BWD_FUSE = os.environ.get("RV3D_NO_META_FUSE") is None
+BNB_PAIR = True
+META_BWD_FUSE = True
 
 
 def modulate_backward(op: "E.MetaModulateOp", t: Tape) -> None:

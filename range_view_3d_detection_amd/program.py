@@ -216,28 +216,6 @@ def dense_head_pair_program(t: Tape, cls_head: nn.Module, reg_head: nn.Module, x
         return dense_head_program(t, cls_head, x), dense_head_program(t, reg_head, x)
     ha: Operand = x
     hb: Operand = x
-    if (E.TWO_STREAM_TOWERS and t.training and x.data.is_cuda
-            and not any(E.bn_sync_world(b[1], True) > 1 for b in ca[:-1] + cb[:-1])):
-        # Training, local BatchNorm statistics: the two towers are independent chains conv -> statistics -> write-out of
-        # relu(bn(y)) -> conv ..., MFMA-bound and HBM-bound launches alternating.  The regression tower runs on a second stream: the
-        # convs of the two towers take turns on the CUs, and one tower's finalize + write-out pass (<= 64 VGPRs: it fits beside a
-        # resident tapconv6 workgroup) streams while the other tower's conv computes.  The tape records the ops in program order as
-        # before; backward runs on the main stream (its weight gradients on the side stream), after the join below.
-        second = E.second_stream(t.device)
-        start = torch.cuda.Event()
-        start.record()
-        second.wait_event(start)  # x and everything before it
-        for ba, bb in zip(ca[:-1], cb[:-1]):
-            ha = E.conv_bn(t, E.tap_layer(ba[0]), ha, ba[1], relu=True)
-            with torch.cuda.stream(second):
-                hb = E.conv_bn(t, E.tap_layer(bb[0]), hb, bb[1], relu=True)
-        out_a = E.ConvOp(t, E.tap_layer(ca[-1][0]), ha, stats=False, out_f32=True)
-        with torch.cuda.stream(second):
-            out_b = E.ConvOp(t, E.tap_layer(cb[-1][0]), hb, stats=False, out_f32=True)
-            done = torch.cuda.Event()
-            done.record()
-        torch.cuda.current_stream().wait_event(done)
-        return out_a, out_b
     for ba, bb in zip(ca[:-1], cb[:-1]):
         ha, hb = E.conv_bn_many(t, [(E.tap_layer(ba[0]), ha, ba[1], True, True), (E.tap_layer(bb[0]), hb, bb[1], True, True)])
     return (E.ConvOp(t, E.tap_layer(ca[-1][0]), ha, stats=False, out_f32=True),
@@ -267,7 +245,7 @@ def operand_for(training: bool) -> str:
     return "f16" if fp16_autocast else "bf16"
 
 
-_MATERIALIZE_GRADS = os.environ.get("RV3D_MATERIALIZE_GRADS") is not None  # (A/B switch: autograd's default zero-filled gradients)
+_MATERIALIZE_GRADS = False  # (True: autograd's default zero-filled gradients; A/B in-process)
 
 
 class _ProgramFn(torch.autograd.Function):

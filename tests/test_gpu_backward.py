@@ -527,7 +527,8 @@ def test_strided_layers_on_the_folded_view(kind, cin, cout, kernel, stride, pad,
         E.FOLD_STRIDED = fold
         m.__dict__.pop("_rv_layer", None)  # a fresh TapLayer: the folded geometry is cached on it
         m.zero_grad(set_to_none=True)
-        old = L.load().rv_set_option(b"tapconv4_min_blocks", ctypes.c_int32(1))
+        sel = L.select(L.SEL_SMALL_GRIDS)
+        sel.__enter__()
         try:
             E.PROFILE = E.KernelProfile()
 
@@ -544,7 +545,7 @@ def test_strided_layers_on_the_folded_view(kind, cin, cout, kernel, stride, pad,
         finally:
             E.PROFILE = None
             E.FOLD_STRIDED = True
-            L.load().rv_set_option(b"tapconv4_min_blocks", ctypes.c_int32(old))
+            sel.__exit__(None, None, None)
 
     y_f, dx_f, dw_f, ran_f = run(True)
     y_u, dx_u, dw_u, ran_u = run(False)
@@ -555,53 +556,6 @@ def test_strided_layers_on_the_folded_view(kind, cin, cout, kernel, stride, pad,
         assert rel_err(got_dx, bf16r(x.grad)) < 8e-3
         assert rel_err(got_dw, w.grad) < 2e-5
     assert rel_err(dw_f, dw_u) < 2e-5 and rel_err(y_f, y_u) < 8e-3 and rel_err(dx_f, dx_u) < 8e-3
-
-
-@pytest.mark.parametrize("C,W", [(128, 256), (256, 256)])
-def test_last_writer_forms_the_block_output_batchnorm_sums(C, W):
-    """A ResidualBlock of four BasicBlocks (the first with a projection, three identity blocks): the gradient of a block output has two writers (the next block's residual
-    and its first conv); the accumulating backward-data launch of that conv -- the last writer -- forms the BatchNorm-backward
-    sums of the block's second BatchNorm over the complete gradient (RV_BNB_MASK, tapconv5 EPI 3) instead of a separate
-    bn_bwd_reduce pass.  Against the same run with the switch off; the launches are counted."""
-    from range_view_3d_detection_amd import _lib as L
-    from range_view_3d_detection_amd import engine as E
-    from range_view_3d_detection_amd import engine_bwd
-    from range_view_3d_detection_amd.nn.blocks import ResidualBlock
-
-    old = L.load().rv_set_option(b"tapconv4_min_blocks", ctypes.c_int32(1))
-    try:
-        gen = torch.Generator().manual_seed(C + 5)
-        m = ResidualBlock(C, C, 4).to(DEV).train()
-        x = torch.randn(2, C, 16, W, generator=gen).to(DEV)
-        probe = torch.randn(2, C, 16, W, generator=gen).to(DEV)
-
-        default = E.BNB_LAST_WRITER  # (opt-in since round 4)
-
-        def run(on: bool):
-            E.BNB_LAST_WRITER = on
-            n0 = engine_bwd.LAST_WRITER_LAUNCHES
-            try:
-                m.zero_grad(set_to_none=True)
-                xi = x.clone().requires_grad_(True)
-                (m(xi).float() * probe).sum().backward()
-                return ({k: p.grad.detach().float().cpu() for k, p in m.named_parameters()}, xi.grad.detach().float().cpu(),
-                        engine_bwd.LAST_WRITER_LAUNCHES - n0)
-            finally:
-                E.BNB_LAST_WRITER = default
-
-        ga, dxa, na = run(True)
-        gb, dxb, nb = run(False)
-        assert na == 2 and nb == 0, (na, nb)  # identity blocks 1 and 2: their outputs feed the next block's conv + residual
-        # blocks.2's second BatchNorm: everything upstream of it is identical in both runs, and (dbeta, dgamma) ARE the sums --
-        # the same bf16 gradient values added in a different order
-        for k in ("blocks.2.net.4.weight", "blocks.2.net.4.bias"):
-            assert rel_err(ga[k], gb[k]) < 2e-5, (k, rel_err(ga[k], gb[k]))
-        # downstream of it the last-place differences of the coefficients flip bf16 roundings of dy: bf16-level agreement
-        assert rel_err(dxa, dxb) < 2e-2 and _cos(dxa, dxb) > 0.9999, (rel_err(dxa, dxb), _cos(dxa, dxb))
-        for k in ga:
-            assert rel_err(ga[k], gb[k]) < 2e-2 and _cos(ga[k], gb[k]) > 0.9999, (k, rel_err(ga[k], gb[k]), _cos(ga[k], gb[k]))
-    finally:
-        L.load().rv_set_option(b"tapconv4_min_blocks", ctypes.c_int32(old))
 
 
 @pytest.mark.parametrize("C,W", [(128, 256), (256, 128)])
@@ -663,40 +617,3 @@ def test_a_training_step_frees_its_activations_without_the_cycle_collector():
     finally:
         gc.enable()
     assert grown < (1 << 20), f"{grown / 2**20:.1f} MiB still allocated after three steps with the cycle collector off"
-
-
-def test_deferred_weight_gradient_reductions_equal_the_immediate_ones(golden, monkeypatch):
-    """The split-K sums of a program's weight gradients leave in ONE batched launch at the end of its backward
-    (``Tape.flush_wgrad_reduces`` / ``rv_wgrad_reduce_batch``) instead of one reduce launch behind every weight-gradient kernel:
-    same slab order per element, so every parameter gradient of the tiny detector is bit-identical to the immediate form, and
-    the number of reduce launches drops to one per program."""
-    from range_view_3d_detection_amd import _lib as L
-    from range_view_3d_detection_amd import engine as E
-    from test_gpu_model import load_tiny
-
-    g = golden("tiny_model")
-
-    def run(defer):
-        monkeypatch.setattr(E, "DEFER_WGRAD_REDUCE", defer)
-        calls = []
-        real = L.call
-        monkeypatch.setattr(L, "call", lambda name, *a: (calls.append(name), real(name, *a))[1])
-        torch.manual_seed(0)
-        backbone, head = load_tiny(g)
-        backbone.train()
-        head.train()
-        d = {"features": g["features"].to(DEV), "cart": g["cart"].to(DEV), "mask": g["mask"].to(DEV)}
-        out, _ = head(backbone(d), d, return_loss=False)
-        (out[1][0]["logits"].float().square().mean() + out[1][0]["regressands"].float().abs().mean()).backward()
-        torch.cuda.synchronize()
-        monkeypatch.setattr(L, "call", real)
-        grads = {n: p.grad.clone() for n, p in list(backbone.named_parameters()) + list(head.named_parameters()) if p.grad is not None}
-        return calls, grads
-
-    calls_d, grads_d = run(True)
-    calls_i, grads_i = run(False)
-    assert calls_d.count("rv_wgrad_reduce_batch") >= 1 and calls_i.count("rv_wgrad_reduce_batch") == 0
-    assert calls_d.count("rv_wgrad_reduce_batch") <= 3  # one per program (backbone + stem, the towers)
-    assert grads_d.keys() == grads_i.keys() and len(grads_d) > 20
-    for k in grads_d:
-        assert torch.equal(grads_d[k], grads_i[k]), k

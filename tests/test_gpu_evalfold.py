@@ -28,12 +28,8 @@ def _small_grids_allowed(request):
     generation (256 x 256 / 256 x 128 tiles) and once on the sixth (512 x 128 tiles, where H >= 16), on both operand builds."""
     from range_view_3d_detection_amd import _lib as L
 
-    olds = {tag: (L.load(tag).rv_set_option(b"tapconv4_min_blocks", ctypes.c_int32(1)),
-                  L.load(tag).rv_set_option(b"tapconv6_min_blocks", ctypes.c_int32(1 if request.param == 6 else 1 << 30))) for tag in ("bf16", "f16")}
-    yield
-    for tag, (o4, o6) in olds.items():
-        L.load(tag).rv_set_option(b"tapconv4_min_blocks", ctypes.c_int32(o4))
-        L.load(tag).rv_set_option(b"tapconv6_min_blocks", ctypes.c_int32(o6))
+    with L.select(L.SEL_SMALL_GRIDS | (L.SEL_SMALL_GRIDS6 if request.param == 6 else L.SEL_NO_GEN6)):
+        yield
 
 
 def _exact_bn(c, g):

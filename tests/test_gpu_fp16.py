@@ -35,10 +35,8 @@ pytestmark = pytest.mark.gpu
 def _small_grids_allowed():
     from range_view_3d_detection_amd import _lib as L
 
-    olds = {tag: L.load(tag).rv_set_option(b"tapconv4_min_blocks", ctypes.c_int32(1)) for tag in ("bf16", "f16")}
-    yield
-    for tag, old in olds.items():
-        L.load(tag).rv_set_option(b"tapconv4_min_blocks", ctypes.c_int32(old))
+    with L.select(L.SEL_SMALL_GRIDS):
+        yield
 
 
 def _run_f16(module, x, expect_kernel, stats=False, out_f32=False):
@@ -120,15 +118,12 @@ def test_full_size_eval_forward_fp16_vs_oracle_and_decode():
     from oracle import model as om
     from range_view_3d_detection_amd import engine as E
     from range_view_3d_detection_amd.nn.decoders.range_decoder import RangeDecoder
-    from test_gpu_realwidth import _prepare
+    from test_gpu_realwidth import full_size_eval_case
 
-    backbone, head, sd, batch = _prepare("rv-av2", 5, 26, 2048, 0.5)
-    head.classification_head["1"]["0"].blocks[-1][0].bias.data.fill_(-1.5)  # some scores above min_confidence
-    sd["head.classification_head.1.0.blocks.4.0.bias"] = head.classification_head["1"]["0"].blocks[-1][0].bias.data.clone()
-    torch.set_num_threads(min(32, torch.get_num_threads()))
+    case = full_size_eval_case()  # (the model, the sweep and the fp32 oracle's outputs: shared with test_gpu_realwidth.py)
+    backbone, head, sd, batch, lg32, rg32 = (case[k] for k in ("backbone", "head", "sd", "batch", "lg32", "rg32"))
     with torch.no_grad():
         _, lg16, rg16 = om.detector_forward(batch["features"], batch["cart"], sd, nm=om.Numerics.fp16(train=False))
-        _, lg32, rg32 = om.detector_forward(batch["features"], batch["cart"], sd, nm=om.Numerics(train=False))
     backbone, head = backbone.to(DEV).eval(), head.to(DEV).eval()
     data = {k: (v.to(DEV) if k != "annotations" else v) for k, v in batch.items()}
     E.PROFILE = E.KernelProfile()

@@ -4,7 +4,9 @@ CPU bf16 emulation as the yardstick, exactly the checks tests/test_gpu_realwidth
 the library's own kernel selection at W = 2048 / 2656: every 3x3 layer on tapconv6, 32 tile columns per row, split-K rounds
 of the weight gradient over the whole image, the ragged last column chunk of 2656 = 41 x 64 + 32.
 
-Slow: two oracle passes (fp32, bf16 storage points) of a whole sweep each, ~60-80 s per pass for rv-av2 on 16 host cores.
+ONE oracle pass per case (fp32 forward + backward of a whole sweep, ~60-80 s for rv-av2 on 16 host cores); the yardstick of the CPU
+bf16 emulation -- a second pass of the same cost in rounds 3-4 -- is RECORDED below (tests/tools/emulation_yardstick.py: the oracle
+itself, run once on the build container; the test checks that its own fp32 loss is the recorded one before using the record).
 """
 
 from __future__ import annotations
@@ -17,11 +19,23 @@ from test_gpu_forward import DEV
 pytestmark = pytest.mark.gpu
 
 
+# tests/tools/emulation_yardstick.py, round 5 (8 threads): what bf16 storage costs the CPU emulation against the fp32 oracle
+EMULATION = {
+    "rv-av2": {"emu~fp32": 0.006288202879581999, "reg emu~fp32": 0.015126619868291266, "cos_logits": 0.9999983404239434,
+               "cos_reg": 0.9999498423650869, "loss32": 0.9327999668632744, "loss16": 0.9330835061844573,
+               "grad_cos_median": 0.9961977800284536, "grad_cos_q05": 0.9896392061437118, "grad_cos_min": 0.9516727428085812},
+    "rv-waymo": {"emu~fp32": 0.004899260393146024, "reg emu~fp32": 0.01794988154751432, "cos_logits": 0.9999993211445424,
+                 "cos_reg": 0.999920294573489, "loss32": 0.7749601747592445, "loss16": 0.774672120470353,
+                 "grad_cos_median": 0.9966902366019017, "grad_cos_q05": 0.9841837880888346, "grad_cos_min": 0.9597309407237882},
+    "first-step": {"loss32": 0.8670136843224887, "loss16": 0.8670791479993034},
+}
+
+
 @pytest.mark.parametrize("widths,n_feat,n_cls,W", [("rv-av2", 5, 26, 2048), ("rv-waymo", 6, 3, 2656)])
 def test_full_size_train_step_vs_oracle(widths, n_feat, n_cls, W):
     from test_gpu_realwidth import _train_step_vs_oracle
 
-    _train_step_vs_oracle(widths, n_feat, n_cls, W, 3.0, small_grids=False)
+    _train_step_vs_oracle(widths, n_feat, n_cls, W, 3.0, small_grids=False, emulation=EMULATION[widths])
 
 
 def test_bench_first_step_loss_matches_the_oracle():
@@ -39,11 +53,11 @@ def test_bench_first_step_loss_matches_the_oracle():
     batch = bench.synthetic_batch(1, 64, 2048, seed=1234, device="cpu")
     torch.set_num_threads(min(32, torch.get_num_threads()))
     tg = otgt.compute_targets(batch["cart"], batch["annotations"], bench.AV2_CLASSES)
-    losses = {}
     with torch.no_grad():
-        for name, nm in (("fp32", om.Numerics(train=True)), ("bf16", om.Numerics.bf16(train=True))):
-            _, logits, reg = om.detector_forward(batch["features"], batch["cart"], sd, nm=nm)
-            losses[name] = float(otgt.detection_loss(logits, reg, batch["cart"], batch["mask"], tg, bench.AV2_CLASSES)["loss"])
-    print(f"loss_first_step: HIP {got:.6f}  oracle fp32 {losses['fp32']:.6f}  oracle bf16 emulation {losses['bf16']:.6f}")
-    assert abs(got - losses["fp32"]) / abs(losses["fp32"]) < 1e-2, (got, losses)
-    assert abs(got - losses["fp32"]) <= 2.0 * abs(losses["bf16"] - losses["fp32"]) + 2e-3 * abs(losses["fp32"]), (got, losses)
+        _, logits, reg = om.detector_forward(batch["features"], batch["cart"], sd, nm=om.Numerics(train=True))
+        fp32 = float(otgt.detection_loss(logits, reg, batch["cart"], batch["mask"], tg, bench.AV2_CLASSES)["loss"])
+    rec = EMULATION["first-step"]  # (the bf16 emulation's loss of the same quantity: recorded, not recomputed)
+    assert abs(fp32 - rec["loss32"]) < 1e-4 * abs(fp32), (fp32, rec)
+    print(f"loss_first_step: HIP {got:.6f}  oracle fp32 {fp32:.6f}  oracle bf16 emulation (recorded) {rec['loss16']:.6f}")
+    assert abs(got - fp32) / abs(fp32) < 1e-2, (got, fp32)
+    assert abs(got - fp32) <= 2.0 * abs(rec["loss16"] - fp32) + 2e-3 * abs(fp32), (got, fp32, rec)

@@ -25,7 +25,7 @@ import torch
 import torch.nn.functional as F
 
 from test_gpu_forward import DEV, rel_err
-from test_gpu_realwidth import _Option, _prepare
+from test_gpu_realwidth import _small_grids, _prepare
 
 pytestmark = pytest.mark.gpu
 
@@ -76,7 +76,7 @@ def test_every_layer_teacher_forced(widths, n_feat, n_cls, W):
         if err > worst[kind][0]:
             worst[kind] = (err, name)
 
-    with _Option("tapconv4_min_blocks", 1):
+    with _small_grids():
         E.PROFILE = E.KernelProfile()
         try:
             for rec in trace:

@@ -24,9 +24,8 @@ def _generation4_only():
     """Multi-tap layers with 256-channel tiles go to tapconv5 by default; these tests pin generation 4."""
     from range_view_3d_detection_amd import _lib as L
 
-    old = L.load().rv_set_option(b"tapconv5_enable", ctypes.c_int32(0))
-    yield
-    L.load().rv_set_option(b"tapconv5_enable", ctypes.c_int32(old))
+    with L.select(L.SEL_NO_GEN5):
+        yield
 
 
 def _ints(shape, g, lo=-3, hi=4):

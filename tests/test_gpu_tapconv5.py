@@ -26,11 +26,8 @@ def _small_grids_allowed():
     """The library keeps grids below one round of CUs on the register-staged kernels (speed heuristic); lift that here."""
     from range_view_3d_detection_amd import _lib as L
 
-    old = L.load().rv_set_option(b"tapconv4_min_blocks", ctypes.c_int32(1))
-    old6 = L.load().rv_set_option(b"tapconv6_enable", ctypes.c_int32(0))  # (these tests pin generation 5)
-    yield
-    L.load().rv_set_option(b"tapconv4_min_blocks", ctypes.c_int32(old))
-    L.load().rv_set_option(b"tapconv6_enable", ctypes.c_int32(old6))
+    with L.select(L.SEL_SMALL_GRIDS | L.SEL_NO_GEN6):  # (these tests pin generation 5)
+        yield
 
 
 def _run(module, x, stats=False):

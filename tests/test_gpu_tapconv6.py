@@ -22,21 +22,13 @@ from test_gpu_tapconv4 import _ints
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["plain", "pipelined"])
-def _small_grids_allowed(request, monkeypatch):
-    """The library keeps grids below one round of CUs on the smaller tiles (speed heuristic); lift that here.  Every test runs twice:
-    with the default tile loop and with the opt-in pipelined tile boundary (RV3D_T6_PIPE=1: tapconv6p, read at every launch)."""
+@pytest.fixture(autouse=True)
+def _small_grids_allowed():
+    """The library keeps grids below one round of CUs on the smaller tiles (speed heuristic); lifted here per call."""
     from range_view_3d_detection_amd import _lib as L
 
-    if request.param == "pipelined":
-        monkeypatch.setenv("RV3D_T6_PIPE", "1")
-    else:
-        monkeypatch.delenv("RV3D_T6_PIPE", raising=False)
-    old4 = L.load().rv_set_option(b"tapconv4_min_blocks", ctypes.c_int32(1))
-    old6 = L.load().rv_set_option(b"tapconv6_min_blocks", ctypes.c_int32(1))
-    yield
-    L.load().rv_set_option(b"tapconv4_min_blocks", ctypes.c_int32(old4))
-    L.load().rv_set_option(b"tapconv6_min_blocks", ctypes.c_int32(old6))
+    with L.select(L.SEL_SMALL_GRIDS | L.SEL_SMALL_GRIDS6):
+        yield
 
 
 def _run(module, x, stats=False):
@@ -155,15 +147,12 @@ def test_matches_generation_5_on_random_data():
     m = m.to(DEV)
     x = torch.randn(2, 256, 64, 512, generator=g).bfloat16().float().to(DEV)
     out6, op6 = _run(m, x, stats=True)
-    L.load().rv_set_option(b"tapconv6_enable", ctypes.c_int32(0))
-    try:
+    with L.select(L.SEL_NO_GEN6):
         from range_view_3d_detection_amd import engine as E
 
         t = E.Tape(True, x.device)
         op5 = E.ConvOp(t, E.tap_layer(m), E.Act.from_nchw(x), stats=True)
         out5 = op5.out.data[..., :256].permute(0, 3, 1, 2).float()
-    finally:
-        L.load().rv_set_option(b"tapconv6_enable", ctypes.c_int32(1))
     assert float((out6 - out5).abs().max()) <= 2 ** -7 * float(out5.abs().max())
     s6 = op6.partial[: op6.rows].double().sum(dim=0)
     s5 = op5.partial[: op5.rows].double().sum(dim=0)

@@ -52,22 +52,29 @@ def test_host_side_geometry(lib):
     assert list(info) == [6, 128, 64 * 4 * 4, 2]  # tapconv6: (16 rows x 32 cols) pixel tiles x two 128-channel tiles
     # statistic rows of a persistent launch: 4 wave rows per group of workgroups sharing a pixel tile (256 workgroups / 2 channel tiles)
     assert h.rv_tap_stats_rows(ctypes.byref(g), ctypes.byref(s), 0) == 4 * 128
-    assert h.rv_set_option(b"tapconv6_enable", 0) == 1
-    assert h.rv_tap_launch_info(ctypes.byref(g), ctypes.byref(s), 0, info) == 0
+    # kernel-selection hints travel PER CALL in rvTapShape.flags (the library holds no mutable option state)
+    assert not hasattr(h, "rv_set_option")
+    s5 = lib.TapShape(4, 64, 2048, 2048, 256, 256, lib.OUT_STATS | lib.SEL_NO_GEN6)
+    assert h.rv_tap_launch_info(ctypes.byref(g), ctypes.byref(s5), 0, info) == 0
     assert list(info) == [5, 256, 64 * 8 * 4, 1]  # tapconv5<256>: (8 rows x 32 cols) pixel tiles x one 256-channel tile
-    assert h.rv_tap_stats_rows(ctypes.byref(g), ctypes.byref(s), 0) == 2 * 64 * 8 * 4
-    assert h.rv_set_option(b"tapconv6_enable", 1) == 0
-    # the same layer with generation 5 switched off, and a pointwise layer: tapconv4<256>, (4 rows x 64 cols) pixel tiles
-    assert h.rv_set_option(b"tapconv5_enable", 0) == 1
-    assert h.rv_tap_launch_info(ctypes.byref(g), ctypes.byref(s), 0, info) == 0 and list(info) == [4, 256, 32 * 16 * 4, 1]
-    assert h.rv_set_option(b"tapconv5_enable", 1) == 0 and h.rv_set_option(b"no such key", 1) == -1
+    assert h.rv_tap_stats_rows(ctypes.byref(g), ctypes.byref(s5), 0) == 2 * 64 * 8 * 4
+    # the same layer without generations 5 / 6, and a pointwise layer: tapconv4<256>, (4 rows x 64 cols) pixel tiles
+    s4 = lib.TapShape(4, 64, 2048, 2048, 256, 256, lib.OUT_STATS | lib.SEL_NO_GEN5)
+    assert h.rv_tap_launch_info(ctypes.byref(g), ctypes.byref(s4), 0, info) == 0 and list(info) == [4, 256, 32 * 16 * 4, 1]
+    with lib.select(lib.SEL_NO_GEN5):  # (the host-side helper ORs the hints into every TapShape built inside the block)
+        assert lib.TapShape(4, 64, 2048, 2048, 256, 256, 0).flags == lib.SEL_NO_GEN5
+    assert lib.TapShape(4, 64, 2048, 2048, 256, 256, 0).flags == 0
+    # a crop below one round of CUs stays on the register-staged kernels unless the call lifts the tile-count heuristic
+    crop = lib.TapShape(1, 16, 64, 64, 256, 256, 0)
+    assert h.rv_tap_launch_info(ctypes.byref(g), ctypes.byref(crop), 0, info) == 0 and info[0] < 4
+    crop6 = lib.TapShape(1, 16, 64, 64, 256, 256, lib.SEL_SMALL_GRIDS | lib.SEL_SMALL_GRIDS6)
+    assert h.rv_tap_launch_info(ctypes.byref(g), ctypes.byref(crop6), 0, info) == 0 and info[0] == 6
     g1 = lib.TapGeom(1, 1, 1, 0, 0, 256, 256)
     assert h.rv_tap_launch_info(ctypes.byref(g1), ctypes.byref(s), 0, info) == 0 and list(info) == [4, 256, 32 * 16 * 4, 1]
     # a folded BatchNorm on the way in needs the register-staged kernel
     s_aff = lib.TapShape(4, 64, 2048, 2048, 256, 256, lib.OUT_STATS | lib.IN_AFFINE | lib.IN_RELU)
     assert h.rv_tap_launch_info(ctypes.byref(g), ctypes.byref(s_aff), 0, info) == 0
-    assert list(info) == [3, 2, 32 * 16 * 4, 2]  # tapconv3<2>: 2 channel tiles of 128
-    assert h.rv_tap_stats_rows(ctypes.byref(g), ctypes.byref(s_aff), 0) == 4 * 32 * 16 * 4
+    assert info[0] == 2  # tapconv2 (2 rows x 64 columns x 128 channels, the folded BatchNorm applied in its operand staging)
     # strided conv: Wv must be Wu * stride
     bad = lib.TapShape(4, 64, 1000, 2048, 256, 256, 0)
     g2 = lib.TapGeom(3, 3, 2, 1, 1, 128, 128)
@@ -87,8 +94,7 @@ def test_host_side_geometry(lib):
 def test_weight_gradient_split_plans(lib):
     """rv_tap_wgrad_info (host only): kernel generation, split-K slabs and workgroups of the weight-gradient launch.  One round of
     workgroups as close to 256 as the tile count allows; the 48-tile 512 <-> 512 layer takes the BALANCED split (five regular slices per
-    tile + sixteen remainder workgroups that each finish three tiles: a sixth slab, all 256 CUs busy), which `RV3D_WGRAD_NO_BALANCE=1`
-    switches off."""
+    tile + sixteen remainder workgroups that each finish three tiles: a sixth slab, all 256 CUs busy)."""
     h = lib.load()
     info = (ctypes.c_int32 * 4)()
     s = lib.TapShape(4, 64, 2048, 2048, 0, 0, 0)
@@ -104,11 +110,6 @@ def test_weight_gradient_split_plans(lib):
     assert plan(256, 256, 3) == [3, 21, 252]      # 12 tiles x 21 slices: already 98 % of the CUs, plain split
     assert plan(128, 128, 3) == [3, 85, 255]
     assert plan(128, 128, 1) == [3, 256, 256]     # 1x1, one tile: 8192 chunks of 64 pixels over 256 workgroups (never fewer than 32 per workgroup)
-    os.environ["RV3D_WGRAD_NO_BALANCE"] = "1"
-    try:
-        assert plan(512, 512, 3) == [3, 5, 240]
-    finally:
-        del os.environ["RV3D_WGRAD_NO_BALANCE"]
 
 
 def test_null_arguments_fail_with_message(lib):
