@@ -503,11 +503,30 @@ HBM_GROUP_KERNELS = {
     "rv_ew_combine": ("ew_combine",), "rv_bn_bwd_reduce": ("bn_bwd_reduce_",), "rv_bn_bwd_apply": ("bn_bwd_apply_",),
     "rv_bn_bwd_reduce_pair": ("bn_bwd_reduce2",), "rv_bn_bwd_apply_pair": ("bn_bwd_apply2",), "rv_meta_modulate": ("meta_modulate_kernel",),
     "rv_meta_modulate_bwd_sums": ("meta_bwd_sums",), "rv_meta_modulate_bwd_apply": ("meta_bwd_apply",), "rv_pos_forward": ("pos_fwd_kernel",),
-    "rv_pos_backward_sums": ("pos_bwd_kernel",),
+    "rv_pos_backward_sums": ("pos_bwd_kernel",), "rv_head_final_bwd_sums": ("head_final_bwd_kernel<false>",),
+    "rv_head_final_bwd_apply": ("head_final_bwd_kernel<true>",),
 }
 
 
 def measure_hbm_group(step, steps: int = 2, pmc_key: str = "kernels") -> dict:
+    """In-run figures (`_hbm_group_pass` in the timed configuration) with the one-stream figures beside them (`isolated`: with the
+    weight gradients free-running at high priority on the side stream a bandwidth-bound pass shares the CUs and the memory system
+    with a resident wgrad3 workgroup, and its event-to-event time includes that)."""
+    from range_view_3d_detection_amd import engine as E
+
+    r = _hbm_group_pass(step, steps, pmc_key)
+    if r and E.OVERLAP_WGRAD:
+        overlap, E.OVERLAP_WGRAD = E.OVERLAP_WGRAD, False
+        try:
+            i = _hbm_group_pass(step, steps, pmc_key)
+        finally:
+            E.OVERLAP_WGRAD = overlap
+        r["isolated"] = {k: i[k] for k in ("achieved", "frac", "ms_per_step")}
+        r["isolated"]["measured"] = "the same events with the side stream off (the passes alone on the GPU)"
+    return r
+
+
+def _hbm_group_pass(step, steps: int, pmc_key: str) -> dict:
     """The HBM-bound kernels of the step (BatchNorm backward reduce / apply, the element-wise block passes, the MetaKernel stem's
     gather / modulation and positional-pair kernels) against the HBM roofline: HIP events around each of their launches in
     ``steps`` extra training steps in the SAME configuration as the timed region (two streams), algorithmic bytes per launch from
@@ -672,7 +691,7 @@ def main(args=None) -> None:
         E.OVERLAP_WGRAD = overlap
         E.PROFILE = None
         # ... and the HBM-bound group (BatchNorm backward, element-wise, stem) in the timed configuration again, with events around ITS launches
-        hbm_group = measure_hbm_group(step) if rank == 0 else {}
+        hbm_group = measure_hbm_group(step)  # (every rank: the steps carry collectives)
     if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)

@@ -271,6 +271,23 @@ int rv_bn_bwd_apply(int64_t pixels, int32_t c, const void* dout, int32_t ld_dout
                     const void* y, int32_t ld_y, const float* scale, const float* shift, const float* mean,
                     const float* invstd, const float* coef, int32_t flags, void* dy, int32_t ld_dy, void* dres,
                     int32_t ld_dres, rvStream stream);
+/* Backward of a tower's FINAL 1x1 conv (c -> n_out <= 32 channels; nn/heads/dense_head.py:44-57, 74-76) fused with the BatchNorm
+ * (+ReLU) backward of the conv -> BatchNorm -> ReLU unit in front of it: the input gradient dA = W^T dY (a K = 32 GEMM of the tiny
+ * output gradient) is RECOMPUTED in both passes instead of being stored and read back twice --
+ *   _sums : g = dA * [scale*y+shift > 0 if relu], partial[row][0][c] = sum g, partial[row][1][c] = sum g * (y-mean)*invstd over
+ *           rv_head_final_bwd_rows(pixels) <= 1024 pixel ranges (the rows rv_bn_bwd_finalize takes; + RV_STATS_SCRATCH_ROWS)
+ *   _apply: dy = coef0 * (g - coef1 - xhat * coef2)  (bf16; coef from rv_bn_bwd_finalize)
+ * y: raw bf16 output of the unit's conv [pixels][ld_y]; dY: the final conv's output gradient as bf16 [pixels][ld_dy >= 32] with
+ * channels n_out..31 zero; w_scatter: the final conv's packed scatter image ([c][32]); c % 256 == 0.
+ * Replaces ATen conv2d backward-data + native_batch_norm_backward + threshold_backward for that pair of layers (three transfers of
+ * a c-channel tensor instead of six). */
+int32_t rv_head_final_bwd_rows(int64_t pixels);
+int rv_head_final_bwd_sums(int64_t pixels, int32_t c, const void* y, int32_t ld_y, const void* dY, int32_t ld_dy, const void* w_scatter,
+                           const float* scale, const float* shift, const float* mean, const float* invstd, int32_t relu, float* partial,
+                           rvStream stream);
+int rv_head_final_bwd_apply(int64_t pixels, int32_t c, const void* y, int32_t ld_y, const void* dY, int32_t ld_dy, const void* w_scatter,
+                            const float* scale, const float* shift, const float* mean, const float* invstd, int32_t relu, const float* coef,
+                            void* dy, int32_t ld_out, rvStream stream);
 /* Small-K layers whose input needs no gradient (1x1 conv with cin <= 8 followed by BatchNorm: the stem's 3 -> C positional
  * conv, the 5/6 -> C feature projections): BatchNorm backward AND the conv's weight gradient from one pass over
  * (dOut, y, v) -- dy is never written.  v = the conv input (bf16 NHWC, >= 8 stored channels), w_packed = the layer's packed

@@ -183,6 +183,9 @@ HBM_BYTES = {
     "rv_meta_modulate_bwd_apply": lambda a: 2.0 * _v(a[9]) * _v(a[10]) * _v(a[11]) * _v(a[12]) * 28,
     "rv_pos_forward": lambda a: float(_v(a[3])) * (16 + 4.0 * _v(a[9])),
     "rv_pos_backward_sums": lambda a: float(_v(a[0])) * (16 + 2.0 * _v(a[1])),
+    # final conv of a tower fused with the BatchNorm backward in front of it: y (+ the 32-channel dY) in; _apply also writes dy
+    "rv_head_final_bwd_sums": lambda a: 2.0 * _v(a[0]) * (_v(a[1]) + 32),
+    "rv_head_final_bwd_apply": lambda a: 2.0 * _v(a[0]) * (2 * _v(a[1]) + 32),
 }
 HBM_HOOK = None  # callable(name, algorithmic bytes, launch) or None: set by bench.py around its HBM-group measurement
 

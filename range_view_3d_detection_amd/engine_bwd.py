@@ -79,6 +79,10 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
         # backward + weight gradient (rv_pos_backward_sums) -- no input-gradient tensor, no second pass over it
         _wait_chained_wgrad(t)
         _pos_pair_backward(op, t, dout)
+    elif op.need_input_grad and _head_final_eligible(op, t, dout):
+        # final 1x1 conv of a head tower behind conv -> BatchNorm -> ReLU: no input-gradient tensor -- the BatchNorm backward of that unit
+        # recomputes dA = W^T dY in both of its passes (rv_head_final_bwd_sums / _apply, csrc/headfinal.hip)
+        t.head_final[id(op.x)] = (dout, layer.packed(bwd))
     elif op.need_input_grad:
         if isinstance(op.x, Lazy):
             dst, accumulate = t.lazy_grad_target(op.x)
@@ -196,6 +200,19 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
         t.used_side_stream = True
     else:
         run_wgrad()
+
+
+HEAD_FINAL_FUSE = True  # (module attribute: tests flip it in-process)
+
+
+def _head_final_eligible(op: "E.ConvOp", t: Tape, dout: Act) -> bool:
+    """``op`` is a tower's final conv (1x1, stride 1, at most 32 output channels, fp32 output) whose ONLY input is the activated
+    output of a conv -> BatchNorm (-> ReLU) unit in training mode that nobody else has contributed a gradient to."""
+    x, lay = op.x, op.layer
+    g = lay.geom
+    return (HEAD_FINAL_FUSE and t.training and op.out_f32 and isinstance(x, Lazy) and x.bn.mean is not None and id(x) not in t.lazy_in
+            and id(x) not in t.head_final and lay.fwd_form == "gather" and g.kh == 1 and g.kw == 1 and g.stride_w == 1 and lay.in_perm is None
+            and pad32(g.cu) == 32 and x.raw.cp % 256 == 0 and x.raw.cp == pad32(g.cv) and dout.ld >= 32 and dout.pixels == x.raw.pixels)
 
 
 def _release_held_wgrads(t: Tape) -> None:
@@ -317,6 +334,17 @@ def bn_backward_begin(op: "E.BnOp", t: Tape):
         assert id(lazy) not in t.lazy_in, "the positional Lazy behind the MetaKernel modulation has exactly one consumer"
         _bn_backward_meta(op, t, meta)
         return None
+    hf = t.head_final.pop(id(lazy), None)
+    if hf is not None:
+        assert id(lazy) not in t.lazy_in, "the last unit of a head tower feeds the final conv only"
+        st, raw = lazy.bn, lazy.raw
+        dY, wp = hf
+        rows = L.load().rv_head_final_bwd_rows(L.i64(raw.pixels))
+        partial = torch.empty((rows + L.STATS_SCRATCH_ROWS, 2, raw.cp), dtype=torch.float32, device=t.device)
+        head = (L.i64(raw.pixels), L.i32(raw.cp), raw.ptr(), L.i32(raw.ld), dY.ptr(), L.i32(dY.ld), L.ptr(wp), L.ptr(st.scale), L.ptr(st.shift),
+                L.ptr(st.mean), L.ptr(st.invstd), L.i32(1 if lazy.relu else 0))
+        L.call("rv_head_final_bwd_sums", *head, L.ptr(partial), L.stream_ptr())
+        return (op, None, partial, rows, raw.pixels, 0, None, ("head_final", head, dY, wp))
     entry = t.lazy_in.pop(id(lazy), None)
     if entry is None:
         return None
@@ -371,7 +399,9 @@ def bn_backward_finish(recs, t: Tape) -> None:
         st, raw = lazy.bn, lazy.raw
         dgamma, dbeta, coef = _bn_finalize(op, t, partial, rows, pixels, glob=g, local=loc)
         dy = raw.like()
-        if res is not None:
+        if common is None:  # the head-final form: dA recomputed from the final conv's output gradient (bn_backward_begin)
+            L.call("rv_head_final_bwd_apply", *_keep[1], L.ptr(coef), dy.ptr(), L.i32(dy.ld), L.stream_ptr())
+        elif res is not None:
             rg, racc = res
             L.call("rv_bn_bwd_apply", *common, L.ptr(coef), L.i32(flags | (L.BNB_RES_ACCUM if racc else 0)), dy.ptr(), L.i32(dy.ld),
                    rg.ptr(), L.i32(rg.ld), L.stream_ptr())

@@ -617,3 +617,71 @@ def test_a_training_step_frees_its_activations_without_the_cycle_collector():
     finally:
         gc.enable()
     assert grown < (1 << 20), f"{grown / 2**20:.1f} MiB still allocated after three steps with the cycle collector off"
+
+
+@pytest.mark.parametrize("C,n_out,W", [(256, 26, 200), (512, 8, 96), (256, 3, 328)])
+def test_head_final_conv_backward_fused_with_the_last_batchnorm(C, n_out, W):
+    """A tower's final 1x1 conv behind conv -> BatchNorm -> ReLU (nn/heads/dense_head.py:44-57): rv_head_final_bwd_sums / _apply
+    recompute the final conv's input gradient inside the BatchNorm backward instead of storing it.  Against (a) the unfused chain of
+    the same library (backward-data launch + rv_bn_bwd_reduce + rv_bn_bwd_apply): parameter gradients of the unit and the gradient
+    w.r.t. the tower input at bf16 level, (dgamma, dbeta) 2e-3 (the unfused chain rounds dA to bf16 before summing); (b) torch fp32
+    autograd on the same bf16-rounded operands.  Pixel counts that are not multiples of 16 (W = 200: 3 x 5 x 200 = 3000 pixels,
+    ragged last range) included."""
+    from range_view_3d_detection_amd import _lib as L
+    from range_view_3d_detection_amd import engine_bwd
+    from range_view_3d_detection_amd.nn.heads.dense_head import DenseHead
+
+    gen = torch.Generator().manual_seed(C + n_out)
+    m = DenseHead(C, C, n_out, 3, 1, num_blocks=1, prior_prob=0.01)
+    m.blocks[0][0].weight.data = 0.05 * torch.randn(m.blocks[0][0].weight.shape, generator=gen)
+    m.blocks[1][0].weight.data = 0.2 * torch.randn(m.blocks[1][0].weight.shape, generator=gen)
+    m.blocks[0][1].weight.data = 0.5 + torch.rand(C, generator=gen)
+    m.blocks[0][1].bias.data = 0.3 * torch.randn(C, generator=gen)
+    x = bf16r(torch.randn(3, C, 5, W, generator=gen))
+    probe = torch.randn(3, n_out, 5, W, generator=gen)
+    # (b) fp32 reference: train-mode BatchNorm, bf16-rounded conv operands as the kernels see them
+    ref = DenseHead(C, C, n_out, 3, 1, num_blocks=1)
+    ref.load_state_dict(m.state_dict())
+    ref.blocks[0][0].weight.data = bf16r(ref.blocks[0][0].weight.data)
+    ref.blocks[1][0].weight.data = bf16r(ref.blocks[1][0].weight.data)
+    xr = x.clone().requires_grad_(True)
+    y = F.conv2d(xr, ref.blocks[0][0].weight, padding=1)
+    a = F.relu(F.batch_norm(y, None, None, ref.blocks[0][1].weight, ref.blocks[0][1].bias, training=True, eps=1e-5))
+    out = F.conv2d(a, ref.blocks[1][0].weight, ref.blocks[1][0].bias)
+    (out * probe).sum().backward()
+    m = m.to(DEV).train()
+
+    def run(fused: bool):
+        old = engine_bwd.HEAD_FINAL_FUSE
+        engine_bwd.HEAD_FINAL_FUSE = fused
+        calls = []
+        real = L._call
+
+        def spy(name, *args):
+            calls.append(name)
+            return real(name, *args)
+
+        L._call = spy
+        try:
+            m.zero_grad(set_to_none=True)
+            xi = x.to(DEV).requires_grad_(True)
+            (m(xi).float() * probe.to(DEV)).sum().backward()
+            torch.cuda.synchronize()
+            return {k: p.grad.detach().float().cpu() for k, p in m.named_parameters()}, xi.grad.detach().float().cpu(), calls
+        finally:
+            L._call = real
+            engine_bwd.HEAD_FINAL_FUSE = old
+
+    gf, dxf, cf = run(True)
+    gu, dxu, cu = run(False)
+    assert cf.count("rv_head_final_bwd_sums") == 1 and cf.count("rv_head_final_bwd_apply") == 1 and "rv_bn_bwd_apply" not in cf, cf
+    assert "rv_head_final_bwd_sums" not in cu and "rv_bn_bwd_apply" in cu
+    for k in gf:
+        assert rel_err(gf[k], gu[k]) < (2e-3 if "blocks.0.1" in k else 2e-2) and _cos(gf[k], gu[k]) > 0.9999, (k, rel_err(gf[k], gu[k]))
+    assert rel_err(dxf, dxu) < 2e-2 and _cos(dxf, dxu) > 0.9999
+    refg = {"blocks.0.0.weight": ref.blocks[0][0].weight.grad, "blocks.0.1.weight": ref.blocks[0][1].weight.grad, "blocks.0.1.bias": ref.blocks[0][1].bias.grad,
+            "blocks.1.0.weight": ref.blocks[1][0].weight.grad, "blocks.1.0.bias": ref.blocks[1][0].bias.grad}
+    for k, r in refg.items():  # vs fp32 autograd: the fused chain is at least as close as the unfused one (+ a bf16 ulp of slack)
+        ef, eu = rel_err(gf[k], r), rel_err(gu[k], r)
+        assert ef < max(1.5 * eu, 4e-3) + 1e-3, (k, ef, eu)
+    assert rel_err(dxf, xr.grad) < max(1.5 * rel_err(dxu, xr.grad), 8e-3) + 1e-3
