@@ -55,6 +55,8 @@ assert torch.equal(ref, ref2), "the one-stream trajectory itself is not reproduc
 bad = 0
 for r in range(reps):
     got = trajectory(True)
+    if (r + 1) % 5 == 0:
+        print(f"... {r + 1} of {reps} runs, {bad} with a wrong step so far", flush=True)
     if torch.equal(got, ref):
         continue
     bad += 1

@@ -167,19 +167,10 @@ def side_stream(device) -> "torch.cuda.Stream":
     return _SIDE_STREAMS[idx]
 
 
-# Forward pass of a head's two towers on two streams, CHAINED (program.dense_head_pair_program): the convs of the two towers take strict
-# turns (conv A_i, conv B_i, conv A_i+1, ... by events) and what runs beside a conv is the other tower's bandwidth-bound write-out pass
-# of relu(bn(y)), which fits on a CU next to a resident tapconv6 workgroup.  (Round 4 measured the FREE-running form -- both towers'
-# convs allowed to overlap -- 0.6 ms per rv-av2 step slower: two persistent launches take the CUs from each other.)
-TOWER_STREAMS = False  # (module attribute; profiles/tools/ab_attr.py program... A/B in-process)
-_SECOND_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
-
-
-def second_stream(device) -> "torch.cuda.Stream":
-    idx = torch.device(device).index or 0
-    if idx not in _SECOND_STREAMS:
-        _SECOND_STREAMS[idx] = torch.cuda.Stream(device=device)
-    return _SECOND_STREAMS[idx]
+# (Measured and dropped: the forward pass of a head's two towers on two streams.  Round 4, free-running: 0.6 ms per rv-av2 step slower
+#  (two persistent tapconv6 launches take the CUs from each other).  Round 5, CHAINED by events so that the convs take strict turns
+#  and only the other tower's bandwidth-bound write-out pass runs beside a conv: 98.53 against 97.75 ms (rv-av2), 54.48 against 54.19
+#  (rv-waymo), three interleaved rounds on one box -- the write-out beside a power-capped conv costs more than it hides.)
 
 
 def _launch(name: str, flops: float, fn, nbytes: float = 0.0) -> None:

@@ -216,34 +216,6 @@ def dense_head_pair_program(t: Tape, cls_head: nn.Module, reg_head: nn.Module, x
         return dense_head_program(t, cls_head, x), dense_head_program(t, reg_head, x)
     ha: Operand = x
     hb: Operand = x
-    if (E.TOWER_STREAMS and t.training and x.data.is_cuda and not any(E.bn_sync_world(b[1], True) > 1 for b in ca[:-1] + cb[:-1])):
-        # chained two-stream form (engine.TOWER_STREAMS): conv A_i | conv B_i beside write-out A_i | conv A_i+1 beside write-out B_i | ...
-        main, second = torch.cuda.current_stream(), E.second_stream(t.device)
-        ev_b = torch.cuda.Event()
-        ev_b.record(main)  # x and everything before it
-        n_units = len(ca) - 1
-        for i, (ba, bb) in enumerate(zip(ca[:-1], cb[:-1])):
-            more = i + 1 < n_units  # (the final 1x1 conv folds the last unit's BatchNorm + ReLU on the way in: nothing to write out)
-            main.wait_event(ev_b)  # conv A_i after conv B_i-1
-            ha = E.conv_bn(t, E.tap_layer(ba[0]), ha, ba[1], relu=True)
-            ev_a = torch.cuda.Event()
-            ev_a.record(main)
-            if more and isinstance(ha, E.Lazy) and E.MATERIALIZE_FOR_DMA:
-                ha.materialized()  # (what the next conv would do on entry: issued now, so that it streams beside conv B_i)
-            with torch.cuda.stream(second):
-                second.wait_event(ev_a)  # conv B_i after conv A_i
-                hb = E.conv_bn(t, E.tap_layer(bb[0]), hb, bb[1], relu=True)
-                ev_b = torch.cuda.Event()
-                ev_b.record(second)
-                if more and isinstance(hb, E.Lazy) and E.MATERIALIZE_FOR_DMA:
-                    hb.materialized()
-        out_a = E.ConvOp(t, E.tap_layer(ca[-1][0]), ha, stats=False, out_f32=True)
-        with torch.cuda.stream(second):
-            out_b = E.ConvOp(t, E.tap_layer(cb[-1][0]), hb, stats=False, out_f32=True)
-            done = torch.cuda.Event()
-            done.record(second)
-        main.wait_event(done)
-        return out_a, out_b
     for ba, bb in zip(ca[:-1], cb[:-1]):
         ha, hb = E.conv_bn_many(t, [(E.tap_layer(ba[0]), ha, ba[1], True, True), (E.tap_layer(bb[0]), hb, bb[1], True, True)])
     return (E.ConvOp(t, E.tap_layer(ca[-1][0]), ha, stats=False, out_f32=True),
