@@ -21,4 +21,13 @@ import os as _os
 # (profiles/r04_hw_queues.md).  Read by the runtime when it initialises, i.e. at the first HIP call after this import; an explicit
 # setting wins.  The opt-in direct RCCL binding (rccl.py) is the exception: 124 ms per step at 8 queues against 101 at the default.
 if _os.environ.get("RV3D_DIRECT_RCCL") is None:
+    if "GPU_MAX_HW_QUEUES" not in _os.environ:
+        import torch as _torch
+
+        if _torch.cuda.is_initialized():  # too late for this process: say so instead of silently running with four queues
+            import warnings as _warnings
+
+            _warnings.warn("range_view_3d_detection_amd: HIP was initialised before this import, so GPU_MAX_HW_QUEUES=8 cannot take "
+                           "effect; the weight-gradient side stream will share a hardware queue once an RCCL process group exists "
+                           "(+2.6..5 ms per rv-av2 step).  Import the package (or export GPU_MAX_HW_QUEUES=8) before the first CUDA/HIP call.")
     _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")

@@ -324,7 +324,11 @@ class GradSync:
         idx = [i for i, (p, g) in enumerate(zip(params, grads)) if g is not None and id(p) in self.offsets]
         if not idx:
             return out
+        pending = {id(p) for p in self.pending}
         for i in idx:
+            if id(params[i]) in pending:
+                raise L.RvError("GradSync: a parameter was reduced by two program nodes in one step -- its region of the flat buffer may still "
+                                "be travelling in the first node's all-reduce (share the parameter inside ONE program, or call finish() between)")
             if params[i].grad is not None and params[i].grad is self._views.get(id(params[i])):
                 raise L.RvError("GradSync: p.grad still is last step's view of the flat buffer -- call zero_grad(set_to_none=True) "
                                 "before backward (gradient accumulation over several backward passes is not supported)")
@@ -348,7 +352,8 @@ class GradSync:
 
     def finish(self) -> None:
         """Before the optimizer step: wait for the collectives, average, and make ``p.grad`` of every parameter reduced this
-        step its view of the flat buffer."""
+        step its view of the flat buffer.  Until then ``p.grad`` of those parameters is None: anything that reads gradients
+        (``clip_grad_norm_``, gradient-norm logging, Lightning's ``on_after_backward``) must run AFTER ``finish()``."""
         for work, seg in self.works:
             if work is not None:
                 work.wait()

@@ -517,7 +517,7 @@ def combine_backward(op: "E.CombineOp", t: Tape) -> None:
         t.mark_written(x)
 
 
-BNB_PAIR = True
+BNB_PAIR = os.environ.get("RV3D_NO_BNB_PAIR") is None  # (environment switch kept for tests/test_gpu_ddp.py: isolates the SyncBN grouping from the one-pass pair apply)
 META_BWD_FUSE = True
 
 

@@ -183,6 +183,9 @@ def test_one_rank_rccl_sync_path_at_the_rv_av2_widths():
     assert abs(rccl["config"]["loss"] - local["config"]["loss"]) < 2e-2 * abs(local["config"]["loss"]), (rccl["config"]["loss"], local["config"]["loss"])
     ungrouped = run({"RV3D_FORCE_DIST": "1", "RV3D_SYNC_WORLD1": "1", "RV3D_DIST_BACKEND": "nccl", "RV3D_NO_GROUP_SYNC_BN": "1"})
     assert ungrouped["config"]["collectives"]["per_step"]["sync_bn_all_reduce"]["calls"] >= 150
-    # grouping changes no statistic; since round 4 the grouped path also takes the ONE-pass apply of projection blocks
-    # (rv_bn_bwd_apply_pair behind one shared all-reduce), whose bf16 gradients differ in last bits from the two separate passes
-    assert abs(ungrouped["config"]["loss"] - rccl["config"]["loss"]) < 3e-3 * abs(rccl["config"]["loss"])
+    # grouping changes no statistic.  The grouped path also takes the ONE-pass apply of projection blocks (rv_bn_bwd_apply_pair behind one
+    # shared all-reduce), whose bf16 gradients differ in last bits from the two separate passes -- so the grouping claim is checked with
+    # that form switched off (1e-3), and the pair-apply difference by itself (3e-3)
+    grouped_plain = run({"RV3D_FORCE_DIST": "1", "RV3D_SYNC_WORLD1": "1", "RV3D_DIST_BACKEND": "nccl", "RV3D_NO_BNB_PAIR": "1"})
+    assert abs(ungrouped["config"]["loss"] - grouped_plain["config"]["loss"]) < 1e-3 * abs(grouped_plain["config"]["loss"]), (ungrouped["config"]["loss"], grouped_plain["config"]["loss"])
+    assert abs(grouped_plain["config"]["loss"] - rccl["config"]["loss"]) < 3e-3 * abs(rccl["config"]["loss"])
