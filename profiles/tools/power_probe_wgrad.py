@@ -1,9 +1,11 @@
 """Is wgrad3 pipeline-bound or POWER-bound?  (round-4 review, item 6: what r03_power_cap.md did for the tap-conv, for the weight
 gradient.)  wgrad3 on the 3x3 512 <-> 512 layer at 4 x 64 x 2048 (2.47 TFLOP per launch, 256 workgroups: the balanced split) in a
-loop while rocm-smi is sampled: random bf16 operands on all 256 CUs, on 128 CUs (a stream created with a CU mask:
-hipExtStreamCreateWithCUMask, every second CU), and all-zero operands on 256 CUs.
+loop while rocm-smi is sampled: random bf16 operands and all-zero operands on all 256 CUs.  Fewer CUs: run the same script under
+`HSA_CU_MASK=0:0-127` (a process-wide mask of the ROCr runtime; a per-stream mask through hipExtStreamCreateWithCUMask did not
+restrict anything on this stack -- round 5, the 128 / 64 rows of the first run took the 256-CU time).
 
   python profiles/tools/power_probe_wgrad.py
+  HSA_CU_MASK=0:0-127 python profiles/tools/power_probe_wgrad.py 128
 """
 import ctypes, os, subprocess, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -12,7 +14,6 @@ from range_view_3d_detection_amd import _lib as L
 
 dev = torch.device("cuda:0")
 torch.cuda.set_device(0)
-hip = ctypes.CDLL("libamdhip64.so")
 N, H, W, C = 4, 64, 2048, 512
 g = L.TapGeom(3, 3, 1, 1, 1, C, C)
 s = L.TapShape(N, H, W, W, 0, 0, L.WGRAD_TORCH_LAYOUT)
@@ -23,21 +24,6 @@ info = (ctypes.c_int32 * 4)()
 lib.rv_tap_wgrad_info(ctypes.byref(g), ctypes.byref(s), info)
 print(f"kernel generation {info[0]}, split-K slabs {info[1]}, workgroups {info[2]}")
 fl = 2.0 * N * H * W * 9 * C * C
-
-
-def masked_stream(n_cus):
-    words = (ctypes.c_uint32 * 8)()
-    if n_cus >= 256:
-        for i in range(8):
-            words[i] = 0xFFFFFFFF
-    else:  # every second CU (128), every fourth (64): spread over all XCDs / shader engines
-        pat = {128: 0x55555555, 64: 0x11111111}[n_cus]
-        for i in range(8):
-            words[i] = pat
-    st = ctypes.c_void_p()
-    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(8), words)
-    assert rc == 0, f"hipExtStreamCreateWithCUMask -> {rc}"
-    return torch.cuda.ExternalStream(st.value, device=dev)
 
 
 def loop(u, v, stream, secs):
@@ -61,8 +47,10 @@ u = torch.randn(N, H, W, C, device=dev).to(torch.bfloat16)
 v = torch.randn(N, H, W, C, device=dev).to(torch.bfloat16)
 uz, vz = torch.zeros_like(u), torch.zeros_like(v)
 print("| data | CUs | us per launch (+ reduce) | TFLOP/s | TFLOP/s scaled to 256 CUs | sclk | package power (W) | cap (W) |\n|---|---|---|---|---|---|---|---|")
-for tag, a, b, cus in (("random", u, v, 256), ("random", u, v, 128), ("random", u, v, 64), ("zeros", uz, vz, 256)):
-    st = masked_stream(cus)
+cus = int(sys.argv[1]) if len(sys.argv) > 1 else 256  # (what HSA_CU_MASK leaves: for the "scaled" column only)
+print(f"HSA_CU_MASK={os.environ.get('HSA_CU_MASK')}")
+for tag, a, b in (("random", u, v), ("zeros", uz, vz)):
+    st = torch.cuda.Stream()
     res = {}
     th = threading.Thread(target=lambda: res.setdefault("us", loop(a, b, st, 6.0)))
     th.start(); time.sleep(3.0); clk, pw, cap = smi(); th.join()
