@@ -257,6 +257,27 @@ def cpu_baseline(seconds_budget: float = 45.0, full: bool = False, auto_full_lim
             v.grad = None
         return time.perf_counter() - t0
 
+    def config1() -> dict:
+        """BASELINE configs[0] (debug-overfit: one synthetic 64 x 512 x 5 sweep, the nearest reference-valid tiny backbone
+        ``layers=[16]*5`` -- RangeBackbone is hard-wired to five entries), CPU only: the oracle's fwd + loss + bwd."""
+        tb, th = build_model("c16", 5)
+        tsd = {**{f"backbone.{k}": v for k, v in tb.state_dict().items()}, **{f"head.{k}": v for k, v in th.state_dict().items()}}
+        tparams = {k: v.clone().requires_grad_(True) for k, v in tsd.items() if v.dtype.is_floating_point and "running_" not in k}
+        tw = {**tsd, **tparams}
+        tbatch = synthetic_batch(1, H, 512, seed=0, device="cpu", boxes_per_sweep=4, n_cls=5)
+        ts = []
+        for _ in range(3):  # (the first one is the warm-up)
+            t0 = time.perf_counter()
+            _, lg, rg = om.detector_forward(tbatch["features"], tbatch["cart"], tw, nm=om.Numerics(train=True))
+            ttg = otgt.compute_targets(tbatch["cart"], tbatch["annotations"], 5)
+            otgt.detection_loss(lg, rg, tbatch["cart"], tbatch["mask"], ttg, 5)["loss"].backward()
+            for v in tparams.values():
+                v.grad = None
+            ts.append(time.perf_counter() - t0)
+        dt1 = sum(ts[1:]) / 2
+        return {"value": 1.0 / dt1, "unit": "sweeps/s", "seconds_per_iteration": round(dt1, 3),
+                "sample": "BASELINE configs[0]: oracle fwd+loss+bwd, layers=[16]*5 (towers 32, 5 classes), fp32, one synthetic 64x512x5 sweep, 1 warm-up + 2 timed iterations"}
+
     # thread count: all granted cores, unless a short probe shows the PyTorch-CPU convolutions are faster on 32
     probes = {}
     for th in sorted({cores, min(cores, 32)}):
@@ -282,7 +303,8 @@ def cpu_baseline(seconds_budget: float = 45.0, full: bool = False, auto_full_lim
             dt = sum(times) / len(times)
             return {"value": 1.0 / dt, "unit": "sweeps/s", "cores": threads, "kind": "port",
                     "sample": f"oracle fwd+loss+bwd, rv-av2 widths, fp32, B=1, 64x{W_full}x5 (the WHOLE sweep), warm-up on a 64x256 crop + "
-                              f"{len(times)} timed iteration(s) of {' / '.join(f'{t:.1f}' for t in times)} s on {threads} threads ({cores} cores visible, {_cpu_model()})"}
+                              f"{len(times)} timed iteration(s) of {' / '.join(f'{t:.1f}' for t in times)} s on {threads} threads ({cores} cores visible, {_cpu_model()})",
+                    "config1": config1()}
         note = f"; the whole sweep was estimated at {est:.0f} s per iteration on this host: cropped sample instead"
     if not full:
         W = 32
@@ -299,6 +321,7 @@ def cpu_baseline(seconds_budget: float = 45.0, full: bool = False, auto_full_lim
         "value": (W / W_full) / dt, "unit": "sweeps/s", "cores": threads, "kind": "port",
         "sample": f"oracle fwd+loss+bwd, rv-av2 widths, fp32, B=1, 64x{W}x5 ({'the full sweep' if W == W_full else f'{W}/{W_full} of a sweep'}), "
                   f"1 warm-up + 2 timed iterations of {times[0]:.1f} / {times[1]:.1f} s on {threads} threads ({cores} cores visible, {_cpu_model()}){note}",
+        "config1": config1(),
     }
 
 
