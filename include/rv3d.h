@@ -275,16 +275,19 @@ int rv_bn_bwd_apply(int64_t pixels, int32_t c, const void* dout, int32_t ld_dout
  * (+ReLU) backward of the conv -> BatchNorm -> ReLU unit in front of it: the input gradient dA = W^T dY (a K = 32 GEMM of the tiny
  * output gradient) is RECOMPUTED in both passes instead of being stored and read back twice --
  *   _sums : g = dA * [scale*y+shift > 0 if relu], partial[row][0][c] = sum g, partial[row][1][c] = sum g * (y-mean)*invstd over
- *           rv_head_final_bwd_rows(pixels) <= 1024 pixel ranges (the rows rv_bn_bwd_finalize takes; + RV_STATS_SCRATCH_ROWS)
+ *           rv_head_final_bwd_rows(pixels) <= 512 pixel ranges (the rows rv_bn_bwd_finalize takes; + RV_STATS_SCRATCH_ROWS);
+ *           dw_partial (may be NULL): [rows][32][c] fp32 partial WEIGHT gradients of the final conv, dW[o][c] = sum_px dY[px][o] *
+ *           relu?(scale*y+shift)[px][c] over the row's pixels -- sum the rows in order (rv_reduce_rows with cols = 32 c) for the
+ *           gradient in the parameter's own layout [n_out][c][1][1] (rows o >= n_out are zero)
  *   _apply: dy = coef0 * (g - coef1 - xhat * coef2)  (bf16; coef from rv_bn_bwd_finalize)
  * y: raw bf16 output of the unit's conv [pixels][ld_y]; dY: the final conv's output gradient as bf16 [pixels][ld_dy >= 32] with
  * channels n_out..31 zero; w_scatter: the final conv's packed scatter image ([c][32]); c % 256 == 0.
- * Replaces ATen conv2d backward-data + native_batch_norm_backward + threshold_backward for that pair of layers (three transfers of
- * a c-channel tensor instead of six). */
+ * Replaces ATen conv2d backward-data + conv2d backward-weight + native_batch_norm_backward + threshold_backward for that pair of
+ * layers (three transfers of a c-channel tensor instead of seven). */
 int32_t rv_head_final_bwd_rows(int64_t pixels);
 int rv_head_final_bwd_sums(int64_t pixels, int32_t c, const void* y, int32_t ld_y, const void* dY, int32_t ld_dy, const void* w_scatter,
                            const float* scale, const float* shift, const float* mean, const float* invstd, int32_t relu, float* partial,
-                           rvStream stream);
+                           float* dw_partial, rvStream stream);
 int rv_head_final_bwd_apply(int64_t pixels, int32_t c, const void* y, int32_t ld_y, const void* dY, int32_t ld_dy, const void* w_scatter,
                             const float* scale, const float* shift, const float* mean, const float* invstd, int32_t relu, const float* coef,
                             void* dy, int32_t ld_out, rvStream stream);

@@ -753,7 +753,7 @@ class Tape:
         self.lazy_in: Dict[int, Tuple[Act, Optional[Act]]] = {}  # id(Lazy) -> (dOut, OUT mask source)
         self.lazy_sums: Dict[int, Tuple[Tensor, int]] = {}  # id(Lazy) -> BatchNorm-backward partial sums its ONE writer formed, rows
         self.meta_in: Dict[int, tuple] = {}      # id(Lazy) -> (dgeo, feat, partial sums, rows): MetaKernel modulation fused into the BatchNorm backward
-        self.head_final: Dict[int, tuple] = {}   # id(Lazy) -> (dY of a tower's final conv, its scatter image): input gradient recomputed in the BatchNorm backward
+        self.head_final: Dict[int, tuple] = {}   # id(Lazy) -> (call head, BatchNorm-backward partial sums, rows, dY of the tower's final conv, its scatter image)
         self.producers: Dict[int, "Op"] = {}     # id(block-output Act) -> the CombineOp that made it
         self.bn_of: Dict[int, "Op"] = {}         # id(Lazy) -> its BnOp
         self.raw_grad: Dict[int, Act] = {}       # id(raw Act) -> gradient w.r.t. the raw conv output

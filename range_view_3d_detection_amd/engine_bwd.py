@@ -82,7 +82,8 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
     elif op.need_input_grad and _head_final_eligible(op, t, dout):
         # final 1x1 conv of a head tower behind conv -> BatchNorm -> ReLU: no input-gradient tensor -- the BatchNorm backward of that unit
         # recomputes dA = W^T dY in both of its passes (rv_head_final_bwd_sums / _apply, csrc/headfinal.hip)
-        t.head_final[id(op.x)] = (dout, layer.packed(bwd))
+        _head_final_sums(op, t, dout)
+        return  # (the final conv's weight gradient came out of the same pass)
     elif op.need_input_grad:
         if isinstance(op.x, Lazy):
             dst, accumulate = t.lazy_grad_target(op.x)
@@ -210,9 +211,28 @@ def _head_final_eligible(op: "E.ConvOp", t: Tape, dout: Act) -> bool:
     output of a conv -> BatchNorm (-> ReLU) unit in training mode that nobody else has contributed a gradient to."""
     x, lay = op.x, op.layer
     g = lay.geom
-    return (HEAD_FINAL_FUSE and t.training and op.out_f32 and isinstance(x, Lazy) and x.bn.mean is not None and id(x) not in t.lazy_in
+    return (HEAD_FINAL_FUSE and t.training and op.out_f32 and isinstance(x, Lazy) and x.relu and x.bn.mean is not None and id(x) not in t.lazy_in
             and id(x) not in t.head_final and lay.fwd_form == "gather" and g.kh == 1 and g.kw == 1 and g.stride_w == 1 and lay.in_perm is None
             and pad32(g.cu) == 32 and x.raw.cp % 256 == 0 and x.raw.cp == pad32(g.cv) and dout.ld >= 32 and dout.pixels == x.raw.pixels)
+
+
+def _head_final_sums(op: "E.ConvOp", t: Tape, dY: Act) -> None:
+    """First pass of the fused form: the BatchNorm-backward sums of the unit in front of the final conv (kept on the tape for
+    ``bn_backward_begin``) and the final conv's own weight gradient, from ONE pass over the unit's raw output."""
+    lazy, layer = op.x, op.layer
+    st, raw = lazy.bn, lazy.raw
+    wp = layer.packed("scatter")
+    rows = L.load().rv_head_final_bwd_rows(L.i64(raw.pixels))
+    partial = torch.empty((rows + L.STATS_SCRATCH_ROWS, 2, raw.cp), dtype=torch.float32, device=t.device)
+    dw_partial = torch.empty((rows, 32 * raw.cp), dtype=torch.float32, device=t.device)
+    head = (L.i64(raw.pixels), L.i32(raw.cp), raw.ptr(), L.i32(raw.ld), dY.ptr(), L.i32(dY.ld), L.ptr(wp), L.ptr(st.scale), L.ptr(st.shift),
+            L.ptr(st.mean), L.ptr(st.invstd), L.i32(1))
+    L.call("rv_head_final_bwd_sums", *head, L.ptr(partial), L.ptr(dw_partial), L.stream_ptr())
+    dw = torch.empty((32, raw.cp), dtype=torch.float32, device=t.device)
+    L.call("rv_reduce_rows", L.ptr(dw_partial), L.i32(rows), L.i32(32 * raw.cp), L.ptr(dw), L.stream_ptr())
+    g = layer.geom
+    t.add_param_grad(layer.weight, dw[: g.cu, : g.cv].reshape(g.cu, g.cv, 1, 1))
+    t.head_final[id(lazy)] = (head, partial, rows, dY, wp)
 
 
 def _release_held_wgrads(t: Tape) -> None:
@@ -337,14 +357,8 @@ def bn_backward_begin(op: "E.BnOp", t: Tape):
     hf = t.head_final.pop(id(lazy), None)
     if hf is not None:
         assert id(lazy) not in t.lazy_in, "the last unit of a head tower feeds the final conv only"
-        st, raw = lazy.bn, lazy.raw
-        dY, wp = hf
-        rows = L.load().rv_head_final_bwd_rows(L.i64(raw.pixels))
-        partial = torch.empty((rows + L.STATS_SCRATCH_ROWS, 2, raw.cp), dtype=torch.float32, device=t.device)
-        head = (L.i64(raw.pixels), L.i32(raw.cp), raw.ptr(), L.i32(raw.ld), dY.ptr(), L.i32(dY.ld), L.ptr(wp), L.ptr(st.scale), L.ptr(st.shift),
-                L.ptr(st.mean), L.ptr(st.invstd), L.i32(1 if lazy.relu else 0))
-        L.call("rv_head_final_bwd_sums", *head, L.ptr(partial), L.stream_ptr())
-        return (op, None, partial, rows, raw.pixels, 0, None, ("head_final", head, dY, wp))
+        head, partial, rows, dY, wp = hf  # (the sums were formed with the final conv's weight gradient: _head_final_sums)
+        return (op, None, partial, rows, lazy.raw.pixels, 0, None, ("head_final", head, dY, wp))
     entry = t.lazy_in.pop(id(lazy), None)
     if entry is None:
         return None
