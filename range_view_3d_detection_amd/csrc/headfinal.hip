@@ -18,9 +18,9 @@
 //
 // MFMA as D = W' dY^T (v_mfma_f32_16x16x32: M = 16 channels, N = 16 pixels, K = 32 output channels = ONE K step): a lane then
 // holds pixel l15 and -- with the rows of the four channel tiles of a wave permuted (tile j, row 4g + r <-> channel 16g + 4j + r) --
-// SIXTEEN consecutive channels 16g .. 16g + 15 of that pixel: y is read and dy written as two 16-byte accesses per lane, 128
-// contiguous bytes per pixel and wave, no LDS.  A workgroup is four waves = 256 channels of one pixel range; the ranges are sized
-// for at most 1024 partial rows (rv_bn_bwd_finalize's one-launch form).
+// 4 NT consecutive channels of that pixel (NT tiles per wave): y is read and dy written as one 8 NT-byte access per lane, 32 NT
+// contiguous bytes per pixel and wave, no LDS.  A workgroup covers 256 channels of one pixel range; the ranges are sized for at
+// most 512 partial rows (rv_bn_bwd_finalize's one-launch form takes up to 1024).
 #include "common.h"
 
 namespace {
@@ -39,9 +39,7 @@ struct HeadFinalArgs {
 };
 
 constexpr int kStepPx = 16;
-constexpr int kARow = 64 * 2 + 16;   // wave-private LDS image of the activated tile: 16 pixel rows x 64 channels (+16 B: bank spread)
-constexpr int kDRow = 32 * 2 + 16;   // ... and of the dY tile: 16 pixel rows x 32 output channels
-constexpr int kWaveLds = kStepPx * (kARow + kDRow);
+constexpr int kHfTiles = 2;  // 16-channel tiles per wave (head_final_bwd_kernel's NT)
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 #ifdef RV_OPERAND_F16
@@ -58,60 +56,60 @@ __device__ __forceinline__ s16x4 lds_read_tr(uint32_t addr) {
     return v;
 }
 
-template <bool APPLY>
-__global__ __launch_bounds__(256) void head_final_bwd_kernel(const HeadFinalArgs a) {
-    __shared__ __attribute__((aligned(16))) uint8_t hf_lds[APPLY ? 16 : 4 * kWaveLds];
+// NT: 16-channel MFMA tiles per wave (a lane holds 4 NT consecutive channels of its pixel; a workgroup of 16 / NT waves covers 256
+// channels).  NT = 2: ~110 / ~150 registers (apply / sums) against 164 / 236 at NT = 4 -- the passes are bandwidth-bound and want
+// the extra waves in flight (measured, one-stream trace: sums + dW 205 us at NT = 4).
+template <bool APPLY, int NT>
+__global__ __launch_bounds__(1024 / NT) void head_final_bwd_kernel(const HeadFinalArgs a) {
+    constexpr int CL = 4 * NT;            // channels per lane
+    constexpr int CW = 16 * NT;           // channels per wave
+    constexpr int NW = 16 / NT;           // waves per workgroup
+    constexpr int kARow = CW * 2 + 16;    // wave-private LDS image of the activated tile: 16 pixel rows x CW channels (+16 B: bank spread)
+    constexpr int kDRow = 32 * 2 + 16;    // ... and of the dY tile: 16 pixel rows x 32 output channels
+    constexpr int kWaveLds = kStepPx * (kARow + kDRow);
+    __shared__ __attribute__((aligned(16))) uint8_t hf_lds[APPLY ? 16 : NW * kWaveLds];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
-    const int cb = blockIdx.y * 256 + wave * 64;  // this wave's 64 channels
-    const int c0 = cb + 16 * lg;                  // this lane's 16 channels
+    const int cb = blockIdx.y * 256 + wave * CW;  // this wave's channels
+    const int c0 = cb + CL * lg;                  // this lane's channels
     const int64_t p_begin = (int64_t)blockIdx.x * a.range;
     const int64_t p_end = p_begin + a.range < a.pixels ? p_begin + a.range : a.pixels;
 
-    // A operand: row m of tile j <-> channel cb + 16 (m >> 2) + 4 j + (m & 3); lane (m = l15, k = 8 lg .. 8 lg + 7)
-    bf16x8 wf[4];
+    // A operand: row m of tile j <-> channel cb + CL (m >> 2) + 4 j + (m & 3); lane (m = l15, k = 8 lg .. 8 lg + 7)
+    bf16x8 wf[NT];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) wf[j] = *(const bf16x8*)(a.w + (int64_t)(cb + 16 * (l15 >> 2) + 4 * j + (l15 & 3)) * 32 + 8 * lg);
+    for (int j = 0; j < NT; ++j) wf[j] = *(const bf16x8*)(a.w + (int64_t)(cb + CL * (l15 >> 2) + 4 * j + (l15 & 3)) * 32 + 8 * lg);
 
-    // per-channel constants of this lane's 16 channels (index q = 4 j + r <-> channel c0 + q)
-    float sc[16], sh[16];
+    // per-channel constants of this lane's channels (index q = 4 j + r <-> channel c0 + q)
+    float sc[CL], sh[CL];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        sc[q] = a.scale[c0 + q];
-        sh[q] = a.shift[c0 + q];
+    for (int q = 0; q < CL; ++q) {
+        sc[q] = a.relu ? a.scale[c0 + q] : 0.f;  // (no ReLU behind the BatchNorm: the gate is always open)
+        sh[q] = a.relu ? a.shift[c0 + q] : 1.f;
     }
     // sums:  s0 = sum g, s1 = sum g * y (turned into sum g * xhat = invstd * (s1 - mean * s0) at the end: two constants fewer in the loop)
     // apply: dy = k0 * g + (ca + cb_ * y),  ca = k0 * (c2 * mean * invstd - c1),  cb_ = -k0 * c2 * invstd   [= k0 (g - c1 - xhat c2)]
-    float s0[16], s1[16];
+    float s0[CL], s1[CL], k0v[APPLY ? CL : 1];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
+    for (int q = 0; q < CL; ++q) {
         if (APPLY) {
             const float k0 = a.coef[c0 + q], c1 = a.coef[a.c + c0 + q], c2 = a.coef[2 * a.c + c0 + q];
             const float is = a.invstd[c0 + q], mu = a.mean[c0 + q];
             s0[q] = k0 * (c2 * mu * is - c1);  // ca
             s1[q] = -k0 * c2 * is;             // cb_
-            sh[q] = a.relu ? sh[q] : 1.f;      // (no ReLU behind the BatchNorm: the gate is always open)
-            sc[q] = a.relu ? sc[q] : 0.f;
+            k0v[APPLY ? q : 0] = k0;
         } else {
             s0[q] = 0.f;
             s1[q] = 0.f;
-            sh[q] = a.relu ? sh[q] : 1.f;
-            sc[q] = a.relu ? sc[q] : 0.f;
         }
     }
-    float k0v[APPLY ? 16 : 1];
-    if (APPLY) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) k0v[q] = a.coef[c0 + q];
-    }
 
-    auto load = [&](int64_t p0, u32x4& ya, u32x4& yb, bf16x8& df) {
+    typedef __attribute__((ext_vector_type(2 * NT))) uint32_t ypack_t;  // 4 NT bf16 of one pixel
+    auto load = [&](int64_t p0, ypack_t& yv, bf16x8& df) {
         int64_t p = p0 + l15;
         const bool ok = p < p_end;
         p = ok ? p : p_end - 1;  // (clamped: the loads stay inside the tensors; the fragment is zeroed instead)
-        const bf16_t* yp = a.y + p * a.ld_y + c0;
-        ya = *(const u32x4*)yp;
-        yb = *(const u32x4*)(yp + 8);
+        yv = *(const ypack_t*)(a.y + p * a.ld_y + c0);
         df = *(const bf16x8*)(a.dY + p * a.ld_dy + 8 * lg);
         if (!ok) {
 #pragma unroll
@@ -119,9 +117,9 @@ __global__ __launch_bounds__(256) void head_final_bwd_kernel(const HeadFinalArgs
         }
     };
 
-    // weight gradient of the final conv (sums pass): D[o][c] over 2 x 4 tiles of 16 x 16; lane holds rows o = 4 lg + r, column c = l15
+    // weight gradient of the final conv (sums pass): D[o][c] over 2 x NT tiles of 16 x 16; lane holds rows o = 4 lg + r, column c = l15
     const bool with_dw = !APPLY && a.dw_partial != nullptr;
-    f32x4 dw[APPLY ? 1 : 2][APPLY ? 1 : 4];
+    f32x4 dw[APPLY ? 1 : 2][APPLY ? 1 : NT];
     uint8_t* my_lds = hf_lds + (APPLY ? 0 : wave * kWaveLds);
     const uint32_t lds_a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)my_lds;
     const uint32_t lds_d = lds_a + kStepPx * kARow;
@@ -130,40 +128,34 @@ __global__ __launch_bounds__(256) void head_final_bwd_kernel(const HeadFinalArgs
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) dw[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NT; ++j) dw[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    u32x4 ya, yb, na, nb;
+    ypack_t yv, nv;
     bf16x8 df, nf;
-    if (p_begin < p_end) load(p_begin, ya, yb, df);
+    if (p_begin < p_end) load(p_begin, yv, df);
     for (int64_t p0 = p_begin; p0 < p_end; p0 += kStepPx) {
-        if (p0 + kStepPx < p_end) load(p0 + kStepPx, na, nb, nf);  // the next step's operands in flight under this step's arithmetic
-        f32x4 acc[4];
+        if (p0 + kStepPx < p_end) load(p0 + kStepPx, nv, nf);  // the next step's operands in flight under this step's arithmetic
+        f32x4 acc[NT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = RV_MFMA_16x16x32(wf[j], df, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        u32x4 oa, ob;
+        for (int j = 0; j < NT; ++j) acc[j] = RV_MFMA_16x16x32(wf[j], df, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        ypack_t ov;
         if (!APPLY && with_dw) *(bf16x8*)(my_lds + kStepPx * kARow + l15 * kDRow + 16 * lg) = df;  // dY tile [pixel l15][o = 8 lg ..]
 #pragma unroll
-        for (int q = 0; q < 16; q += 2) {
+        for (int q = 0; q < CL; q += 2) {
             // channels c0 + q, c0 + q + 1: one packed word of y; accumulator registers (tile q / 4, row q % 4)
-            const uint32_t yw = q < 8 ? ya[q >> 1] : yb[(q - 8) >> 1];
+            const uint32_t yw = yv[q >> 1];
             const float y0 = bf_lo(yw), y1 = bf_hi(yw);
             float g0 = acc[q >> 2][q & 3], g1 = acc[(q + 1) >> 2][(q + 1) & 3];
             const float t0 = y0 * sc[q] + sh[q], t1 = y1 * sc[q + 1] + sh[q + 1];
             g0 = t0 > 0.f ? g0 : 0.f;
             g1 = t1 > 0.f ? g1 : 0.f;
-            if (!APPLY) {  // the activated operand of the final conv (relu: scale, shift as given; no relu: the gate constants above are not a)
-                const uint32_t o = pack_bf2(fmaxf(t0, 0.f), fmaxf(t1, 0.f));
-                if (q < 8) oa[q >> 1] = o;
-                else ob[(q - 8) >> 1] = o;
-            }
             if (APPLY) {
                 const float d0 = k0v[APPLY ? q : 0] * g0 + (s1[q] * y0 + s0[q]);
                 const float d1 = k0v[APPLY ? q + 1 : 0] * g1 + (s1[q + 1] * y1 + s0[q + 1]);
-                const uint32_t o = pack_bf2(d0, d1);
-                if (q < 8) oa[q >> 1] = o;
-                else ob[(q - 8) >> 1] = o;
+                ov[q >> 1] = pack_bf2(d0, d1);
             } else {
+                ov[q >> 1] = pack_bf2(fmaxf(t0, 0.f), fmaxf(t1, 0.f));  // the activated operand of the final conv (weight gradient)
                 s0[q] += g0;
                 s0[q + 1] += g1;
                 s1[q] += g0 * y0;
@@ -172,44 +164,41 @@ __global__ __launch_bounds__(256) void head_final_bwd_kernel(const HeadFinalArgs
         }
         if (APPLY) {
             const int64_t p = p0 + l15;
-            if (p < p_end) {
-                bf16_t* op = a.dy + p * a.ld_out + c0;
-                *(u32x4*)op = oa;
-                *(u32x4*)(op + 8) = ob;
-            }
+            if (p < p_end) *(ypack_t*)(a.dy + p * a.ld_out + c0) = ov;
         } else if (with_dw) {
-            // activated tile [pixel l15][channels 16 lg .. 16 lg + 15] -> LDS, then both operands back transposed (K = pixel)
-            *(u32x4*)(my_lds + l15 * kARow + 32 * lg) = oa;
-            *(u32x4*)(my_lds + l15 * kARow + 32 * lg + 16) = ob;
-            s16x4 fo[2], fc[4];
+            // activated tile [pixel l15][channels CL lg .. CL lg + CL - 1] -> LDS, then both operands back transposed (K = pixel)
+            *(ypack_t*)(my_lds + l15 * kARow + 2 * CL * lg) = ov;
+            s16x4 fo[2], fc[NT];
 #pragma unroll
             for (int i = 0; i < 2; ++i) fo[i] = lds_read_tr(lds_d + (4 * lg + tq) * kDRow + (16 * i + 4 * tp) * 2);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fc[j] = lds_read_tr(lds_a + (4 * lg + tq) * kARow + (16 * j + 4 * tp) * 2);
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fo[0]), "+v"(fo[1]), "+v"(fc[0]), "+v"(fc[1]), "+v"(fc[2]), "+v"(fc[3])::"memory");
+            for (int j = 0; j < NT; ++j) fc[j] = lds_read_tr(lds_a + (4 * lg + tq) * kARow + (16 * j + 4 * tp) * 2);
+            if constexpr (NT == 4)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fo[0]), "+v"(fo[1]), "+v"(fc[0]), "+v"(fc[1]), "+v"(fc[NT - 2]), "+v"(fc[NT - 1])::"memory");
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fo[0]), "+v"(fo[1]), "+v"(fc[0]), "+v"(fc[NT - 1])::"memory");
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) dw[APPLY ? 0 : i][APPLY ? 0 : j] = RV_MFMA_16x16x16(fo[i], fc[j], dw[APPLY ? 0 : i][APPLY ? 0 : j]);
+                for (int j = 0; j < NT; ++j) dw[APPLY ? 0 : i][APPLY ? 0 : j] = RV_MFMA_16x16x16(fo[i], fc[j], dw[APPLY ? 0 : i][APPLY ? 0 : j]);
         }
-        ya = na;
-        yb = nb;
+        yv = nv;
         df = nf;
     }
     if (!APPLY && with_dw) {
-        // dw[i][j][r]: output channel o = 16 i + 4 lg + r, tower channel cb + 16 j + l15
+        // dw[i][j][r]: output channel o = 16 i + 4 lg + r; column l15 of tile j = the tile's 16 consecutive channels cb + 16 j + l15
         float* dwr = a.dw_partial + (int64_t)blockIdx.x * 32 * a.c;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dwr[(int64_t)(16 * i + 4 * lg + r) * a.c + cb + 16 * j + l15] = dw[APPLY ? 0 : i][APPLY ? 0 : j][r];
     }
     if (!APPLY) {
         // lanes with the same lg hold the same channels (sixteen pixels apart): sum over l15, then lane l15 == 0 of each group writes
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
+        for (int q = 0; q < CL; ++q) {
 #pragma unroll
             for (int d = 1; d < 16; d <<= 1) {
                 s0[q] += __shfl_xor(s0[q], d, 64);
@@ -219,7 +208,7 @@ __global__ __launch_bounds__(256) void head_final_bwd_kernel(const HeadFinalArgs
         if (l15 == 0) {
             float* row = a.partial + (int64_t)blockIdx.x * 2 * a.c;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
+            for (int q = 0; q < CL; ++q) {
                 const float is = a.invstd[c0 + q], mu = a.mean[c0 + q];
                 row[c0 + q] = s0[q];
                 row[a.c + c0 + q] = is * (s1[q] - mu * s0[q]);
@@ -275,7 +264,7 @@ int rv_head_final_bwd_sums(int64_t pixels, int32_t c, const void* y, int32_t ld_
     RV_REQUIRE(partial, "rv_head_final_bwd_sums: null partial buffer");
     a.partial = partial;
     a.dw_partial = dw_partial;
-    hipLaunchKernelGGL(head_final_bwd_kernel<false>, dim3(rv_head_final_bwd_rows(pixels), c / 256), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((head_final_bwd_kernel<false, kHfTiles>), dim3(rv_head_final_bwd_rows(pixels), c / 256), dim3(1024 / kHfTiles), 0, (hipStream_t)stream, a);
     RV_CHECK_LAUNCH("head_final_bwd_kernel<sums>");
     return 0;
 }
@@ -289,7 +278,7 @@ int rv_head_final_bwd_apply(int64_t pixels, int32_t c, const void* y, int32_t ld
     a.coef = coef;
     a.dy = (bf16_t*)dy;
     a.ld_out = ld_out;
-    hipLaunchKernelGGL(head_final_bwd_kernel<true>, dim3(rv_head_final_bwd_rows(pixels), c / 256), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((head_final_bwd_kernel<true, kHfTiles>), dim3(rv_head_final_bwd_rows(pixels), c / 256), dim3(1024 / kHfTiles), 0, (hipStream_t)stream, a);
     RV_CHECK_LAUNCH("head_final_bwd_kernel<apply>");
     return 0;
 }
