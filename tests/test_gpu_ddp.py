@@ -38,6 +38,23 @@ def test_two_ranks_sync_bn():
     assert "cpu_baseline" not in j  # rank 0 at N = 1 only
 
 
+def test_two_ranks_as_the_driver_launches_them():
+    """The driver's own N > 1 form -- ``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`` -- still works beside the
+    self-launching one: the ranks see WORLD_SIZE == --gpus and do not launch anything themselves; a mismatch is refused (exit 2)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(RV3D_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29633",
+            os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--widths", "c32", "--width", "512", "--height", "16", "--batch", "2",
+            "--classes", "5", "--no-cpu-baseline"]
+    out = subprocess.run(base + ["--gpus", "2"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "[bench launcher]" not in out.stderr
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 4
+    bad = subprocess.run(base + ["--gpus", "4"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and "WORLD_SIZE=2" in bad.stderr
+
+
 def test_two_ranks_grad_sync_equals_ddp():
     """bench.py's default gradient averaging (engine.GradSync: one flat buffer, one multi-tensor copy and one asynchronous
     all-reduce per finished autograd node) against torch's DistributedDataParallel (RV3D_DDP=1) on the same two-rank run: the
