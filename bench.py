@@ -16,12 +16,16 @@ BatchNorm statistics all-reduced (SyncBN as in conf/trainer/train.yaml:15).
 
 Rank 0 prints ONE JSON line (contract in the task statement) including
   "roofline":     the dominant kernel (tapconv6: 512-pixel x 128-channel-tile bf16 MFMA tap-conv with the input halo resident in LDS)
-                  against the dense bf16 MFMA peak: HIP events around each of its launches with the weight-gradient side stream
-                  off (the kernel's own duration, what rocprofv3 --kernel-trace reports too); `live` = the same events inside the
-                  timed region, where a backward-data launch is often queued behind a weight gradient of the second stream;
-                  `traffic` = its HBM-side bytes per launch from this round's PMC passes (profiles/), `algorithmic_bytes`
-                  = operands once in + result once out per launch (SURVEY 8d);
-  "whole_step":   3 x the model's forward FLOPs (BASELINE.md section 2) over the step time, against the same peak;
+                  against the dense bf16 MFMA peak.  `achieved` / `frac` / `avg_launch_us`: HIP events around each of its launches INSIDE
+                  the timed region, on the stream it runs on -- the configuration that produced ms_per_step, where a backward-data launch
+                  is often queued behind a weight gradient of the second stream; `isolated`: the same events in two extra steps with the
+                  side stream off (the kernel's own duration); `traffic` = its HBM-side bytes per launch from this round's PMC passes
+                  (profiles/), `algorithmic_bytes` = operands once in + result once out per launch (SURVEY 8d);
+  "roofline_hbm": the HBM-bound kernel group (BatchNorm backward, element-wise block passes, MetaKernel stem, head-final passes) against
+                  8 TB/s: events around each of its launches in the timed configuration (`isolated`: side stream off), algorithmic bytes
+                  from the C-ABI arguments, HBM-side traffic from the same PMC passes;
+  "whole_step":   3 x the model's forward FLOPs over the step time, against the same peak; `traffic_ratio` =
+                  HBM-side bytes of ALL kernels per step (PMC passes) over the algorithmic bytes of the step;
   "loss_first_step": the loss of the seed-0 model on sweep 0 of the seed-1234 batch before any update (one reproducible number;
                   tests/test_gpu_fullsize_train.py compares it with the fp32 oracle);
   "kernels" / "kernels_isolated": per-kernel event timings inside the timed region / with nothing else on the GPU;
