@@ -1040,13 +1040,13 @@ extern "C" int rv_bn_bwd_finalize(const float* partial, int32_t rows, int32_t c,
     RV_REQUIRE(partial && gamma && invstd && coef, "rv_bn_bwd_finalize: null argument");
     RV_REQUIRE(count > 0 || (count < 0 && rows == 1), "rv_bn_bwd_finalize: a device-side count (count < 0) needs the single row of all-reduced totals");
     const float* count_dev = count < 0 ? partial + 2 * c : nullptr;
-    if (rows <= 1024) {
+    if (rows <= 2048) {
         hipLaunchKernelGGL(bn_bwd_reduce_finalize_kernel, dim3(rv_ceil_div(c, 16)), dim3(256), 0, (hipStream_t)stream, partial, rows, c,
                            1.0 / (double)count, gamma, invstd, dgamma, dbeta, accumulate, coef, count_dev);
         RV_CHECK_LAUNCH("bn_bwd_reduce_finalize_kernel");
         return 0;
     }
-    RV_REQUIRE(count > 0, "rv_bn_bwd_finalize: the two-stage path (> 1024 rows) takes a host-side count only");
+    RV_REQUIRE(count > 0, "rv_bn_bwd_finalize: the two-stage path (> 2048 rows) takes a host-side count only");
     double* scratch = (double*)(partial + (int64_t)rows * 2 * c);
     int groups;
     if (rv_col_reduce(partial, rows, 2 * c, scratch, &groups, (hipStream_t)stream)) return 1;

@@ -518,14 +518,14 @@ extern "C" int rv_bn_finalize(const float* partial, int32_t rows, int32_t c, int
     const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
     // few partial rows: one launch reduces and finalises; many (4096 rows behind a 512-channel tapconv4 launch): the
     // 64-group column reduction spreads them over the chip first (29 us vs 14 us measured for the single launch)
-    if (rows <= 1024) {
+    if (rows <= 2048) {
         hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3(rv_ceil_div(c, 16)), dim3(256), 0, (hipStream_t)stream, partial, rows, c,
                            1.0 / (double)count, unbias, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, invstd,
                            count_dev);
         RV_CHECK_LAUNCH("bn_reduce_finalize_kernel");
         return 0;
     }
-    RV_REQUIRE(count > 0, "rv_bn_finalize: the two-stage path (> 1024 rows) takes a host-side count only");
+    RV_REQUIRE(count > 0, "rv_bn_finalize: the two-stage path (> 2048 rows) takes a host-side count only");
     double* scratch = (double*)(partial + (int64_t)rows * 2 * c);
     int groups;
     if (rv_col_reduce(partial, rows, 2 * c, scratch, &groups, (hipStream_t)stream)) return 1;

@@ -56,8 +56,9 @@ int rv_build_tap_table(const rvTapGeom* g, bool scatter, TapTable* tt, int* phas
 bool rv_tapconv2_plan(TapConvArgs* a, int* grid_x, int* grid_y, size_t* lds, int* ks);
 int rv_tapconv2_launch(const TapConvArgs& a, int grid_x, int grid_y, size_t lds, int ks, hipStream_t stream);
 
-// fourth-generation kernel (tapconv4.hip): 256 x 256 tiles, LDS-DMA staging, counted waits; stats rows = 2 * tiles
-bool rv_tapconv4_plan(TapConvArgs* a, int* tiles, size_t* lds, int* bn);
+// fourth-generation kernel (tapconv4.hip): 256 x 256 tiles, LDS-DMA staging, counted waits; *stats_rows = rows of the partial-statistics
+// buffer (2 per group of workgroups that share a pixel tile when the launch is persistent, else 2 per tile)
+bool rv_tapconv4_plan(TapConvArgs* a, int* tiles, size_t* lds, int* bn, int* stats_rows);
 int rv_tapconv4_launch(const TapConvArgs& a, size_t lds, int bn, hipStream_t stream);
 
 // fifth-generation kernel (tapconv5.hip): 256 x 256 tiles with the input halo of a channel chunk resident in LDS for all

@@ -498,11 +498,11 @@ static int tap_launch(const rvTapGeom* g, const rvTapShape* s, bool scatter, con
     }
     // 256 x 256 (or x 128) tiles streamed by LDS-DMA, counted waits (tapconv4.hip); plain bf16 inputs only
     {
-        int tiles, bn;
+        int tiles, bn, srows;
         size_t lds4;
         TapConvArgs a4 = a;
-        if (rv_tapconv4_plan(&a4, &tiles, &lds4, &bn)) {
-            if (stats_rows) *stats_rows = tiles * 2;
+        if (rv_tapconv4_plan(&a4, &tiles, &lds4, &bn, &srows)) {
+            if (stats_rows) *stats_rows = srows;
             if (info) {
                 info[0] = 4;
                 info[1] = bn;

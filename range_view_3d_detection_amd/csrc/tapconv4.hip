@@ -47,6 +47,12 @@ struct Staged {   // the K tile a piece belongs to
     uint32_t vb;  // validity of the thread's four tile rows under this tap
 };
 
+// byte offset of the per-workgroup statistic accumulators in dynamic LDS (see the kernel)
+constexpr int stat_acc_offset(int bn) {
+    const int tab_end = (bn == 256 ? kTabOffset : 9 * kPiece) + 256, epi_end = kTR * kTC * (bn + 8) * 2;
+    return ((tab_end > epi_end ? tab_end : epi_end) + 15) & ~15;
+}
+
 // BN: channels per workgroup tile, 256 (two 16 KB weight pieces per K tile) or 128 (one).  ACC: the launch accumulates into dst
 // (RV_OUT_ACCUM) -- a template parameter so that only that instance carries the prefetch registers of the old values.
 template <int BN, bool ACC>
@@ -62,6 +68,20 @@ __global__ __launch_bounds__(512, 2) void tapconv4_kernel(const TapConvArgs a) {
     // per tile: the per-workgroup dispatch is a large share of a tile's life here)
     const int gy = a.n_tiles;
     const int vtotal = 8 * a.tiles_per_xcd * gy;
+    // RV_OUT_STATS of a persistent launch (stats_per_wg, as in tapconv6.hip): the (sum, sum of squares) rows of a workgroup's tiles are
+    // accumulated in LDS and written once at the end -- 2 rows per group of gy workgroups instead of 2 per tile (4096 rows behind a 1x1
+    // layer at 4 x 64 x 2048: the finalize then needs its two-stage column reduction; <= 2048 rows take the one-launch form).
+    // behind the tap table AND behind the staged output tile of the epilogue (which overwrites the buffers from offset 0): float [8 waves][NJ][16 channels][2]
+    constexpr int kStatAcc = stat_acc_offset(BN);
+    auto stat_slot = [&]() { return (float*)(smem + kStatAcc) + (wave * NJ * 16 + l15) * 2; };  // + j * 32
+    if (a.stats_per_wg && lg == 0) {
+        float* stat_acc = stat_slot();
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            stat_acc[j * 32] = 0.f;
+            stat_acc[j * 32 + 1] = 0.f;
+        }
+    }
     for (int vb = blockIdx.x; vb < vtotal; vb += gridDim.x) {
     const int xcd = vb & 7, xslot = vb >> 3;
     const int tile = xcd * a.tiles_per_xcd + xslot / gy;
@@ -302,8 +322,14 @@ __global__ __launch_bounds__(512, 2) void tapconv4_kernel(const TapConvArgs a) {
             q += __shfl_xor(q, 32, 64);
             const int c = n0 + wc * WN + j * 16 + l15;
             if (lg == 0) {
-                prow[c] = s;
-                prow[a.C_dst + c] = q;
+                if (a.stats_per_wg) {
+                    float* stat_acc = stat_slot();
+                    stat_acc[j * 32] += s;
+                    stat_acc[j * 32 + 1] += q;
+                } else {
+                    prow[c] = s;
+                    prow[a.C_dst + c] = q;
+                }
             }
         }
     }
@@ -370,6 +396,19 @@ __global__ __launch_bounds__(512, 2) void tapconv4_kernel(const TapConvArgs a) {
     }
     __syncthreads();  // the staged output of this tile is dead before the next tile's loads land in LDS
     }  // persistent tile loop
+    if ((a.flags & RV_OUT_STATS) && a.stats_per_wg && lg == 0) {
+        // (gridDim.x / 8 is a multiple of gy, checked by the host: the channel tile of a workgroup is the same for all of its tiles, and the
+        //  gy workgroups with the same wslot / gy of one XCD fill one row group between them -- workgroups without a tile write zeros)
+        const int xcd = blockIdx.x & 7, wslot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+        float* prow = a.stats + ((int64_t)((xcd * (nslots / gy) + wslot / gy) * 2 + wr) * 2) * a.C_dst;
+        const float* stat_acc = stat_slot();
+        const int c0 = (wslot % gy) * BN + wc * (BN / 4) + l15;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            prow[c0 + j * 16] = stat_acc[j * 32];
+            prow[a.C_dst + c0 + j * 16] = stat_acc[j * 32 + 1];
+        }
+    }
 }
 
 }  // namespace
@@ -380,7 +419,13 @@ __global__ __launch_bounds__(512, 2) void tapconv4_kernel(const TapConvArgs a) {
 // parity tests run the production kernels on crops the CPU oracle can afford.
 
 // returns false when the layer is not eligible (caller falls back to tapconv3 / tapconv2 / the generic kernel)
-bool rv_tapconv4_plan(TapConvArgs* a, int* tiles, size_t* lds, int* bn) {
+static int tapconv4_grid(const TapConvArgs& a) {
+    int grid = 8 * a.tiles_per_xcd * a.n_tiles;
+    if (grid > rv_cu_count()) grid = rv_cu_count() & ~7;  // persistent: one workgroup per CU
+    return grid;
+}
+
+bool rv_tapconv4_plan(TapConvArgs* a, int* tiles, size_t* lds, int* bn, int* stats_rows) {
     if (a->step != 1) return false;
     if (a->flags & (RV_IN_AFFINE | RV_IN_RELU | RV_OUT_F32)) return false;  // the DMA path has no register prologue
     if (a->C_src % kBK != 0 || a->C_dst % 128 != 0) return false;
@@ -396,9 +441,12 @@ bool rv_tapconv4_plan(TapConvArgs* a, int* tiles, size_t* lds, int* bn) {
     a->n_tiles = a->C_dst / BN;
     a->tiles_per_xcd = rv_ceil_div(a->total_tiles, 8);
     if ((int64_t)a->total_tiles * a->n_tiles < ((a->sel & RV_SEL_SMALL_GRIDS) ? 1 : rv_cu_count())) return false;  // too few tiles to fill the chip
-    *tiles = a->total_tiles;  // stats rows = 2 * tiles
+    *tiles = a->total_tiles;
     *bn = BN;
-    *lds = (size_t)(BN == 256 ? kTabOffset : 9 * kPiece) + 256;
+    const int grid = tapconv4_grid(*a), nslots = grid / 8;
+    a->stats_per_wg = (grid < 8 * a->tiles_per_xcd * a->n_tiles && nslots % a->n_tiles == 0) ? 1 : 0;  // persistent, channel tile fixed per workgroup
+    *stats_rows = a->stats_per_wg ? (grid / a->n_tiles) * 2 : a->total_tiles * 2;
+    *lds = (size_t)stat_acc_offset(BN) + 8 * 4 * 16 * 2 * sizeof(float);
     const size_t epi = (size_t)kTR * kTC * (BN + 8) * sizeof(bf16_t);
     if (*lds < epi) *lds = epi;
     return true;
@@ -413,8 +461,7 @@ int rv_tapconv4_launch(const TapConvArgs& a, size_t lds, int bn, hipStream_t str
         (void)hipFuncSetAttribute((const void*)tapconv4_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    int grid = 8 * a.tiles_per_xcd * a.n_tiles;
-    if (grid > rv_cu_count()) grid = rv_cu_count() & ~7;  // persistent: one workgroup per CU
+    const int grid = tapconv4_grid(a);
     const bool acc = (a.flags & RV_OUT_ACCUM) != 0;
     if (bn == 256) {
         if (acc) hipLaunchKernelGGL((tapconv4_kernel<256, true>), dim3(grid), dim3(512), lds, stream, a);
