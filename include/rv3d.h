@@ -201,12 +201,6 @@ int rv_tap_wgrad_info(const rvTapGeom* g, const rvTapShape* s, int32_t* host_inf
 int rv_tap_wgrad(const rvTapGeom* g, const rvTapShape* s, const void* U, int32_t ld_u, const void* V, int32_t ld_v,
                  const float* in_scale, const float* in_shift, int32_t v_affine, float* dT_packed,
                  void* workspace, rvStream stream);
-/* rv_tap_wgrad with RV_WGRAD_NO_REDUCE in s->flags fills the split-K slabs only; rv_tap_wgrad_reduce (same g, s -- the flag may stay set --
- * same workspace) then sums them in slab order into dT_packed, on a stream of the caller's choice ordered behind the weight-gradient
- * launch: the training engine runs it on a third stream so that the next layer's persistent weight gradient starts at once instead of
- * behind this ~10 us launch and its two kernel boundaries (the result is the same bit for bit). */
-#define RV_WGRAD_NO_REDUCE 512
-int rv_tap_wgrad_reduce(const rvTapGeom* g, const rvTapShape* s, const void* workspace, float* dT_packed, rvStream stream);
 
 /* ---------------------------------------------------------------------------------------
  * BatchNorm2d (nn.BatchNorm2d train/eval; nn/blocks/__init__.py:41,51,63,158; torchvision

@@ -24,7 +24,6 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "rv3d.h")
 IN_AFFINE, IN_RELU, OUT_F32, OUT_BIAS, OUT_STATS, OUT_ACCUM, OUT_RELU = 1, 2, 4, 8, 16, 32, 64
 OUT_RES_RELU = 256
 WGRAD_TORCH_LAYOUT = 128  # rv_tap_wgrad: result in dT[cu][cv][kh][kw] (no unpack pass)
-WGRAD_NO_REDUCE = 512  # rv_tap_wgrad: slabs only; rv_tap_wgrad_reduce sums them (on another stream)
 # kernel-selection hints (rvTapShape.flags, per call: the library keeps no mutable state).  SELECT is OR-ed into every TapShape
 # built while a `select(...)` block is active -- the parity tests' way of running the production kernels on crops / pinning a generation.
 SEL_SMALL_GRIDS, SEL_SMALL_GRIDS6, SEL_NO_GEN6, SEL_NO_GEN5 = 1 << 20, 1 << 21, 1 << 22, 1 << 23

@@ -903,7 +903,7 @@ extern "C" int rv_tap_wgrad(const rvTapGeom* g, const rvTapShape* s, const void*
         b.left_m = p.left_m;
         b.tiles_u = p.tiles_u;
         b.tiles_v = p.tiles_v;
-        b.flags = s->flags & ~(RV_WGRAD_TORCH_LAYOUT | RV_WGRAD_NO_REDUCE | RV_SEL_MASK);
+        b.flags = s->flags & ~(RV_WGRAD_TORCH_LAYOUT | RV_SEL_MASK);
         b.v_affine = v_affine;
         b.xcd_remap = 1;
         int gi = 0;
@@ -932,7 +932,6 @@ extern "C" int rv_tap_wgrad(const rvTapGeom* g, const rvTapShape* s, const void*
             hipLaunchKernelGGL(wgrad2_kernel, dim3(grid2), dim3(512), 0, st2, b);
             RV_CHECK_LAUNCH("wgrad2_kernel");
         }
-        if (s->flags & RV_WGRAD_NO_REDUCE) return 0;  // (the caller sums the slabs itself: rv_tap_wgrad_reduce, on a stream of its choice)
         const int rb2 = (int)((p.elems / 4 + 255) / 256 < 4096 ? (p.elems / 4 + 255) / 256 : 4096);
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb2), dim3(256), 0, st2, (const float*)workspace, p.ksplit, p.elems, dT_packed, up);
         RV_CHECK_LAUNCH("wgrad_reduce_kernel");
@@ -960,7 +959,7 @@ extern "C" int rv_tap_wgrad(const rvTapGeom* g, const rvTapShape* s, const void*
     a.k_per_split = p.k_per_split;
     a.tiles_u = p.tiles_u;
     a.tiles_v = p.tiles_v;
-    a.flags = s->flags & ~(RV_WGRAD_TORCH_LAYOUT | RV_WGRAD_NO_REDUCE | RV_SEL_MASK);
+    a.flags = s->flags & ~(RV_WGRAD_TORCH_LAYOUT | RV_SEL_MASK);
     a.v_affine = v_affine;
     for (int ky = 0; ky < g->kh; ++ky)
         for (int kx = 0; kx < g->kw; ++kx) {
@@ -971,26 +970,8 @@ extern "C" int rv_tap_wgrad(const rvTapGeom* g, const rvTapShape* s, const void*
     const int grid = p.tiles_v * p.tiles_u * p.taps * p.ksplit;
     hipLaunchKernelGGL(wgrad_kernel, dim3(grid), dim3(256), 0, st, a);
     RV_CHECK_LAUNCH("wgrad_kernel");
-    if (s->flags & RV_WGRAD_NO_REDUCE) return 0;
     const int rb = (int)((p.elems / 4 + 255) / 256 < 4096 ? (p.elems / 4 + 255) / 256 : 4096);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, st, (const float*)workspace, p.ksplit, p.elems, dT_packed, up);
-    RV_CHECK_LAUNCH("wgrad_reduce_kernel");
-    return 0;
-}
-
-extern "C" int rv_tap_wgrad_reduce(const rvTapGeom* g, const rvTapShape* s, const void* workspace, float* dT_packed, rvStream stream) {
-    RV_REQUIRE(g && s && workspace && dT_packed, "rv_tap_wgrad_reduce: null argument");
-    WgradPlan p;
-    plan(g, s, &p);
-    UnpackTo up;
-    up.on = (s->flags & RV_WGRAD_TORCH_LAYOUT) ? 1 : 0;
-    up.cu = g->cu;
-    up.cv = g->cv;
-    up.cu_pad = rv_pad32(g->cu);
-    up.cv_pad = rv_pad32(g->cv);
-    up.taps = g->kh * g->kw;
-    const int rb = (int)((p.elems / 4 + 255) / 256 < 4096 ? (p.elems / 4 + 255) / 256 : 4096);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, p.ksplit, p.elems, dT_packed, up);
     RV_CHECK_LAUNCH("wgrad_reduce_kernel");
     return 0;
 }

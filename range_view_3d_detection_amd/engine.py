@@ -173,21 +173,6 @@ def side_stream(device) -> "torch.cuda.Stream":
 #  (rv-waymo), three interleaved rounds on one box -- the write-out beside a power-capped conv costs more than it hides.)
 
 
-# The split-K reduction of a weight gradient (~10 us) on a THIRD stream: on the side stream it sits between two persistent wgrad3
-# launches, and wherever the main stream has no MFMA kernel running at that moment (the tail of the towers' backward, the backbone's
-# small stages) every transition wgrad3 -> reduce -> wgrad3 costs ~38 us instead of one ~8 us boundary (profiles/r05_step_kernels.txt).
-# The reduction's register budget fits beside a resident wgrad3 workgroup (not beside tapconv6: there it simply waits, off the side stream).
-REDUCE_STREAM = True  # (module attribute; profiles/tools/ab_attr.py engine.REDUCE_STREAM=True,False)
-_REDUCE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
-
-
-def reduce_stream(device) -> "torch.cuda.Stream":
-    idx = torch.device(device).index or 0
-    if idx not in _REDUCE_STREAMS:
-        _REDUCE_STREAMS[idx] = torch.cuda.Stream(device=device, priority=-1)
-    return _REDUCE_STREAMS[idx]
-
-
 def _launch(name: str, flops: float, fn, nbytes: float = 0.0) -> None:
     if PROFILE is not None:
         PROFILE.launch(name, flops, fn, nbytes)
@@ -775,7 +760,6 @@ class Tape:
         self._param_grads: Dict[int, Tensor] = {}  # id(param) -> fp32 gradient (read through `param_grads`)
         self.params: Dict[int, nn.Parameter] = {}
         self.used_side_stream = False
-        self.used_reduce_stream = False
         self.chained_wgrad = None  # (RV3D_OVERLAP=chain) event behind the last big weight gradient on the side stream
         self.held_wgrads: List = []  # weight-gradient launches held back for a SyncBN all-reduce (engine_bwd._release_held_wgrads)
         self.bn_counters: List[Tensor] = []
@@ -886,8 +870,6 @@ class Tape:
         engine_bwd._release_held_wgrads(self)
         if self.used_side_stream:  # parameter gradients (and the buffers the side stream read) are final after this
             torch.cuda.current_stream().wait_stream(side_stream(self.device))
-            if self.used_reduce_stream:
-                torch.cuda.current_stream().wait_stream(reduce_stream(self.device))
 
 
 class Op:

@@ -167,35 +167,15 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
         if os.environ.get("RV3D_PROFILE_SHAPES"):
             wname += f" k{g.kh}x{g.kw}s{g.stride_w} {g.cu}<->{g.cv} {wshape.N}x{wshape.H}x{wshape.Wu}"
         # the split-K reduction (one small launch behind the kernel) writes the torch layout dT[cu][cv][kh][kw] itself
-        # (RV_WGRAD_TORCH_LAYOUT): no unpack pass.  On the side stream the reduction goes to a THIRD stream (engine.REDUCE_STREAM).
-        cur = torch.cuda.current_stream()
-        third = E.reduce_stream(t.device) if (E.REDUCE_STREAM and cur == E.side_stream(t.device)) else None
-        wsh_run = wsh if third is None else L.TapShape(wsh.N, wsh.H, wsh.Wu, wsh.Wv, wsh.ld_src, wsh.ld_dst, wsh.flags | L.WGRAD_NO_REDUCE)
+        # (RV_WGRAD_TORCH_LAYOUT): no unpack pass
         E._launch(wname, E.tap_flops(g, wshape),
-                  lambda: L.call("rv_tap_wgrad", ctypes.byref(wg), ctypes.byref(wsh_run), u.ptr(), L.i32(u.ld), v.ptr(), L.i32(ld_v),
+                  lambda: L.call("rv_tap_wgrad", ctypes.byref(wg), ctypes.byref(wsh), u.ptr(), L.i32(u.ld), v.ptr(), L.i32(ld_v),
                                  L.ptr(sc), L.ptr(sh), L.i32(v_affine), L.ptr(grad), L.ptr(ws), L.stream_ptr()),
                   E.tap_bytes(g, wshape, wgrad=True))
-
-        def finish() -> None:
-            nonlocal grad
-            if third is not None:
-                L.call("rv_tap_wgrad_reduce", ctypes.byref(wg), ctypes.byref(wsh_run), L.ptr(ws), L.ptr(grad), L.stream_ptr())
-            if wg is not g:
-                folded, grad = grad, torch.empty((g.cu, g.cv, g.kh, g.kw), dtype=torch.float32, device=t.device)
-                L.call("rv_unfold_weight_grad", ctypes.byref(g), L.ptr(folded), L.ptr(grad), L.i32(0), L.stream_ptr())
-            t.add_param_grad(layer.weight, layer.unpermute_grad(grad))
-
-        if third is None:
-            finish()
-        else:
-            done = torch.cuda.Event()
-            done.record(cur)  # the slabs are complete at this point of the side stream
-            third.wait_event(done)
-            ws.record_stream(third)    # (allocated under the side stream's context, read / written on the third)
-            grad.record_stream(third)
-            with torch.cuda.stream(third):
-                finish()
-            t.used_reduce_stream = True
+        if wg is not g:
+            folded, grad = grad, torch.empty((g.cu, g.cv, g.kh, g.kw), dtype=torch.float32, device=t.device)
+            L.call("rv_unfold_weight_grad", ctypes.byref(g), L.ptr(folded), L.ptr(grad), L.i32(0), L.stream_ptr())
+        t.add_param_grad(layer.weight, layer.unpermute_grad(grad))
 
     small = E.OVERLAP_MAX_TFLOP is None or E.tap_flops(g, wshape) < 1e12 * E.OVERLAP_MAX_TFLOP
     if E.OVERLAP_WGRAD and E.HOLD_WGRAD_FOR_SYNC_BN and E.sync_bn_active():
