@@ -667,4 +667,4 @@ def test_training_trajectory_vs_oracle_overfit():
     upd_o = torch.cat([(oparams[k].detach() - sd[k]).flatten() for k, _ in model.named_parameters()])
     cos = float(torch.nn.functional.cosine_similarity(upd_h, upd_o, dim=0))
     print(f"    cosine of the six-step parameter update against the oracle's: {cos:.4f}")
-    assert cos > 0.5, cos  # (Adam's update is sign-like where gradients are tiny: measured value printed above)
+    assert cos > 0.95, cos  # (measured 0.9905)
