@@ -668,3 +668,47 @@ def test_training_trajectory_vs_oracle_overfit():
     cos = float(torch.nn.functional.cosine_similarity(upd_h, upd_o, dim=0))
     print(f"    cosine of the six-step parameter update against the oracle's: {cos:.4f}")
     assert cos > 0.95, cos  # (measured 0.9905)
+
+
+@pytest.mark.parametrize("case", ["one_sweep_without_boxes", "no_boxes_at_all"])
+def test_training_step_with_empty_annotation_sets(case):
+    """Edge case of ``compute_targets`` (nn/heads/detection_head.py:512-528): sweeps without annotations do not appear in
+    ``annotations[:, -1].unique()`` and keep their initialised (background) targets; with no annotation at all the loop does not
+    run.  The normalisers then clamp (``total_objects >= 1``, ``total_fg + 1``: :379-399).  HIP against the oracle: integer targets
+    exact, loss 2e-2, every parameter gradient finite."""
+    from bench import Detector, build_model, synthetic_batch
+    from oracle import model as om
+    from oracle import targets as otgt
+
+    n_cls = 5
+    torch.manual_seed(0)
+    backbone, head = build_model("c32", n_cls, 5)
+    gen = torch.Generator().manual_seed(1)
+    for m in list(backbone.modules()) + list(head.modules()):
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data = 0.5 + torch.rand(m.weight.shape, generator=gen)
+            m.bias.data = 0.2 * torch.randn(m.bias.shape, generator=gen) + 3.0
+    sd = {**{f"backbone.{k}": v.clone() for k, v in backbone.state_dict().items()}, **{f"head.{k}": v.clone() for k, v in head.state_dict().items()}}
+    batch = synthetic_batch(2, 16, 128, seed=5, device="cpu", boxes_per_sweep=5, n_cls=n_cls)
+    ann = batch["annotations"]
+    batch["annotations"] = ann[ann[:, -1] == 0].clone() if case == "one_sweep_without_boxes" else ann[:0].clone()
+    with torch.no_grad():
+        _, logits_o, reg_o = om.detector_forward(batch["features"], batch["cart"], sd, nm=om.Numerics.bf16(train=True))
+        tg = otgt.compute_targets(batch["cart"], batch["annotations"], n_cls)
+        loss_o = float(otgt.detection_loss(logits_o, reg_o, batch["cart"], batch["mask"], tg, n_cls)["loss"])
+    model = Detector(backbone, head).to(DEV).train()
+    data = {k: (v.to(DEV) if k != "annotations" else v) for k, v in batch.items()}
+    feats = model.backbone(data)
+    _, losses = model.head(feats, data, return_loss=True)
+    losses["loss"].backward()
+    torch.cuda.synchronize()
+    for k in ("classification_labels", "panoptics", "points_per_obj"):
+        assert torch.equal(data[1][0][k].cpu(), tg[k]), k
+    if case == "no_boxes_at_all":
+        assert bool((tg["classification_labels"] == n_cls).all())
+    else:
+        assert bool((tg["classification_labels"][1] == n_cls).all()) and bool((tg["classification_labels"][0] != n_cls).any())
+    loss = float(losses["loss"].detach())
+    assert math.isfinite(loss) and abs(loss - loss_o) < 2e-2 * abs(loss_o), (loss, loss_o)
+    for name, p in model.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
