@@ -515,6 +515,10 @@ int rv_se3_inverse_apply(const double* xyz, int64_t n, const double* q_wxyz, con
 /* Correctly rounded (round-to-nearest-even) fp64 atan2, elementwise -- the azimuth rv_project_indices bins with
  * (np.arctan2 at converters/av2/utils.py:172; see csrc/project.hip for why the device value must be THE rounded one). */
 int rv_atan2_cr(const double* y, const double* x, int64_t n, double* out, rvStream stream);
+/* fp64 hypot with the bits of the C library the reference runs on (np.hypot at math/numpy/conversions.py:64-65 ==
+ * glibc 2.35 hypot: Borges' corrected sqrt, not correctly rounded) -- the range rv_project_indices returns and the
+ * z-buffer compares (csrc/project.hip). */
+int rv_hypot_libc(const double* x, const double* y, int64_t n, double* out, rvStream stream);
 /* cart (n,3) f64 -> rows/cols (i32) + range (f64); variant 0 = converter binning
  * (col = W - round((az+pi)*W/tau)), 1 = library binning (col = round(W - (az+pi)*W/tau - 1));
  * round-half-to-even, clip to [0, W-1] before the integer cast; row = H - laser_mapping[laser] - 1. */

@@ -45,6 +45,15 @@ def atan2_cr(y: Tensor, x: Tensor) -> Tensor:
     return out
 
 
+def hypot_libc(x: Tensor, y: Tensor) -> Tensor:
+    """fp64 ``hypot`` with glibc's bits (what ``np.hypot`` returns in the reference's converter; ``rv_hypot_libc``)."""
+    _require_cuda(x, "x")
+    x, y = x.double().contiguous(), y.double().contiguous()
+    out = torch.empty_like(x)
+    L.call("rv_hypot_libc", L.ptr(x), L.ptr(y), L.i64(x.numel()), L.ptr(out), L.stream_ptr())
+    return out
+
+
 def z_buffer(rows: Tensor, cols: Tensor, distances: Tensor, features: Tensor, height: int, width: int,
              min_distance: float = 1.0) -> Tuple[Tensor, Tensor]:
     """features (C,N) f64 -> (image (C,H,W) f32, winner (H,W) i64); reference z-buffer semantics."""
