@@ -530,6 +530,7 @@ HBM_GROUP_KERNELS = {
     "rv_ew_combine": ("ew_combine",), "rv_bn_bwd_reduce": ("bn_bwd_reduce_",), "rv_bn_bwd_apply": ("bn_bwd_apply_",),
     "rv_bn_bwd_reduce_pair": ("bn_bwd_reduce2",), "rv_bn_bwd_apply_pair": ("bn_bwd_apply2",), "rv_meta_modulate": ("meta_modulate_kernel",),
     "rv_meta_modulate_bwd_sums": ("meta_bwd_sums",), "rv_meta_modulate_bwd_apply": ("meta_bwd_apply",), "rv_pos_forward": ("pos_fwd_kernel",),
+    "rv_meta_chain_bwd_sums": ("meta_chain_bwd_kernel<false",), "rv_meta_chain_bwd_apply": ("meta_chain_bwd_kernel<true",),
     "rv_pos_backward_sums": ("pos_bwd_kernel",), "rv_head_final_bwd_sums": ("head_final_bwd_kernel<false",),
     "rv_head_final_bwd_apply": ("head_final_bwd_kernel<true",),
 }

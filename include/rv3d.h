@@ -379,6 +379,21 @@ int rv_meta_modulate_bwd_apply(const void* dgeo, const void* pos_raw, const floa
                                const float* mean, const float* invstd, const float* coef, const void* feat,
                                int32_t ld_feat, int32_t N, int32_t H, int32_t W, int32_t C, void* dy, rvStream stream);
 
+/* The same two passes CHAINED with conv2d backward-data of the fusion conv in front of the modulation (nn/stems/__init__.py:51-62,
+ * 84: `fusion_kernel[0]`, a 1x1 conv 9C -> K; what ATen's convolution_backward computes as dgeo = dz Wf):  dgeo is recomputed
+ * tile by tile on the matrix cores in BOTH passes -- from `dz` (gradient w.r.t. that conv's output, bf16 [pixels][ld_dz], K
+ * channels) and `w_scatter` (its packed backward-data image [9 * C][K], row = tap * C + c: the reference's channel order
+ * c * 9 + tap already absorbed) -- and consumed in the tile epilogue: the 9C-channel gradient tensor is never written or read.
+ * Outputs, partial-row layout and the finalize step in between are those of rv_meta_modulate_bwd_sums / _apply, with
+ * rv_meta_chain_rows(N, H, W) rows (one per persistent workgroup).  C = 128 or 256, K % 32 == 0, K >= 128; tensors below 4 GB. */
+int32_t rv_meta_chain_rows(int32_t N, int32_t H, int32_t W);
+int rv_meta_chain_bwd_sums(const void* dz, int32_t ld_dz, int32_t K, const void* w_scatter, const void* pos_raw, const float* scale,
+                           const float* shift, const float* mean, const float* invstd, const void* feat, int32_t ld_feat, int32_t N,
+                           int32_t H, int32_t W, int32_t C, void* dfeat, int32_t ld_dfeat, float* partial, rvStream stream);
+int rv_meta_chain_bwd_apply(const void* dz, int32_t ld_dz, int32_t K, const void* w_scatter, const void* pos_raw, const float* scale,
+                            const float* shift, const float* mean, const float* invstd, const float* coef, const void* feat,
+                            int32_t ld_feat, int32_t N, int32_t H, int32_t W, int32_t C, void* dy, rvStream stream);
+
 /* The two positional layers of the MetaKernel stem (nn/stems/__init__.py:41-49, 80: Conv2dNormActivation(3, C, 1) ->
  * Conv2dNormActivation(C, C, 1) on the 9x neighbour grid) as ONE persistent streaming GEMM, C = 256 (rv-av2) or 128 (rv-waymo):
  *   h1 = relu(scale1 * (W1 rel) + shift1)   generated in the K-operand staging from `rel` (bf16 [pixels][ld_rel], cin <= 3
