@@ -332,6 +332,13 @@ int rv_smallk_forward(const void* v, int32_t ld_v, int64_t pixels, int32_t cin, 
 int rv_ew_mask_grad(int64_t pixels, int32_t c, const void* dout, int32_t ld_dout, const void* out, int32_t ld_out,
                     void* d, int32_t ld_d, int32_t accumulate, rvStream stream);
 
+/* RangePartition stem (nn/stems/__init__.py:88-135, the stem RangeNet builds for stem_type RANGE_PARTITION, nn/backbones/dla.py:164-171):
+ * `features = (partitions[:, :, None] * features[:, None]).flatten(1, 2) * mask` with partitions = (||cart|| >= lower) & (||cart|| <= upper)
+ * as the 16-bit NHWC operand of the projecting BasicBlock -- channel band * C + c, zeros in the padding channels.  features / cart fp32
+ * NCHW, mask one byte per pixel; `lower` / `upper`: `bands` host floats (the module's lower_bounds / upper_bounds parameters). */
+int rv_range_partition(const float* features_nchw, const float* cart_nchw, const uint8_t* mask, int32_t N, int32_t C, int32_t H, int32_t W,
+                       const float* lower, const float* upper, int32_t bands, void* dst, int32_t ld_dst, rvStream stream);
+
 /* ---------------------------------------------------------------------------------------
  * Layout conversion at the module boundary (the reference's tensors are NCHW fp32).
  * ------------------------------------------------------------------------------------- */

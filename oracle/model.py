@@ -279,6 +279,18 @@ _AGG = {  # name: (stride, padding, num_blocks)   (dla.py:67-108)
 }
 
 
+def range_partition(features: Tensor, cart: Tensor, mask: Tensor, sd: StateDict, prefix: str, nm: Numerics = FP32) -> Tensor:
+    """``RangePartition.forward`` (``nn/stems/__init__.py:88-135``): six range bands [0,15] [10,20] [15,30] [20,40] [30,60] [45,inf]
+    (closed on both sides, overlapping; ``lower_bounds`` is an int64 parameter, ``upper_bounds`` fp32 -- the comparison promotes to
+    fp32), every input channel repeated once per band and zeroed outside it (channel index band * C_in + c after ``flatten(1, 2)``),
+    times the validity mask, then a projecting BasicBlock (``project=True``; kernel size from the weight)."""
+    dists = cart.norm(dim=1, keepdim=True)
+    lower, upper = sd[f"{prefix}.lower_bounds"], sd[f"{prefix}.upper_bounds"]
+    bands = torch.logical_and(dists >= lower, dists <= upper)
+    x = (bands[:, :, None] * features[:, None]).flatten(1, 2) * mask
+    return basic_block(x, sd, f"{prefix}.projection", project=True, nm=nm)
+
+
 def range_backbone(x: Tensor, sd: StateDict, prefix: str, nm: Numerics = FP32) -> Dict[int, Tensor]:
     """DLA-style trunk (``nn/backbones/dla.py:110-131``)."""
     r: Dict[str, Tensor] = {}
@@ -307,6 +319,7 @@ def range_net(
     num_neighbors: int = 3,
     num_layers: int = 2,
     nm: Numerics = FP32,
+    mask: Optional[Tensor] = None,
 ) -> Dict[int, Tensor]:
     """Stem dispatch + trunk (``nn/backbones/dla.py:193-208``)."""
     p = prefix + "." if prefix else ""
@@ -314,7 +327,9 @@ def range_net(
         stem = meta_kernel(features, cart, sd, p + "stem", num_neighbors, num_layers, nm)
     elif stem_type == "BASIC":
         stem = basic_block(features, sd, p + "stem", project=True, nm=nm)
-    else:  # RANGE_PARTITION is not selected by any shipped config
+    elif stem_type == "RANGE_PARTITION":
+        stem = range_partition(features, cart, mask, sd, p + "stem", nm)
+    else:
         raise NotImplementedError(stem_type)
     return range_backbone(stem, sd, p + "net", nm)
 

@@ -775,6 +775,52 @@ extern "C" int rv_nchw_f32_to_nhwc_bf16(const float* src, int32_t N, int32_t C, 
     RV_CHECK_LAUNCH("nchw_to_nhwc_kernel");
     return 0;
 }
+// ---------------------------------------------------------------------------------------------------------------
+// RangePartition stem operand (nn/stems/__init__.py:121-135): every input channel once per range band, zero outside the band and
+// where the pixel holds no return, as the bf16 NHWC operand of the projecting BasicBlock -- channel index band * C + c (what
+// `flatten(1, 2)` of (B, bands, C, H, W) gives).  d = ||cart|| in fp32 without contraction (torch's fp32 norm: sum of squares, then
+// a correctly rounded square root); the bands are closed intervals compared in fp32.  One thread per pixel.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+struct BandArgs {
+    float lower[8], upper[8];
+};
+__global__ void range_partition_kernel(const float* feat, const float* cart, const uint8_t* mask, int N, int C, int H, int W, BandArgs b, int bands,
+                                       bf16_t* dst, int ld) {
+#pragma clang fp contract(off)
+    const int64_t hw = (int64_t)H * W, total = (int64_t)N * hw;
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = p / hw, r = p - n * hw;
+        const float* cp = cart + n * 3 * hw + r;
+        const float x = cp[0], y = cp[hw], z = cp[2 * hw];
+        const float d = sqrtf(x * x + y * y + z * z);
+        const bool valid = mask[p] != 0;
+        bf16_t* o = dst + p * ld;
+        for (int k = 0; k < bands; ++k) {
+            const bool in = valid && d >= b.lower[k] && d <= b.upper[k];
+            // (the reference multiplies: outside the band the value is 0 * f -- a zero with f's sign, NaN for a non-finite f)
+            for (int c = 0; c < C; ++c) o[k * C + c] = f2bf(feat[(n * C + c) * hw + r] * (in ? 1.f : 0.f));
+        }
+        for (int c = bands * C; c < ld; ++c) o[c] = 0;
+    }
+}
+}  // namespace
+
+extern "C" int rv_range_partition(const float* features_nchw, const float* cart_nchw, const uint8_t* mask, int32_t N, int32_t C, int32_t H, int32_t W,
+                                  const float* lower, const float* upper, int32_t bands, void* dst, int32_t ld_dst, rvStream stream) {
+    RV_REQUIRE(features_nchw && cart_nchw && mask && lower && upper && dst, "rv_range_partition: null argument");
+    RV_REQUIRE(bands >= 1 && bands <= 8 && C >= 1 && bands * C <= ld_dst, "rv_range_partition: %d bands x %d channels do not fit a row of %d", bands, C, ld_dst);
+    BandArgs b;
+    for (int k = 0; k < 8; ++k) {
+        b.lower[k] = k < bands ? lower[k] : 0.f;
+        b.upper[k] = k < bands ? upper[k] : 0.f;
+    }
+    hipLaunchKernelGGL(range_partition_kernel, dim3(ew_grid((int64_t)N * H * W)), dim3(256), 0, (hipStream_t)stream, features_nchw, cart_nchw, mask, N, C, H,
+                       W, b, bands, (bf16_t*)dst, ld_dst);
+    RV_CHECK_LAUNCH("range_partition_kernel");
+    return 0;
+}
+
 extern "C" int rv_nchw_f32_to_nhwc_f32(const float* src, int32_t N, int32_t C, int32_t H, int32_t W, float* dst,
                                        int32_t ld_dst, rvStream stream) {
     RV_REQUIRE(src && dst && C <= ld_dst, "rv_nchw_f32_to_nhwc_f32: bad arguments");

@@ -15,7 +15,7 @@ from typing import Any, Dict, Mapping
 from torch import Tensor, nn
 
 from ..blocks import AggregationBlock, BasicBlock, ResidualBlock
-from ..stems import MetaKernel
+from ..stems import MetaKernel, RangePartition
 
 
 class RangeBackbone(nn.Module):
@@ -64,7 +64,7 @@ def _instantiate(cfg: Mapping[str, Any]) -> Any:
 
 
 class RangeNet(nn.Module):
-    """Stem dispatch (META / BASIC) + trunk."""
+    """Stem dispatch (META / RANGE_PARTITION / BASIC, ``nn/backbones/dla.py:157-180``) + trunk."""
 
     def __init__(self, in_channels: int, layers, out_channels: int, projection_kernel_size: int, dataset_name: str,
                  num_neighbors: int, num_layers: int, stem_type: str, _net: Mapping[str, Any], compile: bool = False) -> None:
@@ -75,6 +75,9 @@ class RangeNet(nn.Module):
         self._net, self.compile = _net, compile  # ``compile`` is accepted and ignored (no tracing compiler here)
         if stem_type == "META":
             self.stem = MetaKernel(in_channels=in_channels, out_channels=self.layers[0], num_neighbors=num_neighbors, num_layers=num_layers)
+        elif stem_type == "RANGE_PARTITION":
+            self.stem = RangePartition(in_channels=in_channels, out_channels=self.layers[0], num_neighbors=num_neighbors, num_layers=num_layers,
+                                       projection_kernel_size=projection_kernel_size)
         elif stem_type == "BASIC":
             self.stem = BasicBlock(in_channels, self.layers[0], kernel_size=projection_kernel_size, project=True)
         else:
@@ -85,9 +88,10 @@ class RangeNet(nn.Module):
         from ... import program
 
         features, cart = x["features"], x["cart"]
+        mask = x["mask"] if self.stem_type == "RANGE_PARTITION" else None  # (the other stems do not read it: dla.py:200-205)
 
         def build(t, f, c):
-            outs = program.range_net_program(t, self, f, c)
+            outs = program.range_net_program(t, self, f, c, mask)
             return [None, None], [outs[1], outs[2], outs[4], outs[16]]
 
         o = program.run(build, self, [features, cart])

@@ -1,4 +1,4 @@
-"""Stems -- ``MetaKernel`` parameter holder (``torchbox3d/nn/stems/__init__.py:12-85``).
+"""Stems -- ``MetaKernel`` (``torchbox3d/nn/stems/__init__.py:12-85``) and ``RangePartition`` (``:88-135``) parameter holders.
 
 ``positional_kernel`` / ``fusion_kernel`` are sequences of torchvision-style
 ``Conv2dNormActivation`` triples; the sub-module names "0" (conv, no bias), "1" (BatchNorm2d),
@@ -7,6 +7,7 @@
 
 from __future__ import annotations
 
+import torch
 from torch import Tensor, nn
 
 from ..blocks import BasicBlock
@@ -48,3 +49,22 @@ class MetaKernel(nn.Module):
         from ... import program
 
         return program.standalone(self, features, cart)
+
+
+class RangePartition(nn.Module):
+    """Six overlapping, closed range bands; every input channel once per band (zero outside it and where the pixel holds no return), then a
+    projecting BasicBlock.  ``lower_bounds`` (int64) / ``upper_bounds`` (fp32) are frozen parameters as in the reference -- they are part of
+    its ``state_dict``."""
+
+    def __init__(self, in_channels: int, out_channels: int, num_neighbors: int, projection_kernel_size: int, num_layers: int = 2) -> None:
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.num_neighbors, self.projection_kernel_size, self.num_layers = num_neighbors, projection_kernel_size, num_layers
+        self.projection = BasicBlock(6 * in_channels, out_channels, kernel_size=projection_kernel_size, project=True)
+        self.lower_bounds = nn.Parameter(torch.as_tensor((0, 10, 15, 20, 30, 45)).view(1, -1, 1, 1), requires_grad=False)
+        self.upper_bounds = nn.Parameter(torch.as_tensor((15, 20, 30, 40, 60, torch.inf)).view(1, -1, 1, 1), requires_grad=False)
+
+    def forward(self, features: Tensor, cart: Tensor, mask: Tensor) -> Tensor:
+        from ... import program
+
+        return program.standalone(self, features, cart, mask)

@@ -9,6 +9,7 @@ the tap tables, the channel concat is written in place.  ``run`` wraps a program
 
 from __future__ import annotations
 
+import ctypes
 import os
 
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
@@ -157,6 +158,25 @@ def meta_kernel_program(t: Tape, m: nn.Module, features: Act, cart: Tensor, out:
     return E.CombineOp(t, geo, None, relu_out=False, out=out).out
 
 
+def range_partition_program(t: Tape, m: nn.Module, features: Tensor, cart: Tensor, mask: Tensor, out: Optional[Act] = None) -> Act:
+    """``RangePartition.forward`` (nn/stems/__init__.py:121-135): the banded, masked operand in one pass over the fp32 inputs
+    (``rv_range_partition``), then the projecting BasicBlock.  No gradient leaves it: its inputs are the sweep itself."""
+    n, c, h, w = features.shape
+    bands = m.lower_bounds.numel()
+    x = Act.empty(n, h, w, bands * c, t.device)
+    feats32, cart32 = features.contiguous().float(), cart.contiguous().float()  # (temporaries referenced across the launch)
+    mask8 = mask.contiguous().view(torch.uint8) if mask.dtype == torch.bool else (mask != 0).to(torch.uint8).contiguous()
+    bounds = m.__dict__.get("_rv_bounds")
+    ver = (m.lower_bounds._version, m.upper_bounds._version, m.lower_bounds.data_ptr())
+    if bounds is None or bounds[0] != ver:  # (host copies of the twelve frozen numbers: read back once, not per step)
+        lo = (ctypes.c_float * bands)(*[float(v) for v in m.lower_bounds.detach().flatten().tolist()])
+        hi = (ctypes.c_float * bands)(*[float(v) for v in m.upper_bounds.detach().flatten().tolist()])
+        m.__dict__["_rv_bounds"] = bounds = (ver, lo, hi)
+    L.call("rv_range_partition", L.ptr(feats32), L.ptr(cart32), L.ptr(mask8), L.i32(n), L.i32(c), L.i32(h), L.i32(w), bounds[1], bounds[2], L.i32(bands),
+           x.ptr(), L.i32(x.ld), L.stream_ptr())
+    return basic_block_program(t, m.projection, x, out=out, need_input_grad=False)
+
+
 def range_backbone_program(t: Tape, m: nn.Module, stem: Act, feat1: Optional[Act]) -> Dict[int, Act]:
     """``RangeBackbone.forward`` (nn/backbones/dla.py:110-131)."""
     res1 = residual_block_program(t, m.res1, stem)
@@ -178,23 +198,28 @@ def range_backbone_program(t: Tape, m: nn.Module, stem: Act, feat1: Optional[Act
     return {1: cat, 2: agg2a, 4: agg2, 16: res3}
 
 
-def range_net_program(t: Tape, m: nn.Module, features: Tensor, cart: Tensor) -> Dict[int, Act]:
+def range_net_program(t: Tape, m: nn.Module, features: Tensor, cart: Tensor, mask: Optional[Tensor] = None) -> Dict[int, Act]:
     """``RangeNet.forward`` (nn/backbones/dla.py:193-208)."""
     n, c, h, w = features.shape
-    x = Act.empty(n, h, w, c, t.device, zero=True)
-    feats32 = features.contiguous().float()  # keep the temporary referenced across the launch
-    L.call("rv_nchw_f32_to_nhwc_bf16", L.ptr(feats32), L.i32(n), L.i32(c), L.i32(h), L.i32(w), x.ptr(),
-           L.i32(x.ld), L.i32(0), L.stream_ptr())
     c0 = m.layers[0]
     in_place = c0 % 32 == 0
     feat1 = Act.empty(n, h, w, 2 * c0, t.device) if in_place else None
     stem_out = feat1.slice(0, c0) if in_place else None
+    if m.stem_type == "RANGE_PARTITION":
+        if mask is None:
+            raise L.RvError("RangeNet(stem_type=RANGE_PARTITION) needs the sweep's validity mask (x['mask'])")
+        stem = range_partition_program(t, m.stem, features, cart, mask, out=stem_out)
+        return range_backbone_program(t, m.net, stem, feat1)
+    x = Act.empty(n, h, w, c, t.device, zero=True)
+    feats32 = features.contiguous().float()  # keep the temporary referenced across the launch
+    L.call("rv_nchw_f32_to_nhwc_bf16", L.ptr(feats32), L.i32(n), L.i32(c), L.i32(h), L.i32(w), x.ptr(),
+           L.i32(x.ld), L.i32(0), L.stream_ptr())
     if m.stem_type == "META":
         stem = meta_kernel_program(t, m.stem, x, cart, out=stem_out)
     elif m.stem_type == "BASIC":
         stem = basic_block_program(t, m.stem, x, out=stem_out, need_input_grad=False)
     else:
-        raise NotImplementedError("stem_type RANGE_PARTITION is not selected by any shipped rv-* config")
+        raise NotImplementedError("This stem type is not implemented!")
     return range_backbone_program(t, m.net, stem, feat1)
 
 
@@ -319,9 +344,12 @@ def standalone(m: nn.Module, *inputs: Tensor):
     """Run a single block-level module on NCHW tensors (API parity with the reference's per-module ``forward``)."""
     from .nn.blocks import AggregationBlock, BasicBlock, ResidualBlock
     from .nn.modules.conv import Conv2dSame
-    from .nn.stems import MetaKernel
+    from .nn.stems import MetaKernel, RangePartition
 
     def build(t: Tape, *xs: Tensor):
+        if isinstance(m, RangePartition):
+            feats, cart, mask = xs
+            return [None, None, None], [range_partition_program(t, m, feats, cart, mask)]
         if isinstance(m, MetaKernel):
             feats, cart = xs
             n, c, h, w = feats.shape

@@ -38,7 +38,7 @@ from torchbox3d.nn.decoders.range_decoder import RangeDecoder, sample_by_range  
 from torchbox3d.nn.heads.dense_head import DenseHead  # noqa: E402
 from torchbox3d.nn.heads.detection_head import COLS, DetectionHead, compute_targets  # noqa: E402
 from torchbox3d.nn.modules.conv import Conv2dSame  # noqa: E402
-from torchbox3d.nn.stems import MetaKernel  # noqa: E402
+from torchbox3d.nn.stems import MetaKernel, RangePartition  # noqa: E402
 from torchbox3d.math.conversions import (  # noqa: E402
     cartesian_to_spherical_coordinates,
     spherical_to_cartesian_coordinates,
@@ -157,6 +157,59 @@ def gen_meta_kernel() -> None:
     m = MetaKernel(in_channels=5, out_channels=16, num_neighbors=3, num_layers=2)
     module_case("meta", m, [features, cart], g, out)
     save("meta_kernel", **out)
+
+
+def gen_range_partition() -> None:
+    """RangePartition stem (nn/stems/__init__.py:88-135) with both projection kernel sizes, train forward + parameter gradients + eval
+    forward; and RangeNet(stem_type="RANGE_PARTITION") end to end (the dispatch of nn/backbones/dla.py:164-171, 200-201).  Some ranges sit
+    EXACTLY on a band edge (10, 15, 20, 30, 45, 60 m: the bands are closed and overlap)."""
+    g = torch.Generator().manual_seed(12)
+    torch.manual_seed(12)
+    out: dict = {}
+    features, cart, mask = synthetic_sweep(g, 2, 6, 32)
+    edges = torch.tensor([10.0, 15.0, 20.0, 30.0, 40.0, 45.0, 60.0, 0.0])
+    for i, d in enumerate(edges):  # points on the x axis: norm == d exactly in fp32
+        cart[0, :, 1, 3 * i] = torch.tensor([float(d), 0.0, 0.0])
+        mask[0, 0, 1, 3 * i] = True
+        features[0, :, 1, 3 * i] = torch.randn(5, generator=g)
+    out["features"], out["cart"], out["mask"] = features, cart, mask
+    for tag, k in (("k1", 1), ("k3", 3)):
+        m = RangePartition(in_channels=5, out_channels=16, num_neighbors=3, projection_kernel_size=k, num_layers=2)
+        randomize_bn(m, g)
+        sd0 = {n: v.clone() for n, v in m.state_dict().items()}
+        m.train()
+        y = m(features, cart, mask)
+        probe = torch.randn(y.shape, generator=g)
+        (y * probe).sum().backward()
+        for n, v in sd0.items():
+            out[f"{tag}/sd/{n}"] = v
+        out[f"{tag}/out"], out[f"{tag}/probe"] = y, probe
+        for n, p in m.named_parameters():
+            if p.grad is not None:
+                out[f"{tag}/grad/{n}"] = p.grad
+        for n, v in m.state_dict().items():
+            if "running_" in n:
+                out[f"{tag}/sd_after/{n}"] = v.clone()
+        m.load_state_dict(sd0)
+        m.eval()
+        with torch.no_grad():
+            out[f"{tag}/out_eval"] = m(features, cart, mask)
+    C = 16
+    L = ListConfig([C] * 5)
+    net = RangeNet(
+        in_channels=5, layers=L, out_channels=C, projection_kernel_size=1, dataset_name="av2", num_neighbors=3,
+        num_layers=2, stem_type="RANGE_PARTITION",
+        _net=DictConfig(_target_="torchbox3d.nn.backbones.dla.RangeBackbone", in_channels=5, layers=L, out_channels=C),
+    )
+    randomize_bn(net, g)
+    for n, v in net.state_dict().items():
+        out[f"net/sd/{n}"] = v.clone()
+    net.eval()
+    with torch.no_grad():
+        feats = net({"features": features, "cart": cart, "mask": mask})
+    for s_, t in feats.items():
+        out[f"net/eval_feat/{s_}"] = t
+    save("range_partition", **out)
 
 
 def make_annotations(g: torch.Generator, cart: torch.Tensor, mask: torch.Tensor, n_per: int, n_cls: int) -> np.ndarray:
@@ -819,7 +872,7 @@ def gen_detections_frame() -> None:
     save("detections_frame", **out)
 
 
-ALL = ("conv_blocks", "meta_kernel", "decode", "projection", "tiny_model", "augment", "loader_item", "raw_sweep", "nms_wrapper",
+ALL = ("conv_blocks", "meta_kernel", "range_partition", "decode", "projection", "tiny_model", "augment", "loader_item", "raw_sweep", "nms_wrapper",
        "loader_train_item", "detections_frame")  # in dependency order: nms_wrapper reads tiny_model / decode, detections_frame reads nms_wrapper
 
 

@@ -204,6 +204,80 @@ def test_meta_kernel_forward(golden, train):
     assert rel_err(out, ref) < 5e-2
 
 
+def test_range_partition_operand_is_exact():
+    """rv_range_partition: the banded, masked 16-bit operand of the RangePartition stem equals bf16(the reference's expression) element for
+    element -- returns exactly ON the closed band edges (10, 15, 20, 30, 40, 45, 60 m) included, 6 input channels (rv-waymo), a masked
+    pixel on an edge, and the padding channels zero."""
+    import ctypes
+
+    from range_view_3d_detection_amd import _lib as L
+
+    gen = torch.Generator().manual_seed(5)
+    N, C, H, W = 2, 6, 5, 48
+    feats = torch.randn(N, C, H, W, generator=gen)
+    cart = torch.randn(N, 3, H, W, generator=gen) * 25
+    mask = torch.rand(N, 1, H, W, generator=gen) > 0.2
+    for i, d in enumerate((0.0, 10.0, 15.0, 20.0, 30.0, 40.0, 45.0, 60.0, 15.0)):
+        cart[1, :, 2, 4 * i] = torch.tensor([0.0, -d, 0.0])
+        mask[1, 0, 2, 4 * i] = i != 8  # (the last one: on an edge but without a return)
+    lower = torch.as_tensor((0, 10, 15, 20, 30, 45)).view(1, -1, 1, 1)
+    upper = torch.as_tensor((15, 20, 30, 40, 60, torch.inf)).view(1, -1, 1, 1)
+    dists = cart.norm(dim=1, keepdim=True)
+    want = ((torch.logical_and(dists >= lower, dists <= upper)[:, :, None] * feats[:, None]).flatten(1, 2) * mask).to(torch.bfloat16)
+    ld = 64
+    out = torch.full((N, H, W, ld), 7.0, dtype=torch.bfloat16, device=DEV)
+    f_d, c_d, m_d = feats.to(DEV), cart.to(DEV), mask.to(DEV).view(torch.uint8)
+    lo = (ctypes.c_float * 6)(*[float(v) for v in lower.flatten()])
+    hi = (ctypes.c_float * 6)(*[float(v) for v in upper.flatten()])
+    L.call("rv_range_partition", L.ptr(f_d), L.ptr(c_d), L.ptr(m_d), L.i32(N), L.i32(C), L.i32(H), L.i32(W), lo, hi, L.i32(6), L.ptr(out), L.i32(ld), L.stream_ptr())
+    got = out.cpu()
+    assert torch.equal(got[..., : 6 * C].permute(0, 3, 1, 2).contiguous().view(torch.int16), want.contiguous().view(torch.int16))
+    assert not got[..., 6 * C :].float().any()
+
+
+@pytest.mark.parametrize("tag", ["k1", "k3"])
+@pytest.mark.parametrize("train", [True, False])
+def test_range_partition_stem_forward(golden, tag, train):
+    """RangePartition (nn/stems/__init__.py:88-135) through the HIP path against the oracle with bf16 storage emulation and against the
+    reference's own fp32 output; running statistics updated as nn.BatchNorm2d does."""
+    from oracle import model as om
+    from range_view_3d_detection_amd.nn.stems import RangePartition
+
+    g = golden("range_partition")
+    sd = g.sub(f"{tag}/sd")
+    m = _load(RangePartition(5, 16, 3, int(tag[1])), sd)
+    m.train(train)
+    f, c, k = g["features"], g["cart"], g["mask"]
+    with torch.no_grad():
+        out = m(f.to(DEV), c.to(DEV), k.to(DEV)).float()
+        exp = om.range_partition(f, c, k, {f"m.{n}": v for n, v in sd.items()}, "m", om.Numerics.bf16(train=train))
+    assert rel_err(out, exp) < 1.5e-2, "vs oracle with bf16 storage emulation"
+    assert rel_err(out, g[f"{tag}/out"] if train else g[f"{tag}/out_eval"]) < 4e-2, "vs the reference's fp32 output"
+    if train:
+        after = {n: v for n, v in m.state_dict().items() if "running_" in n}
+        for n, v in g.sub(f"{tag}/sd_after").items():
+            assert rel_err(after[n], v) < 2e-2, n
+
+
+def test_range_net_dispatches_to_the_range_partition_stem(golden):
+    """RangeNet(stem_type="RANGE_PARTITION") (nn/backbones/dla.py:164-171, 200-201: the stem reads x["mask"]) in eval mode against the
+    reference's feature maps at all four strides."""
+    from range_view_3d_detection_amd.nn.backbones.dla import RangeNet
+
+    g = golden("range_partition")
+    sd = g.sub("net/sd")
+    C = 16
+    net = RangeNet(in_channels=5, layers=[C] * 5, out_channels=C, projection_kernel_size=1, dataset_name="av2", num_neighbors=3, num_layers=2,
+                   stem_type="RANGE_PARTITION", _net={"_target_": "torchbox3d.nn.backbones.dla.RangeBackbone", "in_channels": 5, "layers": [C] * 5, "out_channels": C})
+    net = _load(net, sd).eval()
+    with torch.no_grad():
+        out = net({"features": g["features"].to(DEV), "cart": g["cart"].to(DEV), "mask": g["mask"].to(DEV)})
+    for s_, ref in g.sub("net/eval_feat").items():
+        assert rel_err(out[int(s_)].float(), ref) < 5e-2, s_
+    with pytest.raises(Exception, match="mask"):
+        net({"features": g["features"].to(DEV), "cart": g["cart"].to(DEV)})
+
+
 # ---------------------------------------------------------------------------------------------
 # decode / projection
 # ---------------------------------------------------------------------------------------------

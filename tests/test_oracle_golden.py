@@ -105,6 +105,41 @@ def test_meta_kernel(golden):
     run_case(g, "meta", _wrap(lambda f, c, sd, nm: om.meta_kernel(f, c, sd, "m", nm=nm)), 2, grad_tol=5e-4)
 
 
+@pytest.mark.parametrize("tag", ["k1", "k3"])
+def test_range_partition_stem(golden, tag):
+    """RangePartition (the third stem RangeNet dispatches to, nn/stems/__init__.py:88-135) against the reference's own arrays: train
+    forward, parameter gradients, running statistics, eval forward; the fixture holds returns exactly on the closed band edges."""
+    g = golden("range_partition")
+    feats, cart, mask = g["features"], g["cart"], g["mask"]
+    d = cart.norm(dim=1)
+    assert sum(int((d == e).sum()) for e in (10.0, 15.0, 20.0, 30.0, 40.0, 45.0, 60.0)) >= 7  # (the edge cases are in the data)
+    sd = {"m." + k: v for k, v in g.sub(f"{tag}/sd").items()}
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k and "bounds" not in k}
+    full = dict(sd)
+    full.update(params)
+    nm = om.Numerics(train=True, running={})
+    y = om.range_partition(feats, cart, mask, full, "m", nm)
+    close(y, g[f"{tag}/out"], what=f"{tag} out")
+    (y * g[f"{tag}/probe"]).sum().backward()
+    grads = g.sub(f"{tag}/grad")
+    assert set(grads) == {k[2:] for k in params}
+    for k, v in grads.items():
+        close(params["m." + k].grad, v, 2e-4, f"{tag} grad {k}")
+    for k, v in g.sub(f"{tag}/sd_after").items():
+        close(nm.running["m." + k], v, what=f"{tag} running {k}")
+    with torch.no_grad():
+        close(om.range_partition(feats, cart, mask, sd, "m", om.Numerics(train=False)), g[f"{tag}/out_eval"], what=f"{tag} eval")
+
+
+def test_range_net_with_the_range_partition_stem(golden):
+    g = golden("range_partition")
+    sd = g.sub("net/sd")
+    with torch.no_grad():
+        out = om.range_net(g["features"], g["cart"], sd, stem_type="RANGE_PARTITION", nm=om.Numerics(train=False), mask=g["mask"])
+    for k, v in g.sub("net/eval_feat").items():
+        close(out[int(k)], v, what=f"RangeNet(RANGE_PARTITION) feature {k}")
+
+
 # ----------------------------------------------------------------------------- D1-D3, Q1, L1, S1
 def test_decode_range_view(golden):
     g = golden("decode")
@@ -440,7 +475,7 @@ def test_loader_train_item_augments_before_padding(golden):
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/src/torchbox3d"), reason="build container only: regenerating the fixtures runs the reference")
 def test_fixture_generator_reproduces_every_committed_fixture(tmp_path):
-    """tests/golden/make_golden.py (the reference itself, run in the build container) regenerates all eleven fixtures BYTE for byte:
+    """tests/golden/make_golden.py (the reference itself, run in the build container) regenerates all twelve fixtures BYTE for byte:
     every generator seeds its own torch.Generator and the global one (module constructors initialise from it)."""
     import subprocess
     import sys
@@ -449,6 +484,6 @@ def test_fixture_generator_reproduces_every_committed_fixture(tmp_path):
     out = subprocess.run([sys.executable, os.path.join(GOLDEN, "make_golden.py"), "all"], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     names = sorted(f for f in os.listdir(GOLDEN) if f.endswith(".npz"))
-    assert len(names) == 11
+    assert len(names) == 12
     for f in names:
         assert open(os.path.join(GOLDEN, f), "rb").read() == open(tmp_path / f, "rb").read(), f"{f} is not reproduced"
