@@ -131,7 +131,10 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
         if E.OVERLAP_WGRAD and E.EARLY_WGRAD_FILL > 0:
             # a persistent backward-data launch whose LAST round of tiles fills only part of the chip (1328 tiles on 256 CUs: five full
             # rounds and 48 tiles): the weight gradient of the same layer -- it reads dOut and the layer input, both complete -- is
-            # released BEFORE this launch, queues behind it and takes the CUs as they fall idle in that last round
+            # released on an event recorded BEFORE this launch instead of after it, so both are eligible at once.  Nothing orders the
+            # two on the hardware queues: the intent is that the weight gradient's workgroups take CUs as the last round leaves them idle;
+            # when they take some earlier, this launch's rounds stretch by the same amount.  Kept on the measurement alone: rv-waymo
+            # -1.0 ms chained / -0.15 ms free-running, rv-av2 (no ragged launch) unchanged (profiles/r04_ab_notes.md, r05_ab_notes.md)
             info = (ctypes.c_int32 * 4)()
             if (L.load().rv_tap_launch_info(ctypes.byref(bg), ctypes.byref(bshape), 1 if bwd == "scatter" else 0, info) == 0 and info[0] == 6):
                 wg_tiles, cus = info[2] * info[3], E.cu_count(t.device)
