@@ -3,7 +3,7 @@
   python profiles/tools/shape_prof.py [bench.py arguments]
 """
 import json, subprocess, sys, os
-env = dict(os.environ, RV3D_PROFILE_SHAPES="1", RV3D_NO_OVERLAP="1")
+env = dict(os.environ, RV3D_PROFILE_SHAPES="1", RV3D_OVERLAP="off")
 out = subprocess.run([sys.executable, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))), "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-extra"] + sys.argv[1:], env=env, capture_output=True, text=True).stdout
 j = json.loads(out.strip().splitlines()[-1])
 print("ms/step", j["ms_per_step"])
