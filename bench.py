@@ -530,7 +530,6 @@ HBM_GROUP_KERNELS = {
     "rv_ew_combine": ("ew_combine",), "rv_bn_bwd_reduce": ("bn_bwd_reduce_",), "rv_bn_bwd_apply": ("bn_bwd_apply_",),
     "rv_bn_bwd_reduce_pair": ("bn_bwd_reduce2",), "rv_bn_bwd_apply_pair": ("bn_bwd_apply2",), "rv_meta_modulate": ("meta_modulate_kernel",),
     "rv_meta_modulate_bwd_sums": ("meta_bwd_sums",), "rv_meta_modulate_bwd_apply": ("meta_bwd_apply",), "rv_pos_forward": ("pos_fwd_kernel",),
-    "rv_meta_chain_bwd_sums": ("meta_chain_bwd_kernel<false",), "rv_meta_chain_bwd_apply": ("meta_chain_bwd_kernel<true",),
     "rv_pos_backward_sums": ("pos_bwd_kernel",), "rv_head_final_bwd_sums": ("head_final_bwd_kernel<false",),
     "rv_head_final_bwd_apply": ("head_final_bwd_kernel<true",),
 }
@@ -621,6 +620,104 @@ def traffic_ratio(pmc_key: str, widths: str, width: int, sweeps: int):
     return {"hbm_gb_per_step": round(per_step, 1), "algorithmic_gb_per_step": round(alg, 1), "ratio": round(per_step / alg, 3), "source": PMC_TRAFFIC}
 
 
+SCLK_REFERENCE_MHZ = 2100.0  # ms_per_step_at_reference_sclk = ms_per_step * sclk_mhz_median / this (comparable across boxes of the pool)
+
+
+class GpuSampler:
+    """Shader clock and package power of this rank's GPU, sampled from sysfs in a host thread while the timed region runs (no extra
+    process, nothing that touches the GPU: the hwmon / pp_dpm files of the device's PCI node).  One binary differs by up to 4.5 % between
+    boxes of the pool -- this MFMA-heavy step runs at the package power cap, where the clock a given chip holds decides -- so a bench
+    record without the conditions it ran under cannot tell a slower box from a regression (round-5 review, item 6; the reference's
+    harness states its conditions the same way, tools/benchmark.py:231-238)."""
+
+    def __init__(self, device_index: int, period_s: float = 0.05) -> None:
+        import glob
+        import threading
+
+        self.period = period_s
+        self.clk, self.pw = [], []
+        self.cap_w = None
+        self.source = None
+        self._stop = threading.Event()
+        self._thread = None
+        node = None
+        try:
+            props = torch.cuda.get_device_properties(device_index)
+            bdf = f"{getattr(props, 'pci_domain_id', 0):04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}.0"
+            if os.path.isdir(f"/sys/bus/pci/devices/{bdf}"):
+                node = f"/sys/bus/pci/devices/{bdf}"
+        except Exception:  # noqa: BLE001 (an older torch without the PCI fields)
+            node = None
+        if node is None:  # one visible card: take the only amdgpu node that has an hwmon directory
+            cands = [os.path.dirname(os.path.dirname(h)) for h in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")]
+            node = cands[device_index] if device_index < len(cands) else (cands[0] if cands else None)
+        self.f_clk = self.f_pw = self.f_dpm = None
+        if node is not None:
+            hw = sorted(glob.glob(os.path.join(node, "hwmon", "hwmon*")))
+            if hw:
+                for name in ("power1_average", "power1_input"):
+                    if os.path.exists(os.path.join(hw[0], name)):
+                        self.f_pw = os.path.join(hw[0], name)
+                        break
+                if os.path.exists(os.path.join(hw[0], "freq1_input")):
+                    self.f_clk = os.path.join(hw[0], "freq1_input")
+                cap = self._read(os.path.join(hw[0], "power1_cap"))
+                self.cap_w = round(cap / 1e6, 1) if cap else None
+            if os.path.exists(os.path.join(node, "pp_dpm_sclk")):
+                self.f_dpm = os.path.join(node, "pp_dpm_sclk")
+            self.source = node
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return float(f.read().split()[0])
+        except Exception:  # noqa: BLE001
+            return None
+
+    def _dpm_mhz(self):
+        try:
+            with open(self.f_dpm) as f:
+                for line in f:
+                    if line.rstrip().endswith("*"):
+                        return float(line.split(":")[1].strip().rstrip("*").strip().lower().replace("mhz", ""))
+        except Exception:  # noqa: BLE001
+            pass
+        return None
+
+    def _run(self) -> None:
+        while not self._stop.is_set():
+            c = self._read(self.f_clk) if self.f_clk else None
+            c = c / 1e6 if c else (self._dpm_mhz() if self.f_dpm else None)
+            if c:
+                self.clk.append(c)
+            w = self._read(self.f_pw) if self.f_pw else None
+            if w:
+                self.pw.append(w / 1e6)
+            self._stop.wait(self.period)
+
+    def start(self) -> "GpuSampler":
+        import threading
+
+        if self.f_clk or self.f_pw or self.f_dpm:
+            self._thread = threading.Thread(target=self._run, daemon=True)
+            self._thread.start()
+        return self
+
+    def stop(self) -> dict:
+        self._stop.set()
+        if self._thread is not None:
+            self._thread.join()
+        med = lambda v: round(sorted(v)[len(v) // 2], 1) if v else None
+        return {"sclk_mhz_median": med(self.clk), "power_w_median": med(self.pw), "power_cap_w": self.cap_w,
+                "sclk_mhz_reference": SCLK_REFERENCE_MHZ,
+                "sclk_mhz_min": round(min(self.clk), 1) if self.clk else None, "power_w_max": round(max(self.pw), 1) if self.pw else None,
+                "samples": max(len(self.clk), len(self.pw)), "period_ms": round(1e3 * self.period),
+                "source": (f"sysfs {os.path.basename(self.f_clk or self.f_dpm or '-')} / {os.path.basename(self.f_pw or '-')} of {self.source}") if self.source else None,
+                "note": "host-side sysfs view sampled in a thread during the timed region; the in-kernel clock of an MFMA-dense loop reads up to ~10 % "
+                        "below it (MI355X_MICROARCH.md, DVFS give-back 6) -- for comparing records across boxes, not a kernel measurement"}
+
+
 def main(args=None) -> None:
     args = args if args is not None else parse_args()
 
@@ -694,6 +791,7 @@ def main(args=None) -> None:
     # events around each tap-conv / wgrad launch inside the timed region
     prof = E.KernelProfile()
     E.COLLECTIVES.reset()
+    sampler = GpuSampler(local_rank).start() if rank == 0 else None
     t0 = time.perf_counter()
     E.PROFILE = prof
     for _ in range(args.steps):
@@ -703,6 +801,10 @@ def main(args=None) -> None:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gpu_conditions = sampler.stop() if sampler is not None else None
+    if gpu_conditions is not None and gpu_conditions["sclk_mhz_median"]:
+        # the step is MFMA-dominated and power-capped: to first order its time scales with 1 / (the clock this chip holds under it)
+        gpu_conditions["ms_per_step_at_reference_sclk"] = round(1e3 * elapsed / args.steps * gpu_conditions["sclk_mhz_median"] / SCLK_REFERENCE_MHZ, 3)
     _progress(f"timed region done: {1e3 * elapsed / args.steps:.1f} ms per step")
     E.PROFILE = None
     sync_calls, sync_bytes = E.COLLECTIVES.calls / args.steps, E.COLLECTIVES.bytes / args.steps
@@ -720,10 +822,21 @@ def main(args=None) -> None:
         E.PROFILE = None
         # ... and the HBM-bound group (BatchNorm backward, element-wise, stem) in the timed configuration again, with events around ITS launches
         hbm_group = measure_hbm_group(step)  # (every rank: the steps carry collectives)
+    ranks_seen, devices_seen = 1, 1
     if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
+        # proof of how many ranks the BACKEND saw (not what WORLD_SIZE says): a sum of ones over the real process group, and the number of
+        # distinct (host, PCI device) pairs among them -- two ranks sharing one GPU (tests/test_gpu_ddp.py, gloo) count as one device
+        ones = torch.ones(1, dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(ones)
+        ranks_seen = int(round(float(ones.item())))
+        props = torch.cuda.get_device_properties(dev)
+        ident = f"{os.uname().nodename}/{getattr(props, 'pci_domain_id', 0)}:{getattr(props, 'pci_bus_id', local_rank)}:{getattr(props, 'pci_device_id', 0)}"
+        idents = [None] * world
+        torch.distributed.all_gather_object(idents, ident)
+        devices_seen = len(set(idents))
 
     if rank == 0:
         sweeps = args.batch * world * args.steps
@@ -731,6 +844,8 @@ def main(args=None) -> None:
             "metric": "sweeps/sec (fwd+bwd, 64x2048x5 range image)", "value": sweeps / elapsed, "unit": "sweeps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "ranks_seen": ranks_seen, "devices_seen": devices_seen,
+            "gpu": gpu_conditions,
             "config": {"workload": f"{args.widths} full model (MetaKernel stem + DLA backbone/FPN + cls/reg towers + targets + loss), "
                                    f"fwd+bwd+AdamW, {args.batch} synthetic {args.height}x{args.width}x{args.features} sweeps per GPU"
                                    + (" (BASELINE configs[2])" if (args.widths, args.width, args.height, args.batch) == ("rv-av2", 2048, 64, 4) else ""),

@@ -129,7 +129,11 @@ typedef struct {
 } rvTapShape;
 
 /* Rows of the partial-statistics buffer ([rows][2][c_pad] fp32) a launch with RV_OUT_STATS
- * writes; `scatter` selects the SCATTER form. */
+ * writes; `scatter` selects the SCATTER form.
+ * The planning entry points (this one, rv_tap_launch_info, rv_tap_wgrad_info, rv_tap_wgrad_workspace_bytes, rv_tap_bnb_rows) size
+ * persistent grids by the compute-unit count of the CURRENT device (hipGetDevice + one cached attribute query per device): they
+ * launch nothing but they do initialise the HIP runtime -- call them after any fork and after GPU_MAX_HW_QUEUES is in the
+ * environment; without a visible device they plan for 256 compute units. */
 int32_t rv_tap_stats_rows(const rvTapGeom* g, const rvTapShape* s, int32_t scatter);
 /* Launch plan the library picks for a tap op: info = {kernel generation, variant, grid.x, grid.y}:
  * generation 1 = tapconv_kernel<MT,NT> (variant = 16*MT + NT, block tile 32*MT pixels x 32*NT channels),
@@ -385,21 +389,6 @@ int rv_meta_modulate_bwd_sums(const void* dgeo, const void* pos_raw, const float
 int rv_meta_modulate_bwd_apply(const void* dgeo, const void* pos_raw, const float* scale, const float* shift,
                                const float* mean, const float* invstd, const float* coef, const void* feat,
                                int32_t ld_feat, int32_t N, int32_t H, int32_t W, int32_t C, void* dy, rvStream stream);
-
-/* The same two passes CHAINED with conv2d backward-data of the fusion conv in front of the modulation (nn/stems/__init__.py:51-62,
- * 84: `fusion_kernel[0]`, a 1x1 conv 9C -> K; what ATen's convolution_backward computes as dgeo = dz Wf):  dgeo is recomputed
- * tile by tile on the matrix cores in BOTH passes -- from `dz` (gradient w.r.t. that conv's output, bf16 [pixels][ld_dz], K
- * channels) and `w_scatter` (its packed backward-data image [9 * C][K], row = tap * C + c: the reference's channel order
- * c * 9 + tap already absorbed) -- and consumed in the tile epilogue: the 9C-channel gradient tensor is never written or read.
- * Outputs, partial-row layout and the finalize step in between are those of rv_meta_modulate_bwd_sums / _apply, with
- * rv_meta_chain_rows(N, H, W) rows (one per persistent workgroup).  C = 128 or 256, K % 32 == 0, K >= 128; tensors below 4 GB. */
-int32_t rv_meta_chain_rows(int32_t N, int32_t H, int32_t W);
-int rv_meta_chain_bwd_sums(const void* dz, int32_t ld_dz, int32_t K, const void* w_scatter, const void* pos_raw, const float* scale,
-                           const float* shift, const float* mean, const float* invstd, const void* feat, int32_t ld_feat, int32_t N,
-                           int32_t H, int32_t W, int32_t C, void* dfeat, int32_t ld_dfeat, float* partial, rvStream stream);
-int rv_meta_chain_bwd_apply(const void* dz, int32_t ld_dz, int32_t K, const void* w_scatter, const void* pos_raw, const float* scale,
-                            const float* shift, const float* mean, const float* invstd, const float* coef, const void* feat,
-                            int32_t ld_feat, int32_t N, int32_t H, int32_t W, int32_t C, void* dy, rvStream stream);
 
 /* The two positional layers of the MetaKernel stem (nn/stems/__init__.py:41-49, 80: Conv2dNormActivation(3, C, 1) ->
  * Conv2dNormActivation(C, C, 1) on the 9x neighbour grid) as ONE persistent streaming GEMM, C = 256 (rv-av2) or 128 (rv-waymo):

@@ -55,10 +55,15 @@ class Numerics:
     store: Callable[[Tensor], Tensor] = _identity  # applied to every tensor written to HBM
     running: Optional[StateDict] = None  # receives updated running_mean/var when train
     trace: Optional[List[dict]] = None  # teacher-forcing record: one dict per conv (+ BatchNorm) unit, see ``_trace``
+    # Summation order of the convolutions' channel reductions: 0 = as stored; k > 0 = every conv sums its input channels in a fixed
+    # permuted order (1: reversed, k >= 2: a permutation seeded by k).  Mathematically the same network -- a different, equally valid
+    # fp32 rounding of every accumulation, hence a different REALISATION of the bf16 storage points.  The envelope over a few of them
+    # (tests/tools/emulation_yardstick.py envelope) is the yardstick the chaotic-regime gradient test is held to.
+    sum_order: int = 0
 
     @staticmethod
-    def bf16(train: bool = True) -> "Numerics":
-        return Numerics(train=train, operand=round_bf16, store=round_bf16, running={})
+    def bf16(train: bool = True, sum_order: int = 0) -> "Numerics":
+        return Numerics(train=train, operand=round_bf16, store=round_bf16, running={}, sum_order=sum_order)
 
 
 def round_fp16(x: Tensor) -> Tensor:
@@ -73,6 +78,15 @@ def _numerics_fp16(train: bool = False) -> "Numerics":
 
 Numerics.fp16 = staticmethod(_numerics_fp16)
 FP32 = Numerics()
+
+
+def _channel_order(c: int, sum_order: int) -> Optional[Tensor]:
+    """Input-channel visiting order of a conv under ``Numerics.sum_order`` (None: as stored)."""
+    if sum_order == 0 or c < 2:
+        return None
+    if sum_order == 1:
+        return torch.arange(c - 1, -1, -1)
+    return torch.randperm(c, generator=torch.Generator().manual_seed(1000 * sum_order + c))
 
 
 def _trace(nm: Numerics, y: Tensor, **rec) -> None:
@@ -107,7 +121,11 @@ def conv2d_same(
     th, tw = kh - 1, kw - 1
     pad = [tw // 2, tw - tw // 2, th // 2, th - th // 2]  # F.pad order: W-left, W-right, H-top, H-bottom
     xp = F.pad(nm.operand(x), pad)
-    return F.conv2d(xp, nm.operand(weight), bias=bias, stride=stride)
+    w = nm.operand(weight)
+    order = _channel_order(w.shape[1], nm.sum_order)
+    if order is not None:
+        xp, w = xp[:, order], w[:, order]
+    return F.conv2d(xp, w, bias=bias, stride=stride)
 
 
 def batch_norm(
@@ -213,7 +231,11 @@ def aggregation_block(
 ) -> Tensor:
     """ConvTranspose2d-BN-ReLU on x2, add to x1, ResidualBlock (``nn/blocks/__init__.py:146-182``)."""
     w = sd[f"{prefix}.upscale.weight"]  # (Cin, Cout, kh, kw)
-    up = F.conv_transpose2d(nm.operand(x2), nm.operand(w), stride=stride, padding=padding)
+    x2o, wo = nm.operand(x2), nm.operand(w)
+    order = _channel_order(wo.shape[0], nm.sum_order)
+    if order is not None:
+        x2o, wo = x2o[:, order], wo[order]
+    up = F.conv_transpose2d(x2o, wo, stride=stride, padding=padding)
     _trace(nm, up, kind="convT", x=x2, w=f"{prefix}.upscale.weight", stride=stride, padding=padding, bn=f"{prefix}.normalization")
     up = F.relu(batch_norm(up, sd, f"{prefix}.normalization", nm, y_stored=nm.store(up)))
     return residual_block(nm.store(x1 + up), sd, f"{prefix}.block", num_blocks, nm=nm)
@@ -224,7 +246,11 @@ def aggregation_block(
 # --------------------------------------------------------------------------------------
 def _conv_norm_act(x: Tensor, sd: StateDict, prefix: str, nm: Numerics) -> Tensor:
     """torchvision ``Conv2dNormActivation`` with k=1: conv(no bias) -> BN -> ReLU."""
-    y = F.conv2d(nm.operand(x), nm.operand(sd[f"{prefix}.0.weight"]))
+    xo, wo = nm.operand(x), nm.operand(sd[f"{prefix}.0.weight"])
+    order = _channel_order(wo.shape[1], nm.sum_order)
+    if order is not None:
+        xo, wo = xo[:, order], wo[:, order]
+    y = F.conv2d(xo, wo)
     _trace(nm, y, kind="conv1x1", x=x, w=f"{prefix}.0.weight", stride=(1, 1), bn=f"{prefix}.1")
     return F.relu(batch_norm(y, sd, f"{prefix}.1", nm, y_stored=nm.store(y)))
 

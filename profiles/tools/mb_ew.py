@@ -1,4 +1,4 @@
-"""ew_combine (block output / materialise passes): achieved HBM bandwidth on the bench shapes.  RV3D_EW_COMB=1: the grid-stride kernel."""
+"""ew_combine (block output / materialise passes): achieved HBM bandwidth on the bench shapes."""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from range_view_3d_detection_amd import _lib as L

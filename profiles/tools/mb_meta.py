@@ -1,4 +1,4 @@
-"""MetaKernel gather kernels at the bench shape (4 x 64 x 2048, C = 256): time and algorithmic TB/s.  RV3D_META_PIECE = items per contiguous piece."""
+"""MetaKernel gather kernels at the bench shape (4 x 64 x 2048, C = 256): time and algorithmic TB/s."""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from range_view_3d_detection_amd import _lib as L

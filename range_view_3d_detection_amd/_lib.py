@@ -181,9 +181,6 @@ HBM_BYTES = {
     "rv_meta_modulate": lambda a: 2.0 * _v(a[5]) * _v(a[6]) * _v(a[7]) * _v(a[8]) * 19,
     "rv_meta_modulate_bwd_sums": lambda a: 2.0 * _v(a[8]) * _v(a[9]) * _v(a[10]) * _v(a[11]) * 20,
     "rv_meta_modulate_bwd_apply": lambda a: 2.0 * _v(a[9]) * _v(a[10]) * _v(a[11]) * _v(a[12]) * 28,
-    # ... chained with the fusion conv's backward-data (csrc/metachain.hip): dz (K) + y (9C) + feat (C) in, dfeat (C) / dy (9C) out
-    "rv_meta_chain_bwd_sums": lambda a: 2.0 * _v(a[11]) * _v(a[12]) * _v(a[13]) * (11 * _v(a[14]) + _v(a[2])),
-    "rv_meta_chain_bwd_apply": lambda a: 2.0 * _v(a[12]) * _v(a[13]) * _v(a[14]) * (19 * _v(a[15]) + _v(a[2])),
     "rv_pos_forward": lambda a: float(_v(a[3])) * (16 + 4.0 * _v(a[9])),
     "rv_pos_backward_sums": lambda a: float(_v(a[0])) * (16 + 2.0 * _v(a[1])),
     # final conv of a tower fused with the BatchNorm backward in front of it: y (+ the 32-channel dY) in; _apply also writes dy

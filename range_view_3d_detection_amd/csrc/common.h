@@ -1,5 +1,6 @@
 // Shared device/host helpers for librv3d_hip.so (gfx950 only).
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -49,16 +50,27 @@ void rv_set_error(const char* fmt, ...);
 
 static inline int rv_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int rv_pad32(int c) { return (c + 31) & ~31; }
-// compute units of the current device (a read-only cache of a device property; 256 = an MI355X when no device is visible: the
-// host-side planning entry points also run on GPU-less build boxes)
+// compute units of the CURRENT device (a read-only cache of a device property, one slot per device ordinal: a process that drives
+// several devices gets each one's own count; relaxed atomics: two threads racing on the first call store the same value).  256 = an
+// MI355X when no device is visible: the host-side planning entry points also run on GPU-less build boxes.  Note that hipGetDevice
+// initialises the HIP runtime: the planning calls (rv_tap_launch_info, rv_tap_stats_rows, rv_tap_wgrad_workspace_bytes ...) are not
+// fork-safe "pure" functions (include/rv3d.h says so).
 static inline int rv_cu_count() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
-        else cus = 256;
+    static std::atomic<int> cache[32];
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return 256;
+    if (dev < 32) {
+        n = cache[dev].load(std::memory_order_relaxed);
+        if (n > 0) return n;
     }
-    return cus;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    if (dev < 32) cache[dev].store(n, std::memory_order_relaxed);
+    return n;
+}
+// grid of a persistent launch: one workgroup per CU, a multiple of the 8 XCDs (the blockIdx -> XCD deals assume it), never empty
+static inline int rv_persistent_grid() {
+    const int g = rv_cu_count() & ~7;
+    return g < 8 ? 8 : g;
 }
 
 // ---------------------------------------------------------------------------------------

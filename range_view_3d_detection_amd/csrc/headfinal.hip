@@ -84,9 +84,12 @@ __global__ __launch_bounds__(1024 / NT) void head_final_bwd_kernel(const HeadFin
     float sc[CL], sh[CL];
 #pragma unroll
     for (int q = 0; q < CL; ++q) {
-        sc[q] = a.relu ? a.scale[c0 + q] : 0.f;  // (no ReLU behind the BatchNorm: the gate is always open)
-        sh[q] = a.relu ? a.shift[c0 + q] : 1.f;
+        sc[q] = a.scale[c0 + q];
+        sh[q] = a.shift[c0 + q];
     }
+    // ReLU behind the BatchNorm or not, in one register: the gate is `t > thr` and the activated operand `max(t, thr)` -- with
+    // thr = -inf (no ReLU) the gate is always open and the operand is scale * y + shift itself (round-5 advice: it used to be a constant 1)
+    const float thr = a.relu ? 0.f : -__builtin_inff();
     // sums:  s0 = sum g, s1 = sum g * y (turned into sum g * xhat = invstd * (s1 - mean * s0) at the end: two constants fewer in the loop)
     // apply: dy = k0 * g + (ca + cb_ * y),  ca = k0 * (c2 * mean * invstd - c1),  cb_ = -k0 * c2 * invstd   [= k0 (g - c1 - xhat c2)]
     float s0[CL], s1[CL], k0v[APPLY ? CL : 1];
@@ -148,14 +151,14 @@ __global__ __launch_bounds__(1024 / NT) void head_final_bwd_kernel(const HeadFin
             const float y0 = bf_lo(yw), y1 = bf_hi(yw);
             float g0 = acc[q >> 2][q & 3], g1 = acc[(q + 1) >> 2][(q + 1) & 3];
             const float t0 = y0 * sc[q] + sh[q], t1 = y1 * sc[q + 1] + sh[q + 1];
-            g0 = t0 > 0.f ? g0 : 0.f;
-            g1 = t1 > 0.f ? g1 : 0.f;
+            g0 = t0 > thr ? g0 : 0.f;
+            g1 = t1 > thr ? g1 : 0.f;
             if (APPLY) {
                 const float d0 = k0v[APPLY ? q : 0] * g0 + (s1[q] * y0 + s0[q]);
                 const float d1 = k0v[APPLY ? q + 1 : 0] * g1 + (s1[q + 1] * y1 + s0[q + 1]);
                 ov[q >> 1] = pack_bf2(d0, d1);
             } else {
-                ov[q >> 1] = pack_bf2(fmaxf(t0, 0.f), fmaxf(t1, 0.f));  // the activated operand of the final conv (weight gradient)
+                ov[q >> 1] = pack_bf2(fmaxf(t0, thr), fmaxf(t1, thr));  // the activated operand of the final conv (weight gradient)
                 s0[q] += g0;
                 s0[q + 1] += g1;
                 s1[q] += g0 * y0;

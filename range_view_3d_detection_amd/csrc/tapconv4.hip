@@ -415,13 +415,13 @@ __global__ __launch_bounds__(512, 2) void tapconv4_kernel(const TapConvArgs a) {
 
 
 // Smallest grid (workgroups) the DMA kernel is chosen for: below one round of 256 CUs the register-staged kernels with
-// their smaller tiles fill the chip better.  A speed heuristic only -- rv_set_option("tapconv4_min_blocks", 1) lets the
-// parity tests run the production kernels on crops the CPU oracle can afford.
+// their smaller tiles fill the chip better.  A speed heuristic only -- the per-call hint RV_SEL_SMALL_GRIDS (rvTapShape.flags) lifts
+// it so that the parity tests run the production kernels on crops the CPU oracle can afford.
 
-// returns false when the layer is not eligible (caller falls back to tapconv3 / tapconv2 / the generic kernel)
+// returns false when the layer is not eligible (caller falls back to tapconv2 / the generic kernel)
 static int tapconv4_grid(const TapConvArgs& a) {
     int grid = 8 * a.tiles_per_xcd * a.n_tiles;
-    if (grid > rv_cu_count()) grid = rv_cu_count() & ~7;  // persistent: one workgroup per CU
+    if (grid > rv_cu_count()) grid = rv_persistent_grid();  // persistent: one workgroup per CU
     return grid;
 }
 

@@ -599,7 +599,7 @@ int rv_tapconv5_launch(const TapConvArgs& a, size_t lds, int bn, hipStream_t str
         attr_set = true;
     }
     int grid = 8 * a.tiles_per_xcd * a.n_tiles;
-    if (grid > rv_cu_count()) grid = rv_cu_count() & ~7;  // one workgroup per CU (154 KB of LDS each)
+    if (grid > rv_cu_count()) grid = rv_persistent_grid();  // one workgroup per CU (154 KB of LDS each)
     const int epi = (a.flags & RV_OUT_BNB) ? 1 : ((a.flags & RV_OUT_ACCUM) ? 2 : 0);
 #define RV_T5_LAUNCH(BN_, EPI_) hipLaunchKernelGGL((tapconv5_kernel<BN_, EPI_>), dim3(grid), dim3(512), lds, stream, a)
     if (bn == 256) {

@@ -484,16 +484,17 @@ __global__ __launch_bounds__(512, 2) void tapconv6_kernel(const TapConvArgs a) {
 // returns false when the layer is not eligible (caller falls back to tapconv5 / tapconv4 / ...)
 static int tapconv6_grid(const TapConvArgs& a) {
     int grid = 8 * a.tiles_per_xcd * a.n_tiles;
-    if (grid > rv_cu_count()) grid = rv_cu_count() & ~7;  // one workgroup per CU
+    if (grid > rv_cu_count()) grid = rv_persistent_grid();  // one workgroup per CU
     return grid;
 }
 
 bool rv_tapconv6_plan(TapConvArgs* a, int* tiles, size_t* lds, int* stats_rows, int* bnb_rows) {
     if (a->step != 1) return false;
     if (a->flags & (RV_IN_AFFINE | RV_IN_RELU | RV_OUT_F32)) return false;  // the DMA path has no register prologue
-    // the masked last-writer form (sums over an ACCUMULATED gradient: three 16-byte prefetches per pass, 192 registers over this
-    // tile's sixteen passes) spills 177 registers here and ran at 16 % matrix-pipe occupancy (profiles/r04_mfma_counters.json,
-    // first collection): those few launches stay on the fifth generation, whose 8-pass 128-channel instance holds them
+    // BatchNorm-backward sums over an ACCUMULATED gradient (the round-3/4 "masked last-writer" form: three 16-byte prefetches per
+    // pass, 192 registers over this tile's sixteen passes, 177 of them spilled, 16 % matrix-pipe occupancy -- profiles/r04_mfma_counters.json)
+    // exist in NO generation since round 5 (tapconv5 rejects the combination as well, rv_tap_bnb_rows returns 0): the caller takes the
+    // separate reduce pass over the complete gradient
     if ((a->flags & RV_OUT_BNB) && (a->flags & RV_OUT_ACCUM)) return false;
     if (a->C_src % kBK != 0 || a->C_dst % kBN != 0) return false;
     const int wm_total = a->W_dst / a->phases;

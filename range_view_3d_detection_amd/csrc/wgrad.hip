@@ -719,7 +719,7 @@ __device__ __forceinline__ void wgrad3_body(const Wgrad2Args& a, uint8_t* smem, 
     // A wave does not END with its slab stores in flight, and the reduction reads the slabs with agent-scope loads (slab_load):
     // once in ~2500 two-stream training steps of round 4 the split-K reduction that follows on the SAME stream summed slab lines that
     // held the previous tenant of the recycled workspace -- always the 64-workgroup launch of one 1x1 layer, one wrong weight gradient,
-    // nothing else (profiles/r04_ab_notes.md, "One wrong weight gradient"; the round-5 soak: profiles/r05_race_soak.txt).  Two readings
+    // nothing else (profiles/r04_ab_notes.md, "One wrong weight gradient"; the round-5 soak: profiles/r05_race_soak_*.txt).  Two readings
     // fit that symptom -- stores still in flight at the end of the kernel with another queue busy, or a line of the recycled workspace
     // that the PREVIOUS reduction left in the reading XCD's L2 -- and both are closed: this wait, and loads that do not hit in a
     // non-coherent L2 line.

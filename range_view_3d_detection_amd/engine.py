@@ -753,8 +753,6 @@ class Tape:
         self.lazy_in: Dict[int, Tuple[Act, Optional[Act]]] = {}  # id(Lazy) -> (dOut, OUT mask source)
         self.lazy_sums: Dict[int, Tuple[Tensor, int]] = {}  # id(Lazy) -> BatchNorm-backward partial sums its ONE writer formed, rows
         self.meta_in: Dict[int, tuple] = {}      # id(Lazy) -> (dgeo, feat, partial sums, rows): MetaKernel modulation fused into the BatchNorm backward
-        self.meta_geo: Dict[int, "MetaModulateOp"] = {}  # id(geo Act) -> the modulation that produced it
-        self.meta_chain: Dict[int, tuple] = {}   # id(geo Act) -> (dz, scatter image, K) of the fusion conv: its backward-data is recomputed inside modulate_backward (csrc/metachain.hip)
         self.head_final: Dict[int, tuple] = {}   # id(Lazy) -> (call head, BatchNorm-backward partial sums, rows, dY of the tower's final conv, its scatter image)
         self.producers: Dict[int, "Op"] = {}     # id(block-output Act) -> the CombineOp that made it
         self.bn_of: Dict[int, "Op"] = {}         # id(Lazy) -> its BnOp
@@ -1312,7 +1310,6 @@ class MetaModulateOp(Op):
         L.call("rv_meta_modulate", pos.raw.ptr(), L.ptr(pos.bn.scale), L.ptr(pos.bn.shift), feat.ptr(), L.i32(feat.ld),
                L.i32(n), L.i32(h), L.i32(w), L.i32(cp), self.out.ptr(), L.stream_ptr())
         t.ops.append(self)
-        t.meta_geo[id(self.out)] = self
 
     def backward(self, t: Tape) -> None:
         from . import engine_bwd

@@ -84,10 +84,6 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
         # recomputes dA = W^T dY in both of its passes (rv_head_final_bwd_sums / _apply, csrc/headfinal.hip)
         _head_final_sums(op, t, dout)
         return  # (the final conv's weight gradient came out of the same pass)
-    elif op.need_input_grad and _meta_chain_eligible(op, t, dout):
-        # first fusion conv of the MetaKernel stem: no input-gradient tensor -- the backward of the modulation behind it recomputes
-        # dgeo = dz Wf tile by tile in both of its passes (rv_meta_chain_bwd_sums / _apply, csrc/metachain.hip)
-        t.meta_chain[id(op.x)] = (dout, layer.packed(bwd), layer.c_out)
     elif op.need_input_grad:
         if isinstance(op.x, Lazy):
             dst, accumulate = t.lazy_grad_target(op.x)
@@ -211,25 +207,9 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
 
 
 HEAD_FINAL_FUSE = True  # (module attribute: tests flip it in-process)
-# (likewise) backward-data of the stem's first fusion conv recomputed inside the modulation backward (csrc/metachain.hip).  Built, parity-green
-# and OFF: same-box A/B +0.38 ms per rv-av2 step, +0.97 ms per rv-waymo step (profiles/r05_metachain.md -- the recomputing GEMM's L2 -> LDS
-# fill and the epilogue's y / dy stream share the CU's one vector-memory pipeline and add up instead of overlapping).
-META_CHAIN = False
-
-
-def _meta_chain_eligible(op: "E.ConvOp", t: Tape, dout: Act) -> bool:
-    """``op`` is the 1x1 conv 9C -> K right behind a MetaModulateOp (its only consumer) in training mode, the modulation's positional
-    layer ends in BatchNorm + ReLU with batch statistics, and the widths are the ones csrc/metachain.hip is instantiated for."""
-    x, lay = op.x, op.layer
-    g = lay.geom
-    mo = t.meta_geo.get(id(x)) if not isinstance(x, Lazy) else None
-    if not (META_CHAIN and META_BWD_FUSE and t.training and mo is not None and op.x_plain is None and id(x) not in t.written):
-        return False
-    pos, feat = mo.pos, mo.feat
-    k = lay.c_out
-    return (pos.relu and pos.bn.mean is not None and id(pos) not in t.lazy_in and lay.fwd_form == "gather" and g.kh == 1 and g.kw == 1
-            and g.stride_w == 1 and feat.cp in (128, 256) and x.cp == 9 * feat.cp and x.ld == x.cp and k % 32 == 0 and k >= 128 and dout.cp == k
-            and feat.pixels * 9 * feat.cp * 2 < 0xffff0000 and feat.pixels < (1 << 24) and L.operand_tag() == "bf16")
+# (Round 5 built the same idea for the stem's first fusion conv -- its backward-data GEMM recomputed inside both passes of the modulation
+#  backward, `csrc/metachain.hip` -- parity-green and 0.4-1.0 ms per step SLOWER than the launches it replaced; round 6 removed it from the
+#  library: profiles/r05_metachain.md is the record.)
 
 
 def _head_final_eligible(op: "E.ConvOp", t: Tape, dout: Act) -> bool:
@@ -478,19 +458,13 @@ def _bn_finalize(op: "E.BnOp", t: Tape, partial: Tensor, rows: int, pixels: int,
 
 def _bn_backward_meta(op: "E.BnOp", t: Tape, meta) -> None:
     """BatchNorm backward of the positional layer behind the MetaKernel modulation (sums formed by modulate_backward)."""
-    dgeo, feat, partial, rows, chain = meta
+    dgeo, feat, partial, rows = meta
     lazy = op.lazy
     st, raw = lazy.bn, lazy.raw
     dgamma, dbeta, coef = _bn_finalize(op, t, partial, rows, raw.pixels)
     dy = raw.like()
-    if chain is not None:
-        dz, wp, k = chain
-        L.call("rv_meta_chain_bwd_apply", dz.ptr(), L.i32(dz.ld), L.i32(k), L.ptr(wp), raw.ptr(), L.ptr(st.scale), L.ptr(st.shift), L.ptr(st.mean),
-               L.ptr(st.invstd), L.ptr(coef), feat.ptr(), L.i32(feat.ld), L.i32(feat.N), L.i32(feat.H), L.i32(feat.W), L.i32(feat.cp), dy.ptr(),
-               L.stream_ptr())
-    else:
-        L.call("rv_meta_modulate_bwd_apply", dgeo.ptr(), raw.ptr(), L.ptr(st.scale), L.ptr(st.shift), L.ptr(st.mean), L.ptr(st.invstd),
-               L.ptr(coef), feat.ptr(), L.i32(feat.ld), L.i32(feat.N), L.i32(feat.H), L.i32(feat.W), L.i32(feat.cp), dy.ptr(), L.stream_ptr())
+    L.call("rv_meta_modulate_bwd_apply", dgeo.ptr(), raw.ptr(), L.ptr(st.scale), L.ptr(st.shift), L.ptr(st.mean), L.ptr(st.invstd),
+           L.ptr(coef), feat.ptr(), L.i32(feat.ld), L.i32(feat.N), L.i32(feat.H), L.i32(feat.W), L.i32(feat.cp), dy.ptr(), L.stream_ptr())
     t.raw_grad[id(raw)] = dy
     c = st.module.num_features
     t.add_param_grad(st.module.weight, dgamma[:c])
@@ -570,20 +544,6 @@ META_BWD_FUSE = True
 def modulate_backward(op: "E.MetaModulateOp", t: Tape) -> None:
     pos, feat = op.pos, op.feat
     st = pos.bn
-    chain = t.meta_chain.pop(id(op.out), None)
-    if chain is not None:
-        # the fusion conv behind this op left (dz, its scatter image, K) instead of a gradient tensor: dgeo is recomputed here and in the apply pass
-        gf, have_f = t.grad_buffer(feat)
-        assert not have_f, "MetaKernel projection output has a single consumer"
-        dz, wp, k = chain
-        rows = L.load().rv_meta_chain_rows(L.i32(feat.N), L.i32(feat.H), L.i32(feat.W))
-        partial = torch.empty((rows + L.STATS_SCRATCH_ROWS, 2, feat.cp), dtype=torch.float32, device=t.device)
-        L.call("rv_meta_chain_bwd_sums", dz.ptr(), L.i32(dz.ld), L.i32(k), L.ptr(wp), pos.raw.ptr(), L.ptr(st.scale), L.ptr(st.shift), L.ptr(st.mean),
-               L.ptr(st.invstd), feat.ptr(), L.i32(feat.ld), L.i32(feat.N), L.i32(feat.H), L.i32(feat.W), L.i32(feat.cp), gf.ptr(), L.i32(gf.ld),
-               L.ptr(partial), L.stream_ptr())
-        t.mark_written(feat)
-        t.meta_in[id(pos)] = (None, feat, partial, rows, chain)
-        return
     g, have = t.grad_buffer(op.out)
     if not have:
         return
@@ -598,7 +558,7 @@ def modulate_backward(op: "E.MetaModulateOp", t: Tape) -> None:
                feat.ptr(), L.i32(feat.ld), L.i32(feat.N), L.i32(feat.H), L.i32(feat.W), L.i32(feat.cp), gf.ptr(), L.i32(gf.ld),
                L.ptr(partial), L.stream_ptr())
         t.mark_written(feat)
-        t.meta_in[id(pos)] = (g, feat, partial, rows, None)
+        t.meta_in[id(pos)] = (g, feat, partial, rows)
         return
     dpos = pos.raw.like()
     L.call("rv_meta_modulate_bwd", g.ptr(), pos.raw.ptr(), L.ptr(pos.bn.scale), L.ptr(pos.bn.shift), feat.ptr(), L.i32(feat.ld),

@@ -165,7 +165,13 @@ def range_partition_program(t: Tape, m: nn.Module, features: Tensor, cart: Tenso
     bands = m.lower_bounds.numel()
     x = Act.empty(n, h, w, bands * c, t.device)
     feats32, cart32 = features.contiguous().float(), cart.contiguous().float()  # (temporaries referenced across the launch)
-    mask8 = mask.contiguous().view(torch.uint8) if mask.dtype == torch.bool else (mask != 0).to(torch.uint8).contiguous()
+    if mask.dtype == torch.bool:
+        mask8 = mask.contiguous().view(torch.uint8)
+    else:
+        # the reference multiplies (`features * mask`, nn/stems/__init__.py:128): only a 0/1 mask is the same thing as a gate
+        if not bool(((mask == 0) | (mask == 1)).all()):
+            raise L.RvError("RangePartition: a non-boolean mask must hold only 0 and 1 (the reference MULTIPLIES by it; the kernel gates)")
+        mask8 = mask.to(torch.uint8).contiguous()
     bounds = m.__dict__.get("_rv_bounds")
     ver = (m.lower_bounds._version, m.upper_bounds._version, m.lower_bounds.data_ptr())
     if bounds is None or bounds[0] != ver:  # (host copies of the twelve frozen numbers: read back once, not per step)

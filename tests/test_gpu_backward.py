@@ -434,96 +434,6 @@ def test_meta_kernel_backward_fused_matches_unfused():
         assert _cos(a[k], b[k]) > 0.999 and rel_err(a[k], b[k]) < 2e-2, (k, _cos(a[k], b[k]), rel_err(a[k], b[k]))
 
 
-@pytest.mark.parametrize("N,H,W,C,K", [(2, 16, 100, 256, 256), (1, 8, 64, 128, 128), (1, 3, 70, 256, 128), (1, 32, 333, 128, 256)])
-def test_meta_chain_backward_kernels_vs_fp64(N, H, W, C, K):
-    """rv_meta_chain_bwd_sums / _apply (csrc/metachain.hip: the fusion conv's backward-data GEMM dgeo = dz Wf recomputed on the matrix
-    cores inside both passes of the modulation / BatchNorm backward; the 9C-channel gradient never exists) against the same chain in
-    fp64 torch ops on the bf16 inputs: dfeat and dy to one bf16 rounding of their scale (4e-3 of max), the (sum g, sum g*xhat) rows to
-    2e-4 of their scale (fp32 MFMA accumulation, fp32 running sums).  Ragged widths (the last 64-pixel tile of a row is partial), one
-    and several sweeps, H without a 16-row strip, K != C."""
-    from range_view_3d_detection_amd import _lib as L
-
-    gen = torch.Generator().manual_seed(N * 1000 + W + C)
-    bf = lambda *s, k=1.0: (k * torch.randn(*s, generator=gen)).to(torch.bfloat16).to(DEV)
-    dz, y, feat = bf(N, H, W, K), bf(N, H, W, 9, C), bf(N, H, W, C)
-    w = bf(9 * C, K, k=K ** -0.5)  # scatter image: row tap * C + c, k contiguous
-    scale = (0.5 + torch.rand(C, generator=gen)).to(DEV)
-    shift = (0.3 * torch.randn(C, generator=gen)).to(DEV)
-    mean = (0.2 * torch.randn(C, generator=gen)).to(DEV)
-    invstd = (0.5 + torch.rand(C, generator=gen)).to(DEV)
-    coef = torch.stack([0.5 + torch.rand(C, generator=gen), 0.1 * torch.randn(C, generator=gen), 0.1 * torch.randn(C, generator=gen)]).to(DEV)
-    lib = L.load()
-    rows = lib.rv_meta_chain_rows(L.i32(N), L.i32(H), L.i32(W))
-    assert 0 < rows <= 1024
-    partial = torch.full((rows + L.STATS_SCRATCH_ROWS, 2, C), float("nan"), dtype=torch.float32, device=DEV)
-    dfeat = torch.full_like(feat, float("nan"))
-    dy = torch.full_like(y, float("nan"))
-    L.call("rv_meta_chain_bwd_sums", L.ptr(dz), L.i32(K), L.i32(K), L.ptr(w), L.ptr(y), L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd), L.ptr(feat),
-           L.i32(C), L.i32(N), L.i32(H), L.i32(W), L.i32(C), L.ptr(dfeat), L.i32(C), L.ptr(partial), L.stream_ptr())
-    L.call("rv_meta_chain_bwd_apply", L.ptr(dz), L.i32(K), L.i32(K), L.ptr(w), L.ptr(y), L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd), L.ptr(coef),
-           L.ptr(feat), L.i32(C), L.i32(N), L.i32(H), L.i32(W), L.i32(C), L.ptr(dy), L.stream_ptr())
-    torch.cuda.synchronize()
-    dgeo = (dz.double().reshape(-1, K) @ w.double().t()).reshape(N, H, W, 9, C)
-    fp = F.pad(feat.double(), (0, 0, 1, 1, 1, 1))
-    nbr = torch.stack([fp[:, k // 3 : k // 3 + H, k % 3 : k % 3 + W] for k in range(9)], dim=3)
-    inside = F.pad(torch.ones(N, H, W, 1, device=DEV, dtype=torch.float64), (0, 0, 1, 1, 1, 1))
-    inside = torch.stack([inside[:, k // 3 : k // 3 + H, k % 3 : k % 3 + W] for k in range(9)], dim=3)
-    act = y.float() * scale + shift  # (the kernels gate in fp32)
-    gate = (act > 0).double() * inside
-    z = dgeo * nbr * gate
-    xhat = (y.double() - mean.double()) * invstd.double()
-    s0, s1 = z.sum((0, 1, 2, 3)), (z * xhat).sum((0, 1, 2, 3))
-    got = partial[:rows].double().sum(0)
-    assert torch.isfinite(got).all()
-    ref = float(z.abs().sum((0, 1, 2, 3)).max())
-    for a, b in ((got[0], s0), (got[1], s1)):
-        assert float((a - b).abs().max()) < 2e-4 * ref, (float((a - b).abs().max()), ref)
-    contrib = F.pad(torch.zeros(N, H, W, C, device=DEV, dtype=torch.float64), (0, 0, 1, 1, 1, 1))
-    prod = dgeo * torch.relu(act).double() * inside
-    for k in range(9):
-        contrib[:, k // 3 : k // 3 + H, k % 3 : k % 3 + W] += prod[:, :, :, k]
-    want_dfeat = contrib[:, 1:-1, 1:-1]
-    assert rel_err(dfeat.float(), want_dfeat.float()) < 4e-3, rel_err(dfeat.float(), want_dfeat.float())
-    want_dy = coef[0].double() * (z - coef[1].double() - xhat * coef[2].double())
-    assert rel_err(dy.float(), want_dy.float()) < 4e-3, rel_err(dy.float(), want_dy.float())
-
-
-@pytest.mark.parametrize("C,W", [(256, 160), (128, 200)])
-def test_meta_kernel_backward_chained_matches_unchained(C, W):
-    """MetaKernel training step with the fusion conv's backward-data chained into the modulation backward (engine_bwd.META_CHAIN:
-    no 9C-channel gradient tensor) against the unchained passes (rv_tap_scatter -> rv_meta_modulate_bwd_sums / _apply): every
-    parameter gradient behind the chain (the projection block through dfeat, the positional pair through dy) within the one bf16 rounding
-    of dgeo the unchained passes store (cosine > 0.999, 2e-2 of max); the gradients in FRONT of the chain (the fusion convs and their BatchNorms) bit-identical."""
-    from range_view_3d_detection_amd import engine_bwd
-    from range_view_3d_detection_amd.nn.stems import MetaKernel
-
-    gen = torch.Generator().manual_seed(29)
-    m = MetaKernel(5, C, 3, 2).to(DEV).train()
-    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
-    feats = torch.randn(2, 5, 16, W, generator=gen).to(DEV)
-    cart = (torch.randn(2, 3, 16, W, generator=gen) * 5).to(DEV)
-    probe = torch.randn(2, C, 16, W, generator=gen).to(DEV)
-
-    default = engine_bwd.META_CHAIN
-
-    def run(chained: bool):
-        engine_bwd.META_CHAIN = chained
-        try:
-            m.load_state_dict(sd)
-            m.zero_grad(set_to_none=True)
-            (m(feats, cart).float() * probe).sum().backward()
-            return {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()}
-        finally:
-            engine_bwd.META_CHAIN = default
-
-    a, b = run(True), run(False)
-    for k in a:
-        if k.startswith("fusion_kernel."):
-            assert torch.equal(a[k], b[k]), k
-        else:
-            assert _cos(a[k], b[k]) > 0.999 and rel_err(a[k], b[k]) < 2e-2, (k, _cos(a[k], b[k]), rel_err(a[k], b[k]))
-
-
 @pytest.mark.parametrize("C", [256, 128])
 @pytest.mark.parametrize("P", [999, 41472])
 def test_pos_backward_sums_kernel_vs_fp64(P, C):
@@ -795,3 +705,47 @@ def test_head_final_conv_backward_fused_with_the_last_batchnorm(C, n_out, W):
         ef, eu = rel_err(gf[k], r), rel_err(gu[k], r)
         assert ef < max(1.5 * eu, 4e-3) + 1e-3, (k, ef, eu)
     assert rel_err(dxf, xr.grad) < max(1.5 * rel_err(dxu, xr.grad), 8e-3) + 1e-3
+
+
+@pytest.mark.parametrize("relu", [1, 0])
+def test_head_final_sums_kernel_vs_fp64_with_and_without_relu(relu):
+    """rv_head_final_bwd_sums at the C ABI (include/rv3d.h): the BatchNorm-backward sums and the final conv's weight gradient against
+    fp64 torch ops on the same bf16 operands -- with a ReLU behind the BatchNorm and WITHOUT one (round-5 advice: with relu = 0 the
+    kernel used to pack a constant 1.0 as the weight gradient's activated operand instead of scale * y + shift; the engine only ever
+    passes relu = 1)."""
+    from range_view_3d_detection_amd import _lib as L
+
+    lib = L.load()
+    gen = torch.Generator().manual_seed(77 + relu)
+    P, C, n_out = 3000, 256, 8
+    y = bf16r(torch.randn(P, C, generator=gen)).to(DEV).to(torch.bfloat16)
+    dY = torch.zeros(P, 32)
+    dY[:, :n_out] = bf16r(torch.randn(P, n_out, generator=gen))
+    dY = dY.to(DEV).to(torch.bfloat16)
+    W = bf16r(0.3 * torch.randn(n_out, C, generator=gen))
+    wp = torch.zeros(C, 32)
+    wp[:, :n_out] = W.t()
+    wp = wp.to(DEV).to(torch.bfloat16)
+    scale = (0.5 + torch.rand(C, generator=gen)).to(DEV)
+    shift = (0.3 * torch.randn(C, generator=gen)).to(DEV)
+    mean = (0.1 * torch.randn(C, generator=gen)).to(DEV)
+    invstd = (0.8 + 0.4 * torch.rand(C, generator=gen)).to(DEV)
+    rows = lib.rv_head_final_bwd_rows(L.i64(P))
+    partial = torch.zeros((rows + L.STATS_SCRATCH_ROWS, 2, C), dtype=torch.float32, device=DEV)
+    dw_partial = torch.zeros((rows, 32 * C), dtype=torch.float32, device=DEV)
+    L.call("rv_head_final_bwd_sums", L.i64(P), L.i32(C), L.ptr(y), L.i32(C), L.ptr(dY), L.i32(32), L.ptr(wp), L.ptr(scale), L.ptr(shift),
+           L.ptr(mean), L.ptr(invstd), L.i32(relu), L.ptr(partial), L.ptr(dw_partial), L.stream_ptr())
+    dw = torch.empty((32, C), dtype=torch.float32, device=DEV)
+    L.call("rv_reduce_rows", L.ptr(dw_partial), L.i32(rows), L.i32(32 * C), L.ptr(dw), L.stream_ptr())
+    torch.cuda.synchronize()
+    yd, dYd = y.double().cpu(), dY.double().cpu()
+    t = yd * scale.double().cpu() + shift.double().cpu()
+    dA = dYd[:, :n_out] @ W.double()
+    g = dA * (t > 0) if relu else dA
+    xhat = (yd - mean.double().cpu()) * invstd.double().cpu()
+    s = partial[:rows].double().sum(0).cpu()
+    assert rel_err(s[0].float(), g.sum(0).float()) < 1e-4 and rel_err(s[1].float(), (g * xhat).sum(0).float()) < 1e-4
+    act = bf16r((t.clamp_min(0) if relu else t).float()).double()  # (the operand is packed to bf16 before the MFMA)
+    want_dw = dYd[:, :n_out].t() @ act
+    assert rel_err(dw[:n_out].cpu(), want_dw.float()) < 1e-4, rel_err(dw[:n_out].cpu(), want_dw.float())
+    assert float(dw[n_out:].abs().max()) == 0.0

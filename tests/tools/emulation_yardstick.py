@@ -4,6 +4,14 @@ on the fly; at 64 x 2048 / 64 x 2656 one emulation pass costs 50-80 s of a 16-co
 script and recorded in tests/test_gpu_fullsize_train.py (``EMULATION``).  CPU only; run from the repo root:
 
     python tests/tools/emulation_yardstick.py [rv-av2|rv-waymo|first-step]
+    python tests/tools/emulation_yardstick.py envelope     # rewrites tests/golden/emulation_envelope.json
+
+``envelope`` (round-5 review, item 9): the crop cases of tests/test_gpu_realwidth.py under FOUR summation orders of the CPU bf16
+emulation (``Numerics.bf16(sum_order=k)``: every conv visits its input channels in a permuted order -- the same network, another
+valid fp32 rounding of every accumulation).  In the chaotic regime (BatchNorm shifts around zero: half of the ReLU gates within a
+bf16 ulp of zero) two such realisations differ from each other as much as each differs from fp32; min / max of the per-parameter
+gradient cosine's median and 5 % quantile over the realisations is the ENVELOPE the HIP result is asserted against (envelope minimum
+- 0.02), instead of a margin that was re-tuned whenever a kernel changed.
 """
 
 from __future__ import annotations
@@ -70,7 +78,53 @@ def first_step():
     return out
 
 
+ENVELOPE_CASES = {"rv-av2/256/3.0": ("rv-av2", 5, 26, 256, 3.0), "rv-av2/256/0.0": ("rv-av2", 5, 26, 256, 0.0), "rv-waymo/336/3.0": ("rv-waymo", 6, 3, 336, 3.0)}
+ENVELOPE_ORDERS = (0, 1, 2, 3)
+
+
+def envelope_case(widths, n_feat, n_cls, W, shift):
+    from oracle import model as om
+    from oracle import targets as otgt
+    from test_gpu_realwidth import _prepare
+
+    _, _, sd, batch = _prepare(widths, n_feat, n_cls, W, shift)
+
+    def run(nm):
+        params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
+        _, logits, reg = om.detector_forward(batch["features"], batch["cart"], {**sd, **params}, nm=nm)
+        tg = otgt.compute_targets(batch["cart"], batch["annotations"], n_cls)
+        loss = otgt.detection_loss(logits, reg, batch["cart"], batch["mask"], tg, n_cls)["loss"]
+        loss.backward()
+        return float(loss.detach()), {k: p.grad for k, p in params.items()}
+
+    loss32, g32 = run(om.Numerics(train=True))
+    keys = [k for k in g32 if float(g32[k].norm()) >= 1e-9]
+    # the permuted order is the same network: in fp32 its gradients agree with the stored order to fp32 rounding
+    _, g32p = run(om.Numerics(train=True, sum_order=2))
+    fp32_check = min(_cos(g32p[k], g32[k]) for k in keys)
+    rows = []
+    for order in ENVELOPE_ORDERS:
+        loss16, g16 = run(om.Numerics.bf16(train=True, sum_order=order))
+        cos = np.array([_cos(g16[k], g32[k]) for k in keys])
+        rows.append({"sum_order": order, "loss16": loss16, "median": float(np.median(cos)), "q05": float(np.quantile(cos, 0.05)), "min": float(cos.min())})
+        print("   ", rows[-1], flush=True)
+    return {"loss32": loss32, "parameters": len(keys), "fp32_permuted_order_min_cos": fp32_check, "realisations": rows,
+            "median_min": min(r["median"] for r in rows), "median_max": max(r["median"] for r in rows),
+            "q05_min": min(r["q05"] for r in rows), "q05_max": max(r["q05"] for r in rows)}
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["envelope"]:
+        out = {}
+        for name, case in ENVELOPE_CASES.items():
+            print(name, flush=True)
+            out[name] = envelope_case(*case)
+        path = os.path.join(ROOT, "tests", "golden", "emulation_envelope.json")
+        with open(path, "w") as f:
+            json.dump({"threads": torch.get_num_threads(), "torch": torch.__version__, "cases": out}, f, indent=1)
+            f.write("\n")
+        print("wrote", path)
+        sys.exit(0)
     which = sys.argv[1:] or ["rv-av2", "rv-waymo", "first-step"]
     for w in which:
         r = first_step() if w == "first-step" else train_case(*{"rv-av2": ("rv-av2", 5, 26, 2048), "rv-waymo": ("rv-waymo", 6, 3, 2656)}[w])
