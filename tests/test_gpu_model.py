@@ -215,6 +215,69 @@ def test_detector_gradients_vs_oracle(bn_bias_shift, n_feat, n_cls, width):
         assert med32 > 0.98 and q32 > 0.9, (med32, q32)
 
 
+def test_baseline_config0_shape_vs_oracle():
+    """BASELINE.json configs[0] on the HIP path (round-5 review, item 9): the debug-overfit configuration's own shape -- ONE synthetic
+    64 x 512 x 5 sweep, the nearest reference-valid tiny backbone ``layers=[16]*5`` (towers 32, 5 classes; what bench.py times on the CPU as
+    ``cpu_baseline.config1``) -- one training step against the oracle: logits / regressands against the oracle with the same bf16
+    storage points (2e-2 of the maximum: one to two bf16 ulps over ~40 layers; smoke() measured 1.2e-2 on its 16 x 128 model) and the
+    fp32 oracle (direction), loss 2e-3 relative to the bf16-emulating oracle and 1e-2 to fp32, per-parameter gradient cosines against
+    fp32 no worse than the CPU emulation's (median - 0.02, 5 % quantile - 0.05) and median > 0.99 (gates firmly open: BatchNorm shift
+    3.0 as in test_detector_gradients_vs_oracle; 16 logical channels = one 32-channel padded slab per tensor)."""
+    from bench import Detector, build_model, synthetic_batch
+    from oracle import model as om
+    from oracle import targets as otgt
+
+    n_cls = 5
+    torch.manual_seed(0)
+    backbone, head = build_model("c16", n_cls)
+    gen = torch.Generator().manual_seed(1)
+    for m in list(backbone.modules()) + list(head.modules()):
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data = 0.5 + torch.rand(m.weight.shape, generator=gen)
+            m.bias.data = 0.2 * torch.randn(m.bias.shape, generator=gen) + 3.0
+    sd = {**{f"backbone.{k}": v.clone() for k, v in backbone.state_dict().items()}, **{f"head.{k}": v.clone() for k, v in head.state_dict().items()}}
+    batch = synthetic_batch(1, 64, 512, seed=0, device="cpu", boxes_per_sweep=4, n_cls=n_cls)  # (bench.py::cpu_baseline.config1's sweep)
+
+    def oracle_run(nm):
+        params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
+        _, logits, reg = om.detector_forward(batch["features"], batch["cart"], {**sd, **params}, nm=nm)
+        tg = otgt.compute_targets(batch["cart"], batch["annotations"], n_cls)
+        loss = otgt.detection_loss(logits, reg, batch["cart"], batch["mask"], tg, n_cls)["loss"]
+        loss.backward()
+        return logits.detach(), reg.detach(), float(loss.detach()), {k: p.grad for k, p in params.items()}, tg
+
+    lg32, rg32, loss32, g32, tg = oracle_run(om.Numerics(train=True))
+    lg16, rg16, loss16, g16, _ = oracle_run(om.Numerics.bf16(train=True))
+    model = Detector(backbone, head).to(DEV).train()
+    data = {k: (v.to(DEV) if k != "annotations" else v) for k, v in batch.items()}
+    feats = model.backbone(data)
+    outputs, losses = model.head(feats, data, return_loss=True)
+    losses["loss"].backward()
+    torch.cuda.synchronize()
+    for k in ("classification_labels", "panoptics", "points_per_obj"):
+        assert torch.equal(data[1][0][k].cpu(), tg[k]), k
+    logits, reg = outputs[1][0]["logits"].float().cpu(), outputs[1][0]["regressands"].float().cpu()
+    assert logits.shape == (1, n_cls, 64, 512) and reg.shape == (1, 8, 64, 512)
+    e_l, e_r = rel_err(logits, lg16), rel_err(reg, rg16)
+    print(f"configs[0] shape: logits {e_l:.3e} / regressands {e_r:.3e} of max against the bf16-emulating oracle; cosine vs fp32 "
+          f"{_cos(logits, lg32):.5f} / {_cos(reg, rg32):.5f}; loss {float(losses['loss']):.6f} (emulation {loss16:.6f}, fp32 {loss32:.6f})")
+    assert e_l < 2e-2 and e_r < 2e-2, (e_l, e_r)
+    assert _cos(logits, lg32) > 0.999 and _cos(reg, rg32) > 0.999
+    loss = float(losses["loss"])
+    assert abs(loss - loss16) / abs(loss16) < 2e-3 and abs(loss - loss32) / abs(loss32) < 1e-2, (loss, loss16, loss32)
+    cos32, cos_emu = [], []
+    for k, p in model.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+        if float(g32[k].norm()) < 1e-9:
+            continue
+        cos32.append(_cos(p.grad.cpu(), g32[k]))
+        cos_emu.append(_cos(g16[k], g32[k]))
+    cos32, cos_emu = np.array(cos32), np.array(cos_emu)
+    med32, q32, med_emu, q_emu = np.median(cos32), np.quantile(cos32, 0.05), np.median(cos_emu), np.quantile(cos_emu, 0.05)
+    print(f"    {len(cos32)} parameters; gradient cosine vs fp32: HIP median {med32:.4f} q05 {q32:.4f}; CPU bf16 emulation {med_emu:.4f} / {q_emu:.4f}")
+    assert med32 > med_emu - 0.02 and q32 > q_emu - 0.05 and med32 > 0.99, (med32, med_emu, q32, q_emu)
+
+
 def test_tiny_detector_eval_and_decode(golden):
     from range_view_3d_detection_amd.nn.decoders.range_decoder import RangeDecoder
 

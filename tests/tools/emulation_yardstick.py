@@ -6,7 +6,7 @@ script and recorded in tests/test_gpu_fullsize_train.py (``EMULATION``).  CPU on
     python tests/tools/emulation_yardstick.py [rv-av2|rv-waymo|first-step]
     python tests/tools/emulation_yardstick.py envelope     # rewrites tests/golden/emulation_envelope.json
 
-``envelope`` (round-5 review, item 9): the crop cases of tests/test_gpu_realwidth.py under FOUR summation orders of the CPU bf16
+``envelope`` (round-5 review, item 9): the crop cases of tests/test_gpu_realwidth.py under EIGHT summation orders of the CPU bf16
 emulation (``Numerics.bf16(sum_order=k)``: every conv visits its input channels in a permuted order -- the same network, another
 valid fp32 rounding of every accumulation).  In the chaotic regime (BatchNorm shifts around zero: half of the ReLU gates within a
 bf16 ulp of zero) two such realisations differ from each other as much as each differs from fp32; min / max of the per-parameter
@@ -79,7 +79,7 @@ def first_step():
 
 
 ENVELOPE_CASES = {"rv-av2/256/3.0": ("rv-av2", 5, 26, 256, 3.0), "rv-av2/256/0.0": ("rv-av2", 5, 26, 256, 0.0), "rv-waymo/336/3.0": ("rv-waymo", 6, 3, 336, 3.0)}
-ENVELOPE_ORDERS = (0, 1, 2, 3)
+ENVELOPE_ORDERS = (0, 1, 2, 3, 4, 5, 6, 7)
 
 
 def envelope_case(widths, n_feat, n_cls, W, shift):
