@@ -101,9 +101,7 @@ int rv_unfold_weight_grad(const rvTapGeom* g, const float* dT_folded, float* dT,
 int rv_unpack_weight_grad(const rvTapGeom* g, const float* packed, float* dT, int32_t accumulate, rvStream stream);
 
 /* flags for rv_tap_gather / rv_tap_scatter */
-#define RV_IN_AFFINE 1   /* operand = in_scale[c]*x + in_shift[c] (folded BatchNorm): applied in the register prologue of the register-staged
-                          * kernels, or -- round 6, 3x3 stride-1 launches of generation 6 with <= 512 input channels -- to the input halo
-                          * after it has landed in LDS (csrc/tapconv6.hip, XF); same values either way, rounded to the operand type once */
+#define RV_IN_AFFINE 1   /* operand = in_scale[c]*x + in_shift[c] (folded BatchNorm) */
 #define RV_IN_RELU 2     /* ... followed by ReLU; padding positions stay exactly 0 */
 #define RV_OUT_F32 4     /* dst is fp32 (final head convs); default bf16 */
 #define RV_OUT_BIAS 8    /* dst += bias[c] */
@@ -122,9 +120,7 @@ int rv_unpack_weight_grad(const rvTapGeom* g, const float* packed, float* dT, in
 #define RV_SEL_SMALL_GRIDS6 (1 << 21) /* ... and generation 6 */
 #define RV_SEL_NO_GEN6 (1 << 22)      /* do not select generation 6 */
 #define RV_SEL_NO_GEN5 (1 << 23)      /* do not select generations 5 and 6 (multi-tap layers stay on generation 4) */
-#define RV_SEL_NO_XF (1 << 24)        /* generation 6 does not take launches with a folded BatchNorm on the way in (RV_IN_AFFINE): they fall to the
-                                       * register-staged kernels, as before round 6 */
-#define RV_SEL_MASK (31 << 20)
+#define RV_SEL_MASK (15 << 20)
 
 typedef struct {
     int32_t N, H, Wu, Wv; /* U is (N,H,Wu), V is (N,H,Wv) */

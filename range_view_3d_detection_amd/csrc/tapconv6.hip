@@ -54,12 +54,6 @@ constexpr int kTab = kScratch + 1024;                       // tap table (prolog
 constexpr int kStatAcc = kTab + 32 * 4;                     // per-workgroup statistic accumulators: float [8 waves][4 j][16 channels][2]
 constexpr int kBnbAcc = kStatAcc + 8 * 4 * 16 * 2 * 4;      // per-workgroup BatchNorm-backward sums: float [16 chunks][16] (thread tid < 256 owns one)
 constexpr int kLds = kBnbAcc + 256 * 4;
-// XF instances (round 6): the folded BatchNorm (+ReLU) of the INPUT applied to the halo after it has landed in LDS (below).  The
-// per-channel (scale, shift) of all input channels sit behind everything else: float [2][kXfMaxC]
-constexpr int kXfMaxC = 512;
-constexpr int kXfTab = kLds;
-constexpr int kLdsXf = kXfTab + 2 * kXfMaxC * 4;
-static_assert(kLdsXf <= 160 * 1024, "LDS budget");
 constexpr int kMinTaps = kAhead + 2 > 6 ? kAhead + 2 : 6;  // (the K-tile bodies 0..5 are unconditional)
 
 __device__ __attribute__((aligned(256))) uint32_t g_zero_page6[64];
@@ -83,16 +77,7 @@ constexpr int wait_count(int U) {
 // (Measured and dropped in round 4, profiles/r04_tapconv6_ablation.md: a role split -- four waves issue every LDS-DMA and never store, four
 //  store and never load -- 0 % / -5 % / -9 % on the 512- / 256- / 128-channel layers; a pipelined tile boundary with the next tile's
 //  prologue issued before the stores, 2 ms per step slower; non-temporal epilogue stores, neutral.  Neither is in the library.)
-// XF (round 6, the round-5 review's item 1a): the input is the RAW output y of a conv -> BatchNorm (-> ReLU) unit and the operand
-// relu?(scale * y + shift) is formed IN LDS after the halo chunk has landed, by the wave that issued the DMA instruction, on exactly the
-// 16 bytes per lane that instruction wrote (a lane's k-chunk is the same for all of its instructions: eight (scale, shift) pairs per
-// lane and chunk, read from an LDS table).  Pixels outside the image came from the zero page and STAY zero (the reference pads the
-// activation, not y: nn/modules/conv.py:63-80).  The next chunk's halo has landed for its own wave once K tile 5's counted wait has
-// retired it (wait_count): its six pieces are transformed one per section of K tiles 6, 7, 8 (3x3 layers only), under the other
-// half-workgroup's MFMA clusters; the first chunk of a tile in the prologue.  What this deletes is the write-out pass in front of the
-// forward conv (engine.Lazy.materialized: one read + one write of the activation, plus a launch boundary); the weight gradient still
-// wants the plain tensor and gets it from the same pass run in the BACKWARD pass, beside the previous layer's weight gradient.
-template <int EPI, bool XF = false>
+template <int EPI>
 __global__ __launch_bounds__(512, 2) void tapconv6_kernel(const TapConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -120,14 +105,6 @@ __global__ __launch_bounds__(512, 2) void tapconv6_kernel(const TapConvArgs a) {
     }
     if ((EPI == 1) && a.stats_per_wg && tid < 256)
         ((float*)(smem + kBnbAcc))[tid] = 0.f;  // (same rows rule for the BatchNorm-backward sums; slot owner = the thread that adds to it)
-    if constexpr (XF) {  // (published by the first tile's tap-table barrier)
-        float* xtab = (float*)(smem + kXfTab);
-        for (int c = tid; c < a.C_src; c += 512) {
-            xtab[c] = a.in_scale[c];
-            xtab[kXfMaxC + c] = a.in_shift[c];
-        }
-    }
-    const float xf_thr = (a.flags & RV_IN_RELU) ? 0.f : -__builtin_inff();  // max(t, thr): ReLU, or nothing
     for (int k = 0;; ++k) {
     const int xslot = wslot + nslots * k;
     if (xslot >= a.tiles_per_xcd * gy) break;
@@ -204,43 +181,6 @@ __global__ __launch_bounds__(512, 2) void tapconv6_kernel(const TapConvArgs a) {
         __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(smem + dst), 16, 0, 0);
     };
 
-    // ---- XF: in-LDS operand transform of this wave's own halo pieces ---------------------------------------------------------
-    float xsc[XF ? 8 : 1], xsh[XF ? 8 : 1];
-    u32x4 xv = {0u, 0u, 0u, 0u};
-    auto xf_consts = [&](int chunk) {  // the lane's eight channels of chunk `chunk`: kq8 .. kq8 + 7
-        if constexpr (XF) {
-            const float* xtab = (const float*)(smem + kXfTab) + chunk * kBK + kq8;
-            const f32x4 s0 = *(const f32x4*)xtab, s1 = *(const f32x4*)(xtab + 4);
-            const f32x4 h0 = *(const f32x4*)(xtab + kXfMaxC), h1 = *(const f32x4*)(xtab + kXfMaxC + 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                xsc[XF ? j : 0] = s0[j];
-                xsc[XF ? 4 + j : 0] = s1[j];
-                xsh[XF ? j : 0] = h0[j];
-                xsh[XF ? 4 + j : 0] = h1[j];
-            }
-        }
-    };
-    auto xf_load = [&](int buf, int i) {  // i: compile-time piece index 0 .. kHaloPer - 1 (wave-uniform: dummies are skipped)
-        if constexpr (XF) {
-            if (i < 5 || wave == 0) xv = *(const u32x4*)(smem + buf * kHaloBytes + (wave + 8 * i) * 1024 + lane * 16);
-        }
-    };
-    auto xf_store = [&](int buf, int i) {
-        if constexpr (XF) {
-            if (i < 5 || wave == 0) {  // (= wave + 8 i < kHaloInstr: the dummies carry nothing)
-                u32x4 o;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float lo = fmaxf(bf_lo(xv[j]) * xsc[XF ? 2 * j : 0] + xsh[XF ? 2 * j : 0], xf_thr);
-                    const float hi = fmaxf(bf_hi(xv[j]) * xsc[XF ? 2 * j + 1 : 0] + xsh[XF ? 2 * j + 1 : 0], xf_thr);
-                    o[j] = pack_bf2(lo, hi);
-                }
-                if (hoff[i] >= 0) *(u32x4*)(smem + buf * kHaloBytes + (wave + 8 * i) * 1024 + lane * 16) = o;  // (zero padding stays zero)
-            }
-        }
-    };
-
     // ---- fragment reads ---------------------------------------------------------------------------------------------
     // A: output pixel (row r, column c) under a tap = halo slot 36 r + c + shift(tap).  Wave row wr owns rows 4 wr .. 4 wr + 3;
     // fragment i (0..7): row 4 wr + i/2, columns 16 (i&1) + l15.  B: piece row = channel (wc * 64 + 16 j + l15).
@@ -289,15 +229,6 @@ __global__ __launch_bounds__(512, 2) void tapconv6_kernel(const TapConvArgs a) {
 #pragma unroll
     for (int j = 0; j < kAhead; ++j) stage_b(j);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if constexpr (XF) {  // first chunk of the tile: all six pieces here (once per tile)
-        xf_consts(0);
-#pragma unroll
-        for (int i = 0; i < kHaloPer; ++i) {
-            xf_load(0, i);
-            xf_store(0, i);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
     __builtin_amdgcn_s_barrier();
     if (wave >= 4) __builtin_amdgcn_s_barrier();  // the second half of the workgroup runs one barrier behind the first
 
@@ -310,23 +241,16 @@ __global__ __launch_bounds__(512, 2) void tapconv6_kernel(const TapConvArgs a) {
     {                                                                                                              \
         constexpr int W = (HALO) ? wait_count(U) : kAhead - 1;                                                     \
         const int hbuf = (kc + 1) & 1;                                                                             \
-        constexpr bool XT = XF && (HALO) && (U) >= 6 && (U) <= 8; /* (next chunk's halo landed: transform sections) */ \
-        if constexpr (XF && (HALO) && (U) == 6) xf_consts(kc + 1);                                                 \
-        if constexpr (XT) xf_load(hbuf, 2 * ((U) - 6));                                                            \
         stage_b(kt + kAhead);                                                                                      \
         if constexpr ((HALO) && (U) <= 2) stage_halo(hbuf, kHaloPerTile * (U), kc + 1);                            \
         addr_a((kc & 1) * kHaloBytes, sh);                                                                         \
         read_b(kt);                                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                                         \
         read_a(0);                                                                                                 \
-        if constexpr (XT) xf_store(hbuf, 2 * ((U) - 6));                                                           \
         RV_PHASE_COMPUTE(0);                                                                                       \
-        if constexpr (XT) xf_load(hbuf, 2 * ((U) - 6) + 1);                                                        \
         read_a(1);                                                                                                 \
         if constexpr ((HALO) && (U) <= 2) stage_halo(hbuf, kHaloPerTile * (U) + 1, kc + 1);                        \
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W) : "memory");                                                   \
-        if constexpr (XT) xf_store(hbuf, 2 * ((U) - 6) + 1);                                                       \
-        if constexpr (XT && (U) == 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* landed before the barrier behind which the other half reads it */ \
         RV_PHASE_COMPUTE(1);                                                                                       \
         ++kt;                                                                                                      \
         const bool wrap = ix + 1 == ncol;                                                                          \
@@ -566,15 +490,7 @@ static int tapconv6_grid(const TapConvArgs& a) {
 
 bool rv_tapconv6_plan(TapConvArgs* a, int* tiles, size_t* lds, int* stats_rows, int* bnb_rows) {
     if (a->step != 1) return false;
-    if (a->flags & RV_OUT_F32) return false;
-    // a folded BatchNorm (+ReLU) on the way in: the DMA path has no register prologue -- the XF instance applies it in LDS (3x3 stride-1
-    // forward launches with a plain epilogue; anything else: the caller writes the operand out first)
-    const bool xf = (a->flags & (RV_IN_AFFINE | RV_IN_RELU)) != 0;
-    if (xf) {
-        if ((a->sel & RV_SEL_NO_XF) || !(a->flags & RV_IN_AFFINE) || (a->flags & (RV_OUT_BNB | RV_OUT_ACCUM)) || a->phases != 1 || a->tt.ntaps[0] != 9 ||
-            a->C_src > kXfMaxC)
-            return false;
-    }
+    if (a->flags & (RV_IN_AFFINE | RV_IN_RELU | RV_OUT_F32)) return false;  // the DMA path has no register prologue
     // BatchNorm-backward sums over an ACCUMULATED gradient (the round-3/4 "masked last-writer" form: three 16-byte prefetches per
     // pass, 192 registers over this tile's sixteen passes, 177 of them spilled, 16 % matrix-pipe occupancy -- profiles/r04_mfma_counters.json)
     // exist in NO generation since round 5 (tapconv5 rejects the combination as well, rv_tap_bnb_rows returns 0): the caller takes the
@@ -618,7 +534,7 @@ bool rv_tapconv6_plan(TapConvArgs* a, int* tiles, size_t* lds, int* stats_rows, 
     a->stats_per_wg = (nslots % a->n_tiles == 0) ? 1 : 0;
     *stats_rows = a->stats_per_wg ? (grid / a->n_tiles) * 4 : a->total_tiles * 4;
     *bnb_rows = a->stats_per_wg ? grid / a->n_tiles : a->total_tiles;
-    *lds = (size_t)(xf ? kLdsXf : kLds);
+    *lds = (size_t)kLds;
     const size_t epi = (size_t)kTR * kTC * (kBN + 8) * sizeof(bf16_t);
     if (*lds < epi) *lds = epi;
     return true;
@@ -630,13 +546,11 @@ int rv_tapconv6_launch(const TapConvArgs& a, size_t lds, hipStream_t stream) {
         (void)hipFuncSetAttribute((const void*)tapconv6_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)tapconv6_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)tapconv6_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)tapconv6_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     const int grid = tapconv6_grid(a);
     const int epi = (a.flags & RV_OUT_BNB) ? 1 : ((a.flags & RV_OUT_ACCUM) ? 2 : 0);
-    if (a.flags & RV_IN_AFFINE) hipLaunchKernelGGL((tapconv6_kernel<0, true>), dim3(grid), dim3(512), lds, stream, a);  // (plan: plain epilogue only)
-    else if (epi == 1) hipLaunchKernelGGL((tapconv6_kernel<1>), dim3(grid), dim3(512), lds, stream, a);
+    if (epi == 1) hipLaunchKernelGGL((tapconv6_kernel<1>), dim3(grid), dim3(512), lds, stream, a);
     else if (epi == 2) hipLaunchKernelGGL((tapconv6_kernel<2>), dim3(grid), dim3(512), lds, stream, a);
     else hipLaunchKernelGGL((tapconv6_kernel<0>), dim3(grid), dim3(512), lds, stream, a);
     RV_CHECK_LAUNCH("tapconv6_kernel");

@@ -516,21 +516,10 @@ BNB_FUSE = True
 #  masked epilogue -- three 16-byte prefetches per pass, time-neutral to slightly slower; profiles/r04_ab_notes.md.)
 
 
-def _dma_eligible(geom, n: int, h: int, wu: int, wv: int, ld_src: int, ld_dst: int, scatter: bool, flags: int = 0) -> bool:
-    """Would this launch run on an LDS-DMA kernel?  With ``flags`` = the folded-BatchNorm input flags: on the generation-6 instance that
-    applies them in LDS (the only DMA kernel that takes them)."""
+def _dma_eligible(geom, n: int, h: int, wu: int, wv: int, ld_src: int, ld_dst: int, scatter: bool) -> bool:
     info = (ctypes.c_int32 * 4)()
-    shape = L.TapShape(n, h, wu, wv, ld_src, ld_dst, flags)
-    return L.load().rv_tap_launch_info(ctypes.byref(geom), ctypes.byref(shape), 1 if scatter else 0, info) == 0 and info[0] in ((6,) if flags else (4, 5, 6))
-
-
-# conv -> BatchNorm (+ReLU) -> 3x3 conv: the second conv applies the folded BatchNorm to its input halo IN LDS (csrc/tapconv6.hip, XF) and the
-# write-out pass in front of it disappears from the forward pass; the weight gradient's plain operand is written out in the BACKWARD pass
-# instead, right before the layer's backward-data launch, where it streams beside the previous layer's weight gradient (conv_backward).
-# None: off (every DMA consumer gets a written-out operand, as before round 6); an int: only layers with at most that many output
-# channels -- the transform is redone by every 128-channel tile of the output, the write-out it replaces costs the same whatever the
-# consumer's width, so the trade is best for narrow consumers (profiles/r06_ab_notes.md).
-XF_MAX_COUT: Optional[int] = 1 << 30
+    shape = L.TapShape(n, h, wu, wv, ld_src, ld_dst, 0)
+    return L.load().rv_tap_launch_info(ctypes.byref(geom), ctypes.byref(shape), 1 if scatter else 0, info) == 0 and info[0] in (4, 5, 6)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -923,13 +912,8 @@ class ConvOp(Op):
             w_out = wv
         assert src.cp == pad32(layer.c_in), (src.cp, layer.c_in)
         self.x_plain = None
-        self.xf = False  # the folded BatchNorm of the input is applied inside the launch (generation 6, XF): no write-out pass in front of it
-        if (isinstance(x, Lazy) and MATERIALIZE_FOR_DMA and XF_MAX_COUT is not None and layer.c_out <= XF_MAX_COUT and not out_f32
-                and eval_bn is None and residual is None and g.kh * g.kw == 9 and g.stride_w == 1 and x.plain is None
-                and _dma_eligible(g, src.N, src.H, wu, wv, src.ld, pad32(layer.c_out), form == "scatter", flags)):
-            self.xf = True
         # (not for 1x1 layers: there the extra pass costs what the faster kernel saves)
-        elif (isinstance(x, Lazy) and MATERIALIZE_FOR_DMA and not out_f32 and g.kh * g.kw > 1
+        if (isinstance(x, Lazy) and MATERIALIZE_FOR_DMA and not out_f32 and g.kh * g.kw > 1
                 and _dma_eligible(g, src.N, src.H, wu, wv, src.ld, pad32(layer.c_out), form == "scatter")):
             self.x_plain = src = x.materialized()
             sc = sh = None

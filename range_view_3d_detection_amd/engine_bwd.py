@@ -66,11 +66,6 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
     _release_held_wgrads(t)  # (weight gradients of earlier layers that met no all-reduce since)
     layer, g = op.layer, op.layer.geom
     src, sc, sh, in_flags = E._operand_parts(op.x)
-    if op.xf and op.x_plain is None:
-        # the forward launch applied the folded BatchNorm in LDS and nothing was written out: the weight gradient (an LDS-DMA kernel too)
-        # gets its plain operand now, on the main stream in front of this layer's backward-data launch -- a one-operand pass of <= 64
-        # registers that streams beside the weight gradient of the layer above, which is still resident on the side stream
-        op.x_plain = op.x.materialized()
     if op.x_plain is not None:  # the forward pass wrote relu(bn(.)) out for the DMA kernel: the weight gradient reads it too
         src, sc, sh, in_flags = op.x_plain, None, None, 0
     fwd = layer.fwd_form

@@ -50,6 +50,16 @@ def _check_direction(logits, lg16, lg32, reg, rg16, rg32):
         assert c > 0.99 and c > c_emu - 2e-3, (name, c, c_emu)
 
 
+def _envelope(key):
+    """Recorded envelope of the CPU bf16 emulation's gradient cosines for a crop case (tests/golden/emulation_envelope.json), or None."""
+    import json
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "emulation_envelope.json")
+    with open(path) as f:
+        return json.load(f)["cases"].get(key)
+
+
 def _prepare(widths, n_feat, n_cls, W, bn_bias_shift, B=1, H=64, boxes=12):
     from bench import build_model, synthetic_batch
 
@@ -168,17 +178,23 @@ def _train_step_vs_oracle(widths, n_feat, n_cls, W, bn_bias_shift, small_grids, 
     for i in np.argsort(cos32)[:4]:
         print(f"    worst: {names[i]:60s} HIP {cos32[i]:.4f}" + (f"  emulation {cos_emu[i]:.4f}" if g16 is not None else "") + f"  |g| {float(g32[names[i]].norm()):.2e}")
     # gradients: at least as close to the fp32 oracle as the CPU bf16 emulation (median - 0.02, 5 % quantile - 0.05);
-    # in the well-conditioned regime (gates firmly open) additionally median > 0.99, 5 % quantile > 0.95
-    # (shift 0.0 is the chaotic regime: half of the ReLU gates sit within a bf16 ulp of zero and EVERY bf16 realisation of the
-    #  model has a median cosine of only ~0.62-0.64 against fp32.  Two equally valid kernel selections of this library measured
-    #  0.6286 / 0.4088 and 0.6199 / 0.4171 (median / 5 % quantile) against the emulation's 0.6445 / 0.4372 on one box: the
-    #  spread between realisations is ~0.01-0.02, so the median margin there is 0.04; the well-conditioned case keeps 0.02.
-    #  Round 5: with the head towers' last BatchNorm backward formed from the UNROUNDED input gradient (csrc/headfinal.hip) the same
-    #  test measured 0.6025 / 0.3873 against the emulation's 0.6429 / 0.4371 on one box and passed at 0.04 / 0.05 on another: a third
-    #  realisation 0.02 below the first two, i.e. the spread is ~0.03.  Margins of the chaotic case: 0.06 (median), 0.08 (5 % quantile);
-    #  the well-conditioned case, the full-size cases and the per-layer teacher-forced test are where an error would show.)
-    med_margin, q_margin = (0.02, 0.05) if bn_bias_shift >= 3.0 else (0.06, 0.08)
-    assert med32 > med_emu - med_margin and q32 > q_emu - q_margin, (med32, med_emu, q32, q_emu)
+    # in the well-conditioned regime (gates firmly open) additionally median > 0.99, 5 % quantile > 0.95.
+    # The crop cases are held to a RECORDED ENVELOPE instead of to this run's one emulation (round-5 review, item 9): shift 0.0 is the chaotic
+    # regime -- half of the ReLU gates sit within a bf16 ulp of zero and EVERY bf16 realisation of the model has a median cosine of only
+    # ~0.61-0.64 against fp32; the emulation's own number moves by 0.03 with nothing but the order in which each conv sums its input
+    # channels (tests/golden/emulation_envelope.json: eight orders, tests/tools/emulation_yardstick.py envelope -- median 0.6138 .. 0.6429, 5 %
+    # quantile 0.4086 .. 0.4389), and three equally valid kernel selections of this library measured 0.6286 / 0.4088, 0.6199 / 0.4171
+    # and 0.6025 / 0.3873 in rounds 3-5 (rounds 3-5 compared against ONE emulation and re-tuned the margin twice).  Bound: the envelope's
+    # minimum - 0.02 (median) / - 0.03 (5 % quantile: the tenth-smallest of ~190 cosines is the noisier statistic); fixed numbers that no
+    # kernel change moves.  The well-conditioned case, the full-size cases and the per-layer teacher-forced test are where an error shows.
+    env = _envelope(f"{widths}/{W}/{bn_bias_shift}") if emulation is None else None
+    if env is not None:
+        assert abs(loss32 - env["loss32"]) < 1e-4 * abs(loss32), (loss32, env["loss32"])  # (the case the envelope was recorded for)
+        print(f"    envelope of {len(env['realisations'])} CPU bf16 realisations: median {env['median_min']:.4f} .. {env['median_max']:.4f}, "
+              f"q05 {env['q05_min']:.4f} .. {env['q05_max']:.4f}")
+        assert med32 > env["median_min"] - 0.02 and q32 > env["q05_min"] - 0.03, (med32, q32, env["median_min"], env["q05_min"])
+    else:
+        assert med32 > med_emu - 0.02 and q32 > q_emu - 0.05, (med32, med_emu, q32, q_emu)
     if bn_bias_shift >= 3.0:
         assert med32 > 0.99 and q32 > 0.95, (med32, q32)
 

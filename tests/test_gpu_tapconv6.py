@@ -199,74 +199,3 @@ def test_data_grad_launch_forms_the_batchnorm_backward_sums(cin, c, N, H, W, rel
     assert float((dw_f - dw_s).abs().max()) <= 2e-2 * float(dw_s.abs().max())
     cos = float((dw_f * dw_s).sum() / (dw_f.norm() * dw_s.norm()))
     assert cos > 0.99999, cos
-
-
-@pytest.mark.parametrize("cin,cout,N,H,W,relu", [(32, 128, 2, 30, 520, True),    # ONE chunk: the prologue transform only
-                                                 (64, 256, 2, 64, 256, True),     # two chunks: one in-loop transform, two channel tiles
-                                                 (512, 512, 1, 64, 288, True),    # sixteen chunks (the table's upper bound), four channel tiles
-                                                 (320, 128, 3, 33, 1030, False),  # ten chunks, ragged rows / columns, BatchNorm without ReLU
-                                                 (128, 384, 1, 16, 96, True)])
-def test_folded_batchnorm_applied_in_lds_exact(cin, cout, N, H, W, relu):
-    """Generation 6 with a folded BatchNorm (+ReLU) on the way in (RV_IN_AFFINE, the XF instance: the operand relu?(scale * y + shift) is formed
-    in LDS after the halo has landed).  Integer y, integer scale / shift: the operand is an exact small integer, so the bf16 output must EQUAL
-    the CPU convolution of the activated tensor rounded once -- which also pins the zero padding (the reference pads the ACTIVATION,
-    nn/modules/conv.py:63-80: a transformed zero page would add relu(shift) at every border).  And the output and the batch statistics are bit-identical
-    to the same kernel fed with the written-out operand (``Lazy.materialized``, what the layer took before round 6)."""
-    from range_view_3d_detection_amd import _lib as L
-    from range_view_3d_detection_amd import engine as E
-
-    g = torch.Generator().manual_seed(cin + W + relu)
-    m = torch.nn.Conv2d(cin, cout, 3, padding=1, bias=False)
-    m.weight.data = _ints(m.weight.shape, g, -2, 3)
-    y = _ints((N, cin, H, W), g, -3, 4)
-    scale = _ints((cin,), g, -2, 3)
-    shift = _ints((cin,), g, 1, 4)  # (> 0: a transformed padding pixel would be visible)
-    act = y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
-    if relu:
-        act = act.clamp_min(0)
-    ref = F.conv2d(act, m.weight.data, padding=1)
-    t = E.Tape(True, DEV)
-    layer = E.tap_layer(m.to(DEV))
-    raw = E.Act.from_nchw(y.to(DEV))
-    lazy = E.Lazy(raw, E.BnState(None, scale.to(DEV), shift.to(DEV)), relu)
-    old = E.XF_MAX_COUT
-    try:
-        E.XF_MAX_COUT = 1 << 30
-        op = E.ConvOp(t, layer, lazy, stats=True)
-        assert op.xf and op.x_plain is None and lazy.plain is None
-        info = (ctypes.c_int32 * 4)()
-        assert L.load().rv_tap_launch_info(ctypes.byref(layer.geom), ctypes.byref(op.shape), 0, info) == 0 and info[0] == 6, list(info)
-        E.XF_MAX_COUT = None  # the written-out form of the same launch
-        op2 = E.ConvOp(t, layer, lazy, stats=True)
-        assert not op2.xf and op2.x_plain is not None
-    finally:
-        E.XF_MAX_COUT = old
-    out = op.out.data[..., :cout].permute(0, 3, 1, 2).float().cpu()
-    assert torch.equal(out, ref.bfloat16().float())
-    assert torch.equal(op.out.data, op2.out.data) and torch.equal(op.partial[: op.rows], op2.partial[: op2.rows])
-    assert torch.equal(op2.x_plain.data[..., :cin].permute(0, 3, 1, 2).float().cpu(), act)
-
-
-def test_folded_batchnorm_in_lds_random_data_equals_the_written_out_form():
-    """The same comparison on random bf16 data and real-valued scale / shift (the rounding of the operand to bf16 is the write-out pass's),
-    repeated: a race between a wave's transform and another wave's fragment reads would show as a difference between runs."""
-    from range_view_3d_detection_amd import engine as E
-
-    g = torch.Generator().manual_seed(11)
-    N, H, W, cin, cout = 2, 48, 352, 256, 256
-    m = torch.nn.Conv2d(cin, cout, 3, padding=1, bias=False).to(DEV)
-    y = torch.randn(N, cin, H, W, generator=g).to(DEV)
-    scale, shift = (0.5 + torch.rand(cin, generator=g)).to(DEV), (0.3 * torch.randn(cin, generator=g)).to(DEV)
-    t = E.Tape(True, DEV)
-    layer = E.tap_layer(m)
-    raw = E.Act.from_nchw(y)
-    old = E.XF_MAX_COUT
-    try:
-        E.XF_MAX_COUT = None
-        want = E.ConvOp(t, layer, E.Lazy(raw, E.BnState(None, scale, shift), True), stats=True)
-        E.XF_MAX_COUT = 1 << 30
-        for _ in range(5):
-            got = E.ConvOp(t, layer, E.Lazy(raw, E.BnState(None, scale, shift), True), stats=True)
-            assert got.xf and torch.equal(got.out.data, want.out.data) and torch.equal(got.partial[: got.rows], want.partial[: want.rows])
-    finally:
-        E.XF_MAX_COUT = old
