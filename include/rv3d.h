@@ -120,7 +120,8 @@ int rv_unpack_weight_grad(const rvTapGeom* g, const float* packed, float* dT, in
 #define RV_SEL_SMALL_GRIDS6 (1 << 21) /* ... and generation 6 */
 #define RV_SEL_NO_GEN6 (1 << 22)      /* do not select generation 6 */
 #define RV_SEL_NO_GEN5 (1 << 23)      /* do not select generations 5 and 6 (multi-tap layers stay on generation 4) */
-#define RV_SEL_MASK (15 << 20)
+#define RV_SEL_NO_POINTWISE (1 << 24) /* 1x1 C -> C layers stay on the tiled kernels (generation 7 = the pointwise streaming GEMM, round 6) */
+#define RV_SEL_MASK (31 << 20)
 
 typedef struct {
     int32_t N, H, Wu, Wv; /* U is (N,H,Wu), V is (N,H,Wv) */
@@ -139,7 +140,8 @@ int32_t rv_tap_stats_rows(const rvTapGeom* g, const rvTapShape* s, int32_t scatt
  * generation 1 = tapconv_kernel<MT,NT> (variant = 16*MT + NT, block tile 32*MT pixels x 32*NT channels),
  * generation 2 = tapconv2_kernel<KS> (variant = KS, block tile 2 rows x 64 columns x 128 channels, 32*KS-channel
  * chunks), generations 4 / 5 / 6 = the LDS-DMA kernels (variant = channels per workgroup, grid.x = pixel tiles, grid.y = channel
- * tiles).  Used by bench.py to label per-kernel timings. */
+ * tiles), generation 7 = the pointwise streaming GEMM (1x1 stride-1 C -> C layers, C = 256 / 128: variant = C, grid.x = persistent
+ * workgroups).  Used by bench.py to label per-kernel timings. */
 int rv_tap_launch_info(const rvTapGeom* g, const rvTapShape* s, int32_t scatter, int32_t* host_info);
 /* Every partial-statistics buffer handed to rv_bn_finalize / rv_bn_bwd_finalize must have room
  * for this many extra rows after its `rows` partial rows (second-stage reduction scratch). */
@@ -588,12 +590,14 @@ int rv_assign_targets(const double* cuboids, int32_t m, const int32_t* box_offse
 
 /* Fused detection loss.  logits / regressands are NHWC fp32 with channel strides ld_* (the layout
  * the head kernels write); cart / reg_targets NCHW fp32; mask (B,H,W) u8.
- * forward : sums[16] (f64, device) -- [0] sum w*VFL*mask, [1] foreground part, [2] background part,
+ * forward : sums[24] (f64, device; 16 before round 6) -- [0] sum w*VFL*mask, [1] foreground part, [2] background part,
  *           [3] #foreground, [4..11] un-normalised regression sums per regressand, [12] max(objects,1),
- *           [13] #foreground + smoothing; optional soft targets (B,n_cls,H,W) and foreground map.
- *           loss = sums[0]/sums[13] + (sums[4]+...+sums[11])/sums[12].
- * backward: d loss / d logits, d loss / d regressands (same NHWC strides), scaled by grad_scale;
- *           reads sums[12], sums[13] on device (no host round trip). */
+ *           [13] #foreground + smoothing, [15] = 1.0 (the backward pass's device-side factor, below), [16..23] the scalars
+ *           detection_head.py:379-449 reports: loss = sums[0]/sums[13] + (sums[4]+...+sums[11])/sums[12], classification, foreground,
+ *           background, coordinate, dimension, rotation, regression loss; optional soft targets (B,n_cls,H,W) and foreground map.
+ * backward: d loss / d logits, d loss / d regressands (same NHWC strides), scaled by grad_scale * sums[15] -- the caller may copy
+ *           the incoming gradient of the loss (a device scalar) into sums[15] instead of multiplying both tensors afterwards;
+ *           reads sums[12], sums[13], sums[15] on device (no host round trip).  Padding channels of the gradient buffers are not written. */
 int rv_detection_loss_forward(const float* logits, int32_t ld_logits, const float* regressands, int32_t ld_reg,
                               const float* cart, const uint8_t* mask, const int64_t* labels, const int64_t* panoptics,
                               const float* reg_targets, const int64_t* points_per_obj, const int32_t* num_objects,

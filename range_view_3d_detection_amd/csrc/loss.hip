@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256) void loss_kernel(const LossArgs a) {
     for (int j = 0; j < 12; ++j) acc[j] = 0.0;
     const double total_fg = BACKWARD ? a.sums[13] : 1.0;
     const double total_obj = BACKWARD ? a.sums[12] : 1.0;
+    const float gscale = BACKWARD ? a.grad_scale * (float)a.sums[15] : 1.f;  // host factor x device factor (sums[15]: 1 unless the caller wrote the incoming gradient there)
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t b = i / hw, pix = i - b * hw;
         const float m = a.mask[i] ? 1.f : 0.f;
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256) void loss_kernel(const LossArgs a) {
                     g = t * (p - t);
                 else
                     g = a.alpha * pg * (a.gamma * (1.f - p) * sp + p);
-                a.d_logits[i * a.ld_logits + c] = (float)((double)(g * a.cls_w * m) / total_fg) * a.grad_scale;
+                a.d_logits[i * a.ld_logits + c] = (float)((double)(g * a.cls_w * m) / total_fg) * gscale;
             }
         }
         // ---- regression: L1 with the per-object normaliser in fp64 ----
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(256) void loss_kernel(const LossArgs a) {
                 const float d = r[j] - tg[j];
                 const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
                 const double g = reg_on ? (double)(sgn * a.reg_w) * norm * (double)m * (double)a.coding[j] / 8.0 / total_obj : 0.0;
-                dr[j] = (float)g * a.grad_scale;
+                dr[j] = (float)g * gscale;
             }
             *(f32x4*)(a.d_reg + i * a.ld_reg) = f32x4{dr[0], dr[1], dr[2], dr[3]};
             *(f32x4*)(a.d_reg + i * a.ld_reg + 4) = f32x4{dr[4], dr[5], dr[6], dr[7]};
@@ -195,8 +196,21 @@ __global__ __launch_bounds__(256) void loss_kernel(const LossArgs a) {
 
 __global__ void loss_finish_kernel(double* sums, const int32_t* num_objects, float smoothing) {
     const double n = (double)*num_objects;
-    sums[12] = n < 1.0 ? 1.0 : n;
-    sums[13] = sums[3] + (double)smoothing;
+    const double obj = n < 1.0 ? 1.0 : n, fg = sums[3] + (double)smoothing;
+    sums[12] = obj;
+    sums[13] = fg;
+    sums[15] = 1.0;  // device-side factor of the backward pass (the caller copies the incoming gradient of the loss here: no host round trip)
+    // the scalars detection_head.py:379-449 reports, formed here instead of by a dozen one-element launches on the host side
+    const double coord = (sums[4] + sums[5] + sums[6]) / obj, dim = (sums[7] + sums[8] + sums[9]) / obj, rot = (sums[10] + sums[11]) / obj;
+    const double cls = sums[0] / fg, reg = (((((((sums[4] + sums[5]) + sums[6]) + sums[7]) + sums[8]) + sums[9]) + sums[10]) + sums[11]) / obj;
+    sums[16] = cls + reg;  // loss
+    sums[17] = cls;
+    sums[18] = sums[1] / fg;
+    sums[19] = sums[2] / fg;
+    sums[20] = coord;
+    sums[21] = dim;
+    sums[22] = rot;
+    sums[23] = coord + dim + rot;
 }
 
 int fill(LossArgs* a, const float* logits, int32_t ld_logits, const float* reg, int32_t ld_reg, const float* cart,
@@ -258,7 +272,7 @@ extern "C" int rv_detection_loss_forward(const float* logits, int32_t ld_logits,
     a.soft = soft_targets;
     a.fg = foreground;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(sums, 0, 16 * sizeof(double), st);
+    hipError_t e = hipMemsetAsync(sums, 0, 24 * sizeof(double), st);
     if (e != hipSuccess) RV_FAIL("rv_detection_loss_forward: %s", hipGetErrorString(e));
     const int fwd_grid = grid_for((int64_t)B * H * W) < 512 ? grid_for((int64_t)B * H * W) : 512;  // (grid-stride: fewer, longer workgroups -> fewer atomics)
     hipLaunchKernelGGL(loss_kernel<false>, dim3(fwd_grid), dim3(256), 0, st, a);

@@ -27,6 +27,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "tapconv.h"
 
 namespace {
 
@@ -65,6 +66,8 @@ struct PosFwdArgs {
     int ld_feat, H, W;
 };
 
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef rv_elem_t bf16x2_t __attribute__((ext_vector_type(2)));
 // two floats -> one dword of bf16 (round to nearest even): ONE v_cvt_pk_bf16_f32
@@ -356,9 +359,6 @@ struct PosBwdArgs {
     int ld_rel, ld_w1, cin, planes;
 };
 
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef const __attribute__((address_space(1))) void glb_void_t;
-
 template <int C>
 __global__ __launch_bounds__(512, 1) void pos_bwd_kernel(const PosBwdArgs a) {
     using G = Pos<C>;
@@ -516,7 +516,206 @@ __global__ __launch_bounds__(512, 1) void pos_bwd_kernel(const PosBwdArgs a) {
     }
 }
 
+// -----------------------------------------------------------------------------------------------------------------
+// Pointwise (1x1, stride 1) C -> C layers on plain bf16 tensors as the same persistent streaming GEMM (round 6).
+// conv2d with a 1x1 kernel (nn/modules/conv.py:47-54 with kernel_size 1; the projection convs of nn/blocks/__init__.py:58-66 and the
+// stem's second fusion conv) is y[p] = W x[p] over P = N*H*W pixels: 268 MB in, 268 MB out and 69 GFLOP at 4 x 64 x 2048 x 256 -- bound by
+// HBM, not by the matrix cores.  The fourth-generation tap-conv runs these launches at 3.4-3.6 TB/s of algorithmic traffic (a 256-pixel tile is
+// four K tiles long: two thirds of its life are fill and drain, and every tile fetches the 128 KB weight matrix again).  Here: the image fill of
+// pos_bwd_kernel (LDS-DMA, swizzle on the per-lane source address) in front of the multiply / store / statistics of pos_fwd_kernel, weights in
+// registers for the whole launch.  Loads and stores share vmcnt in issue order: the NEXT step's eight DMA instructions are issued BEFORE this
+// step's eight stores, so the wait for them is `vmcnt(8)` -- it leaves the stores in flight (a step that has a successor is never ragged:
+// all eight store instructions are issued).
+// -----------------------------------------------------------------------------------------------------------------
+struct PwArgs {
+    const bf16_t* x;  // [P][ld_x]
+    const bf16_t* w;  // [C][C] packed 1x1 image, K contiguous (gather image: forward; scatter image: backward-data)
+    bf16_t* y;        // [P][ld_y]
+    float* partial;   // [gridDim.x][2][C] fp32 (sum, sum of squares of the fp32 accumulators) or NULL
+    int64_t P;
+    int ld_x, ld_y;
+};
+
+template <int C>
+__global__ __launch_bounds__(512, 1) void pointwise_kernel(const PwArgs a) {
+    using G = Pos<C>;
+    constexpr int kC = G::kC, kTM = G::kTM, kBuf = G::kBuf, kRow = G::kRow, kKS = G::kKS;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wn % G::kWC, wp = wn / G::kWC;
+    const int l15_ = lane & 15, lg_ = lane >> 4;
+    // weights of this wave: A operand, row m = l15 of tile j is channel 32 wc + 8 (m >> 2) + 4 j + (m & 3) (see pos_fwd_kernel)
+    bf16x8 fw[2][kKS];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int ch = wc * 32 + (l15_ >> 2) * 8 + j * 4 + (l15_ & 3);
+#pragma unroll
+        for (int ks = 0; ks < kKS; ++ks) fw[j][ks] = *(const bf16x8*)(a.w + (int64_t)ch * kC + ks * 32 + lg_ * 8);
+    }
+    uint32_t rb[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) rb[x] = (wp * G::kGroups * 32 + l15_) * kRow + (((((x << 2) | lg_) ^ l15_) & 15) * 16);
+    int yoff = (wp * G::kGroups * 32 + l15_) * a.ld_y + wc * 32 + lg_ * 8;
+    asm volatile("" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(yoff));
+    // image fill: DMA instruction q (0..63) of a step moves 1 KB = kSel pixels (lane = pixel x kOct slots); wave w issues q = w, w + 8, ...
+    // The LDS side is lane-linear, so slot s of pixel p receives source octet s ^ (p & 15).  Per-lane source offsets once (32-bit elements).
+    __device__ __attribute__((aligned(256))) static uint32_t pw_zero_page[64];
+    int foff[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int q = wn + 8 * i;
+        const int pl = G::kSel * q + lane / G::kOct, slot = lane % G::kOct;
+        foff[i] = pl * a.ld_x + ((slot ^ (pl & 15)) * 8);
+    }
+    auto fill = [&](int64_t step, int buf) __attribute__((always_inline)) {
+        const bf16_t* const x_step = a.x + step * (int64_t)kTM * a.ld_x;
+        const int64_t left = a.P - step * kTM;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int q = wn + 8 * i;
+            const int pl = G::kSel * q + lane / G::kOct;
+            const bf16_t* src = pl < left ? x_step + foff[i] : (const bf16_t*)pw_zero_page + (lane & 7) * 8;
+            __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(smem + buf * kBuf + q * 1024), 16, 0, 0);
+        }
+    };
+    f32x2 ssum[4], ssq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ssum[q] = ssq[q] = f32x2{0.f, 0.f};
+    auto multiply = [&](int64_t s, int cur) __attribute__((always_inline)) {
+        const int64_t left64 = a.P - s * kTM;
+        const int left = left64 < kTM ? (int)left64 : kTM;
+        const bool full = left == kTM;
+        const uint32_t rbc[4] = {rb[0] + cur * kBuf, rb[1] + cur * kBuf, rb[2] + cur * kBuf, rb[3] + cur * kBuf};
+        bf16_t* const y_step = a.y + s * (int64_t)kTM * a.ld_y;
+#pragma unroll
+        for (int hq = 0; hq < G::kGroups; ++hq) {
+            f32x4 acc[2][2];
+            bf16x8 fa[4][2];
+            auto read_fa = [&](int ks, bf16x8 (&f)[2]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) f[i] = *(const bf16x8*)(smem + rbc[ks & 3] + ((hq * 2 + i) * 16 * kRow + (ks >> 2) * 256));
+            };
+            read_fa(0, fa[0]);
+            read_fa(1, fa[1]);
+            read_fa(2, fa[2]);
+#pragma unroll
+            for (int ks = 0; ks < kKS; ++ks) {
+                if (ks + 3 < kKS) read_fa(ks + 3, fa[(ks + 3) & 3]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const f32x4 c0 = ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[i][j];
+                        acc[i][j] = RV_MFMA_16x16x32(fw[j][ks], fa[ks & 3][i], c0, 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int pl0 = (hq * 2 + i) * 16;
+                const bool ok = full || (wp * G::kGroups * 32 + pl0 + l15_) < left;
+                u32x4 out;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r2 = 0; r2 < 2; ++r2) {
+                        f32x2 x = {acc[i][j][2 * r2], acc[i][j][2 * r2 + 1]};
+                        if (!full) x = ok ? x : f32x2{0.f, 0.f};
+                        ssum[j * 2 + r2] += x;
+                        ssq[j * 2 + r2] += x * x;
+                        out[j * 2 + r2] = pack2(x);
+                    }
+                if (ok) *(u32x4*)(y_step + pl0 * a.ld_y + yoff) = out;
+            }
+        }
+    };
+    const int64_t steps = (a.P + kTM - 1) / kTM;
+    if ((int64_t)blockIdx.x < steps) fill(blockIdx.x, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    for (int64_t s = blockIdx.x; s < steps; s += gridDim.x) {
+        const int64_t nxt = s + gridDim.x;
+        const bool has_next = nxt < steps;
+        if (has_next) fill(nxt, cur ^ 1);  // (in front of this step's stores: see the note on vmcnt above)
+        multiply(s, cur);
+        // this wave's share of the next image has landed (the eight stores behind it stay in flight); everyone is done reading image cur
+        if (has_next) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        cur ^= 1;
+    }
+    if (a.partial) {
+        float* const red = (float*)smem;  // [2][C]
+        float sv[8], qv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            sv[q] = ssum[q >> 1][q & 1], qv[q] = ssq[q >> 1][q & 1];
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) {
+                sv[q] += __shfl_xor(sv[q], d, 64);
+                qv[q] += __shfl_xor(qv[q], d, 64);
+            }
+        }
+        if (G::kWP > 1) {
+            if (wp == 1 && l15_ == 0) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    red[wc * 32 + lg_ * 8 + q] = sv[q];
+                    red[kC + wc * 32 + lg_ * 8 + q] = qv[q];
+                }
+            }
+            __syncthreads();
+        }
+        if (wp == 0 && l15_ == 0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int ch = wc * 32 + lg_ * 8 + q;
+                const float s2 = G::kWP > 1 ? red[ch] : 0.f, q2 = G::kWP > 1 ? red[kC + ch] : 0.f;
+                a.partial[((int64_t)blockIdx.x * 2) * kC + ch] = sv[q] + s2;
+                a.partial[((int64_t)blockIdx.x * 2 + 1) * kC + ch] = qv[q] + q2;
+            }
+        }
+    }
+}
+
 }  // namespace
+
+// Pointwise path of the tap-conv dispatcher (tapconv.hip::tap_launch): 1x1 stride-1 layers C -> C, C = 256 or 128, plain bf16 in and out,
+// at most the batch-statistics epilogue, and enough pixels for one step per workgroup and round.
+bool rv_pointwise_plan(const TapConvArgs* a, int* grid, size_t* lds) {
+    if (a->sel & RV_SEL_NO_POINTWISE) return false;
+    if (a->phases != 1 || a->step != 1 || a->tt.ntaps[0] != 1 || a->tt.dh[0][0] != 0 || a->tt.dw[0][0] != 0) return false;
+    if (a->C_src != a->C_dst || (a->C_src != 256 && a->C_src != 128)) return false;
+    if (a->flags & ~RV_OUT_STATS) return false;  // (no folded input, bias, fp32 output, accumulate, ReLU, BatchNorm-backward sums)
+    if (a->W_src != a->W_dst) return false;
+    const int64_t P = (int64_t)a->N * a->H * a->W_src;
+    const int tm = a->C_src == 256 ? Pos<256>::kTM : Pos<128>::kTM;
+    if (P * a->ld_src >= ((int64_t)1 << 31) || P * a->ld_dst >= ((int64_t)1 << 31)) return false;  // (32-bit per-lane offsets inside a step only, but keep the tensors addressable the same way)
+    const int64_t steps = (P + tm - 1) / tm;
+    const int cus = rv_persistent_grid();
+    if (steps < ((a->sel & RV_SEL_SMALL_GRIDS) ? 1 : 2 * (int64_t)cus)) return false;  // fewer than two steps per CU: the tiled kernels fill the chip better
+    *grid = (int)(steps < cus ? steps : cus);
+    *lds = (size_t)2 * Pos<256>::kBuf;
+    return true;
+}
+
+int rv_pointwise_launch(const TapConvArgs& a, int grid, size_t lds, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)pointwise_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Pos<256>::kBuf);
+        (void)hipFuncSetAttribute((const void*)pointwise_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Pos<128>::kBuf);
+        attr_set = true;
+    }
+    PwArgs p{};
+    p.x = a.src, p.w = a.w, p.y = (bf16_t*)a.dst, p.partial = (a.flags & RV_OUT_STATS) ? a.stats : nullptr;
+    p.P = (int64_t)a.N * a.H * a.W_src, p.ld_x = a.ld_src, p.ld_y = a.ld_dst;
+    if (a.C_src == 256) hipLaunchKernelGGL(pointwise_kernel<256>, dim3(grid), dim3(512), lds, stream, p);
+    else hipLaunchKernelGGL(pointwise_kernel<128>, dim3(grid), dim3(512), lds, stream, p);
+    RV_CHECK_LAUNCH("pointwise_kernel");
+    return 0;
+}
 
 // launcher used by rv_pos_backward_sums (bnbwd.hip, which owns the small-K reduction workspace layout)
 int rv_pos_bwd_launch(int64_t pixels, const void* dy2, const void* w2_scatter, const void* rel, int32_t ld_rel, int32_t cin,

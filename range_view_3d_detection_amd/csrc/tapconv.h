@@ -71,3 +71,8 @@ int rv_tapconv5_launch(const TapConvArgs& a, size_t lds, int bn, hipStream_t str
 // launch is persistent, else 4 per tile), *bnb_rows = rows of the BatchNorm-backward partial sums (one per such group, else per tile)
 bool rv_tapconv6_plan(TapConvArgs* a, int* tiles, size_t* lds, int* stats_rows, int* bnb_rows);
 int rv_tapconv6_launch(const TapConvArgs& a, size_t lds, hipStream_t stream);
+
+// pointwise streaming GEMM (posconv.hip): 1x1 stride-1 layers C -> C (C = 256 / 128) on plain bf16 tensors, weights in registers,
+// pixels streamed through LDS; stats rows = one (sum, sum of squares) pair per workgroup = grid
+bool rv_pointwise_plan(const TapConvArgs* a, int* grid, size_t* lds);
+int rv_pointwise_launch(const TapConvArgs& a, int grid, size_t lds, hipStream_t stream);

@@ -496,6 +496,22 @@ static int tap_launch(const rvTapGeom* g, const rvTapShape* s, bool scatter, con
         if (dry_run) return 0;   // (rows = 0: the caller takes the separate reduce pass)
         RV_FAIL("rv_tap_data_grad_bnb: this launch has no fused BatchNorm-backward sums (rv_tap_bnb_rows returned 0)");
     }
+    // 1x1 stride-1 C -> C layers on plain tensors: the persistent streaming GEMM with the weights in registers (posconv.hip, round 6)
+    {
+        int grid7;
+        size_t lds7;
+        if (rv_pointwise_plan(&a, &grid7, &lds7)) {
+            if (stats_rows) *stats_rows = grid7;
+            if (info) {
+                info[0] = 7;
+                info[1] = a.C_dst;
+                info[2] = grid7;
+                info[3] = 1;
+            }
+            if (dry_run) return 0;
+            return rv_pointwise_launch(a, grid7, lds7, (hipStream_t)stream);
+        }
+    }
     // 256 x 256 (or x 128) tiles streamed by LDS-DMA, counted waits (tapconv4.hip); plain bf16 inputs only
     {
         int tiles, bn, srows;

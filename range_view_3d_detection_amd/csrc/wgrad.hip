@@ -905,7 +905,11 @@ extern "C" int rv_tap_wgrad(const rvTapGeom* g, const rvTapShape* s, const void*
         b.tiles_v = p.tiles_v;
         b.flags = s->flags & ~(RV_WGRAD_TORCH_LAYOUT | RV_SEL_MASK);
         b.v_affine = v_affine;
+#ifdef RV_DIAG_NO_XCD_REMAP  // (diagnostic build only, profiles/tools/diag_wgrad.sh: every K slice spread over all eight L2s -- the slope of time against L2-miss traffic)
+        b.xcd_remap = 0;
+#else
         b.xcd_remap = 1;
+#endif
         int gi = 0;
         for (int ky = 0; ky < g->kh; ++ky)
             for (int kx = 0; kx < g->kw; ++kx) {
@@ -932,9 +936,11 @@ extern "C" int rv_tap_wgrad(const rvTapGeom* g, const rvTapShape* s, const void*
             hipLaunchKernelGGL(wgrad2_kernel, dim3(grid2), dim3(512), 0, st2, b);
             RV_CHECK_LAUNCH("wgrad2_kernel");
         }
+#ifndef RV_DIAG_SKIP_REDUCE  // (diagnostic build only: WRONG gradients -- an upper bound on what ANY way of folding the split-K reduction away can return)
         const int rb2 = (int)((p.elems / 4 + 255) / 256 < 4096 ? (p.elems / 4 + 255) / 256 : 4096);
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb2), dim3(256), 0, st2, (const float*)workspace, p.ksplit, p.elems, dT_packed, up);
         RV_CHECK_LAUNCH("wgrad_reduce_kernel");
+#endif
         return 0;
     }
     WgradArgs a;

@@ -187,6 +187,8 @@ def tap_kernel_name(geom, shape, scatter: bool) -> str:
         name = f"tapconv{info[0]}_kernel<{info[1]}>"
     elif info[0] in (2, 3):
         name = f"tapconv{info[0]}_kernel<{info[1]}>"
+    elif info[0] == 7:
+        name = f"pointwise_kernel<{info[1]}>"
     else:
         name = f"tapconv_kernel<{info[1] // 16},{info[1] % 16}>"
     if os.environ.get("RV3D_PROFILE_SHAPES"):
@@ -516,10 +518,21 @@ BNB_FUSE = True
 #  masked epilogue -- three 16-byte prefetches per pass, time-neutral to slightly slower; profiles/r04_ab_notes.md.)
 
 
-def _dma_eligible(geom, n: int, h: int, wu: int, wv: int, ld_src: int, ld_dst: int, scatter: bool) -> bool:
+def _dma_generation(geom, n: int, h: int, wu: int, wv: int, ld_src: int, ld_dst: int, scatter: bool) -> int:
+    """Kernel generation the library would pick for this launch on a PLAIN bf16 operand (rv_tap_launch_info)."""
     info = (ctypes.c_int32 * 4)()
     shape = L.TapShape(n, h, wu, wv, ld_src, ld_dst, 0)
-    return L.load().rv_tap_launch_info(ctypes.byref(geom), ctypes.byref(shape), 1 if scatter else 0, info) == 0 and info[0] in (4, 5, 6)
+    return info[0] if L.load().rv_tap_launch_info(ctypes.byref(geom), ctypes.byref(shape), 1 if scatter else 0, info) == 0 else 0
+
+
+def _dma_eligible(geom, n: int, h: int, wu: int, wv: int, ld_src: int, ld_dst: int, scatter: bool) -> bool:
+    return _dma_generation(geom, n, h, wu, wv, ld_src, ld_dst, scatter) in (4, 5, 6)
+
+
+# 1x1 C -> C layers fed by a folded BatchNorm+ReLU (the stem's second fusion conv): written out once as well when the plain launch runs on the
+# pointwise streaming GEMM (generation 7, round 6) -- write-out + streaming GEMM + wgrad3 on the plain operand against the register-staged
+# tapconv2 + wgrad2 (profiles/r06_ab_notes.md).  Other 1x1 shapes keep the folded operand (the tiled kernel saves what the pass costs).
+MATERIALIZE_FOR_POINTWISE = True
 
 
 # ---------------------------------------------------------------------------------------------
@@ -602,6 +615,7 @@ class TapLayer:
         self._fold_geom = None
         self._fold_image: Optional[Tensor] = None
         self._fold_version = None
+        self._bias_pad: Optional[Tuple[tuple, Tensor]] = None
         _LAYERS.add(self)
 
     # forward direction of the torch module: conv = gather, conv-transpose = scatter
@@ -695,6 +709,14 @@ class TapLayer:
             bias[:c] = shift.float()
             cache[(form, L.operand_tag())] = hit = (key, img, bias)
         return hit[1], hit[2]
+
+    def padded_bias(self) -> Tensor:
+        """fp32 bias padded to the 32-channel slab, cached until the parameter changes (two launches per step and biased layer otherwise)."""
+        b = self.bias
+        key = (b._version, b.data_ptr())
+        if self._bias_pad is None or self._bias_pad[0] != key:
+            self._bias_pad = (key, torch.nn.functional.pad(b.detach().float(), (0, pad32(self.c_out) - self.c_out)))
+        return self._bias_pad[1]
 
     def invalidate(self) -> None:
         """Drop the packed bf16 images.  They are re-packed automatically when ``weight._version`` or its storage changes
@@ -912,9 +934,14 @@ class ConvOp(Op):
             w_out = wv
         assert src.cp == pad32(layer.c_in), (src.cp, layer.c_in)
         self.x_plain = None
-        # (not for 1x1 layers: there the extra pass costs what the faster kernel saves)
+        # (not for 1x1 layers in general: there the extra pass costs what the faster kernel saves)
         if (isinstance(x, Lazy) and MATERIALIZE_FOR_DMA and not out_f32 and g.kh * g.kw > 1
                 and _dma_eligible(g, src.N, src.H, wu, wv, src.ld, pad32(layer.c_out), form == "scatter")):
+            self.x_plain = src = x.materialized()
+            sc = sh = None
+            flags = 0
+        elif (isinstance(x, Lazy) and MATERIALIZE_FOR_DMA and MATERIALIZE_FOR_POINTWISE and not out_f32 and g.kh * g.kw == 1 and layer.bias is None
+              and eval_bn is None and _dma_generation(g, src.N, src.H, wu, wv, src.ld, pad32(layer.c_out), form == "scatter") == 7):
             self.x_plain = src = x.materialized()
             sc = sh = None
             flags = 0
@@ -942,7 +969,7 @@ class ConvOp(Op):
             bias_p = None  # (filled below, with the folded weight image)
         elif bias is not None:
             flags |= L.OUT_BIAS
-            bias_p = torch.nn.functional.pad(bias.detach().float(), (0, pad32(layer.c_out) - layer.c_out))
+            bias_p = layer.padded_bias()
         else:
             bias_p = None
         self.shape = L.TapShape(src.N, src.H, wu, wv, src.ld, ld_dst, flags | (L.OUT_STATS if stats else 0))

@@ -28,6 +28,19 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(autouse=True)
+def _seed_global_rng_per_test(request):
+    """Every test starts from a global torch / numpy RNG state that depends on ITS OWN name only: modules built without an explicit generator
+    (``MetaKernel(...)``, ``Conv2d(...)``) used to draw from whatever state the tests before them had left, so a bound on the distance between two
+    bf16 realisations could pass or fail with the composition of the suite (round 6: adding a test file moved one such bound from 0.025 to 0.057)."""
+    import zlib
+
+    seed = zlib.crc32(request.node.nodeid.encode()) & 0x7FFFFFFF
+    torch.manual_seed(seed)
+    np.random.seed(seed % (2**32 - 1))
+    yield
+
+
 class Golden:
     """Lazy view of a ``tests/golden/<name>.npz`` fixture generated from the reference."""
 

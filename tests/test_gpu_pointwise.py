@@ -1,0 +1,130 @@
+"""The pointwise streaming GEMM (generation 7, csrc/posconv.hip::pointwise_kernel): 1x1 stride-1 C -> C layers, C = 256 / 128, on plain
+bf16 tensors -- ``conv2d`` with ``kernel_size=1`` (/root/reference/src/torchbox3d/nn/modules/conv.py:47-54, the projection convs of
+nn/blocks/__init__.py:58-66) and its backward-data.
+
+Method of tests/test_gpu_tapconv4/5/6.py: small-integer activations and weights make every partial sum an integer below 2^24, so the
+bf16 output must EQUAL the CPU convolution rounded once, whatever the summation order; every case asserts from ``rv_tap_launch_info`` that
+generation 7 is what runs.  Shapes: pixel counts that are not multiples of the 128- / 256-pixel step (ragged last step), exactly two steps per
+workgroup and many, a destination that is a channel slice of a wider tensor (the backbone's in-place concat), the batch statistics, the
+backward-data form (scatter image), and a race screen on random data (the next step's LDS-DMA fill is issued in front of this step's stores and
+waited for with a counted vmcnt).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_gpu_forward import DEV
+from test_gpu_tapconv4 import _ints
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _small_grids_allowed():
+    from range_view_3d_detection_amd import _lib as L
+
+    with L.select(L.SEL_SMALL_GRIDS):
+        yield
+
+
+def _info(layer, shape, scatter):
+    from range_view_3d_detection_amd import _lib as L
+
+    info = (ctypes.c_int32 * 4)()
+    assert L.load().rv_tap_launch_info(ctypes.byref(layer.geom), ctypes.byref(shape), 1 if scatter else 0, info) == 0
+    return list(info)
+
+
+@pytest.mark.parametrize("C,N,H,W", [(256, 4, 32, 520), (256, 1, 5, 77), (256, 2, 64, 2048), (128, 4, 32, 520), (128, 3, 7, 100), (128, 2, 64, 2656)])
+def test_forward_1x1_exact_with_statistics(C, N, H, W):
+    from range_view_3d_detection_amd import engine as E
+
+    g = torch.Generator().manual_seed(C + W)
+    m = torch.nn.Conv2d(C, C, 1, bias=False)
+    m.weight.data = _ints(m.weight.shape, g, -2, 3)
+    x = _ints((N, C, H, W), g)
+    ref = F.conv2d(x, m.weight.data)
+    t = E.Tape(True, DEV)
+    layer = E.tap_layer(m.to(DEV))
+    op = E.ConvOp(t, layer, E.Act.from_nchw(x.to(DEV)), stats=True)
+    assert _info(layer, op.shape, False)[:2] == [7, C]
+    out = op.out.data[..., :C].permute(0, 3, 1, 2).float().cpu()
+    assert torch.equal(out, ref.bfloat16().float())
+    rows = op.partial[: op.rows].double().sum(dim=0).cpu()
+    assert torch.allclose(rows[0, :C], ref.double().sum(dim=(0, 2, 3)), rtol=1e-6, atol=1e-3)
+    assert torch.allclose(rows[1, :C], (ref.double() ** 2).sum(dim=(0, 2, 3)), rtol=1e-5)
+
+
+@pytest.mark.parametrize("C", [256, 128])
+def test_backward_data_and_sliced_destination_exact(C):
+    """Backward-data of a 1x1 conv (the scatter image through the same kernel), written into a channel slice of a wider tensor (row pitch
+    2 C: what the in-place concat of the backbone hands over) from a source that is itself a slice."""
+    from range_view_3d_detection_amd import _lib as L
+    from range_view_3d_detection_amd import engine as E
+
+    g = torch.Generator().manual_seed(3 * C)
+    N, H, W = 2, 24, 333
+    m = torch.nn.Conv2d(C, C, 1, bias=False)
+    m.weight.data = _ints(m.weight.shape, g, -2, 3)
+    dy = _ints((N, C, H, W), g)
+    ref = F.conv_transpose2d(dy, m.weight.data)  # d/dx of conv2d(x, w)
+    layer = E.tap_layer(m.to(DEV))
+    wide_src = E.Act.empty(N, H, W, 2 * C, DEV, zero=True)
+    wide_src.data[..., C:] = dy.permute(0, 2, 3, 1).to(DEV).to(wide_src.data.dtype)
+    src = wide_src.slice(C, 2 * C)
+    wide_dst = E.Act.empty(N, H, W, 2 * C, DEV, zero=True)
+    wide_dst.data.fill_(7.0)
+    dst = wide_dst.slice(0, C)
+    shape = L.TapShape(N, H, W, W, src.ld, dst.ld, 0)
+    assert _info(layer, shape, True)[:2] == [7, C]
+    L.call("rv_tap_scatter", ctypes.byref(layer.geom), ctypes.byref(shape), src.ptr(), None, None, L.ptr(layer.packed("scatter")), None, dst.ptr(), None,
+           L.stream_ptr())
+    got = wide_dst.data[..., :C].permute(0, 3, 1, 2).float().cpu()
+    assert torch.equal(got, ref.bfloat16().float())
+    assert bool((wide_dst.data[..., C:] == 7.0).all())  # the other slice is untouched
+
+
+def test_other_1x1_launches_stay_on_the_tiled_kernels():
+    """What generation 7 does not take: C_in != C_out, a folded BatchNorm on the way in, accumulate, fp32 output, too few pixels."""
+    from range_view_3d_detection_amd import _lib as L
+    from range_view_3d_detection_amd import engine as E
+
+    def gen(cin, cout, flags, n=4, h=64, w=2048, sel=0):
+        layer = E.tap_layer(torch.nn.Conv2d(cin, cout, 1, bias=False).to(DEV))
+        return _info(layer, L.TapShape(n, h, w, w, E.pad32(cin), E.pad32(cout), flags | sel), False)[0]
+
+    assert gen(256, 256, 0) == 7 and gen(128, 128, L.OUT_STATS) == 7
+    assert gen(256, 128, 0) != 7 and gen(512, 512, 0) != 7
+    for flags in (L.IN_AFFINE | L.IN_RELU, L.OUT_ACCUM, L.OUT_F32, L.OUT_BIAS):
+        assert gen(256, 256, flags) != 7, flags
+    with L.select(0):
+        pass
+    assert gen(256, 256, L.SEL_NO_POINTWISE) == 4
+
+
+def test_repeatable_on_random_data_and_equal_to_generation_4():
+    """Race screen, and the summation order is the tiled kernel's (K ascending in 32-channel steps, fp32 accumulators): outputs of the two
+    generations agree to the last bit on random data; the statistics (different partial-row partition) to 1e-6."""
+    from range_view_3d_detection_amd import _lib as L
+    from range_view_3d_detection_amd import engine as E
+
+    g = torch.Generator().manual_seed(9)
+    m = torch.nn.Conv2d(256, 256, 1, bias=False)
+    m.weight.data = torch.randn(m.weight.shape, generator=g) * 0.05
+    layer = E.tap_layer(m.to(DEV))
+    x = E.Act.from_nchw(torch.randn(4, 256, 64, 1024, generator=g).to(DEV))
+    t = E.Tape(True, DEV)
+    first = E.ConvOp(t, layer, x, stats=True)
+    for _ in range(20):
+        again = E.ConvOp(t, layer, x, stats=True)
+        assert torch.equal(first.out.data, again.out.data) and torch.equal(first.partial[: first.rows], again.partial[: again.rows])
+    with L.select(L.SEL_NO_POINTWISE):
+        tiled = E.ConvOp(t, layer, x, stats=True)
+    assert _info(layer, tiled.shape, False)[0] == 4
+    assert torch.equal(first.out.data, tiled.out.data)
+    a, b = first.partial[: first.rows].double().sum(0), tiled.partial[: tiled.rows].double().sum(0)
+    assert torch.allclose(a, b, rtol=1e-6, atol=1e-6 * float(b.abs().max()))

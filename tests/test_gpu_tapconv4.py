@@ -21,10 +21,11 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True)
 def _generation4_only():
-    """Multi-tap layers with 256-channel tiles go to tapconv5 by default; these tests pin generation 4."""
+    """Multi-tap layers with 256-channel tiles go to tapconv5 by default, 1x1 C -> C layers to the pointwise streaming GEMM (generation 7,
+    tests/test_gpu_pointwise.py); these tests pin generation 4."""
     from range_view_3d_detection_amd import _lib as L
 
-    with L.select(L.SEL_NO_GEN5):
+    with L.select(L.SEL_NO_GEN5 | L.SEL_NO_POINTWISE):
         yield
 
 

@@ -70,7 +70,11 @@ def test_host_side_geometry(lib):
     crop6 = lib.TapShape(1, 16, 64, 64, 256, 256, lib.SEL_SMALL_GRIDS | lib.SEL_SMALL_GRIDS6)
     assert h.rv_tap_launch_info(ctypes.byref(g), ctypes.byref(crop6), 0, info) == 0 and info[0] == 6
     g1 = lib.TapGeom(1, 1, 1, 0, 0, 256, 256)
-    assert h.rv_tap_launch_info(ctypes.byref(g1), ctypes.byref(s), 0, info) == 0 and list(info) == [4, 256, 32 * 16 * 4, 1]
+    # a pointwise C -> C layer: the streaming GEMM (generation 7: 256 persistent workgroups = 256 statistic rows); pinned back: tapconv4<256>
+    assert h.rv_tap_launch_info(ctypes.byref(g1), ctypes.byref(s), 0, info) == 0 and list(info) == [7, 256, 256, 1]
+    assert h.rv_tap_stats_rows(ctypes.byref(g1), ctypes.byref(s), 0) == 256
+    s1 = lib.TapShape(4, 64, 2048, 2048, 256, 256, lib.OUT_STATS | lib.SEL_NO_POINTWISE)
+    assert h.rv_tap_launch_info(ctypes.byref(g1), ctypes.byref(s1), 0, info) == 0 and list(info) == [4, 256, 32 * 16 * 4, 1]
     # a folded BatchNorm on the way in needs the register-staged kernel
     s_aff = lib.TapShape(4, 64, 2048, 2048, 256, 256, lib.OUT_STATS | lib.IN_AFFINE | lib.IN_RELU)
     assert h.rv_tap_launch_info(ctypes.byref(g), ctypes.byref(s_aff), 0, info) == 0
