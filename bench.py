@@ -425,11 +425,15 @@ def rv_waymo_leg(dev, batch_size: int = 4, warmup: int = 3, steps: int = 10) -> 
         step()
     torch.cuda.synchronize()
     E.PROFILE = prof = E.KernelProfile()  # events around each tap-conv / wgrad launch, as in the headline's timed region
+    sampler = GpuSampler(dev.index or 0).start()
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    gpu_conditions = sampler.stop()
+    if gpu_conditions["sclk_mhz_median"]:
+        gpu_conditions["ms_per_step_at_reference_sclk"] = round(1e3 * dt / steps * gpu_conditions["sclk_mhz_median"] / SCLK_REFERENCE_MHZ, 3)
     E.PROFILE = iso = E.KernelProfile()  # ... and with the side stream off (the kernels' own durations; see roofline() below)
     overlap, E.OVERLAP_WGRAD = E.OVERLAP_WGRAD, False
     for _ in range(2):
@@ -446,7 +450,7 @@ def rv_waymo_leg(dev, batch_size: int = 4, warmup: int = 3, steps: int = 10) -> 
     hbm = measure_hbm_group(step, pmc_key="rv_waymo")
     return {"workload": f"rv-waymo full model, fwd+bwd+AdamW, {batch_size} synthetic 64x2656x6 sweeps (single-GPU shard of BASELINE configs[4])",
             "sweeps_per_s": round(batch_size * steps / dt, 2), "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps, "warmup": warmup,
-            "loss": float(loss.detach().item()), "dtype": "bf16",
+            "loss": float(loss.detach().item()), "dtype": "bf16", "gpu": gpu_conditions,
             "roofline": roof, "roofline_hbm": hbm, "whole_step": ws,
             "kernels": {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "tflops": round(v["tflops"], 1)} for k, v in summ.items()},
             "kernels_isolated": {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "tflops": round(v["tflops"], 1)} for k, v in isum.items()}}

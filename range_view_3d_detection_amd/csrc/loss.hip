@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void loss_kernel(const LossArgs a) {
                 cls_sum += t > 0.f ? t * bce : a.alpha * pg * bce;
             } else {
                 const float g = t > 0.f ? t * (p - t) : a.alpha * pg * (a.gamma * (1.f - p) * sp + p);
-                gv[c >> 2][c & 3] = (float)((double)(g * a.cls_w * m) / total_fg) * a.grad_scale;
+                gv[c >> 2][c & 3] = (float)((double)(g * a.cls_w * m) / total_fg) * gscale;
             }
         }
         if (BACKWARD && row32) {

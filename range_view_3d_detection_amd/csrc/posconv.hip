@@ -687,11 +687,15 @@ __global__ __launch_bounds__(512, 1) void pointwise_kernel(const PwArgs a) {
 bool rv_pointwise_plan(const TapConvArgs* a, int* grid, size_t* lds) {
     if (a->sel & RV_SEL_NO_POINTWISE) return false;
     if (a->phases != 1 || a->step != 1 || a->tt.ntaps[0] != 1 || a->tt.dh[0][0] != 0 || a->tt.dw[0][0] != 0) return false;
-    if (a->C_src != a->C_dst || (a->C_src != 256 && a->C_src != 128)) return false;
+    // C = 256 only.  The 128-channel instance (190 VGPRs: the one instance that other workgroups can share a CU with) passed every parity test and
+    // a call-by-call synchronised rv-waymo run, and HUNG the GPU twice within ~30 free-running two-stream rv-waymo steps (round 6,
+    // profiles/r06_ab_notes.md section 4: watchdog reset after ~100 s, reported as a memory fault at address nil; no cause found by reading the
+    // ISA): not shipped.  rv-av2's 256-channel instance: 300-step two-stream soak, profiles/r06_soak_pointwise_av2.txt.
+    if (a->C_src != a->C_dst || a->C_src != 256) return false;
     if (a->flags & ~RV_OUT_STATS) return false;  // (no folded input, bias, fp32 output, accumulate, ReLU, BatchNorm-backward sums)
     if (a->W_src != a->W_dst) return false;
     const int64_t P = (int64_t)a->N * a->H * a->W_src;
-    const int tm = a->C_src == 256 ? Pos<256>::kTM : Pos<128>::kTM;
+    const int tm = Pos<256>::kTM;
     if (P * a->ld_src >= ((int64_t)1 << 31) || P * a->ld_dst >= ((int64_t)1 << 31)) return false;  // (32-bit per-lane offsets inside a step only, but keep the tensors addressable the same way)
     const int64_t steps = (P + tm - 1) / tm;
     const int cus = rv_persistent_grid();
@@ -705,14 +709,13 @@ int rv_pointwise_launch(const TapConvArgs& a, int grid, size_t lds, hipStream_t 
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)pointwise_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Pos<256>::kBuf);
-        (void)hipFuncSetAttribute((const void*)pointwise_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Pos<128>::kBuf);
         attr_set = true;
     }
     PwArgs p{};
     p.x = a.src, p.w = a.w, p.y = (bf16_t*)a.dst, p.partial = (a.flags & RV_OUT_STATS) ? a.stats : nullptr;
     p.P = (int64_t)a.N * a.H * a.W_src, p.ld_x = a.ld_src, p.ld_y = a.ld_dst;
-    if (a.C_src == 256) hipLaunchKernelGGL(pointwise_kernel<256>, dim3(grid), dim3(512), lds, stream, p);
-    else hipLaunchKernelGGL(pointwise_kernel<128>, dim3(grid), dim3(512), lds, stream, p);
+    RV_REQUIRE(a.C_src == 256, "pointwise kernel: 256 channels only");
+    hipLaunchKernelGGL(pointwise_kernel<256>, dim3(grid), dim3(512), lds, stream, p);
     RV_CHECK_LAUNCH("pointwise_kernel");
     return 0;
 }

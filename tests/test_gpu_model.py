@@ -99,6 +99,11 @@ def test_loss_kernel_matches_oracle(golden):
         assert rel_err(val.reshape(()), g[f"loss/{key}"].reshape(())) < 1e-4, key
     assert rel_err(ld.grad, logits.grad) < 1e-4
     assert rel_err(rd.grad, reg.grad) < 1e-4
+    # an incoming gradient other than one reaches the kernel as a DEVICE scalar (sums[15]: no pass over the gradients afterwards)
+    ld2, rd2 = g["logits"].to(DEV).requires_grad_(True), g["regressands"].to(DEV).requires_grad_(True)
+    loss2, *_ = _DetectionLossFn.apply(ld2, rd2, g["cart"].to(DEV), g["mask"].to(DEV), t, hp)
+    (loss2 * -2.5).backward()
+    assert rel_err(ld2.grad, -2.5 * ld.grad) < 1e-6 and rel_err(rd2.grad, -2.5 * rd.grad) < 1e-6
 
 
 def test_tiny_detector_forward_backward(golden):

@@ -1,10 +1,10 @@
-"""The pointwise streaming GEMM (generation 7, csrc/posconv.hip::pointwise_kernel): 1x1 stride-1 C -> C layers, C = 256 / 128, on plain
+"""The pointwise streaming GEMM (generation 7, csrc/posconv.hip::pointwise_kernel): 1x1 stride-1 C -> C layers, C = 256, on plain
 bf16 tensors -- ``conv2d`` with ``kernel_size=1`` (/root/reference/src/torchbox3d/nn/modules/conv.py:47-54, the projection convs of
 nn/blocks/__init__.py:58-66) and its backward-data.
 
 Method of tests/test_gpu_tapconv4/5/6.py: small-integer activations and weights make every partial sum an integer below 2^24, so the
 bf16 output must EQUAL the CPU convolution rounded once, whatever the summation order; every case asserts from ``rv_tap_launch_info`` that
-generation 7 is what runs.  Shapes: pixel counts that are not multiples of the 128- / 256-pixel step (ragged last step), exactly two steps per
+generation 7 is what runs.  Shapes: pixel counts that are not multiples of the 128-pixel step (ragged last step), exactly two steps per
 workgroup and many, a destination that is a channel slice of a wider tensor (the backbone's in-place concat), the batch statistics, the
 backward-data form (scatter image), and a race screen on random data (the next step's LDS-DMA fill is issued in front of this step's stores and
 waited for with a counted vmcnt).
@@ -39,7 +39,7 @@ def _info(layer, shape, scatter):
     return list(info)
 
 
-@pytest.mark.parametrize("C,N,H,W", [(256, 4, 32, 520), (256, 1, 5, 77), (256, 2, 64, 2048), (128, 4, 32, 520), (128, 3, 7, 100), (128, 2, 64, 2656)])
+@pytest.mark.parametrize("C,N,H,W", [(256, 4, 32, 520), (256, 1, 5, 77), (256, 2, 64, 2048), (256, 3, 7, 100)])
 def test_forward_1x1_exact_with_statistics(C, N, H, W):
     from range_view_3d_detection_amd import engine as E
 
@@ -59,7 +59,7 @@ def test_forward_1x1_exact_with_statistics(C, N, H, W):
     assert torch.allclose(rows[1, :C], (ref.double() ** 2).sum(dim=(0, 2, 3)), rtol=1e-5)
 
 
-@pytest.mark.parametrize("C", [256, 128])
+@pytest.mark.parametrize("C", [256])
 def test_backward_data_and_sliced_destination_exact(C):
     """Backward-data of a 1x1 conv (the scatter image through the same kernel), written into a channel slice of a wider tensor (row pitch
     2 C: what the in-place concat of the backbone hands over) from a source that is itself a slice."""
@@ -97,8 +97,9 @@ def test_other_1x1_launches_stay_on_the_tiled_kernels():
         layer = E.tap_layer(torch.nn.Conv2d(cin, cout, 1, bias=False).to(DEV))
         return _info(layer, L.TapShape(n, h, w, w, E.pad32(cin), E.pad32(cout), flags | sel), False)[0]
 
-    assert gen(256, 256, 0) == 7 and gen(128, 128, L.OUT_STATS) == 7
-    assert gen(256, 128, 0) != 7 and gen(512, 512, 0) != 7
+    assert gen(256, 256, 0) == 7 and gen(256, 256, L.OUT_STATS) == 7
+    # (C = 128 is built and exact but not shipped: it hung the GPU in free-running rv-waymo steps -- csrc/posconv.hip::rv_pointwise_plan)
+    assert gen(128, 128, 0) != 7 and gen(256, 128, 0) != 7 and gen(512, 512, 0) != 7
     for flags in (L.IN_AFFINE | L.IN_RELU, L.OUT_ACCUM, L.OUT_F32, L.OUT_BIAS):
         assert gen(256, 256, flags) != 7, flags
     with L.select(0):
