@@ -534,6 +534,7 @@ struct PwArgs {
     float* partial;   // [gridDim.x][2][C] fp32 (sum, sum of squares of the fp32 accumulators) or NULL
     int64_t P;
     int ld_x, ld_y;
+    int slices;  // C_out = slices x C: workgroup (group, t) multiplies the steps of its group by the t-th C x C block of the weight rows
 };
 
 template <int C>
@@ -545,18 +546,25 @@ __global__ __launch_bounds__(512, 1) void pointwise_kernel(const PwArgs a) {
     const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wc = wn % G::kWC, wp = wn / G::kWC;
     const int l15_ = lane & 15, lg_ = lane >> 4;
+    // Workgroup -> (step group, output slice), XCD-aware: the `slices` workgroups that multiply the SAME pixels by different blocks of the
+    // weight rows sit on one XCD (blockIdx & 7) and fetch the image through one L2; slots of an XCD that do not fill a whole group idle
+    // (slices = 9 on 32 slots: 27 busy).  slices = 1: a permutation of the workgroups.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = (gridDim.x >> 3) / a.slices;  // (gridDim.x % 8 == 0: the launcher)
+    if (slot >= per_xcd * a.slices) return;  // (before any barrier)
+    const int tsl = slot % a.slices;
+    const int64_t group = xcd * per_xcd + slot / a.slices, n_groups = 8 * per_xcd;
     // weights of this wave: A operand, row m = l15 of tile j is channel 32 wc + 8 (m >> 2) + 4 j + (m & 3) (see pos_fwd_kernel)
     bf16x8 fw[2][kKS];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int ch = wc * 32 + (l15_ >> 2) * 8 + j * 4 + (l15_ & 3);
+        const int ch = tsl * kC + wc * 32 + (l15_ >> 2) * 8 + j * 4 + (l15_ & 3);
 #pragma unroll
         for (int ks = 0; ks < kKS; ++ks) fw[j][ks] = *(const bf16x8*)(a.w + (int64_t)ch * kC + ks * 32 + lg_ * 8);
     }
     uint32_t rb[4];
 #pragma unroll
     for (int x = 0; x < 4; ++x) rb[x] = (wp * G::kGroups * 32 + l15_) * kRow + (((((x << 2) | lg_) ^ l15_) & 15) * 16);
-    int yoff = (wp * G::kGroups * 32 + l15_) * a.ld_y + wc * 32 + lg_ * 8;
+    int yoff = (wp * G::kGroups * 32 + l15_) * a.ld_y + tsl * kC + wc * 32 + lg_ * 8;
     asm volatile("" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(yoff));
     // image fill: DMA instruction q (0..63) of a step moves 1 KB = kSel pixels (lane = pixel x kOct slots); wave w issues q = w, w + 8, ...
     // The LDS side is lane-linear, so slot s of pixel p receives source octet s ^ (p & 15).  Per-lane source offsets once (32-bit elements).
@@ -631,12 +639,12 @@ __global__ __launch_bounds__(512, 1) void pointwise_kernel(const PwArgs a) {
         }
     };
     const int64_t steps = (a.P + kTM - 1) / kTM;
-    if ((int64_t)blockIdx.x < steps) fill(blockIdx.x, 0);
+    if (group < steps) fill(group, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0;
-    for (int64_t s = blockIdx.x; s < steps; s += gridDim.x) {
-        const int64_t nxt = s + gridDim.x;
+    for (int64_t s = group; s < steps; s += n_groups) {
+        const int64_t nxt = s + n_groups;
         const bool has_next = nxt < steps;
         if (has_next) fill(nxt, cur ^ 1);  // (in front of this step's stores: see the note on vmcnt above)
         multiply(s, cur);
@@ -691,16 +699,23 @@ bool rv_pointwise_plan(const TapConvArgs* a, int* grid, size_t* lds) {
     // a call-by-call synchronised rv-waymo run, and HUNG the GPU twice within ~30 free-running two-stream rv-waymo steps (round 6,
     // profiles/r06_ab_notes.md section 4: watchdog reset after ~100 s, reported as a memory fault at address nil; no cause found by reading the
     // ISA): not shipped.  rv-av2's 256-channel instance: 300-step two-stream soak, profiles/r06_soak_pointwise_av2.txt.
-    if (a->C_src != a->C_dst || a->C_src != 256) return false;
+    if (a->C_src != 256 || a->C_dst % 256 != 0) return false;
+    const int slices = a->C_dst / 256;  // C_out = slices x 256: the backward-data of the stem's 9 C -> C fusion conv is nine 256-channel blocks of one input
+    if (slices > 16) return false;
     if (a->flags & ~RV_OUT_STATS) return false;  // (no folded input, bias, fp32 output, accumulate, ReLU, BatchNorm-backward sums)
+    if (slices > 1 && a->flags) return false;    // (statistics: one row per workgroup of a whole-width launch)
     if (a->W_src != a->W_dst) return false;
     const int64_t P = (int64_t)a->N * a->H * a->W_src;
     const int tm = Pos<256>::kTM;
     if (P * a->ld_src >= ((int64_t)1 << 31) || P * a->ld_dst >= ((int64_t)1 << 31)) return false;  // (32-bit per-lane offsets inside a step only, but keep the tensors addressable the same way)
     const int64_t steps = (P + tm - 1) / tm;
     const int cus = rv_persistent_grid();
-    if (steps < ((a->sel & RV_SEL_SMALL_GRIDS) ? 1 : 2 * (int64_t)cus)) return false;  // fewer than two steps per CU: the tiled kernels fill the chip better
-    *grid = (int)(steps < cus ? steps : cus);
+    const int groups = 8 * ((cus / 8) / slices);
+    if (groups < 8 || steps < ((a->sel & RV_SEL_SMALL_GRIDS) ? 1 : 2 * (int64_t)groups)) return false;  // fewer than two steps per group: the tiled kernels fill the chip better
+    // one workgroup per CU; fewer steps than groups (crops in the tests): eight workgroups per row of `slices` x 8 ... keep the grid a multiple of 8 x slices
+    int g = cus;
+    if (steps < groups) g = 8 * slices * (int)((steps + 7) / 8);
+    *grid = g;
     *lds = (size_t)2 * Pos<256>::kBuf;
     return true;
 }
@@ -714,7 +729,8 @@ int rv_pointwise_launch(const TapConvArgs& a, int grid, size_t lds, hipStream_t 
     PwArgs p{};
     p.x = a.src, p.w = a.w, p.y = (bf16_t*)a.dst, p.partial = (a.flags & RV_OUT_STATS) ? a.stats : nullptr;
     p.P = (int64_t)a.N * a.H * a.W_src, p.ld_x = a.ld_src, p.ld_y = a.ld_dst;
-    RV_REQUIRE(a.C_src == 256, "pointwise kernel: 256 channels only");
+    p.slices = a.C_dst / 256;
+    RV_REQUIRE(a.C_src == 256 && grid % 8 == 0 && (grid / 8) / p.slices >= 1, "pointwise kernel: 256 input channels, grid a multiple of 8 with room for a group per XCD");
     hipLaunchKernelGGL(pointwise_kernel<256>, dim3(grid), dim3(512), lds, stream, p);
     RV_CHECK_LAUNCH("pointwise_kernel");
     return 0;

@@ -506,7 +506,7 @@ static int tap_launch(const rvTapGeom* g, const rvTapShape* s, bool scatter, con
                 info[0] = 7;
                 info[1] = a.C_dst;
                 info[2] = grid7;
-                info[3] = 1;
+                info[3] = a.C_dst / a.C_src;  // 256-channel output slices per step group
             }
             if (dry_run) return 0;
             return rv_pointwise_launch(a, grid7, lds7, (hipStream_t)stream);

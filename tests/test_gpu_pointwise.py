@@ -129,3 +129,28 @@ def test_repeatable_on_random_data_and_equal_to_generation_4():
     assert torch.equal(first.out.data, tiled.out.data)
     a, b = first.partial[: first.rows].double().sum(0), tiled.partial[: tiled.rows].double().sum(0)
     assert torch.allclose(a, b, rtol=1e-6, atol=1e-6 * float(b.abs().max()))
+
+
+@pytest.mark.parametrize("N,H,W,blocks", [(1, 16, 160, 9), (2, 33, 250, 9), (1, 64, 2048, 9), (2, 16, 100, 2)])
+def test_wide_output_backward_data_exact(N, H, W, blocks):
+    """C_out = blocks x 256 from 256 input channels: the backward-data of the stem's fusion conv (nn/stems/__init__.py:51-62: a 1x1 conv 9 C -> C,
+    so its input gradient is nine 256-channel blocks of ONE 256-channel tensor) as ONE launch -- the workgroups of a step group hold one
+    256 x 256 block of the weight rows each and share the image through their XCD's L2."""
+    from range_view_3d_detection_amd import _lib as L
+    from range_view_3d_detection_amd import engine as E
+
+    g = torch.Generator().manual_seed(W + blocks)
+    m = torch.nn.Conv2d(blocks * 256, 256, 1, bias=False)
+    m.weight.data = _ints(m.weight.shape, g, -2, 3)
+    dy = _ints((N, 256, H, W), g)
+    ref = F.conv_transpose2d(dy, m.weight.data)
+    layer = E.tap_layer(m.to(DEV))
+    src = E.Act.from_nchw(dy.to(DEV))
+    dst = E.Act.empty(N, H, W, blocks * 256, DEV)
+    shape = L.TapShape(N, H, W, W, src.ld, dst.ld, 0)
+    info = _info(layer, shape, True)
+    assert info[0] == 7 and info[1] == blocks * 256 and info[3] == blocks, info
+    L.call("rv_tap_scatter", ctypes.byref(layer.geom), ctypes.byref(shape), src.ptr(), None, None, L.ptr(layer.packed("scatter")), None, dst.ptr(), None,
+           L.stream_ptr())
+    got = dst.data.permute(0, 3, 1, 2).float().cpu()
+    assert torch.equal(got, ref.bfloat16().float())
