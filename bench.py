@@ -125,7 +125,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PMC_TRAFFIC = "profiles/r05_pmc_traffic.json"  # HBM bytes per launch per kernel, collected over this same command this round
+PMC_TRAFFIC = "profiles/r06_pmc_traffic.json"  # HBM bytes per launch per kernel, collected over this same command this round
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 (MI355X_MICROARCH.md: ~2.5 PF dense; 2:1-sparsity figures are not used)
 HBM_PEAK_GBS = 8000.0
 
