@@ -2,7 +2,7 @@
 around each tap-conv / weight-gradient launch (engine.KernelProfile; RV3D_PROFILE_SHAPES=1 for per-shape names) plus the HBM-group hook
 of bench.py for the bandwidth-bound launches.  Prints ms per step per kernel for each value, side by side.
 
-    RV3D_PROFILE_SHAPES=1 python profiles/tools/ab_kernels.py engine.XF_MAX_COUT=None,1073741824 [--widths rv-av2|rv-waymo] [--min-ms 0.05]
+    RV3D_PROFILE_SHAPES=1 python profiles/tools/ab_kernels.py _lib.SELECT=0,16777216 [--widths rv-av2|rv-waymo] [--min-ms 0.05]
 """
 import argparse
 import importlib
