@@ -535,6 +535,9 @@ struct PwArgs {
     int64_t P;
     int ld_x, ld_y;
     int slices;  // C_out = slices x C: workgroup (group, t) multiplies the steps of its group by the t-th C x C block of the weight rows
+    int pair;    // 128 -> 128 layers on DENSE rows (ld = 128): two adjacent pixels are one 256-channel "pixel" and the weights are diag(W, W),
+                 // formed in the register prologue from the 128 x 128 image (the zero blocks cost MFMAs this bandwidth-bound kernel has to spare);
+                 // P, ld_x, ld_y are then those of the paired view; statistics rows: two per workgroup (one per pixel parity), 128 channels wide
 };
 
 template <int C>
@@ -559,7 +562,17 @@ __global__ __launch_bounds__(512, 1) void pointwise_kernel(const PwArgs a) {
     for (int j = 0; j < 2; ++j) {
         const int ch = tsl * kC + wc * 32 + (l15_ >> 2) * 8 + j * 4 + (l15_ & 3);
 #pragma unroll
-        for (int ks = 0; ks < kKS; ++ks) fw[j][ks] = *(const bf16x8*)(a.w + (int64_t)ch * kC + ks * 32 + lg_ * 8);
+        for (int ks = 0; ks < kKS; ++ks) {
+            if (!a.pair) {
+                fw[j][ks] = *(const bf16x8*)(a.w + (int64_t)ch * kC + ks * 32 + lg_ * 8);
+            } else {  // diag(W, W): output half ch >> 7 against input half ks >> 2 (K-steps 0..3 = the first pixel's 128 channels)
+                const bf16x8 wv = *(const bf16x8*)(a.w + (int64_t)(ch & 127) * 128 + (ks & 3) * 32 + lg_ * 8);
+                bf16x8 z;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) z[e] = (rv_elem_t)0.f;
+                fw[j][ks] = ((ch >> 7) == (ks >> 2)) ? wv : z;
+            }
+        }
     }
     uint32_t rb[4];
 #pragma unroll
@@ -654,6 +667,7 @@ __global__ __launch_bounds__(512, 1) void pointwise_kernel(const PwArgs a) {
         __builtin_amdgcn_s_barrier();
         cur ^= 1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no wave ends with memory operations in flight (the rule of csrc/wgrad.hip::wgrad3_body)
     if (a.partial) {
         float* const red = (float*)smem;  // [2][C]
         float sv[8], qv[8];
@@ -681,8 +695,14 @@ __global__ __launch_bounds__(512, 1) void pointwise_kernel(const PwArgs a) {
             for (int q = 0; q < 8; ++q) {
                 const int ch = wc * 32 + lg_ * 8 + q;
                 const float s2 = G::kWP > 1 ? red[ch] : 0.f, q2 = G::kWP > 1 ? red[kC + ch] : 0.f;
-                a.partial[((int64_t)blockIdx.x * 2) * kC + ch] = sv[q] + s2;
-                a.partial[((int64_t)blockIdx.x * 2 + 1) * kC + ch] = qv[q] + q2;
+                if (a.pair) {  // rows of 128 channels: row 2 b + (pixel parity), the paired channel ch is logical channel ch & 127
+                    float* row = a.partial + ((int64_t)(blockIdx.x * 2 + (ch >> 7)) * 2) * 128 + (ch & 127);
+                    row[0] = sv[q] + s2;
+                    row[128] = qv[q] + q2;
+                } else {
+                    a.partial[((int64_t)blockIdx.x * 2) * kC + ch] = sv[q] + s2;
+                    a.partial[((int64_t)blockIdx.x * 2 + 1) * kC + ch] = qv[q] + q2;
+                }
             }
         }
     }
@@ -692,15 +712,21 @@ __global__ __launch_bounds__(512, 1) void pointwise_kernel(const PwArgs a) {
 
 // Pointwise path of the tap-conv dispatcher (tapconv.hip::tap_launch): 1x1 stride-1 layers C -> C, C = 256 or 128, plain bf16 in and out,
 // at most the batch-statistics epilogue, and enough pixels for one step per workgroup and round.
-bool rv_pointwise_plan(const TapConvArgs* a, int* grid, size_t* lds) {
+static bool pointwise_pair(const TapConvArgs* a) {  // 128 -> 128 on dense rows, an even number of pixels: the paired 256-channel view
+    return a->C_src == 128 && a->C_dst == 128 && a->ld_src == 128 && a->ld_dst == 128 && (((int64_t)a->N * a->H * a->W_src) & 1) == 0;
+}
+
+bool rv_pointwise_plan(const TapConvArgs* a, bool scatter, int* grid, size_t* lds, int* stats_rows) {
     if (a->sel & RV_SEL_NO_POINTWISE) return false;
+    if (scatter && !(a->sel & RV_SEL_POINTWISE_BWD)) return false;  // FORWARD launches only (see below)
     if (a->phases != 1 || a->step != 1 || a->tt.ntaps[0] != 1 || a->tt.dh[0][0] != 0 || a->tt.dw[0][0] != 0) return false;
-    // C = 256 only.  The 128-channel instance (190 VGPRs: the one instance that other workgroups can share a CU with) passed every parity test and
-    // a call-by-call synchronised rv-waymo run, and HUNG the GPU twice within ~30 free-running two-stream rv-waymo steps (round 6,
-    // profiles/r06_ab_notes.md section 4: watchdog reset after ~100 s, reported as a memory fault at address nil; no cause found by reading the
-    // ISA): not shipped.  rv-av2's 256-channel instance: 300-step two-stream soak, profiles/r06_soak_pointwise_av2.txt.
-    if (a->C_src != 256 || a->C_dst % 256 != 0) return false;
-    const int slices = a->C_dst / 256;  // C_out = slices x 256: the backward-data of the stem's 9 C -> C fusion conv is nine 256-channel blocks of one input
+    // 256 input channels (the 256-channel instance), or 128 -> 128 as PAIRS of pixels through the same instance.  A native 128-channel instance
+    // (190 VGPRs: the one instance that other workgroups can share a CU with) passed every parity test and a call-by-call synchronised rv-waymo
+    // run, and HUNG the GPU twice within ~30 free-running two-stream rv-waymo steps (round 6, profiles/r06_ab_notes.md section 4: watchdog reset
+    // after ~100 s, reported as a memory fault at address nil; no cause found by reading the ISA): not shipped.
+    const bool pair = pointwise_pair(a);
+    if (!pair && (a->C_src != 256 || a->C_dst % 256 != 0)) return false;
+    const int slices = pair ? 1 : a->C_dst / 256;  // C_out = slices x 256: the backward-data of the stem's 9 C -> C fusion conv is nine 256-channel blocks of one input
     if (slices > 16) return false;
     if (a->flags & ~RV_OUT_STATS) return false;  // (no folded input, bias, fp32 output, accumulate, ReLU, BatchNorm-backward sums)
     if (slices > 1 && a->flags) return false;    // (statistics: one row per workgroup of a whole-width launch)
@@ -708,7 +734,7 @@ bool rv_pointwise_plan(const TapConvArgs* a, int* grid, size_t* lds) {
     const int64_t P = (int64_t)a->N * a->H * a->W_src;
     const int tm = Pos<256>::kTM;
     if (P * a->ld_src >= ((int64_t)1 << 31) || P * a->ld_dst >= ((int64_t)1 << 31)) return false;  // (32-bit per-lane offsets inside a step only, but keep the tensors addressable the same way)
-    const int64_t steps = (P + tm - 1) / tm;
+    const int64_t steps = ((pair ? P / 2 : P) + tm - 1) / tm;
     const int cus = rv_persistent_grid();
     const int groups = 8 * ((cus / 8) / slices);
     if (groups < 8 || steps < ((a->sel & RV_SEL_SMALL_GRIDS) ? 1 : 2 * (int64_t)groups)) return false;  // fewer than two steps per group: the tiled kernels fill the chip better
@@ -716,6 +742,7 @@ bool rv_pointwise_plan(const TapConvArgs* a, int* grid, size_t* lds) {
     int g = cus;
     if (steps < groups) g = 8 * slices * (int)((steps + 7) / 8);
     *grid = g;
+    *stats_rows = pair ? 2 * g : g;
     *lds = (size_t)2 * Pos<256>::kBuf;
     return true;
 }
@@ -729,8 +756,10 @@ int rv_pointwise_launch(const TapConvArgs& a, int grid, size_t lds, hipStream_t 
     PwArgs p{};
     p.x = a.src, p.w = a.w, p.y = (bf16_t*)a.dst, p.partial = (a.flags & RV_OUT_STATS) ? a.stats : nullptr;
     p.P = (int64_t)a.N * a.H * a.W_src, p.ld_x = a.ld_src, p.ld_y = a.ld_dst;
-    p.slices = a.C_dst / 256;
-    RV_REQUIRE(a.C_src == 256 && grid % 8 == 0 && (grid / 8) / p.slices >= 1, "pointwise kernel: 256 input channels, grid a multiple of 8 with room for a group per XCD");
+    p.pair = pointwise_pair(&a) ? 1 : 0;
+    if (p.pair) p.P /= 2, p.ld_x = 256, p.ld_y = 256;
+    p.slices = p.pair ? 1 : a.C_dst / 256;
+    RV_REQUIRE((p.pair || a.C_src == 256) && grid % 8 == 0 && (grid / 8) / p.slices >= 1, "pointwise kernel: 256 input channels (or paired 128), grid a multiple of 8 with room for a group per XCD");
     hipLaunchKernelGGL(pointwise_kernel<256>, dim3(grid), dim3(512), lds, stream, p);
     RV_CHECK_LAUNCH("pointwise_kernel");
     return 0;

@@ -73,6 +73,6 @@ bool rv_tapconv6_plan(TapConvArgs* a, int* tiles, size_t* lds, int* stats_rows, 
 int rv_tapconv6_launch(const TapConvArgs& a, size_t lds, hipStream_t stream);
 
 // pointwise streaming GEMM (posconv.hip): 1x1 stride-1 layers C -> C (C = 256 / 128) on plain bf16 tensors, weights in registers,
-// pixels streamed through LDS; stats rows = one (sum, sum of squares) pair per workgroup = grid
-bool rv_pointwise_plan(const TapConvArgs* a, int* grid, size_t* lds);
+// pixels streamed through LDS; stats rows = one (sum, sum of squares) pair per workgroup (two for the paired 128 -> 128 form)
+bool rv_pointwise_plan(const TapConvArgs* a, bool scatter, int* grid, size_t* lds, int* stats_rows);
 int rv_pointwise_launch(const TapConvArgs& a, int grid, size_t lds, hipStream_t stream);

@@ -498,15 +498,15 @@ static int tap_launch(const rvTapGeom* g, const rvTapShape* s, bool scatter, con
     }
     // 1x1 stride-1 C -> C layers on plain tensors: the persistent streaming GEMM with the weights in registers (posconv.hip, round 6)
     {
-        int grid7;
+        int grid7, rows7;
         size_t lds7;
-        if (rv_pointwise_plan(&a, &grid7, &lds7)) {
-            if (stats_rows) *stats_rows = grid7;
+        if (rv_pointwise_plan(&a, scatter, &grid7, &lds7, &rows7)) {
+            if (stats_rows) *stats_rows = rows7;
             if (info) {
                 info[0] = 7;
                 info[1] = a.C_dst;
                 info[2] = grid7;
-                info[3] = a.C_dst / a.C_src;  // 256-channel output slices per step group
+                info[3] = a.C_dst / a.C_src;  // 256-channel output slices per step group (1: also the paired 128 -> 128 form)
             }
             if (dry_run) return 0;
             return rv_pointwise_launch(a, grid7, lds7, (hipStream_t)stream);

@@ -59,7 +59,7 @@ def _run_f16(module, x, expect_kernel, stats=False, out_f32=False):
 
 
 @pytest.mark.parametrize("cin,cout,N,H,W,k,kernel", [(128, 512, 2, 64, 256, 3, 6), (320, 128, 3, 17, 1030, 3, 5), (64, 256, 4, 30, 520, 3, 6),
-                                                     (256, 256, 2, 32, 512, 1, 7), (128, 128, 2, 16, 1024, 1, 4)])  # (7: the pointwise streaming GEMM, fp16 operands)
+                                                     (256, 256, 2, 32, 512, 1, 7), (128, 128, 2, 16, 1024, 1, 7)])  # (7: the pointwise streaming GEMM, fp16 operands)
 def test_fp16_tap_conv_exact_on_integers(cin, cout, N, H, W, k, kernel):
     g = torch.Generator().manual_seed(cin + W + k)
     m = torch.nn.Conv2d(cin, cout, k, padding=k // 2, bias=False)

@@ -27,7 +27,9 @@ pytestmark = pytest.mark.gpu
 def _small_grids_allowed():
     from range_view_3d_detection_amd import _lib as L
 
-    with L.select(L.SEL_SMALL_GRIDS):
+    # SEL_POINTWISE_BWD: the backward-data (scatter-form) launches are exact as well and are tested here, but the library does not take them by
+    # default -- free-running two-stream rv-waymo steps faulted with them (profiles/r06_ab_notes.md section 4)
+    with L.select(L.SEL_SMALL_GRIDS | L.SEL_POINTWISE_BWD):
         yield
 
 
@@ -39,7 +41,8 @@ def _info(layer, shape, scatter):
     return list(info)
 
 
-@pytest.mark.parametrize("C,N,H,W", [(256, 4, 32, 520), (256, 1, 5, 77), (256, 2, 64, 2048), (256, 3, 7, 100)])
+@pytest.mark.parametrize("C,N,H,W", [(256, 4, 32, 520), (256, 1, 5, 77), (256, 2, 64, 2048), (256, 3, 7, 100),
+                                     (128, 4, 32, 520), (128, 3, 7, 100), (128, 2, 64, 2656), (128, 1, 6, 333)])  # 128: pairs of pixels through the 256-channel instance
 def test_forward_1x1_exact_with_statistics(C, N, H, W):
     from range_view_3d_detection_amd import engine as E
 
@@ -62,7 +65,7 @@ def test_forward_1x1_exact_with_statistics(C, N, H, W):
 @pytest.mark.parametrize("C", [256])
 def test_backward_data_and_sliced_destination_exact(C):
     """Backward-data of a 1x1 conv (the scatter image through the same kernel), written into a channel slice of a wider tensor (row pitch
-    2 C: what the in-place concat of the backbone hands over) from a source that is itself a slice."""
+    2 C: what the in-place concat of the backbone hands over) from a source that is itself a slice.  (256 channels: the paired 128-channel form needs dense rows.)"""
     from range_view_3d_detection_amd import _lib as L
     from range_view_3d_detection_amd import engine as E
 
@@ -98,13 +101,21 @@ def test_other_1x1_launches_stay_on_the_tiled_kernels():
         return _info(layer, L.TapShape(n, h, w, w, E.pad32(cin), E.pad32(cout), flags | sel), False)[0]
 
     assert gen(256, 256, 0) == 7 and gen(256, 256, L.OUT_STATS) == 7
-    # (C = 128 is built and exact but not shipped: it hung the GPU in free-running rv-waymo steps -- csrc/posconv.hip::rv_pointwise_plan)
-    assert gen(128, 128, 0) != 7 and gen(256, 128, 0) != 7 and gen(512, 512, 0) != 7
+    # 128 -> 128 on dense rows and an even pixel count: two pixels = one 256-channel pixel of the SAME instance (a native 128-channel instance
+    # is exact too but hung the GPU in free-running rv-waymo steps and is not shipped -- csrc/posconv.hip::rv_pointwise_plan)
+    assert gen(128, 128, 0) == 7 and gen(128, 128, 0, n=1, h=3, w=2047) != 7
+    assert gen(256, 128, 0) != 7 and gen(512, 512, 0) != 7
     for flags in (L.IN_AFFINE | L.IN_RELU, L.OUT_ACCUM, L.OUT_F32, L.OUT_BIAS):
         assert gen(256, 256, flags) != 7, flags
-    with L.select(0):
-        pass
     assert gen(256, 256, L.SEL_NO_POINTWISE) == 4
+    # backward-data launches: only with the test hint
+    layer = E.tap_layer(torch.nn.Conv2d(256, 256, 1, bias=False).to(DEV))
+    old, L.SELECT = L.SELECT, L.SEL_SMALL_GRIDS
+    try:
+        assert _info(layer, L.TapShape(4, 64, 2048, 2048, 256, 256, 0), True)[0] != 7
+        assert _info(layer, L.TapShape(4, 64, 2048, 2048, 256, 256, 0), False)[0] == 7
+    finally:
+        L.SELECT = old
 
 
 def test_repeatable_on_random_data_and_equal_to_generation_4():
@@ -154,3 +165,26 @@ def test_wide_output_backward_data_exact(N, H, W, blocks):
            L.stream_ptr())
     got = dst.data.permute(0, 3, 1, 2).float().cpu()
     assert torch.equal(got, ref.bfloat16().float())
+
+
+def test_paired_128_channel_backward_data_exact_and_sliced_rows_stay_tiled():
+    """128 -> 128 backward-data on dense rows through the paired form; the same layer writing into a channel slice (row pitch 256) is NOT eligible."""
+    from range_view_3d_detection_amd import _lib as L
+    from range_view_3d_detection_amd import engine as E
+
+    g = torch.Generator().manual_seed(128)
+    N, H, W = 2, 24, 334
+    m = torch.nn.Conv2d(128, 128, 1, bias=False)
+    m.weight.data = _ints(m.weight.shape, g, -2, 3)
+    dy = _ints((N, 128, H, W), g)
+    ref = F.conv_transpose2d(dy, m.weight.data)
+    layer = E.tap_layer(m.to(DEV))
+    src = E.Act.from_nchw(dy.to(DEV))
+    dst = E.Act.empty(N, H, W, 128, DEV)
+    shape = L.TapShape(N, H, W, W, src.ld, dst.ld, 0)
+    assert _info(layer, shape, True)[:2] == [7, 128]
+    L.call("rv_tap_scatter", ctypes.byref(layer.geom), ctypes.byref(shape), src.ptr(), None, None, L.ptr(layer.packed("scatter")), None, dst.ptr(), None,
+           L.stream_ptr())
+    assert torch.equal(dst.data.permute(0, 3, 1, 2).float().cpu(), ref.bfloat16().float())
+    wide = E.Act.empty(N, H, W, 256, DEV)
+    assert _info(layer, L.TapShape(N, H, W, W, src.ld, wide.slice(0, 128).ld, 0), True)[0] != 7
