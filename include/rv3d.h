@@ -121,8 +121,7 @@ int rv_unpack_weight_grad(const rvTapGeom* g, const float* packed, float* dT, in
 #define RV_SEL_NO_GEN6 (1 << 22)      /* do not select generation 6 */
 #define RV_SEL_NO_GEN5 (1 << 23)      /* do not select generations 5 and 6 (multi-tap layers stay on generation 4) */
 #define RV_SEL_NO_POINTWISE (1 << 24) /* 1x1 C -> C layers stay on the tiled kernels (generation 7 = the pointwise streaming GEMM, round 6) */
-#define RV_SEL_POINTWISE_BWD (1 << 25) /* ... and let SCATTER-form (backward-data) launches take it too: exact in every test, but free-running two-stream rv-waymo steps
-                                       * faulted with it (round 6, profiles/r06_ab_notes.md section 4) -- tests and diagnostics only */
+#define RV_SEL_NO_POINTWISE_BWD (1 << 25) /* ... only its SCATTER-form (backward-data) launches stay on the tiled kernels (diagnostics: profiles/r06_ab_notes.md section 4) */
 #define RV_SEL_MASK (63 << 20)
 
 typedef struct {

@@ -26,7 +26,7 @@ OUT_RES_RELU = 256
 WGRAD_TORCH_LAYOUT = 128  # rv_tap_wgrad: result in dT[cu][cv][kh][kw] (no unpack pass)
 # kernel-selection hints (rvTapShape.flags, per call: the library keeps no mutable state).  SELECT is OR-ed into every TapShape
 # built while a `select(...)` block is active -- the parity tests' way of running the production kernels on crops / pinning a generation.
-SEL_SMALL_GRIDS, SEL_SMALL_GRIDS6, SEL_NO_GEN6, SEL_NO_GEN5, SEL_NO_POINTWISE, SEL_POINTWISE_BWD = 1 << 20, 1 << 21, 1 << 22, 1 << 23, 1 << 24, 1 << 25
+SEL_SMALL_GRIDS, SEL_SMALL_GRIDS6, SEL_NO_GEN6, SEL_NO_GEN5, SEL_NO_POINTWISE, SEL_NO_POINTWISE_BWD = 1 << 20, 1 << 21, 1 << 22, 1 << 23, 1 << 24, 1 << 25
 SELECT = 0
 EW_RELU_A, EW_RELU_B, EW_RELU_OUT = 1, 2, 4
 BNB_RELU_Z, BNB_RES_ACCUM, BNB_Y_FROM_INPUT = 1, 2, 4

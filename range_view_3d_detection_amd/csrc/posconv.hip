@@ -718,12 +718,10 @@ static bool pointwise_pair(const TapConvArgs* a) {  // 128 -> 128 on dense rows,
 
 bool rv_pointwise_plan(const TapConvArgs* a, bool scatter, int* grid, size_t* lds, int* stats_rows) {
     if (a->sel & RV_SEL_NO_POINTWISE) return false;
-    if (scatter && !(a->sel & RV_SEL_POINTWISE_BWD)) return false;  // FORWARD launches only (see below)
+    if (scatter && (a->sel & RV_SEL_NO_POINTWISE_BWD)) return false;
     if (a->phases != 1 || a->step != 1 || a->tt.ntaps[0] != 1 || a->tt.dh[0][0] != 0 || a->tt.dw[0][0] != 0) return false;
-    // 256 input channels (the 256-channel instance), or 128 -> 128 as PAIRS of pixels through the same instance.  A native 128-channel instance
-    // (190 VGPRs: the one instance that other workgroups can share a CU with) passed every parity test and a call-by-call synchronised rv-waymo
-    // run, and HUNG the GPU twice within ~30 free-running two-stream rv-waymo steps (round 6, profiles/r06_ab_notes.md section 4: watchdog reset
-    // after ~100 s, reported as a memory fault at address nil; no cause found by reading the ISA): not shipped.
+    // 256 input channels, or 128 -> 128 on dense rows as PAIRS of pixels through the same 256-channel instance (a native 128-channel instance was
+    // written too and is exact; it is not instantiated: one kernel to soak instead of two -- profiles/r06_ab_notes.md section 4)
     const bool pair = pointwise_pair(a);
     if (!pair && (a->C_src != 256 || a->C_dst % 256 != 0)) return false;
     const int slices = pair ? 1 : a->C_dst / 256;  // C_out = slices x 256: the backward-data of the stem's 9 C -> C fusion conv is nine 256-channel blocks of one input

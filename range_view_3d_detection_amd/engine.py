@@ -941,7 +941,12 @@ class ConvOp(Op):
             sc = sh = None
             flags = 0
         elif (isinstance(x, Lazy) and MATERIALIZE_FOR_DMA and MATERIALIZE_FOR_POINTWISE and not out_f32 and g.kh * g.kw == 1 and layer.bias is None
-              and eval_bn is None and _dma_generation(g, src.N, src.H, wu, wv, src.ld, pad32(layer.c_out), form == "scatter") == 7):
+              and eval_bn is None and pad32(layer.c_in) == 256
+              and _dma_generation(g, src.N, src.H, wu, wv, pad32(layer.c_in), out.ld if out is not None else pad32(layer.c_out), form == "scatter") == 7):
+            # (256 input channels only -- rv-av2's stem.  The same write-out for rv-waymo's 128-channel stem conv FAULTED free-running two-stream
+            #  rv-waymo steps in every build that had it (five of five soaks; clean in both builds without it), whichever kernel then ran the forward
+            #  launch -- i.e. with its weight gradient on wgrad3 over the written-out operand -- and passed call-by-call synchronised: cause not
+            #  found, profiles/r06_ab_notes.md section 4.  Asked with the strides the launch will really have.)
             self.x_plain = src = x.materialized()
             sc = sh = None
             flags = 0

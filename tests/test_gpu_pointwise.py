@@ -27,9 +27,7 @@ pytestmark = pytest.mark.gpu
 def _small_grids_allowed():
     from range_view_3d_detection_amd import _lib as L
 
-    # SEL_POINTWISE_BWD: the backward-data (scatter-form) launches are exact as well and are tested here, but the library does not take them by
-    # default -- free-running two-stream rv-waymo steps faulted with them (profiles/r06_ab_notes.md section 4)
-    with L.select(L.SEL_SMALL_GRIDS | L.SEL_POINTWISE_BWD):
+    with L.select(L.SEL_SMALL_GRIDS):
         yield
 
 
@@ -108,14 +106,10 @@ def test_other_1x1_launches_stay_on_the_tiled_kernels():
     for flags in (L.IN_AFFINE | L.IN_RELU, L.OUT_ACCUM, L.OUT_F32, L.OUT_BIAS):
         assert gen(256, 256, flags) != 7, flags
     assert gen(256, 256, L.SEL_NO_POINTWISE) == 4
-    # backward-data launches: only with the test hint
+    # the backward-data launches can be pinned back on their own
     layer = E.tap_layer(torch.nn.Conv2d(256, 256, 1, bias=False).to(DEV))
-    old, L.SELECT = L.SELECT, L.SEL_SMALL_GRIDS
-    try:
-        assert _info(layer, L.TapShape(4, 64, 2048, 2048, 256, 256, 0), True)[0] != 7
-        assert _info(layer, L.TapShape(4, 64, 2048, 2048, 256, 256, 0), False)[0] == 7
-    finally:
-        L.SELECT = old
+    assert _info(layer, L.TapShape(4, 64, 2048, 2048, 256, 256, L.SEL_NO_POINTWISE_BWD), True)[0] != 7
+    assert _info(layer, L.TapShape(4, 64, 2048, 2048, 256, 256, L.SEL_NO_POINTWISE_BWD), False)[0] == 7
 
 
 def test_repeatable_on_random_data_and_equal_to_generation_4():

@@ -134,3 +134,34 @@ def test_repeatable_on_random_data():
     for _ in range(30):
         again, _ = _run(m, x)
         assert torch.equal(first, again)
+
+
+@pytest.mark.parametrize("C,N,H,W", [(128, 2, 8, 2656), (128, 1, 16, 333), (256, 1, 8, 520)])
+def test_gather_1x1_into_a_channel_slice_exact(C, N, H, W):
+    """1x1 C -> C on a plain operand, written into a channel slice of a wider tensor (row pitch 2 C: the stem's last conv writes the backbone's
+    in-place concat) with the batch statistics, widths that are not multiples of the 64-column tile (2656 = rv-waymo): the output must equal the CPU
+    convolution, the statistics its sums, and the OTHER slice must stay untouched.  (Round 6: written while hunting a fault of free-running rv-waymo
+    steps whose stem conv took this launch on a written-out operand -- profiles/r06_ab_notes.md section 4.)"""
+    from range_view_3d_detection_amd import _lib as L
+    from range_view_3d_detection_amd import engine as E
+
+    g = torch.Generator().manual_seed(C + W)
+    m = torch.nn.Conv2d(C, C, 1, bias=False)
+    m.weight.data = _ints(m.weight.shape, g, -2, 3)
+    x = _ints((N, C, H, W), g)
+    ref = F.conv2d(x, m.weight.data)
+    t = E.Tape(True, DEV)
+    layer = E.tap_layer(m.to(DEV))
+    wide = E.Act.empty(N, H, W, 2 * C, DEV)
+    wide.data.fill_(7.0)
+    guard = torch.full((4096,), 5.0, dtype=wide.data.dtype, device=DEV)  # (allocated right behind: a write past the end of `wide` would land here)
+    with L.select(L.SEL_SMALL_GRIDS):  # (a crop: lift the tile-count heuristic so that generation 4 runs)
+        op = E.ConvOp(t, layer, E.Act.from_nchw(x.to(DEV)), stats=True, out=wide.slice(0, C))
+    info = (ctypes.c_int32 * 4)()
+    assert L.load().rv_tap_launch_info(ctypes.byref(layer.geom), ctypes.byref(op.shape), 0, info) == 0 and info[0] == 4, list(info)
+    torch.cuda.synchronize()
+    assert torch.equal(wide.data[..., :C].permute(0, 3, 1, 2).float().cpu(), ref.bfloat16().float())
+    assert bool((wide.data[..., C:] == 7.0).all()) and bool((guard == 5.0).all())
+    rows = op.partial[: op.rows].double().sum(dim=0).cpu()
+    assert torch.allclose(rows[0, :C], ref.double().sum(dim=(0, 2, 3)), rtol=1e-6, atol=1e-3)
+    assert torch.allclose(rows[1, :C], (ref.double() ** 2).sum(dim=(0, 2, 3)), rtol=1e-5)
