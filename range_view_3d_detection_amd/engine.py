@@ -533,6 +533,7 @@ def _dma_eligible(geom, n: int, h: int, wu: int, wv: int, ld_src: int, ld_dst: i
 # pointwise streaming GEMM (generation 7, round 6) -- write-out + streaming GEMM + wgrad3 on the plain operand against the register-staged
 # tapconv2 + wgrad2 (profiles/r06_ab_notes.md).  Other 1x1 shapes keep the folded operand (the tiled kernel saves what the pass costs).
 MATERIALIZE_FOR_POINTWISE = True
+MATERIALIZE_POINTWISE_C = (256,)  # input widths that take it (128: faults free-running rv-waymo steps, profiles/r06_ab_notes.md section 4; diagnostics add it back)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -941,7 +942,7 @@ class ConvOp(Op):
             sc = sh = None
             flags = 0
         elif (isinstance(x, Lazy) and MATERIALIZE_FOR_DMA and MATERIALIZE_FOR_POINTWISE and not out_f32 and g.kh * g.kw == 1 and layer.bias is None
-              and eval_bn is None and pad32(layer.c_in) == 256
+              and eval_bn is None and pad32(layer.c_in) in MATERIALIZE_POINTWISE_C
               and _dma_generation(g, src.N, src.H, wu, wv, pad32(layer.c_in), out.ld if out is not None else pad32(layer.c_out), form == "scatter") == 7):
             # (256 input channels only -- rv-av2's stem.  The same write-out for rv-waymo's 128-channel stem conv FAULTED free-running two-stream
             #  rv-waymo steps in every build that had it (five of five soaks; clean in both builds without it), whichever kernel then ran the forward

@@ -66,7 +66,8 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
     _release_held_wgrads(t)  # (weight gradients of earlier layers that met no all-reduce since)
     layer, g = op.layer, op.layer.geom
     src, sc, sh, in_flags = E._operand_parts(op.x)
-    if op.x_plain is not None:  # the forward pass wrote relu(bn(.)) out for the DMA kernel: the weight gradient reads it too
+    if op.x_plain is not None and not (DIAG_WGRAD_IGNORES_PLAIN_1X1 and g.kh * g.kw == 1):
+        # the forward pass wrote relu(bn(.)) out for the DMA kernel: the weight gradient reads it too
         src, sc, sh, in_flags = op.x_plain, None, None, 0
     fwd = layer.fwd_form
     bwd = "scatter" if fwd == "gather" else "gather"
@@ -207,6 +208,7 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
 
 
 HEAD_FINAL_FUSE = True  # (module attribute: tests flip it in-process)
+DIAG_WGRAD_IGNORES_PLAIN_1X1 = False  # (diagnostic, profiles/r06_ab_notes.md section 4: a 1x1 layer's weight gradient re-forms the folded operand instead of reading the written-out one)
 # (Round 5 built the same idea for the stem's first fusion conv -- its backward-data GEMM recomputed inside both passes of the modulation
 #  backward, `csrc/metachain.hip` -- parity-green and 0.4-1.0 ms per step SLOWER than the launches it replaced; round 6 removed it from the
 #  library: profiles/r05_metachain.md is the record.)
