@@ -3,6 +3,7 @@ A/B tools flip the module attribute).  One model, one batch, the variants interl
 thermal drift cancel:
 
     python profiles/tools/ab_attr.py engine_bwd.HEAD_FINAL_FUSE=True,False [--widths rv-av2|rv-waymo] [--steps 10] [--rounds 3]
+                                     [--set module.ATTR=value ...]   (attributes held fixed for every variant)
 """
 import argparse
 import importlib
@@ -23,11 +24,16 @@ def main():
     ap.add_argument("--widths", default="rv-av2")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--set", action="append", default=[])
     args = ap.parse_args()
+    for fixed in args.set:
+        ftarget, fvalue = fixed.split("=")
+        fmod, fattr = ftarget.rsplit(".", 1)
+        setattr(importlib.import_module("range_view_3d_detection_amd." + fmod), fattr, eval(fvalue))
     target, values = args.spec.split("=")
     modname, attr = target.rsplit(".", 1)
     mod = importlib.import_module("range_view_3d_detection_amd." + modname)
-    values = [eval(v) for v in values.split(",")]
+    values = [eval(v) for v in values.split(";" if ";" in values else ",")]  # (";" between values that contain commas)
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
     from range_view_3d_detection_amd.nn.meta.arch import configure_optimizers

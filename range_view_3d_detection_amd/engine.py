@@ -496,6 +496,10 @@ class Lazy:
     def materialized(self) -> Act:
         if self.plain is None:
             out = self.raw.like()
+            if DIAG_PLAIN_GUARD_PIXELS:  # (diagnostic: the written-out tensor in the middle of a larger allocation, zeros either side)
+                r, gp = self.raw, DIAG_PLAIN_GUARD_PIXELS
+                buf = torch.zeros((r.pixels + 2 * gp) * r.cp, dtype=L.act_dtype(), device=r.data.device)
+                out = Act(buf[gp * r.cp: (gp + r.pixels) * r.cp].view(r.N, r.H, r.W, r.cp), r.c)
             L.call("rv_ew_combine", L.i64(self.raw.pixels), L.i32(self.raw.cp), self.raw.ptr(), L.i32(self.raw.ld), L.ptr(self.bn.scale),
                    L.ptr(self.bn.shift), None, L.i32(0), None, None, out.ptr(), L.i32(out.ld), L.i32(L.EW_RELU_A if self.relu else 0),
                    L.stream_ptr())
@@ -509,6 +513,7 @@ Operand = Union[Act, Lazy]
 # apply a folded BatchNorm(+ReLU) on the way in.  On the layers it is eligible for it is enough faster than the
 # register-staged kernels (3x3 512 -> 512: 1330 vs 980 TFLOP/s, one box) to pay for writing the operand out once
 # (one HBM-bound pass); forward conv, and the weight gradient in backward, then both read the plain tensor.
+DIAG_PLAIN_GUARD_PIXELS = 0  # (diagnostic, profiles/r06_ab_notes.md section 4)
 MATERIALIZE_FOR_DMA = True  # (module attribute: tests and A/B tools flip it in-process; no environment switch)
 # (Measured and dropped in round 4: the split-K sums of all weight gradients in ONE batched launch at the end of a program's backward --
 #  bit-identical, 76 launches fewer, 1.0-1.6 ms per step SLOWER: the immediate reduction reads slabs that are still in the Infinity Cache.)

@@ -190,6 +190,8 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
         # (_release_held_wgrads: bn_backward_finish / the next conv / the end of the pass); it then runs beside the finalize + apply passes
         # exactly as in the local case.
         t.held_wgrads.append(run_wgrad)
+    elif DIAG_PLAIN_1X1_WGRAD_ON_MAIN and op.x_plain is not None and g.kh * g.kw == 1:
+        run_wgrad()
     elif E.OVERLAP_WGRAD and (small or E.OVERLAP_CHAIN):
         side = E.side_stream(t.device)
         ready = early_ready
@@ -208,6 +210,7 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
 
 
 HEAD_FINAL_FUSE = True  # (module attribute: tests flip it in-process)
+DIAG_PLAIN_1X1_WGRAD_ON_MAIN = False  # (diagnostic, same section: that weight gradient in the main stream's order instead of beside it)
 DIAG_WGRAD_IGNORES_PLAIN_1X1 = False  # (diagnostic, profiles/r06_ab_notes.md section 4: a 1x1 layer's weight gradient re-forms the folded operand instead of reading the written-out one)
 # (Round 5 built the same idea for the stem's first fusion conv -- its backward-data GEMM recomputed inside both passes of the modulation
 #  backward, `csrc/metachain.hip` -- parity-green and 0.4-1.0 ms per step SLOWER than the launches it replaced; round 6 removed it from the
