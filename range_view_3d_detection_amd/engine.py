@@ -950,9 +950,9 @@ class ConvOp(Op):
               and eval_bn is None and pad32(layer.c_in) in MATERIALIZE_POINTWISE_C
               and _dma_generation(g, src.N, src.H, wu, wv, pad32(layer.c_in), out.ld if out is not None else pad32(layer.c_out), form == "scatter") == 7):
             # (256 input channels only -- rv-av2's stem.  The same write-out for rv-waymo's 128-channel stem conv FAULTED free-running two-stream
-            #  rv-waymo steps in every build that had it (five of five soaks; clean in both builds without it), whichever kernel then ran the forward
-            #  launch -- i.e. with its weight gradient on wgrad3 over the written-out operand -- and passed call-by-call synchronised: cause not
-            #  found, profiles/r06_ab_notes.md section 4.  Asked with the strides the launch will really have.)
+            #  rv-waymo steps: bisected (profiles/r06_ab_notes.md section 4) to that layer's wgrad3 launch over the written-out operand running on
+            #  the side stream BESIDE the stem's backward -- clean in the main stream's order, clean on wgrad2 over the folded operand, and
+            #  time-neutral either way, so the 128-channel write-out stays off.  Asked with the strides the launch will really have.)
             self.x_plain = src = x.materialized()
             sc = sh = None
             flags = 0
