@@ -1,7 +1,7 @@
 """Bisect of the rv-waymo fault of round 6 (profiles/r06_ab_notes.md section 4): free-running two-stream rv-waymo steps with the stem's 128-channel
 operand write-out forced ON (engine.MATERIALIZE_POINTWISE_C += 128), optionally with that layer's weight gradient kept off the written-out tensor.
 
-    python profiles/tools/diag_waymo_stem.py <variant> [steps]      variant: control | wgrad_ignores_plain | wgrad_on_main | guard
+    python profiles/tools/diag_waymo_stem.py <variant> [steps]      variant: control | wgrad_ignores_plain | wgrad_on_main | guard | side_workspace
 """
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,7 +13,8 @@ from range_view_3d_detection_amd.nn.meta.arch import configure_optimizers
 
 E.MATERIALIZE_POINTWISE_C = (256, 128)
 variant = sys.argv[1] if len(sys.argv) > 1 else "control"
-assert variant in ("control", "wgrad_ignores_plain", "wgrad_on_main", "guard"), variant
+assert variant in ("control", "wgrad_ignores_plain", "wgrad_on_main", "guard", "side_workspace"), variant
+EB.DIAG_SIDE_WORKSPACE = variant == "side_workspace"
 EB.DIAG_WGRAD_IGNORES_PLAIN_1X1 = variant == "wgrad_ignores_plain"
 EB.DIAG_PLAIN_1X1_WGRAD_ON_MAIN = variant == "wgrad_on_main"
 E.DIAG_PLAIN_GUARD_PIXELS = 4096 if variant == "guard" else 0  # (1 MB of zeros either side of every written-out operand)

@@ -699,7 +699,18 @@ __device__ __forceinline__ void wgrad3_body(const Wgrad2Args& a, uint8_t* smem, 
         step(w3_int<3>{});
         if (++c >= c_end) break;
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // The last step's read_unit -- unit 0 of a chunk that does not exist -- is still IN FLIGHT here, and its twelve destination register pairs are dead
+    // as far as the compiler knows (inline asm: it sees them written at the asm statement).  Untied, it hoisted the epilogue's address arithmetic above
+    // this wait and formed the first slab address in two of those registers; the hardware does not order a VALU write against the return of an older LDS
+    // read, so a read that came back late (a neighbour on the CU keeping the LDS busy) overwrote the address -- with the zeros of the past-the-slice
+    // slot: sixteen-byte stores to address 0, "memory access fault on address (nil)", free-running rv-waymo steps of round 6 (profiles/r06_ab_notes.md
+    // section 4: found with the debug agent's register dump); with other contents, stores to a wrong place.  The registers are operands of the wait.
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                 : "+v"(fa[0][0].lo), "+v"(fa[0][0].hi), "+v"(fa[0][1].lo), "+v"(fa[0][1].hi), "+v"(fa[0][2].lo), "+v"(fa[0][2].hi), "+v"(fa[0][3].lo),
+                   "+v"(fa[0][3].hi), "+v"(fb[0][0].lo), "+v"(fb[0][0].hi), "+v"(fb[0][1].lo), "+v"(fb[0][1].hi)
+                 :
+                 : "memory");
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < TG; ++t) {
         float* slab = a.slabs + ((int64_t)ks * a.taps + tap0 + t) * a.cu_pad * a.cv_pad;

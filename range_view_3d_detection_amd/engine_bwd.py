@@ -161,7 +161,7 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
 
     def run_wgrad() -> None:
         ws_bytes = L.load().rv_tap_wgrad_workspace_bytes(ctypes.byref(wg), ctypes.byref(wsh))
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=t.device)
+        ws = _wgrad_workspace(ws_bytes, t.device, 1 if (op.x_plain is not None and g.kh * g.kw == 1) else 0)
         grad = torch.empty((wg.cu, wg.cv, wg.kh, wg.kw), dtype=torch.float32, device=t.device)
         wname = "wgrad_kernel(+reduce)"
         if E.PROFILE is not None:
@@ -207,6 +207,22 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
         t.used_side_stream = True
     else:
         run_wgrad()
+
+
+DIAG_SIDE_WORKSPACE = False  # (diagnostic, profiles/r06_ab_notes.md section 4: one persistent split-K workspace for the side stream instead of one allocation per launch)
+_SIDE_WS: dict = {}
+
+
+def _wgrad_workspace(nbytes: int, device, tag: int = 0) -> torch.Tensor:
+    """Split-K slabs of one weight-gradient launch (written by the kernel, summed by the reduction enqueued right behind it on the same stream)."""
+    if DIAG_SIDE_WORKSPACE and torch.cuda.current_stream(device) == E.side_stream(device):
+        key = (torch.device(device).index or 0, tag)  # (tag 1: the 1x1 layers on a written-out operand -- their own arena, so that a register dump tells them apart)
+        ws = _SIDE_WS.get(key)
+        if ws is None or ws.numel() < nbytes:  # (launches on one stream take turns: the next one starts after this one's reduction)
+            ws = _SIDE_WS[key] = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+            print(f"side workspace {key}: {ws.data_ptr():#x} + {ws.numel():#x}", flush=True)
+        return ws
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
 
 
 HEAD_FINAL_FUSE = True  # (module attribute: tests flip it in-process)
