@@ -1,24 +1,21 @@
-"""Bisect of the rv-waymo fault of round 6 (profiles/r06_ab_notes.md section 4): free-running two-stream rv-waymo steps with the stem's 128-channel
-operand write-out forced ON (engine.MATERIALIZE_POINTWISE_C += 128), optionally with that layer's weight gradient kept off the written-out tensor.
+"""Soak of the configuration that exposed round 6's wgrad3 fault (profiles/r06_ab_notes.md section 4): free-running two-stream rv-waymo steps with the
+stem's 128-channel operand write-out forced ON (engine.MATERIALIZE_POINTWISE_C += 128), so that the stem conv's weight gradient is a wgrad3 launch on the
+side stream beside the stem's backward.  Before the fix this died within 15-100 steps on every box (eight runs of eight); the variants of the bisect
+(`wgrad_ignores_plain`, `wgrad_on_main`, `guard`, `side_workspace`) were switches of engine.py / engine_bwd.py at commit "wgrad3: tie the dangling LDS
+prefetch registers ..." and went with the fix.
 
-    python profiles/tools/diag_waymo_stem.py <variant> [steps]      variant: control | wgrad_ignores_plain | wgrad_on_main | guard | side_workspace
+    python profiles/tools/diag_waymo_stem.py [steps]
 """
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import bench
-from range_view_3d_detection_amd import engine as E, engine_bwd as EB
+from range_view_3d_detection_amd import engine as E
 from range_view_3d_detection_amd.nn.meta.arch import configure_optimizers
 
 E.MATERIALIZE_POINTWISE_C = (256, 128)
-variant = sys.argv[1] if len(sys.argv) > 1 else "control"
-assert variant in ("control", "wgrad_ignores_plain", "wgrad_on_main", "guard", "side_workspace"), variant
-EB.DIAG_SIDE_WORKSPACE = variant == "side_workspace"
-EB.DIAG_WGRAD_IGNORES_PLAIN_1X1 = variant == "wgrad_ignores_plain"
-EB.DIAG_PLAIN_1X1_WGRAD_ON_MAIN = variant == "wgrad_on_main"
-E.DIAG_PLAIN_GUARD_PIXELS = 4096 if variant == "guard" else 0  # (1 MB of zeros either side of every written-out operand)
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+steps = int(sys.argv[-1]) if len(sys.argv) > 1 and sys.argv[-1].isdigit() else 300
 dev = torch.device("cuda:0")
 torch.cuda.set_device(0)
 torch.manual_seed(0)
@@ -37,4 +34,4 @@ for i in range(steps):
         torch.cuda.synchronize()
         print(f"step {i + 1}: loss {float(loss.detach()):.5f}, {1e3 * (time.perf_counter() - t0) / (i + 1):.2f} ms per step", flush=True)
 torch.cuda.synchronize()
-print("done: no fault in", steps, "steps; variant =", variant)
+print("done: no fault in", steps, "steps")

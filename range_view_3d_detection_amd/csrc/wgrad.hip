@@ -733,7 +733,7 @@ __device__ __forceinline__ void wgrad3_body(const Wgrad2Args& a, uint8_t* smem, 
     // nothing else (profiles/r04_ab_notes.md, "One wrong weight gradient"; the round-5 soak: profiles/r05_race_soak_*.txt).  Two readings
     // fit that symptom -- stores still in flight at the end of the kernel with another queue busy, or a line of the recycled workspace
     // that the PREVIOUS reduction left in the reading XCD's L2 -- and both are closed: this wait, and loads that do not hit in a
-    // non-coherent L2 line.
+    // non-coherent L2 line.  (Round 6: a third reading, and the likeliest -- the address race fixed above the stores misplaces a wave's slab lines.)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 

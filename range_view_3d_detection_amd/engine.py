@@ -496,10 +496,6 @@ class Lazy:
     def materialized(self) -> Act:
         if self.plain is None:
             out = self.raw.like()
-            if DIAG_PLAIN_GUARD_PIXELS:  # (diagnostic: the written-out tensor in the middle of a larger allocation, zeros either side)
-                r, gp = self.raw, DIAG_PLAIN_GUARD_PIXELS
-                buf = torch.zeros((r.pixels + 2 * gp) * r.cp, dtype=L.act_dtype(), device=r.data.device)
-                out = Act(buf[gp * r.cp: (gp + r.pixels) * r.cp].view(r.N, r.H, r.W, r.cp), r.c)
             L.call("rv_ew_combine", L.i64(self.raw.pixels), L.i32(self.raw.cp), self.raw.ptr(), L.i32(self.raw.ld), L.ptr(self.bn.scale),
                    L.ptr(self.bn.shift), None, L.i32(0), None, None, out.ptr(), L.i32(out.ld), L.i32(L.EW_RELU_A if self.relu else 0),
                    L.stream_ptr())
@@ -513,7 +509,6 @@ Operand = Union[Act, Lazy]
 # apply a folded BatchNorm(+ReLU) on the way in.  On the layers it is eligible for it is enough faster than the
 # register-staged kernels (3x3 512 -> 512: 1330 vs 980 TFLOP/s, one box) to pay for writing the operand out once
 # (one HBM-bound pass); forward conv, and the weight gradient in backward, then both read the plain tensor.
-DIAG_PLAIN_GUARD_PIXELS = 0  # (diagnostic, profiles/r06_ab_notes.md section 4)
 MATERIALIZE_FOR_DMA = True  # (module attribute: tests and A/B tools flip it in-process; no environment switch)
 # (Measured and dropped in round 4: the split-K sums of all weight gradients in ONE batched launch at the end of a program's backward --
 #  bit-identical, 76 launches fewer, 1.0-1.6 ms per step SLOWER: the immediate reduction reads slabs that are still in the Infinity Cache.)
@@ -949,10 +944,9 @@ class ConvOp(Op):
         elif (isinstance(x, Lazy) and MATERIALIZE_FOR_DMA and MATERIALIZE_FOR_POINTWISE and not out_f32 and g.kh * g.kw == 1 and layer.bias is None
               and eval_bn is None and pad32(layer.c_in) in MATERIALIZE_POINTWISE_C
               and _dma_generation(g, src.N, src.H, wu, wv, pad32(layer.c_in), out.ld if out is not None else pad32(layer.c_out), form == "scatter") == 7):
-            # (256 input channels only -- rv-av2's stem.  The same write-out for rv-waymo's 128-channel stem conv FAULTED free-running two-stream
-            #  rv-waymo steps: bisected (profiles/r06_ab_notes.md section 4) to that layer's wgrad3 launch over the written-out operand running on
-            #  the side stream BESIDE the stem's backward -- clean in the main stream's order, clean on wgrad2 over the folded operand, and
-            #  time-neutral either way, so the 128-channel write-out stays off.  Asked with the strides the launch will really have.)
+            # (256 input channels only -- rv-av2's stem.  For 128 input channels (rv-waymo's stem conv, the 1/2 .. 1/8-resolution layers of both models) the
+            #  write-out is time-neutral on rv-waymo and +0.27 ms per rv-av2 step: off on that measurement, profiles/r06_ab_notes.md section 4 -- the fault
+            #  first met on this route was wgrad3's, fixed there.  Asked with the strides the launch will really have.)
             self.x_plain = src = x.materialized()
             sc = sh = None
             flags = 0

@@ -66,7 +66,7 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
     _release_held_wgrads(t)  # (weight gradients of earlier layers that met no all-reduce since)
     layer, g = op.layer, op.layer.geom
     src, sc, sh, in_flags = E._operand_parts(op.x)
-    if op.x_plain is not None and not (DIAG_WGRAD_IGNORES_PLAIN_1X1 and g.kh * g.kw == 1):
+    if op.x_plain is not None:
         # the forward pass wrote relu(bn(.)) out for the DMA kernel: the weight gradient reads it too
         src, sc, sh, in_flags = op.x_plain, None, None, 0
     fwd = layer.fwd_form
@@ -161,7 +161,7 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
 
     def run_wgrad() -> None:
         ws_bytes = L.load().rv_tap_wgrad_workspace_bytes(ctypes.byref(wg), ctypes.byref(wsh))
-        ws = _wgrad_workspace(ws_bytes, t.device, 1 if (op.x_plain is not None and g.kh * g.kw == 1) else 0)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=t.device)
         grad = torch.empty((wg.cu, wg.cv, wg.kh, wg.kw), dtype=torch.float32, device=t.device)
         wname = "wgrad_kernel(+reduce)"
         if E.PROFILE is not None:
@@ -190,8 +190,6 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
         # (_release_held_wgrads: bn_backward_finish / the next conv / the end of the pass); it then runs beside the finalize + apply passes
         # exactly as in the local case.
         t.held_wgrads.append(run_wgrad)
-    elif DIAG_PLAIN_1X1_WGRAD_ON_MAIN and op.x_plain is not None and g.kh * g.kw == 1:
-        run_wgrad()
     elif E.OVERLAP_WGRAD and (small or E.OVERLAP_CHAIN):
         side = E.side_stream(t.device)
         ready = early_ready
@@ -209,25 +207,7 @@ def conv_backward(op: "E.ConvOp", t: Tape) -> None:
         run_wgrad()
 
 
-DIAG_SIDE_WORKSPACE = False  # (diagnostic, profiles/r06_ab_notes.md section 4: one persistent split-K workspace for the side stream instead of one allocation per launch)
-_SIDE_WS: dict = {}
-
-
-def _wgrad_workspace(nbytes: int, device, tag: int = 0) -> torch.Tensor:
-    """Split-K slabs of one weight-gradient launch (written by the kernel, summed by the reduction enqueued right behind it on the same stream)."""
-    if DIAG_SIDE_WORKSPACE and torch.cuda.current_stream(device) == E.side_stream(device):
-        key = (torch.device(device).index or 0, tag)  # (tag 1: the 1x1 layers on a written-out operand -- their own arena, so that a register dump tells them apart)
-        ws = _SIDE_WS.get(key)
-        if ws is None or ws.numel() < nbytes:  # (launches on one stream take turns: the next one starts after this one's reduction)
-            ws = _SIDE_WS[key] = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
-            print(f"side workspace {key}: {ws.data_ptr():#x} + {ws.numel():#x}", flush=True)
-        return ws
-    return torch.empty(nbytes, dtype=torch.uint8, device=device)
-
-
 HEAD_FINAL_FUSE = True  # (module attribute: tests flip it in-process)
-DIAG_PLAIN_1X1_WGRAD_ON_MAIN = False  # (diagnostic, same section: that weight gradient in the main stream's order instead of beside it)
-DIAG_WGRAD_IGNORES_PLAIN_1X1 = False  # (diagnostic, profiles/r06_ab_notes.md section 4: a 1x1 layer's weight gradient re-forms the folded operand instead of reading the written-out one)
 # (Round 5 built the same idea for the stem's first fusion conv -- its backward-data GEMM recomputed inside both passes of the modulation
 #  backward, `csrc/metachain.hip` -- parity-green and 0.4-1.0 ms per step SLOWER than the launches it replaced; round 6 removed it from the
 #  library: profiles/r05_metachain.md is the record.)

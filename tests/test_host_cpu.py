@@ -391,3 +391,58 @@ def test_bench_gpus_flag_launches_the_ranks_itself():
     # N = 1 is not a launcher
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=120)
     assert "[bench launcher]" not in one.stderr and "needs an MI355X" in one.stderr
+
+
+def _gfx950_code_objects(path):
+    """The gfx950 code objects of a HIP shared library (the clang offload bundles of its .hip_fatbin section)."""
+    import re
+    import struct
+    import tempfile
+
+    objcopy = "/opt/rocm/lib/llvm/bin/llvm-objcopy"
+    with tempfile.TemporaryDirectory() as d:
+        fat = os.path.join(d, "fat.bin")
+        subprocess.run([objcopy, "--dump-section", ".hip_fatbin=" + fat, path], check=True)
+        data = open(fat, "rb").read()
+    out = []
+    for m in re.finditer(b"__CLANG_OFFLOAD_BUNDLE__", data):
+        hdr = data[m.start():]
+        (num,) = struct.unpack_from("<Q", hdr, 24)
+        off = 32
+        for _ in range(num):
+            o, sz, tl = struct.unpack_from("<QQQ", hdr, off)
+            off += 24
+            triple = hdr[off:off + tl].decode()
+            off += tl
+            if "gfx950" in triple and sz > 0:
+                out.append(hdr[o:o + sz])
+    return out
+
+
+@pytest.mark.parametrize("tag", ["bf16", "f16"])
+def test_wgrad3_epilogue_waits_before_it_touches_a_register(tmp_path, lib, tag):
+    """Round 6's rv-waymo fault: wgrad3's transposing LDS reads are inline asm, the last one of the K loop is a prefetch nobody consumes, and the
+    compiler -- which takes its destination registers for dead -- had scheduled the epilogue's slab-address arithmetic ABOVE the ``s_waitcnt`` that
+    follows the loop, into two of those registers; a late LDS return then overwrote the address (stores to address 0).  The registers are now operands
+    of the wait.  This checks the machine code of the library as built: in every instance of the kernel the ``s_waitcnt vmcnt(0) lgkmcnt(0)`` that
+    closes the K loop is the FIRST instruction of the loop's exit block (what precedes it is the branch), not something behind vector arithmetic."""
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("no llvm-objdump")
+    path = lib.LIB_PATH_F16 if tag == "f16" else lib.LIB_PATH
+    cos = [c for c in _gfx950_code_objects(path) if b"wgrad3_kernel" in c]
+    assert len(cos) == 1
+    co = tmp_path / "wgrad.co"
+    co.write_bytes(cos[0])
+    text = subprocess.run([objdump, "-d", "--no-show-raw-insn", str(co)], check=True, capture_output=True, text=True).stdout
+    start = next(i for i, ln in enumerate(text.splitlines()) if "wgrad3_kernel" in ln and ln.rstrip().endswith(">:"))
+    lines = text.splitlines()[start + 1:]
+    end = next((i for i, ln in enumerate(lines) if ln.rstrip().endswith(">:")), len(lines))
+    body = [ln.split("//")[0].strip() for ln in lines[:end] if ln.strip()]
+    waits = [i for i, ln in enumerate(body) if ln.startswith("s_waitcnt vmcnt(0) lgkmcnt(0)")]
+    assert len(waits) == 3, waits  # one per tap-group size (1, 2, 3 taps)
+    for i in waits:
+        assert body[i - 1].startswith(("s_cbranch", "s_branch")), body[i - 6:i + 1]
+        # ... and the first vector instruction behind the wait is arithmetic on registers nobody is still loading into
+        nxt = next(ln for ln in body[i + 1:] if ln.startswith(("v_", "global_", "ds_")))
+        assert nxt.startswith("v_"), nxt
