@@ -533,7 +533,7 @@ def _dma_eligible(geom, n: int, h: int, wu: int, wv: int, ld_src: int, ld_dst: i
 # pointwise streaming GEMM (generation 7, round 6) -- write-out + streaming GEMM + wgrad3 on the plain operand against the register-staged
 # tapconv2 + wgrad2 (profiles/r06_ab_notes.md).  Other 1x1 shapes keep the folded operand (the tiled kernel saves what the pass costs).
 MATERIALIZE_FOR_POINTWISE = True
-MATERIALIZE_POINTWISE_C = (256,)  # input widths that take it (128: faults free-running rv-waymo steps, profiles/r06_ab_notes.md section 4; diagnostics add it back)
+MATERIALIZE_POINTWISE_C = (256,)  # input widths that take it (128: time-neutral on rv-waymo, +0.27 ms on rv-av2 -- profiles/r06_ab_notes.md section 4; profiles/tools/diag_waymo_stem.py adds it back)
 
 
 # ---------------------------------------------------------------------------------------------

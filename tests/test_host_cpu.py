@@ -446,3 +446,32 @@ def test_wgrad3_epilogue_waits_before_it_touches_a_register(tmp_path, lib, tag):
         # ... and the first vector instruction behind the wait is arithmetic on registers nobody is still loading into
         nxt = next(ln for ln in body[i + 1:] if ln.startswith(("v_", "global_", "ds_")))
         assert nxt.startswith("v_"), nxt
+
+
+def _kernel_body(text, name):
+    lines = text.splitlines()
+    start = next(i for i, ln in enumerate(lines) if name in ln and ln.rstrip().endswith(">:"))
+    rest = lines[start + 1:]
+    end = next((i for i, ln in enumerate(rest) if ln.rstrip().endswith(">:")), len(rest))
+    return [ln.split("//")[0].strip() for ln in rest[:end] if ln.strip()]
+
+
+@pytest.mark.parametrize("tag", ["bf16", "f16"])
+def test_pointwise_kernel_counts_its_wait_over_the_order_it_was_written_in(tmp_path, lib, tag):
+    """``pointwise_kernel`` (csrc/posconv.hip) waits for the NEXT tile's eight LDS-DMA loads with ``s_waitcnt vmcnt(8)`` while this tile's eight
+    16-byte stores stay in flight: the counter retires in issue order, so the wait is right only if the machine code issues the eight loads BEFORE
+    the eight stores -- an order the compiler is free to change (the two touch different memory).  Checked on the library as built."""
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("no llvm-objdump")
+    path = lib.LIB_PATH_F16 if tag == "f16" else lib.LIB_PATH
+    cos = [c for c in _gfx950_code_objects(path) if b"pointwise_kernel" in c]
+    assert len(cos) == 1
+    co = tmp_path / "posconv.co"
+    co.write_bytes(cos[0])
+    text = subprocess.run([objdump, "-d", "--no-show-raw-insn", str(co)], check=True, capture_output=True, text=True).stdout
+    body = _kernel_body(text, "pointwise_kernel")
+    waits = [i for i, ln in enumerate(body) if ln.startswith("s_waitcnt vmcnt(8)")]
+    assert len(waits) == 1, waits
+    mem = [ln.split()[0] for ln in body[:waits[0]] if ln.startswith(("global_load_lds", "global_store", "global_load", "buffer_"))]
+    assert mem[-16:] == ["global_load_lds_dwordx4"] * 8 + ["global_store_dwordx4"] * 8, mem[-20:]
