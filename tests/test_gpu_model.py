@@ -121,15 +121,20 @@ def test_tiny_detector_forward_backward(golden):
         assert feats[s].shape == g[f"feat/{s}"].shape
         # ~60 conv+BN layers on 2x8x{4..64} pixels: vs the oracle with the same bf16 storage points, and (looser) vs fp32
         # (max-norm is dominated by single ReLU-gate flips that propagate through the 16-channel, 8x4..8x64-pixel layers)
-        assert rel_err(feats[s].float(), feats_o[s]) < 2e-1 and _cos(feats[s].float(), feats_o[s]) > 0.99, (
-            s, rel_err(feats[s].float(), feats_o[s]), _cos(feats[s].float(), feats_o[s]))
-        assert rel_err(feats[s].float(), g[f"feat/{s}"]) < 2e-1 and _cos(feats[s].float(), g[f"feat/{s}"]) > 0.985, (
-            s, rel_err(feats[s].float(), g[f"feat/{s}"]), _cos(feats[s].float(), g[f"feat/{s}"]))
+        # The yardstick is the CPU bf16 emulation's OWN distance from the reference's fp32 output on this fixture (round 5's review: a constant
+        # 2e-1 says nothing): the HIP result may be 1.5x that far from fp32 and 2x that far from the emulation (two bf16 realisations), + 1e-2.
+        emu = rel_err(feats_o[s], g[f"feat/{s}"])
+        e_ref, e_orc = rel_err(feats[s].float(), g[f"feat/{s}"]), rel_err(feats[s].float(), feats_o[s])
+        assert e_orc < max(3e-2, 2.0 * emu + 1e-2) and _cos(feats[s].float(), feats_o[s]) > 0.99, (s, e_orc, emu, _cos(feats[s].float(), feats_o[s]))
+        assert e_ref < max(3e-2, 1.5 * emu + 1e-2) and _cos(feats[s].float(), g[f"feat/{s}"]) > 0.985, (s, e_ref, emu, _cos(feats[s].float(), g[f"feat/{s}"]))
+        print(f"tiny detector feat/{s}: emulation {emu:.3e}, HIP vs fp32 {e_ref:.3e}, HIP vs emulation {e_orc:.3e}")
     outputs, losses = head(feats, data, return_loss=True)
-    # (BatchNorm over as few as 2x8x4 = 64 values amplifies bf16 rounding: max-norm 0.2, direction within 1 %)
+    # (BatchNorm over as few as 2x8x4 = 64 values amplifies bf16 rounding: the same yardstick)
     for got, orc, ref in ((outputs[1][0]["logits"], logits_o, g["logits"]), (outputs[1][0]["regressands"], reg_o, g["regressands"])):
-        assert rel_err(got, orc) < 2e-1 and _cos(got, orc) > 0.99, (rel_err(got, orc), _cos(got, orc))
-        assert rel_err(got, ref) < 2e-1 and _cos(got, ref) > 0.985, (rel_err(got, ref), _cos(got, ref))
+        emu = rel_err(orc, ref)
+        assert rel_err(got, orc) < max(3e-2, 2.0 * emu + 1e-2) and _cos(got, orc) > 0.99, (rel_err(got, orc), emu, _cos(got, orc))
+        assert rel_err(got, ref) < max(3e-2, 1.5 * emu + 1e-2) and _cos(got, ref) > 0.985, (rel_err(got, ref), emu, _cos(got, ref))
+        print(f"tiny detector head output: emulation {emu:.3e}, HIP vs fp32 {rel_err(got, ref):.3e}, HIP vs emulation {rel_err(got, orc):.3e}")
     for k in ("classification_labels", "panoptics", "points_per_obj"):
         assert torch.equal(data[1][0][k].cpu(), g[f"targets/{k}"])
     assert rel_err(losses["loss"].reshape(()), g["loss/loss"].reshape(())) < 3e-2
