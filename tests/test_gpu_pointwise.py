@@ -100,7 +100,7 @@ def test_other_1x1_launches_stay_on_the_tiled_kernels():
 
     assert gen(256, 256, 0) == 7 and gen(256, 256, L.OUT_STATS) == 7
     # 128 -> 128 on dense rows and an even pixel count: two pixels = one 256-channel pixel of the SAME instance (a native 128-channel instance
-    # is exact too but hung the GPU in free-running rv-waymo steps and is not shipped -- csrc/posconv.hip::rv_pointwise_plan)
+    # was written too and is exact; it is not instantiated -- csrc/posconv.hip::rv_pointwise_plan)
     assert gen(128, 128, 0) == 7 and gen(128, 128, 0, n=1, h=3, w=2047) != 7
     assert gen(256, 128, 0) != 7 and gen(512, 512, 0) != 7
     for flags in (L.IN_AFFINE | L.IN_RELU, L.OUT_ACCUM, L.OUT_F32, L.OUT_BIAS):
